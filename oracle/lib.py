@@ -1,0 +1,86 @@
+"""
+oracle/lib.py -- builds and loads the C oracle (oracle/r3o.c) through ctypes.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by rend3_amd/.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libr3o.so")
+_SRC = os.path.join(_HERE, "r3o.c")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+vp = ctypes.c_void_p
+
+
+def build(force=False):
+    """gcc -O2 -ffp-contract=off: no FMA contraction so every f32 op rounds once."""
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
+        return _SO
+    cmd = [
+        "gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+        "-Wall", "-Wextra", "-o", _SO, _SRC, "-lm",
+    ]
+    subprocess.run(cmd, check=True)
+    return _SO
+
+
+class OracleLib:
+    def __init__(self):
+        build()
+        self.c = ctypes.CDLL(_SO)
+        c = self.c
+        c.r3o_hiz_mip_count.restype = ctypes.c_uint32
+        c.r3o_hiz_mip_count.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        c.r3o_hiz_mip_offset.restype = ctypes.c_uint64
+        c.r3o_hiz_mip_offset.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        c.r3o_frustum_contains_sphere.restype = ctypes.c_int
+        c.r3o_frustum_contains_sphere.argtypes = [vp, vp, ctypes.c_float]
+        c.r3o_f32_to_f16.restype = ctypes.c_uint16
+        c.r3o_f32_to_f16.argtypes = [ctypes.c_float]
+        c.r3o_f16_to_f32.restype = ctypes.c_float
+        c.r3o_f16_to_f32.argtypes = [ctypes.c_uint16]
+        for name, args in {
+            "r3o_mat4_mul": [vp, vp, vp],
+            "r3o_uniform_bake": [vp, vp, vp],
+            "r3o_frustum_from_matrix": [vp, vp],
+            "r3o_frustum_cull": [vp, vp, vp],
+            "r3o_hiz_build": [vp, ctypes.c_uint32, ctypes.c_uint32],
+            "r3o_cull_triangles": [vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp],
+            "r3o_raster_visibility": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32,
+                                      ctypes.c_uint32, vp],
+            "r3o_raster_depth": [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint32,
+                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32],
+            "r3o_vis_to_depth": [vp, ctypes.c_uint64, vp],
+            "r3o_shade": [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp,
+                          ctypes.c_uint32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp],
+            "r3o_tonemap": [vp, ctypes.c_uint64, vp, vp],
+        }.items():
+            fn = getattr(c, name)
+            fn.restype = None
+            fn.argtypes = args
+
+    @staticmethod
+    def ptr(a):
+        if a is None:
+            return None
+        assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], "need contiguous ndarray"
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def __getattr__(self, name):
+        return getattr(self.c, name)
+
+
+_LIB = None
+
+
+def get():
+    global _LIB
+    if _LIB is None:
+        _LIB = OracleLib()
+    return _LIB

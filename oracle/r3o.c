@@ -1,0 +1,899 @@
+/*
+ * r3o.c -- CPU ORACLE for the rend3 GPU-driven object pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (rend3_amd/, include/)
+ * may include, link or call this file.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, as the checker / reported baseline.
+ *
+ * It is a plain-C restatement (f32, fixed operation order, built with
+ * -ffp-contract=off) of the reference's WGSL shaders and of the fixed-function
+ * raster state they run under:
+ *
+ *   uniform bake          rend3-routine/shaders/src/uniform_prep.wgsl:9-27
+ *   frustum / sphere      rend3/src/util/frustum.rs:96-161
+ *   per-triangle cull     rend3-routine/shaders/src/cull.wgsl:243-324,326-390
+ *   Hi-Z pyramid          rend3-routine/shaders/src/hi_z.wgsl:19-32
+ *   depth-only raster     rend3-routine/shaders/src/depth.wgsl:51-127
+ *                         + pipeline state rend3-routine/src/forward.rs:318-371
+ *   opaque VS + FS        rend3-routine/shaders/src/opaque.wgsl:91-135,203-551
+ *                         math/brdf.wgsl, math/color.wgsl, math/matrix.wgsl, shadow/pcf.wgsl
+ *   tonemap blit          rend3-routine/shaders/src/blit.wgsl:22-31, tonemapping.rs:44
+ *
+ * PARITY PINNING: the reference cannot be executed in this environment (no Rust, no
+ * Vulkan ICD).  The oracle is pinned against the reference's own golden images
+ * (rend3-test/tests/results/ PNGs, examples/src/cube/screenshot.png; committed as
+ * tests/golden/) by tests/test_oracle_goldens.py.  Per-triangle cull decisions and
+ * HDR float values are parity-UNPINNED by the reference itself (no reference test
+ * reads them back); for those the oracle is the definition.
+ *
+ * Choices where WGSL / the GPU leave the result implementation-defined (all
+ * documented in DESIGN.md "Arithmetic contract"):
+ *   - mat4*vec4 = ((c0*x + c1*y) + c2*z) + c3*w, no FMA contraction.
+ *   - rasteriser: 2D homogeneous edge functions (no clipping, no snapping),
+ *     top-left rule, pixel centres at +0.5, depth = sum(E_i*z_i)/det, depth clip
+ *     0<=z<=1, reverse-Z GreaterEqual; exact depth ties resolved toward the larger
+ *     canonical triangle slot (the reference's atomics make ties unordered).
+ *   - out-of-range / NaN Hi-Z coordinates clamp into the mip, mip index clamps to
+ *     the last level, OOB Hi-Z source loads read 0.0.
+ *   - pow(x,5) = ((x*x)*(x*x))*x ; normalize(v) = v * (1/sqrt(dot(v,v))).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define R3O_INVALID 0xFFFFFFFFu
+
+/* ------------------------------------------------------------------ layouts */
+/* Object record, 128 B (rend3/src/managers/object.rs:23-36). */
+typedef struct {
+    float transform[16];
+    float centre[3];
+    float radius;
+    uint32_t first_index;
+    uint32_t index_count;
+    uint32_t material_index;
+    uint32_t attr_off[6]; /* pos, normal, tangent, uv0, uv1, color0 (pbr/material.rs:486-494) */
+    uint32_t enabled;
+    uint32_t _pad[2];
+} r3o_object;
+
+/* Per-camera uniform header, 240 B (rend3-routine/src/culling/culler.rs:158-175). */
+typedef struct {
+    float view[16];
+    float view_proj[16];
+    uint32_t shadow_index;
+    uint32_t _pad0[3];
+    float frustum[20];
+    float resolution[2];
+    uint32_t flags;
+    uint32_t object_count;
+} r3o_camera_header;
+
+/* Per-object baked matrices, 128 B (culler.rs:177-183). */
+typedef struct {
+    float model_view[16];
+    float model_view_proj[16];
+} r3o_baked;
+
+/* Material record, 208 B (rend3/src/managers/material.rs:25-29 + pbr/material.rs:526-543). */
+typedef struct {
+    uint32_t tex[10];
+    uint32_t _pad[2];
+    float uv_transform0[12];
+    float uv_transform1[12];
+    float albedo[4];
+    float emissive[3];
+    float roughness;
+    float metallic;
+    float reflectance;
+    float clear_coat;
+    float clear_coat_roughness;
+    float anisotropy;
+    float ambient_occlusion;
+    float alpha_cutout;
+    uint32_t flags;
+} r3o_material;
+
+/* Directional light, 128 B stride (rend3/src/managers/directional.rs:38-53). */
+typedef struct {
+    float view_proj[16];
+    float color[3];
+    float _p0;
+    float direction[3];
+    float _p1;
+    float inv_resolution[2];
+    float atlas_offset[2];
+    float atlas_size[2];
+    float _p2[2];
+} r3o_dir_light;
+
+/* Point light, 32 B (rend3/src/managers/point.rs:21-26). */
+typedef struct {
+    float position[4];
+    float color[3];
+    float radius;
+} r3o_point_light;
+
+/* FrameUniforms, 496 B (rend3-routine/src/uniforms.rs:17-27). */
+typedef struct {
+    float view[16];
+    float view_proj[16];
+    float origin_view_proj[16];
+    float inv_view[16];
+    float inv_view_proj[16];
+    float inv_origin_view_proj[16];
+    float frustum[20];
+    float ambient[4];
+    uint32_t resolution[2];
+    uint32_t _pad[2];
+} r3o_frame_uniforms;
+
+#define FLAGS_ALBEDO_ACTIVE 0x0001u
+#define FLAGS_ALBEDO_BLEND 0x0002u
+#define FLAGS_ALBEDO_VERTEX_SRGB 0x0004u
+#define FLAGS_UNLIT 0x2000u
+
+#define PCU_POSITIVE_AREA_VISIBLE 0x1u
+#define PCU_MULTISAMPLED 0x2u
+
+/* ------------------------------------------------------------------ math */
+static inline void mat4_mul_vec4(const float *m, float x, float y, float z, float w, float *o) {
+    for (int r = 0; r < 4; ++r) o[r] = ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+
+void r3o_mat4_mul(const float *a, const float *b, float *out) {
+    float tmp[16];
+    for (int c = 0; c < 4; ++c) mat4_mul_vec4(a, b[4 * c + 0], b[4 * c + 1], b[4 * c + 2], b[4 * c + 3], tmp + 4 * c);
+    memcpy(out, tmp, sizeof tmp);
+}
+
+static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float sat(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+static inline void normalize3(float *v) {
+    float r = 1.0f / sqrtf(dot3(v, v));
+    v[0] *= r; v[1] *= r; v[2] *= r;
+}
+/* mat3 (columns c0,c1,c2 given as pointers to 3 floats) * vec3 */
+static inline void mat3_mul_vec3(const float *c0, const float *c1, const float *c2, const float *v, float *o) {
+    for (int r = 0; r < 3; ++r) o[r] = (c0[r] * v[0] + c1[r] * v[1]) + c2[r] * v[2];
+}
+
+/* float -> IEEE half, round to nearest even; half -> float exact. */
+static uint16_t f32_to_f16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ex = (x >> 23) & 0xFFu;
+    uint32_t man = x & 0x7FFFFFu;
+    if (ex == 0xFF) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
+    int32_t e = (int32_t)ex - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        uint32_t shift = (uint32_t)(14 - e);
+        uint32_t h = man >> shift;
+        uint32_t rem = man & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (man >> 13);
+    uint32_t rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+static float f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t ex = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t x;
+    if (ex == 0) {
+        if (man == 0) x = sign;
+        else {
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (ex == 31) x = sign | 0x7F800000u | (man << 13);
+    else x = sign | ((ex + 127 - 15) << 23) | (man << 13);
+    float f; memcpy(&f, &x, 4);
+    return f;
+}
+uint16_t r3o_f32_to_f16(float f) { return f32_to_f16(f); }
+float r3o_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+
+/* ------------------------------------------------------------------ K1: uniform bake */
+/* uniform_prep.wgsl:9-27: runs over buffer capacity, leaves disabled slots untouched. */
+void r3o_uniform_bake(const r3o_camera_header *hdr, const r3o_object *objects, r3o_baked *out) {
+    for (uint32_t i = 0; i < hdr->object_count; ++i) {
+        if (objects[i].enabled == 0u) continue;
+        r3o_mat4_mul(hdr->view, objects[i].transform, out[i].model_view);
+        r3o_mat4_mul(hdr->view_proj, objects[i].transform, out[i].model_view_proj);
+    }
+}
+
+/* ------------------------------------------------------------------ A2: frustum */
+/* frustum.rs:96-145 -- planes left,right,top,bottom,near from a column-major matrix, normalised. */
+void r3o_frustum_from_matrix(const float *m, float *planes) {
+    /* mat_arr[c][r] = m[4*c+r] */
+    const float sgn[5] = {1.0f, -1.0f, -1.0f, 1.0f, -1.0f};
+    const int row[5] = {0, 0, 1, 1, 2};
+    for (int p = 0; p < 5; ++p) {
+        float a = m[0 * 4 + 3] + sgn[p] * m[0 * 4 + row[p]];
+        float b = m[1 * 4 + 3] + sgn[p] * m[1 * 4 + row[p]];
+        float c = m[2 * 4 + 3] + sgn[p] * m[2 * 4 + row[p]];
+        float d = m[3 * 4 + 3] + sgn[p] * m[3 * 4 + row[p]];
+        float mag = sqrtf((a * a + b * b) + c * c);
+        planes[4 * p + 0] = a / mag;
+        planes[4 * p + 1] = b / mag;
+        planes[4 * p + 2] = c / mag;
+        planes[4 * p + 3] = d / mag;
+    }
+}
+
+/* frustum.rs:148-161 */
+int r3o_frustum_contains_sphere(const float *planes, const float *centre, float radius) {
+    float neg_radius = -radius;
+    for (int p = 0; p < 5; ++p) {
+        float dist = dot3(planes + 4 * p, centre) + planes[4 * p + 3];
+        if (!(dist >= neg_radius)) return 0;
+    }
+    return 1;
+}
+
+/* L1 visible set: batching.rs:144-148 over live objects.  Disabled slots are not visible. */
+void r3o_frustum_cull(const r3o_camera_header *hdr, const r3o_object *objects, uint8_t *visible) {
+    for (uint32_t i = 0; i < hdr->object_count; ++i) {
+        visible[i] = (objects[i].enabled != 0u && objects[i].index_count >= 3u &&
+                      r3o_frustum_contains_sphere(hdr->frustum, objects[i].centre, objects[i].radius))
+                         ? 1 : 0;
+    }
+}
+
+/* ------------------------------------------------------------------ Hi-Z */
+typedef struct {
+    const float *data;  /* mips stored consecutively, mip0 first */
+    uint32_t width, height, mips;
+} r3o_hiz;
+
+static inline uint32_t mip_dim(uint32_t d, uint32_t k) { uint32_t v = d >> k; return v ? v : 1u; }
+uint32_t r3o_hiz_mip_count(uint32_t w, uint32_t h) {
+    uint32_t m = w > h ? w : h, n = 0;
+    while (m) { n++; m >>= 1; }
+    return n;
+}
+uint64_t r3o_hiz_mip_offset(uint32_t w, uint32_t h, uint32_t mip) {
+    uint64_t off = 0;
+    for (uint32_t k = 0; k < mip; ++k) off += (uint64_t)mip_dim(w, k) * mip_dim(h, k);
+    return off;
+}
+/* hi_z.wgsl:19-32; mip0 (depth) must already be at pyr[0..w*h). */
+void r3o_hiz_build(float *pyr, uint32_t w, uint32_t h) {
+    uint32_t mips = r3o_hiz_mip_count(w, h);
+    for (uint32_t k = 1; k < mips; ++k) {
+        const float *src = pyr + r3o_hiz_mip_offset(w, h, k - 1);
+        float *dst = pyr + r3o_hiz_mip_offset(w, h, k);
+        uint32_t sw = mip_dim(w, k - 1), sh = mip_dim(h, k - 1), dw = mip_dim(w, k), dh = mip_dim(h, k);
+        uint32_t ox = sw & 1u, oy = sh & 1u;
+        for (uint32_t y = 0; y < dh; ++y)
+            for (uint32_t x = 0; x < dw; ++x) {
+                float nearest = 1.0f;
+                for (uint32_t ix = 0; ix < 2u + ox; ++ix)
+                    for (uint32_t iy = 0; iy < 2u + oy; ++iy) {
+                        uint32_t sx = 2u * x + ix, sy = 2u * y + iy;
+                        float v = (sx < sw && sy < sh) ? src[(uint64_t)sy * sw + sx] : 0.0f;
+                        nearest = fminf(nearest, v);
+                    }
+                dst[(uint64_t)y * dw + x] = nearest;
+            }
+    }
+}
+
+/* float -> texel coordinate with NaN/out-of-range made deterministic. */
+static inline uint32_t clamp_texel(float v, uint32_t dim) {
+    if (!(v >= 0.0f)) return 0u; /* negative or NaN */
+    float top = (float)(dim - 1u);
+    if (v >= top) return dim - 1u;
+    return (uint32_t)v;
+}
+
+/* cull.wgsl:243-262 */
+static float hiz_sample_min(const r3o_hiz *hz, float u, float v, uint32_t mip) {
+    uint32_t mw = mip_dim(hz->width, mip), mh = mip_dim(hz->height, mip);
+    const float *tex = hz->data + r3o_hiz_mip_offset(hz->width, hz->height, mip);
+    float px = u * (float)mw - 0.5f;
+    float py = v * (float)mh - 0.5f;
+    uint32_t lx = clamp_texel(fmaxf(floorf(px), 0.0f), mw);
+    uint32_t ly = clamp_texel(fmaxf(floorf(py), 0.0f), mh);
+    uint32_t hx = clamp_texel(fminf(ceilf(px), (float)mw - 1.0f), mw);
+    uint32_t hy = clamp_texel(fminf(ceilf(py), (float)mh - 1.0f), mh);
+    float m = tex[(uint64_t)ly * mw + lx];
+    m = fminf(m, tex[(uint64_t)ly * mw + hx]);
+    m = fminf(m, tex[(uint64_t)hy * mw + lx]);
+    m = fminf(m, tex[(uint64_t)hy * mw + hx]);
+    return m;
+}
+
+/* ceil(log2(max(x,1))) computed exactly from the float's exponent. */
+static uint32_t ceil_log2_ge1(float x) {
+    x = fmaxf(x, 1.0f);  /* NaN -> 1 */
+    if (isinf(x)) return 1000u;
+    int e;
+    float m = frexpf(x, &e); /* x = m*2^e, m in [0.5,1) */
+    return (uint32_t)((m == 0.5f) ? e - 1 : e);
+}
+
+/* ------------------------------------------------------------------ vertex fetch */
+static inline void fetch_vec3(const uint32_t *mesh, uint32_t byte_off, uint32_t vtx, float *o) {
+    uint32_t w = byte_off / 4u + vtx * 3u; /* vertex_attributes.wgsl:51-58 */
+    memcpy(o, mesh + w, 12);
+}
+
+static inline float det3_xyw(const float *p0, const float *p1, const float *p2) {
+    /* determinant(mat3x3(p0.xyw, p1.xyw, p2.xyw)), columns a,b,c */
+    float ax = p0[0], ay = p0[1], az = p0[3];
+    float bx = p1[0], by = p1[1], bz = p1[3];
+    float cx = p2[0], cy = p2[1], cz = p2[3];
+    return (ax * (by * cz - cy * bz) - bx * (ay * cz - cy * az)) + cx * (ay * bz - by * az);
+}
+
+/* cull.wgsl:264-324 */
+static int execute_culling(const r3o_camera_header *hdr, const float *mvp, const float v[3][3], const r3o_hiz *hz) {
+    float p[3][4];
+    for (int k = 0; k < 3; ++k) mat4_mul_vec4(mvp, v[k][0], v[k][1], v[k][2], 1.0f, p[k]);
+    float det = det3_xyw(p[0], p[1], p[2]);
+    if ((hdr->flags & PCU_POSITIVE_AREA_VISIBLE) && det <= 0.0f) return 0;
+    if (!(hdr->flags & PCU_POSITIVE_AREA_VISIBLE) && det >= 0.0f) return 0;
+
+    float ndc[3][3];
+    for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 3; ++c) ndc[k][c] = p[k][c] / p[k][3];
+    float mn[2], mx[2];
+    for (int c = 0; c < 2; ++c) {
+        mn[c] = fminf(ndc[0][c], fminf(ndc[1][c], ndc[2][c]));
+        mx[c] = fmaxf(ndc[0][c], fmaxf(ndc[1][c], ndc[2][c]));
+    }
+    float half_res[2] = {hdr->resolution[0] / 2.0f, hdr->resolution[1] / 2.0f};
+    float smin[2], smax[2];
+    for (int c = 0; c < 2; ++c) {
+        smin[c] = (mn[c] + 1.0f) * half_res[c];
+        smax[c] = (mx[c] + 1.0f) * half_res[c];
+    }
+    if (!(hdr->flags & PCU_MULTISAMPLED)) {
+        /* WGSL round = ties to even = rintf under the default rounding mode */
+        if (rintf(smin[0]) == rintf(smax[0]) || rintf(smin[1]) == rintf(smax[1])) return 0;
+    }
+    if (hdr->shadow_index != R3O_INVALID) return 1;
+
+    float mintc[2] = {(mn[0] + 1.0f) / 2.0f, (mn[1] + 1.0f) / 2.0f};
+    float maxtc[2] = {(mx[0] + 1.0f) / 2.0f, (mx[1] + 1.0f) / 2.0f};
+    mintc[1] = 1.0f - mintc[1];
+    maxtc[1] = 1.0f - maxtc[1];
+    float uv[2] = {(maxtc[0] + mintc[0]) / 2.0f, (maxtc[1] + mintc[1]) / 2.0f};
+    float edges[2] = {smax[0] - smin[0], smax[1] - smin[1]};
+    float longest = fmaxf(edges[0], edges[1]);
+    uint32_t mip = ceil_log2_ge1(longest);
+    if (mip > hz->mips - 1u) mip = hz->mips - 1u;
+    float depth = fmaxf(fmaxf(ndc[0][2], ndc[1][2]), ndc[2][2]);
+    float occ = hiz_sample_min(hz, uv[0], uv[1], mip);
+    if (depth < occ) return 0;
+    return 1;
+}
+
+/*
+ * K2 for one camera.  Canonical triangle slot of (object o, triangle t) = tri_base[o] + t where
+ * tri_base is the exclusive scan of index_count/3 over object slots (built by the caller).
+ * pass[slot]     = 1 iff object o is in the L1 visible set and execute_culling passes (L2 set).
+ * residual[slot] = 1 iff pass && viewport camera && the triangle did not pass last frame
+ *                  (cull.wgsl:362-372, get_previous_culling_result :152-160).
+ * prev_tri_base[o] = last frame's base, or INVALID when o was not in last frame's batch
+ * (batching.rs:226).  prev_pass may be NULL on the first frame.
+ */
+void r3o_cull_triangles(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
+                        const r3o_baked *baked, const uint8_t *visible, const uint32_t *tri_base,
+                        const float *hiz_data, uint32_t hiz_w, uint32_t hiz_h,
+                        const uint32_t *prev_tri_base, const uint8_t *prev_pass,
+                        uint8_t *pass, uint8_t *residual) {
+    r3o_hiz hz = {hiz_data, hiz_w, hiz_h, hiz_data ? r3o_hiz_mip_count(hiz_w, hiz_h) : 0};
+    int shadow = hdr->shadow_index != R3O_INVALID;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t o = 0; o < hdr->object_count; ++o) {
+        if (!visible[o]) continue;
+        const r3o_object *ob = &objects[o];
+        uint32_t ntri = ob->index_count / 3u;
+        for (uint32_t t = 0; t < ntri; ++t) {
+            uint32_t idx[3];
+            float v[3][3];
+            for (int k = 0; k < 3; ++k) {
+                idx[k] = mesh[ob->first_index + t * 3u + (uint32_t)k];
+                fetch_vec3(mesh, ob->attr_off[0], idx[k], v[k]);
+            }
+            int ok = execute_culling(hdr, baked[o].model_view_proj, v, &hz);
+            uint32_t slot = tri_base[o] + t;
+            pass[slot] = (uint8_t)ok;
+            if (residual) {
+                int prev = 0;
+                if (prev_pass && prev_tri_base && prev_tri_base[o] != R3O_INVALID) prev = prev_pass[prev_tri_base[o] + t];
+                residual[slot] = (uint8_t)(ok && !shadow && !prev);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ rasteriser */
+typedef struct {
+    float e[3][3];   /* oriented edge functions (A,B,C): inside >= 0 */
+    float z[3];      /* clip-space z per vertex */
+    float det;       /* oriented determinant (> 0) */
+    int valid;
+} tri_setup;
+
+/*
+ * Homogeneous 2D triangle setup in viewport-local pixel space.
+ * Xh = (x + w) * W/2, Yh = (w - y) * H/2 (y down), third coordinate w.
+ * e0 = v1 x v2, e1 = v2 x v0, e2 = v0 x v1; det = v0 . e0.
+ * A triangle with positive area in NDC (cull.wgsl's det > 0) has det < 0 here because of the
+ * y flip; forward.rs:338-342 front-face/cull-mode folded into `positive_visible` exactly as
+ * culler.rs:133-141 does.
+ */
+static void setup_triangle(const float *mvp, const float v[3][3], float half_w, float half_h, int positive_visible,
+                           tri_setup *ts) {
+    float h[3][3];
+    for (int k = 0; k < 3; ++k) {
+        float p[4];
+        mat4_mul_vec4(mvp, v[k][0], v[k][1], v[k][2], 1.0f, p);
+        h[k][0] = (p[0] + p[3]) * half_w;
+        h[k][1] = (p[3] - p[1]) * half_h;
+        h[k][2] = p[3];
+        ts->z[k] = p[2];
+    }
+    for (int i = 0; i < 3; ++i) {
+        const float *a = h[(i + 1) % 3], *b = h[(i + 2) % 3];
+        ts->e[i][0] = a[1] * b[2] - a[2] * b[1];
+        ts->e[i][1] = a[2] * b[0] - a[0] * b[2];
+        ts->e[i][2] = a[0] * b[1] - a[1] * b[0];
+    }
+    float det = (h[0][0] * ts->e[0][0] + h[0][1] * ts->e[0][1]) + h[0][2] * ts->e[0][2];
+    ts->valid = positive_visible ? (det < 0.0f) : (det > 0.0f);
+    if (!ts->valid) return;
+    if (det < 0.0f) {
+        det = -det;
+        for (int i = 0; i < 3; ++i)
+            for (int c = 0; c < 3; ++c) ts->e[i][c] = -ts->e[i][c];
+    }
+    ts->det = det;
+    /* conservative pixel bounds are computed by the caller */
+    (void)h;
+}
+
+/* Evaluate edge functions at pixel centre; returns 1 if covered (top-left rule). */
+static inline int edge_eval(const tri_setup *ts, float px, float py, float E[3]) {
+    for (int i = 0; i < 3; ++i) {
+        float A = ts->e[i][0], B = ts->e[i][1];
+        float v = (A * px + B * py) + ts->e[i][2];
+        E[i] = v;
+        if (v > 0.0f) continue;
+        if (v == 0.0f && (A > 0.0f || (A == 0.0f && B > 0.0f))) continue;
+        return 0; /* negative, NaN, or on a non-owned edge */
+    }
+    return 1;
+}
+
+/* Conservative integer pixel bounds of a triangle in a (vw x vh) viewport. */
+static void tri_bounds(const float *mvp, const float v[3][3], float half_w, float half_h, int vw, int vh, int *x0,
+                       int *y0, int *x1, int *y1) {
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    int all_front = 1;
+    for (int k = 0; k < 3; ++k) {
+        float p[4];
+        mat4_mul_vec4(mvp, v[k][0], v[k][1], v[k][2], 1.0f, p);
+        if (!(p[3] > 0.0f)) { all_front = 0; break; }
+        float sx = (p[0] / p[3] + 1.0f) * half_w;
+        float sy = (1.0f - p[1] / p[3]) * half_h;
+        mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx);
+        mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+    }
+    if (!all_front || !(mnx == mnx) || !(mny == mny) || !(mxx == mxx) || !(mxy == mxy)) {
+        *x0 = 0; *y0 = 0; *x1 = vw - 1; *y1 = vh - 1;
+        return;
+    }
+    /* one pixel of slack each side: bounds only limit the scan, coverage decides */
+    float fx0 = floorf(mnx) - 1.0f, fy0 = floorf(mny) - 1.0f, fx1 = ceilf(mxx) + 1.0f, fy1 = ceilf(mxy) + 1.0f;
+    *x0 = fx0 < 0.0f ? 0 : (fx0 > (float)(vw - 1) ? vw : (int)fx0);
+    *y0 = fy0 < 0.0f ? 0 : (fy0 > (float)(vh - 1) ? vh : (int)fy0);
+    *x1 = fx1 < 0.0f ? -1 : (fx1 > (float)(vw - 1) ? vw - 1 : (int)fx1);
+    *y1 = fy1 < 0.0f ? -1 : (fy1 > (float)(vh - 1) ? vh - 1 : (int)fy1);
+}
+
+static inline float frag_depth(const tri_setup *ts, const float E[3]) {
+    return ((E[0] * ts->z[0] + E[1] * ts->z[1]) + E[2] * ts->z[2]) / ts->det;
+}
+
+static void fetch_triangle(const r3o_object *ob, const uint32_t *mesh, uint32_t t, uint32_t idx[3], float v[3][3]) {
+    for (int k = 0; k < 3; ++k) {
+        idx[k] = mesh[ob->first_index + t * 3u + (uint32_t)k];
+        fetch_vec3(mesh, ob->attr_off[0], idx[k], v[k]);
+    }
+}
+
+/* alpha for the cutout test (opaque.wgsl:213-235 / depth.wgsl:112-125), untextured */
+static float material_alpha(const r3o_material *m, float vertex_alpha) {
+    float alpha = 1.0f;
+    if (m->flags & FLAGS_ALBEDO_ACTIVE) {
+        if (m->flags & FLAGS_ALBEDO_BLEND) alpha *= vertex_alpha;
+    }
+    alpha *= m->albedo[3];
+    return alpha;
+}
+
+static float fetch_color_alpha(const r3o_object *ob, const uint32_t *mesh, uint32_t vtx) {
+    if (ob->attr_off[5] == R3O_INVALID) return 1.0f;
+    uint32_t w = mesh[ob->attr_off[5] / 4u + vtx];
+    return (float)((w >> 24) & 0xFFu) / 255.0f;
+}
+
+/*
+ * Visibility rasterisation of a list of (object, triangle) pairs into a 64-bit buffer:
+ * key = depth_bits << 32 | (canonical slot + 1); larger key wins (reverse-Z GreaterEqual,
+ * forward.rs:347-351).  material_keys[material] : 0 opaque, 1 cutout, 2 blend (pbr/material.rs:497-499);
+ * blend objects are skipped here (drawn by the transparent pass, base.rs:451-465).
+ */
+void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
+                           const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
+                           const uint32_t *tri_base, const uint32_t *list_obj, const uint32_t *list_tri,
+                           uint64_t n, uint32_t w, uint32_t h, uint64_t *vis) {
+    float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
+    int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t o = list_obj[i], t = list_tri[i];
+        const r3o_object *ob = &objects[o];
+        if (ob->enabled == 0u) continue; /* opaque.wgsl:104-112 */
+        const r3o_material *mat = &materials[ob->material_index];
+        uint8_t key = material_keys[ob->material_index];
+        if (key > 1) continue;
+        uint32_t idx[3];
+        float v[3][3];
+        fetch_triangle(ob, mesh, t, idx, v);
+        tri_setup ts;
+        setup_triangle(baked[o].model_view_proj, v, half_w, half_h, positive_visible, &ts);
+        if (!ts.valid) continue;
+        int x0, y0, x1, y1;
+        tri_bounds(baked[o].model_view_proj, v, half_w, half_h, (int)w, (int)h, &x0, &y0, &x1, &y1);
+        float va[3] = {1.0f, 1.0f, 1.0f};
+        int need_alpha = key == 1;
+        if (need_alpha)
+            for (int k = 0; k < 3; ++k) va[k] = fetch_color_alpha(ob, mesh, idx[k]);
+        uint32_t slot = tri_base[o] + t;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                float E[3];
+                if (!edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E)) continue;
+                float z = frag_depth(&ts, E);
+                if (!(z >= 0.0f && z <= 1.0f)) continue;
+                if (need_alpha) {
+                    float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+                    float a = ((E[0] * rs) * va[0] + (E[1] * rs) * va[1]) + (E[2] * rs) * va[2];
+                    if (material_alpha(mat, a) < mat->alpha_cutout) continue;
+                }
+                uint32_t zb; memcpy(&zb, &z, 4);
+                uint64_t k64 = ((uint64_t)zb << 32) | (uint64_t)(slot + 1u);
+                uint64_t *dst = &vis[(uint64_t)y * w + (uint64_t)x];
+                if (k64 > *dst) *dst = k64;
+            }
+    }
+}
+
+/*
+ * Depth-only rasterisation for a shadow view into an atlas viewport (depth.wgsl, base.rs:366-396).
+ * Depth compare GreaterEqual + write == max.
+ */
+void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
+                      const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
+                      const uint32_t *list_obj, const uint32_t *list_tri, uint64_t n, float *atlas,
+                      uint32_t atlas_w, uint32_t vp_x, uint32_t vp_y, uint32_t vp_size) {
+    float half = (float)vp_size / 2.0f;
+    int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t o = list_obj[i], t = list_tri[i];
+        const r3o_object *ob = &objects[o];
+        if (ob->enabled == 0u) continue;
+        const r3o_material *mat = &materials[ob->material_index];
+        uint8_t key = material_keys[ob->material_index];
+        if (key > 1) continue;
+        uint32_t idx[3];
+        float v[3][3];
+        fetch_triangle(ob, mesh, t, idx, v);
+        tri_setup ts;
+        setup_triangle(baked[o].model_view_proj, v, half, half, positive_visible, &ts);
+        if (!ts.valid) continue;
+        int x0, y0, x1, y1;
+        tri_bounds(baked[o].model_view_proj, v, half, half, (int)vp_size, (int)vp_size, &x0, &y0, &x1, &y1);
+        float va[3] = {1.0f, 1.0f, 1.0f};
+        int need_alpha = key == 1;
+        if (need_alpha)
+            for (int k = 0; k < 3; ++k) va[k] = fetch_color_alpha(ob, mesh, idx[k]);
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                float E[3];
+                if (!edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E)) continue;
+                float z = frag_depth(&ts, E);
+                if (!(z >= 0.0f && z <= 1.0f)) continue;
+                if (need_alpha) {
+                    float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+                    float a = ((E[0] * rs) * va[0] + (E[1] * rs) * va[1]) + (E[2] * rs) * va[2];
+                    if (material_alpha(mat, a) < mat->alpha_cutout) continue;
+                }
+                float *dst = &atlas[(uint64_t)(vp_y + (uint32_t)y) * atlas_w + vp_x + (uint32_t)x];
+                if (z >= *dst) *dst = z;
+            }
+    }
+}
+
+/* depth plane of a visibility buffer (high 32 bits), background = 0.0 */
+void r3o_vis_to_depth(const uint64_t *vis, uint64_t n, float *depth) {
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t zb = (uint32_t)(vis[i] >> 32);
+        memcpy(&depth[i], &zb, 4);
+    }
+}
+
+/* ------------------------------------------------------------------ shading */
+/* pcf.wgsl + comparison sampler common/samplers.rs:24,42-57 (linear, GreaterEqual, Repeat). */
+static float sample_compare(const float *atlas, uint32_t aw, uint32_t ah, float u, float v, float ref, int ox, int oy) {
+    float tx = (u * (float)aw - 0.5f) + (float)ox;
+    float ty = (v * (float)ah - 0.5f) + (float)oy;
+    float fx0 = floorf(tx), fy0 = floorf(ty);
+    float fx = tx - fx0, fy = ty - fy0;
+    /* Repeat addressing; NaN / huge coordinates -> texel 0 deterministically */
+    int64_t ix = (fx0 == fx0 && fabsf(fx0) < 1e9f) ? (int64_t)fx0 : 0;
+    int64_t iy = (fy0 == fy0 && fabsf(fy0) < 1e9f) ? (int64_t)fy0 : 0;
+    if (!(fx == fx)) fx = 0.0f;
+    if (!(fy == fy)) fy = 0.0f;
+    uint32_t x0 = (uint32_t)(((ix % (int64_t)aw) + aw) % aw), x1 = (uint32_t)((((ix + 1) % (int64_t)aw) + aw) % aw);
+    uint32_t y0 = (uint32_t)(((iy % (int64_t)ah) + ah) % ah), y1 = (uint32_t)((((iy + 1) % (int64_t)ah) + ah) % ah);
+    float c00 = ref >= atlas[(uint64_t)y0 * aw + x0] ? 1.0f : 0.0f;
+    float c10 = ref >= atlas[(uint64_t)y0 * aw + x1] ? 1.0f : 0.0f;
+    float c01 = ref >= atlas[(uint64_t)y1 * aw + x0] ? 1.0f : 0.0f;
+    float c11 = ref >= atlas[(uint64_t)y1 * aw + x1] ? 1.0f : 0.0f;
+    float top = c00 * (1.0f - fx) + c10 * fx;
+    float bot = c01 * (1.0f - fx) + c11 * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+static float shadow_pcf5(const float *atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
+    float r = 0.0f;
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, 0);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, 1);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, -1);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 1, 0);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, -1, 0);
+    return r * 0.2f;
+}
+
+typedef struct {
+    float albedo[4];
+    float diffuse[3];
+    float roughness;
+    float normal[3];
+    float f0[3];
+    float emissive[3];
+    float ao;
+} pixel_data;
+
+#define R3O_PI 3.14159265359f
+
+/* opaque.wgsl:440-468 */
+static void surface_shading(const float *l, const float *intensity, const pixel_data *px, const float *v,
+                            float occlusion, float *out) {
+    const float *n = px->normal;
+    float h[3] = {v[0] + l[0], v[1] + l[1], v[2] + l[2]};
+    normalize3(h);
+    float nov = fabsf(dot3(n, v)) + 0.00001f;
+    float nol = sat(dot3(n, l));
+    float noh = sat(dot3(n, h));
+    float loh = sat(dot3(l, h));
+    float c165[3] = {16.5f, 16.5f, 16.5f};
+    float f90 = sat(dot3(px->f0, c165));
+    float a = px->roughness;
+    float a2 = a * a;
+    float f = (noh * a2 - noh) * noh + 1.0f;
+    float d = a2 / ((R3O_PI * f) * f);
+    float x = 1.0f - loh, x2 = x * x, x5 = (x2 * x2) * x;
+    float ggxl = nov * sqrtf((-nol * a2 + nol) * nol + a2);
+    float ggxv = nol * sqrtf((-nov * a2 + nov) * nov + a2);
+    float vis = 0.5f / (ggxl + ggxv);
+    float k = nol * occlusion;
+    for (int c = 0; c < 3; ++c) {
+        float fres = px->f0[c] + (f90 - px->f0[c]) * x5;
+        float fr = (d * vis) * fres;
+        float fd = px->diffuse[c] * (1.0f / R3O_PI);
+        float color = fd + fr;
+        out[c] = (color * intensity[c]) * k;
+    }
+}
+
+static float srgb_to_linear(float e) {
+    return e > 0.04045f ? powf((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f;
+}
+
+/*
+ * Deferred evaluation of opaque.wgsl's VS+FS for the nearest fragment of every pixel.
+ * light_mats[i] = dir_lights[i].view_proj * uniforms.inv_view (opaque.wgsl:491), built by the caller
+ * with r3o_mat4_mul; point_view_pos[i] = (uniforms.view * light.position).xyz (opaque.wgsl:528).
+ * Output: Rgba16Float bits (base.rs:236-244).
+ */
+void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, const r3o_frame_uniforms *fu,
+               const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
+               const r3o_baked *baked, const r3o_material *materials, const uint32_t *tri_base,
+               uint32_t n_dir, const r3o_dir_light *dir, uint32_t n_point, const r3o_point_light *point,
+               const float *atlas, uint32_t atlas_w, uint32_t atlas_h, const float *clear_color,
+               uint16_t *hdr_out) {
+    float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
+    int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+    uint32_t nobj = hdr->object_count;
+    float *light_mats = (float *)malloc(sizeof(float) * 16 * (n_dir ? n_dir : 1));
+    float *light_l = (float *)malloc(sizeof(float) * 3 * (n_dir ? n_dir : 1));
+    float *pview = (float *)malloc(sizeof(float) * 4 * (n_point ? n_point : 1));
+    for (uint32_t i = 0; i < n_dir; ++i) {
+        r3o_mat4_mul(dir[i].view_proj, fu->inv_view, light_mats + 16 * i);
+        float nd[3] = {-dir[i].direction[0], -dir[i].direction[1], -dir[i].direction[2]};
+        mat3_mul_vec3(fu->view + 0, fu->view + 4, fu->view + 8, nd, light_l + 3 * i);
+        normalize3(light_l + 3 * i);
+    }
+    for (uint32_t i = 0; i < n_point; ++i)
+        mat4_mul_vec4(fu->view, point[i].position[0], point[i].position[1], point[i].position[2], point[i].position[3],
+                      pview + 4 * i);
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            uint64_t key = vis[(uint64_t)y * w + x];
+            uint16_t *o16 = hdr_out + 4 * ((uint64_t)y * w + x);
+            float out[4];
+            uint32_t id = (uint32_t)(key & 0xFFFFFFFFu);
+            if (id == 0u) {
+                for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(clear_color[c]);
+                continue;
+            }
+            uint32_t slot = id - 1u;
+            /* object = last slot o with tri_base[o] <= slot and a non-empty range */
+            uint32_t lo = 0, hi = nobj;
+            while (hi - lo > 1u) {
+                uint32_t mid = lo + (hi - lo) / 2u;
+                if (tri_base[mid] <= slot) lo = mid; else hi = mid;
+            }
+            uint32_t o = lo, t = slot - tri_base[o];
+            const r3o_object *ob = &objects[o];
+            const r3o_material *mat = &materials[ob->material_index];
+            uint32_t idx[3];
+            float v[3][3];
+            fetch_triangle(ob, mesh, t, idx, v);
+            tri_setup ts;
+            setup_triangle(baked[o].model_view_proj, v, half_w, half_h, positive_visible, &ts);
+            float E[3];
+            (void)edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E);
+            float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+            float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
+
+            /* vertex stage, opaque.wgsl:114-134 */
+            const float *mv = baked[o].model_view;
+            float inv_s2[3] = {1.0f / dot3(mv + 0, mv + 0), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
+            float vpos[4] = {0, 0, 0, 0}, nrm[3] = {0, 0, 0}, col[4] = {0, 0, 0, 0};
+            float vp[3][4], vn[3][3], vc[3][4];
+            for (int k = 0; k < 3; ++k) {
+                mat4_mul_vec4(mv, v[k][0], v[k][1], v[k][2], 1.0f, vp[k]);
+                float nm[3] = {0, 0, 0};
+                if (ob->attr_off[1] != R3O_INVALID) fetch_vec3(mesh, ob->attr_off[1], idx[k], nm);
+                float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
+                mat3_mul_vec3(mv + 0, mv + 4, mv + 8, sn, vn[k]);
+                normalize3(vn[k]);
+                if (ob->attr_off[5] != R3O_INVALID) {
+                    uint32_t cw = mesh[ob->attr_off[5] / 4u + idx[k]];
+                    for (int c = 0; c < 4; ++c) vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
+                } else
+                    for (int c = 0; c < 4; ++c) vc[k][c] = 1.0f;
+            }
+            for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
+            for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
+            for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
+
+            /* fragment stage, opaque.wgsl:203-424 (untextured paths) */
+            pixel_data px;
+            if (mat->flags & FLAGS_ALBEDO_ACTIVE) {
+                for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
+                if (mat->flags & FLAGS_ALBEDO_BLEND) {
+                    if (mat->flags & FLAGS_ALBEDO_VERTEX_SRGB) {
+                        for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
+                        px.albedo[3] *= col[3];
+                    } else
+                        for (int c = 0; c < 4; ++c) px.albedo[c] *= col[c];
+                }
+            } else {
+                px.albedo[0] = px.albedo[1] = px.albedo[2] = 0.0f;
+                px.albedo[3] = 1.0f;
+            }
+            for (int c = 0; c < 4; ++c) px.albedo[c] *= mat->albedo[c];
+
+            if (mat->flags & FLAGS_UNLIT) {
+                for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
+            } else {
+                for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
+                normalize3(px.normal);
+                float ao = mat->ambient_occlusion, pr = mat->roughness, metallic = mat->metallic;
+                float cc = mat->clear_coat, ccpr = mat->clear_coat_roughness;
+                for (int c = 0; c < 3; ++c) px.emissive[c] = mat->emissive[c];
+                for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
+                float refl = (0.16f * mat->reflectance) * mat->reflectance;
+                for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
+                if (cc != 0.0f) {
+                    float base_pr = fmaxf(pr, ccpr);
+                    pr = pr * (1.0f - cc) + base_pr * cc;
+                }
+                px.roughness = pr * pr;
+                px.ao = ao;
+
+                float vv[3] = {vpos[0], vpos[1], vpos[2]};
+                normalize3(vv);
+                for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
+                float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
+                for (uint32_t i = 0; i < n_dir; ++i) {
+                    float sn[4];
+                    mat4_mul_vec4(light_mats + 16 * i, vpos[0], vpos[1], vpos[2], vpos[3], sn);
+                    float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
+                    float local[2] = {fl[0], 1.0f - fl[1]};
+                    float tl[2] = {dir[i].atlas_offset[0], dir[i].atlas_offset[1]};
+                    float tr[2] = {tl[0] + dir[i].atlas_size[0], tl[1] + dir[i].atlas_size[1]};
+                    float coords[2] = {tl[0] * (1.0f - local[0]) + tr[0] * local[0],
+                                       tl[1] * (1.0f - local[1]) + tr[1] * local[1]};
+                    float border[2] = {dir[i].inv_resolution[0] * 1.5f, dir[i].inv_resolution[1] * 1.5f};
+                    tl[0] += border[0]; tl[1] += border[1];
+                    tr[0] -= border[0]; tr[1] -= border[1];
+                    float shadow = 1.0f;
+                    if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f &&
+                        sn[2] <= 1.0f)
+                        shadow = shadow_pcf5(atlas, atlas_w, atlas_h, coords[0], coords[1], sn[2]);
+                    float res[3];
+                    surface_shading(light_l + 3 * i, dir[i].color, &px, vv, shadow * px.ao, res);
+                    for (int c = 0; c < 3; ++c) color[c] += res[c];
+                }
+                for (uint32_t i = 0; i < n_point; ++i) {
+                    float delta[3] = {pview[4 * i + 0] - vpos[0], pview[4 * i + 1] - vpos[1], pview[4 * i + 2] - vpos[2]};
+                    float d = sqrtf(dot3(delta, delta));
+                    float s = sat(d / point[i].radius);
+                    float s2 = s * s, is2 = 1.0f - s2;
+                    float att = is2 * is2 / (1.0f + s2);
+                    float inten[3] = {point[i].color[0] * att, point[i].color[1] * att, point[i].color[2] * att};
+                    float l[3] = {delta[0] / d, delta[1] / d, delta[2] / d};
+                    float res[3];
+                    surface_shading(l, inten, &px, vv, px.ao, res);
+                    for (int c = 0; c < 3; ++c) color[c] += (res[c] > 0.0f ? res[c] : 0.0f);
+                }
+                for (int c = 0; c < 3; ++c) out[c] = fmaxf(fu->ambient[c] * px.albedo[c], color[c]);
+                out[3] = fmaxf(fu->ambient[3] * px.albedo[3], px.albedo[3]);
+            }
+            for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(out[c]);
+        }
+    free(light_mats);
+    free(light_l);
+    free(pview);
+}
+
+/* ------------------------------------------------------------------ tonemap */
+/* blit.wgsl fs_main_scene into an Rgba8UnormSrgb target (tonemapping.rs:44): exact sRGB OETF. */
+static float srgb_oetf(float x) {
+    if (!(x > 0.0f)) return 0.0f; /* also NaN */
+    if (x >= 1.0f) return 1.0f;
+    if (x <= 0.0031308f) return x * 12.92f;
+    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+}
+void r3o_tonemap(const uint16_t *hdr_in, uint64_t npix, float *out_f32, uint8_t *out_u8) {
+    for (uint64_t i = 0; i < npix; ++i) {
+        for (int c = 0; c < 4; ++c) {
+            float v = f16_to_f32(hdr_in[4 * i + c]);
+            float e = c < 3 ? srgb_oetf(v) : ((!(v > 0.0f)) ? 0.0f : (v >= 1.0f ? 1.0f : v));
+            if (out_f32) out_f32[4 * i + c] = e;
+            if (out_u8) out_u8[4 * i + c] = (uint8_t)(e * 255.0f + 0.5f);
+        }
+    }
+}

@@ -1,0 +1,341 @@
+"""
+oracle/world.py -- oracle-side world bookkeeping + the frame schedule of BaseRenderGraph::add_to_graph
+(rend3-routine/src/base.rs:129-185), driving the C oracle (oracle/r3o.c).
+
+TEST INFRASTRUCTURE ONLY.
+
+Mirrors, at the level the hot path needs:
+  Renderer::{add_mesh, add_material, add_object, remove_object, set_object_transform,
+             add_directional_light, add_point_light, set_camera_data}   rend3/src/renderer/mod.rs:126-424
+  ObjectManager (128-byte records, deferred removal)                    rend3/src/managers/object.rs:236-364
+  MeshManager (SoA attribute runs + indices in one u32 buffer)          rend3/src/managers/mesh.rs:123-184
+  temporal two-pass culling state                                       SURVEY.md App. B.4
+"""
+import numpy as np
+
+from . import host
+from .lib import get as get_lib
+
+f32 = np.float32
+INVALID = 0xFFFFFFFF
+
+# rend3-routine/shaders/src/material.wgsl:1-15
+FLAGS_ALBEDO_ACTIVE = 0x0001
+FLAGS_ALBEDO_BLEND = 0x0002
+FLAGS_ALBEDO_VERTEX_SRGB = 0x0004
+FLAGS_AOMR_COMBINED = 0x0040
+FLAGS_AOMR_SPLIT = 0x0100
+FLAGS_CC_GLTF_COMBINED = 0x0400
+FLAGS_UNLIT = 0x2000
+
+OPAQUE, CUTOUT, BLEND = 0, 1, 2  # TransparencyType as u64 key, pbr/material.rs:383-392,497-499
+
+
+def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, roughness=0.0, metallic=0.0,
+                    reflectance=0.5, emissive=(0, 0, 0), ao=1.0, clear_coat=0.0, clear_coat_roughness=0.0,
+                    cutout=None, vertex_srgb=True):
+    """ShaderMaterial::from_material (pbr/material.rs:548-583) behind the 48-byte texture-id prefix
+    (managers/material.rs:25-29).  albedo_mode: "none" | "vertex" | "value" | "value_vertex"
+    (AlbedoComponent, pbr/material.rs:60-140; Default = None -> flags 0, value (0,0,0,1))."""
+    rec = np.zeros(52, dtype=f32)
+    ru = rec.view(np.uint32)
+    # uv transforms = identity mat3 as 3 vec4 columns
+    for base in (12, 24):
+        rec[base + 0] = rec[base + 5] = rec[base + 10] = 1.0
+    flags = 0
+    if albedo_mode == "none":
+        alb = (0.0, 0.0, 0.0, 1.0)
+    elif albedo_mode == "vertex":
+        flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
+        alb = (1.0, 1.0, 1.0, 1.0)
+    elif albedo_mode == "value":
+        flags |= FLAGS_ALBEDO_ACTIVE
+        alb = albedo
+    elif albedo_mode == "value_vertex":
+        flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
+        alb = albedo
+    else:
+        raise ValueError(albedo_mode)
+    # NormalTexture::None -> 0 ; AoMRTextures::None -> AOMR_SPLIT ; ClearcoatTextures::None -> CC_GLTF_COMBINED
+    flags |= FLAGS_AOMR_SPLIT | FLAGS_CC_GLTF_COMBINED
+    if unlit:
+        flags |= FLAGS_UNLIT
+    rec[36:40] = alb
+    rec[40:43] = emissive
+    rec[43] = roughness
+    rec[44] = metallic
+    rec[45] = reflectance
+    rec[46] = clear_coat
+    rec[47] = clear_coat_roughness
+    rec[48] = 0.0  # anisotropy
+    rec[49] = ao
+    rec[50] = 0.0 if cutout is None else cutout
+    ru[51] = flags
+    return rec
+
+
+class _Mesh:
+    __slots__ = ("attr_off", "first_index", "index_count", "centre", "radius")
+
+
+class OracleRenderer:
+    def __init__(self, handedness=host.LEFT, aspect_ratio=None):
+        self.lib = get_lib()
+        self.handedness = handedness
+        self.aspect_ratio = aspect_ratio
+        self.mesh_words = np.zeros(0, dtype=np.uint32)
+        self.meshes = []
+        self.materials = []  # (record f32[52], key)
+        self.capacity = 16  # FreelistDerivedBuffer::STARTING_SIZE (util/freelist/buffer.rs:19)
+        self.objects = np.zeros((self.capacity, 32), dtype=np.uint32)
+        self.object_meta = {}  # handle -> dict(mesh, mesh sphere)
+        self.free_handles = []
+        self.pending_free = []
+        self.deferred_removals = []
+        self.next_handle = 0
+        self.dir_lights = []
+        self.point_lights = []
+        self.camera = host.CameraState(host.identity(), ("raw", host.identity()), handedness, aspect_ratio)
+        self.cam_state = {}  # camera specifier -> temporal state
+        self.frame_index = 0
+
+    # ------------------------------------------------------------------ world edits
+    def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT):
+        positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
+        if indices is None:
+            indices = np.arange(len(positions), dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        if normals is None:  # MeshBuilder::build, rend3-types/src/lib.rs:501-504
+            normals = host.calculate_normals(positions, indices, mesh_handedness == host.LEFT)
+        normals = np.ascontiguousarray(normals, dtype=f32).reshape(-1, 3)
+        m = _Mesh()
+        m.attr_off = [INVALID] * 6
+        chunks = [self.mesh_words]
+        cursor = len(self.mesh_words)
+
+        def push(words):
+            nonlocal cursor
+            start = cursor
+            chunks.append(words)
+            cursor += len(words)
+            return start
+
+        m.attr_off[0] = 4 * push(positions.view(np.uint32).reshape(-1))
+        m.attr_off[1] = 4 * push(normals.view(np.uint32).reshape(-1))
+        if colors is not None:
+            colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 4)
+            m.attr_off[5] = 4 * push(colors.view(np.uint32).reshape(-1))
+        m.first_index = push(indices)
+        m.index_count = len(indices)
+        self.mesh_words = np.concatenate(chunks)
+        m.centre, m.radius = host.bounding_sphere_from_mesh(positions)
+        self.meshes.append(m)
+        return len(self.meshes) - 1
+
+    def add_material(self, record, key=OPAQUE):
+        self.materials.append((np.asarray(record, dtype=f32), key))
+        return len(self.materials) - 1
+
+    def _alloc_handle(self):
+        if self.free_handles:
+            return self.free_handles.pop(0)
+        h = self.next_handle
+        self.next_handle += 1
+        return h
+
+    def _use_index(self, idx):
+        cap = self.capacity
+        if idx > cap:  # freelist/buffer.rs:48-52 (sic: strictly greater)
+            cap = 1 << (int(idx) - 1).bit_length()
+        while cap <= idx:  # never index out of bounds (the reference would)
+            cap *= 2
+        if cap != self.capacity:
+            grown = np.zeros((cap, 32), dtype=np.uint32)
+            grown[: self.capacity] = self.objects
+            self.objects = grown
+            self.capacity = cap
+
+    def _write_object(self, h):
+        meta = self.object_meta[h]
+        mesh = self.meshes[meta["mesh"]]
+        rec = np.zeros(32, dtype=np.uint32)
+        rf = rec.view(f32)
+        rf[0:16] = meta["transform"]
+        c, r = host.bounding_sphere_apply_transform(mesh.centre, mesh.radius, meta["transform"])
+        rf[16:19] = c
+        rf[19] = r
+        rec[20] = mesh.first_index
+        rec[21] = mesh.index_count
+        rec[22] = meta["material"]
+        rec[23:29] = mesh.attr_off
+        rec[29] = 1 if meta["enabled"] else 0
+        self._use_index(h)
+        self.objects[h] = rec
+
+    def add_object(self, mesh, material, transform):
+        h = self._alloc_handle()
+        self.object_meta[h] = dict(mesh=mesh, material=material, transform=np.asarray(transform, dtype=f32).copy(),
+                                   enabled=True)
+        self._write_object(h)
+        return h
+
+    def set_object_transform(self, h, transform):
+        self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
+        self._write_object(h)
+
+    def remove_object(self, h):
+        # object.rs:330-342: only disabled now, really removed at the next evaluate
+        self.object_meta[h]["enabled"] = False
+        self._write_object(h)
+        self.deferred_removals.append(h)
+
+    def add_directional_light(self, color=(1, 1, 1), intensity=1.0, direction=(0, -1, 0), distance=100.0,
+                              resolution=2048):
+        self.dir_lights.append(dict(color=color, intensity=intensity, direction=direction, distance=distance,
+                                    resolution=resolution))
+        return len(self.dir_lights) - 1
+
+    def add_point_light(self, position, color=(1, 1, 1), intensity=1.0, radius=1.0):
+        self.point_lights.append(dict(position=position, color=color, intensity=intensity, radius=radius))
+        return len(self.point_lights) - 1
+
+    def set_camera_data(self, view, projection):
+        self.camera = host.CameraState(view, projection, self.handedness, self.aspect_ratio)
+
+    # ------------------------------------------------------------------ boundary buffers
+    def material_buffers(self):
+        n = max(1, len(self.materials))
+        recs = np.zeros((n, 52), dtype=f32)
+        keys = np.zeros(n, dtype=np.uint8)
+        for i, (r, k) in enumerate(self.materials):
+            recs[i] = r
+            keys[i] = k
+        return recs, keys
+
+    def tri_base(self):
+        counts = (self.objects[:, 21] // 3) * (self.objects[:, 29] != 0)
+        base = np.zeros(self.capacity, dtype=np.uint32)
+        base[1:] = np.cumsum(counts[:-1], dtype=np.uint64).astype(np.uint32)
+        return base, int(counts.sum())
+
+    # ------------------------------------------------------------------ per-camera cull
+    def _cull(self, spec, hdr, baked, hiz, hiz_w, hiz_h):
+        lib = self.lib
+        cap = self.capacity
+        visible = np.zeros(cap, dtype=np.uint8)
+        lib.r3o_frustum_cull(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(visible))
+        tri_base, total = self.tri_base()
+        pass_bits = np.zeros(max(total, 1), dtype=np.uint8)
+        residual = np.zeros(max(total, 1), dtype=np.uint8)
+        st = self.cam_state.get(spec)
+        prev_base = prev_pass = None
+        if st is not None:
+            prev_base = np.full(cap, INVALID, dtype=np.uint32)
+            n = min(cap, len(st["tri_base_or_invalid"]))
+            prev_base[:n] = st["tri_base_or_invalid"][:n]
+            prev_pass = st["pass"]
+        lib.r3o_cull_triangles(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words), lib.ptr(baked),
+                               lib.ptr(visible), lib.ptr(tri_base), lib.ptr(hiz), hiz_w, hiz_h,
+                               lib.ptr(prev_base), lib.ptr(prev_pass), lib.ptr(pass_bits), lib.ptr(residual))
+        # batching.rs:226,230: only objects that were batched (frustum-visible) carry history
+        base_or_invalid = np.where(visible != 0, tri_base, np.uint32(INVALID)).astype(np.uint32)
+        self.cam_state[spec] = dict(tri_base_or_invalid=base_or_invalid, **{"pass": pass_bits})
+        return visible, tri_base, pass_bits, residual
+
+    def _list_from_bits(self, bits, tri_base):
+        slots = np.flatnonzero(bits).astype(np.uint32)
+        obj = (np.searchsorted(tri_base, slots, side="right") - 1).astype(np.uint32)
+        # skip empty objects sharing a base: searchsorted(right)-1 lands on the last object with base<=slot
+        tri = (slots - tri_base[obj]).astype(np.uint32)
+        return np.ascontiguousarray(obj), np.ascontiguousarray(tri)
+
+    # ------------------------------------------------------------------ frame
+    def render(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0)):
+        assert samples == 1, "MSAA is row N4 (not built)"
+        lib = self.lib
+        # Renderer::evaluate_instructions (renderer/eval.rs): last frame's removals become real
+        for h in self.pending_free:
+            self.objects[h] = 0
+            self.object_meta.pop(h, None)
+            self.free_handles.append(h)
+        self.pending_free = self.deferred_removals
+        self.deferred_removals = []
+
+        cap = self.capacity
+        mats, mat_keys = self.material_buffers()
+        cam = self.camera
+        atlas_size, shadows, dir_buf = host.evaluate_directional_lights(self.dir_lights, cam)
+        point_buf = host.point_light_buffer(self.point_lights)
+        out = {"shadows": []}
+
+        # 1. clear shadow atlas (clear.rs:4-20)
+        atlas = np.zeros((atlas_size[1], atlas_size[0]), dtype=f32)
+        # 2. frame uniforms (uniforms.rs)
+        fu = host.frame_uniforms(cam, ambient, (width, height), lib)
+        # 4-6. shadow views: bake, cull, depth draw (base.rs:148-153)
+        for si, sh in enumerate(shadows):
+            hdr = host.camera_header(sh["camera"], si, (sh["size"], sh["size"]), 1, cap, lib)
+            baked = np.zeros((cap, 32), dtype=f32)
+            lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
+            visible, tri_base, pass_bits, _ = self._cull(("shadow", si), hdr, baked, None, 0, 0)
+            lo, lt = self._list_from_bits(pass_bits, tri_base)
+            lib.r3o_raster_depth(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words), lib.ptr(baked),
+                                 lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(lo), lib.ptr(lt), len(lo),
+                                 lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"])
+            out["shadows"].append(dict(header=hdr, visible=visible, tri_base=tri_base, **{"pass": pass_bits}))
+
+        # 7. viewport bake
+        hdr = host.camera_header(cam, None, (width, height), samples, cap, lib)
+        baked = np.zeros((cap, 32), dtype=f32)
+        lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
+        vis = np.zeros((height, width), dtype=np.uint64)
+        tri_base_now, _ = self.tri_base()
+
+        def draw(lo, lt):
+            if len(lo):
+                lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
+                                          lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
+                                          lib.ptr(lo), lib.ptr(lt), len(lo), width, height, lib.ptr(vis))
+
+        # 8. pass 1: last frame's predicted triangles (forward.rs:224-232)
+        predicted = self.cam_state.get("predicted_list")
+        if predicted is not None:
+            lo, lt = predicted
+            keep = lo < cap
+            draw(np.ascontiguousarray(lo[keep]), np.ascontiguousarray(lt[keep]))
+        # 9. Hi-Z from pass-1 depth (hi_z.rs:161-234)
+        nm = lib.r3o_hiz_mip_count(width, height)
+        pyr = np.zeros(int(lib.r3o_hiz_mip_offset(width, height, nm)), dtype=f32)
+        lib.r3o_vis_to_depth(lib.ptr(vis), width * height, lib.ptr(pyr))
+        lib.r3o_hiz_build(lib.ptr(pyr), width, height)
+        out["depth_pass1"] = pyr[: width * height].reshape(height, width).copy()
+        out["hiz"] = pyr
+        # 10. cull (culler.rs:531-659)
+        visible, tri_base, pass_bits, residual = self._cull("viewport", hdr, baked, pyr, width, height)
+        assert np.array_equal(tri_base, tri_base_now)
+        # 11. pass 2: residual triangles
+        draw(*self._list_from_bits(residual, tri_base))
+        self.cam_state["predicted_list"] = self._list_from_bits(pass_bits, tri_base)
+
+        # opaque shading of the nearest fragment + 14. tonemap
+        hdr16 = np.zeros((height, width, 4), dtype=np.uint16)
+        n_dir = int(np.frombuffer(dir_buf[:4], dtype=np.uint32)[0])
+        n_pt = int(np.frombuffer(point_buf[:4], dtype=np.uint32)[0])
+        dir_arr = np.frombuffer(dir_buf, dtype=np.uint8)[16:].copy()
+        pt_arr = np.frombuffer(point_buf, dtype=np.uint8)[16:].copy()
+        clear = np.asarray(clear_color, dtype=f32)
+        lib.r3o_shade(lib.ptr(vis), width, height, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
+                      lib.ptr(self.mesh_words), lib.ptr(baked), lib.ptr(mats), lib.ptr(tri_base), n_dir,
+                      lib.ptr(dir_arr) if n_dir else None, n_pt, lib.ptr(pt_arr) if n_pt else None,
+                      lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), lib.ptr(hdr16))
+        rgba_f = np.zeros((height, width, 4), dtype=f32)
+        rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
+        lib.r3o_tonemap(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8))
+
+        out.update(header=hdr, frame_uniforms=fu, baked=baked, visible=visible, tri_base=tri_base,
+                   residual=residual, vis=vis, atlas=atlas, atlas_size=atlas_size, hdr16=hdr16, rgba_f32=rgba_f,
+                   rgba8=rgba8, dir_buf=dir_buf, point_buf=point_buf, objects=self.objects.copy(),
+                   materials=mats, material_keys=mat_keys, mesh=self.mesh_words, shadow_descs=shadows,
+                   capacity=cap, **{"pass": pass_bits})
+        self.frame_index += 1
+        return out

@@ -1,0 +1,206 @@
+"""
+Pins the CPU oracle against the reference's own golden images:
+rend3-test/tests/results/**.png (copied to tests/golden/rend3-test/) and
+examples/src/cube/screenshot.png (tests/golden/cube-screenshot.png).
+
+Each test rebuilds the scene of the reference test it cites and renders it through the oracle's
+restatement of BaseRenderGraph::add_to_graph.  `Threshold::Mean(0.0)` goldens are compared
+pixel-exactly; the lit ones within the tolerance the reference test itself uses (FLIP is not
+available offline, so a per-channel LSB bound stands in for it and is stated in each test).
+MSAA goldens (msaa/four.png, msaa/sample-coverage-4.png) belong to row N4 (not built) and are not pinned.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import scenes
+from oracle import host as hm
+from oracle.world import OracleRenderer, material_record as mk
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+f32 = np.float32
+
+
+def load(path):
+    return np.array(Image.open(os.path.join(GOLD, path)).convert("RGBA"))
+
+
+def raw_identity_camera(r):
+    r.set_camera_data(hm.identity(), ("raw", hm.identity()))
+
+
+def test_empty():
+    """rend3-test/tests/simple.rs:7-26"""
+    r = OracleRenderer(hm.LEFT)
+    raw_identity_camera(r)
+    out = r.render(64, 64)
+    assert np.array_equal(out["rgba8"], load("rend3-test/simple/empty.png"))
+
+
+@pytest.mark.parametrize(
+    "handedness,winding_ccw,visible",
+    [(hm.LEFT, False, True), (hm.LEFT, True, False), (hm.RIGHT, False, False), (hm.RIGHT, True, True)],
+)
+def test_triangle(handedness, winding_ccw, visible):
+    """rend3-test/tests/simple.rs:28-84: winding x handedness truth table, top-left rule, OETF."""
+    r = OracleRenderer(handedness)
+    if winding_ccw:
+        pos = [(0.5, -0.5, 0.0), (0.0, 0.5, 0.0), (-0.5, -0.5, 0.0)]
+        mh = hm.RIGHT
+    else:
+        pos = [(0.5, -0.5, 0.0), (-0.5, -0.5, 0.0), (0.0, 0.5, 0.0)]
+        mh = hm.LEFT
+    mesh = r.add_mesh(pos, mesh_handedness=mh)
+    mat = scenes.unlit(r, mk, (0.25, 0.5, 0.75, 1.0))
+    r.add_object(mesh, mat, hm.identity())
+    raw_identity_camera(r)
+    out = r.render(64, 64)
+    name = "triangle.png" if visible else "triangle-backface.png"
+    assert np.array_equal(out["rgba8"], load("rend3-test/simple/" + name))
+
+
+COORD_TESTS = [
+    ("NegZ", (1, 0, 0), (0, 1, 0), (0, 0, -1)),
+    ("Z", (-1, 0, 0), (0, 1, 0), (0, 0, 1)),
+    ("NegY", (1, 0, 0), (0, 0, -1), (0, -1, 0)),
+    ("Y", (1, 0, 0), (0, 0, 1), (0, 1, 0)),
+    ("NegX", (0, 0, -1), (0, 1, 0), (-1, 0, 0)),
+    ("X", (0, 0, 1), (0, 1, 0), (1, 0, 0)),
+]
+
+
+def test_coordinate_space():
+    """rend3-test/tests/simple.rs:86-141: six triangles, one visible per look direction; one renderer
+    renders all six frames, so the two-pass temporal state is exercised too."""
+    r = OracleRenderer(hm.LEFT)
+    for _name, right, up, camv in COORD_TESTS:
+        right, up, camv = (np.array(v, dtype=f32) for v in (right, up, camv))
+        pos = [f32(0.5) * right + f32(-0.5) * up, f32(-0.5) * right + f32(-0.5) * up, f32(0.0) * right + f32(0.5) * up]
+        mesh = r.add_mesh(pos, mesh_handedness=hm.LEFT)
+        neg = bool((camv < 0).any())
+        color = camv * f32(-0.25) if neg else camv
+        mat = scenes.unlit(r, mk, (color[0], color[1], color[2], 1.0))
+        r.add_object(mesh, mat, hm.identity())
+    for name, _right, up, camv in COORD_TESTS:
+        r.set_camera_data(hm.look_at_lh(camv, (0, 0, 0), up), ("raw", hm.identity()))
+        out = r.render(64, 64)
+        assert np.array_equal(out["rgba8"], load(f"rend3-test/simple/coordinate-space-{name}.png")), name
+
+
+def srt(s, t):
+    return hm.mat4_mul(hm.translation(t), hm.scale(s))
+
+
+def test_duplicate_object_retain():
+    """rend3-test/tests/object.rs:9-59: deferred removal (enabled == 0) + new object in the residual pass."""
+    r = OracleRenderer(hm.LEFT)
+    raw_identity_camera(r)
+    mat = scenes.unlit(r, mk, (1, 1, 1, 1))
+    mesh = scenes.plane_mesh(r)
+    o1 = r.add_object(mesh, mat, srt((-0.25, 0.25, 0.25), (-0.5, 0, 0)))
+    out = r.render(64, 64)
+    assert np.array_equal(out["rgba8"], load("rend3-test/object/duplicate-object-retain-left.png"))
+    r.add_object(mesh, mat, srt((-0.25, 0.25, 0.25), (0.5, 0, 0)))
+    r.remove_object(o1)
+    out = r.render(64, 64)
+    assert np.array_equal(out["rgba8"], load("rend3-test/object/duplicate-object-retain-right.png"))
+
+
+def test_multi_frame_add():
+    """rend3-test/tests/object.rs:61-109: object buffer grows 16 -> 32 between frames."""
+    r = OracleRenderer(hm.LEFT)
+    mat = scenes.unlit(r, mk, (1, 1, 1, 1))
+    base = hm.mat4_mul(hm.translation((0.5, 0.5, 0.0)), hm.scale((0.5, 1.0, 1.0)))
+    r.set_camera_data(hm.identity(), ("raw", hm.orthographic_lh(0.0, 2.0, 16.0, 0.0, 0.0, 1.0)))
+    mesh = scenes.plane_mesh(r)
+    for x in range(2):
+        for y in range(16):
+            r.add_object(mesh, mat, hm.mat4_mul(hm.translation((x, y, 0.0)), base))
+        out = r.render(64, 64)
+        assert np.array_equal(out["rgba8"], load(f"rend3-test/object/multi-frame-add-{x}.png")), x
+
+
+def test_sample_coverage_1():
+    """rend3-test/tests/msaa.rs:41-82 at 1 spp: 64x64 planes of shrinking size -- pins the sub-pixel
+    cull (cull.wgsl:292-298) against the rasteriser's pixel-centre rule."""
+    r = OracleRenderer(hm.LEFT)
+    mat = scenes.unlit(r, mk, (1, 1, 1, 1))
+    base = hm.mat4_mul(hm.translation((0.5, 0.5, 0.0)), hm.scale((0.5, 0.5, 1.0)))
+    mesh = scenes.plane_mesh(r)
+    for x in range(64):
+        for y in range(64):
+            sx = f32(1.0) - (f32(x) / f32(63.0))
+            sy = f32(1.0) - (f32(y) / f32(63.0))
+            m = hm.mat4_mul(hm.mat4_mul(hm.translation((x, y, 0.0)), hm.scale((sx, sy, 1.0))), base)
+            r.add_object(mesh, mat, m)
+    r.set_camera_data(hm.identity(), ("raw", hm.orthographic_lh(0.0, 64.0, 64.0, 0.0, 0.0, 1.0)))
+    out = r.render(64, 64)
+    assert np.array_equal(out["rgba8"], load("rend3-test/msaa/sample-coverage-1.png"))
+
+
+def _shadow_scene():
+    r = OracleRenderer(hm.LEFT)
+    r.add_directional_light(color=(1, 1, 1), intensity=1.0, direction=(-1.0, -1.0, 1.0), distance=5.0, resolution=256)
+    m1 = scenes.lit(r, mk, (0.25, 0.5, 0.75, 1.0))
+    r.add_object(scenes.plane_mesh(r), m1, hm.rotation_x(-math.pi / 2))
+    r.set_camera_data(hm.look_at_lh((0.0, 1.0, -1.0), (0, 0, 0), (0, 1, 0)), ("orthographic", (2.5, 2.5, 5.0)))
+    return r
+
+
+def test_shadow_plane():
+    """rend3-test/tests/shadow.rs:9-37.  Reference tolerance: FLIP 50th percentile <= 0.04; here: same
+    lit-pixel set exactly, every lit pixel within 1 LSB of the golden's [61,86,104]."""
+    r = _shadow_scene()
+    out = r.render(256, 256)
+    gold = load("rend3-test/shadow/plane.png")
+    lit_gold = gold[..., :3].any(axis=2)
+    lit_ours = out["rgba8"][..., :3].any(axis=2)
+    assert lit_gold.sum() == 29376
+    assert np.array_equal(lit_gold, lit_ours)
+    diff = np.abs(out["rgba8"].astype(int) - gold.astype(int))
+    assert diff.max() <= 1, diff.max()
+
+
+def test_shadow_cube():
+    """rend3-test/tests/shadow.rs:39-54 (same runner: second frame adds the cube)."""
+    r = _shadow_scene()
+    r.render(256, 256)
+    m2 = scenes.lit(r, mk, (0.75, 0.5, 0.25, 1.0))
+    cube = scenes.cube_mesh(r)
+    r.add_object(cube, m2, srt((0.25, 0.25, 0.25), (0.25, 0.25, -0.25)))
+    out = r.render(256, 256)
+    gold = load("rend3-test/shadow/cube.png")
+    diff = np.abs(out["rgba8"].astype(int) - gold.astype(int)).max(axis=2)
+    # reference: 50th percentile of FLIP error <= 0.04.  Here: >= 99% of pixels within 2 LSB
+    # (residual = PCF penumbra / silhouette pixels where GPU filtering precision differs).
+    frac = (diff <= 2).mean()
+    assert frac >= 0.99, frac
+    assert np.median(diff) == 0
+
+
+def test_cube_example():
+    """examples/src/cube/mod.rs:70-135,189-200 at 1280x720 (reference threshold: FLIP mean 0.01)."""
+    w, h = 1280, 720
+    r = OracleRenderer(hm.LEFT, aspect_ratio=f32(w) / f32(h))
+    mesh = scenes.cube_mesh(r)
+    mat = r.add_material(mk(albedo=(0.5, 0.5, 0.5, 1.0), albedo_mode="value"), scenes.OPAQUE)
+    r.add_object(mesh, mat, hm.identity())
+    view = hm.mat4_mul(hm.from_euler_xyz(-0.55, 0.5, 0.0), hm.translation((-3.0, -3.0, 5.0)))
+    r.set_camera_data(view, ("perspective", 60.0, 0.1))
+    r.add_directional_light(color=(1, 1, 1), intensity=1.0, direction=(-1.0, -4.0, 2.0), distance=400.0, resolution=2048)
+    r.add_point_light((0.1, 1.2, -1.5), (1.0, 0.0, 0.0), 4.0, 2.0)
+    r.add_point_light((1.5, 1.2, -0.1), (0.0, 1.0, 0.0), 4.0, 2.0)
+    out = r.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+    gold = np.array(Image.open(os.path.join(GOLD, "cube-screenshot.png")).convert("RGBA"))
+    assert tuple(out["rgba8"][0, 0]) == (89, 63, 89, 255)
+    bg = np.array([89, 63, 89, 255])
+    cov_gold = (gold != bg).any(axis=2)
+    cov_ours = (out["rgba8"] != bg).any(axis=2)
+    # silhouettes agree except for a handful of edge pixels (float edge placement vs the GPU's snapping)
+    assert (cov_gold != cov_ours).sum() <= 0.002 * cov_gold.sum(), (cov_gold != cov_ours).sum()
+    diff = np.abs(out["rgba8"].astype(int) - gold.astype(int)).max(axis=2)
+    assert diff.mean() <= 1.0, diff.mean()
+    assert (diff <= 3).mean() >= 0.995, (diff <= 3).mean()
