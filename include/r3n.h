@@ -1,0 +1,266 @@
+/*
+ * r3n.h -- C ABI of the MI355X-native rend3 object pipeline (librend3_amd.so).
+ *
+ * rend3 has no FFI boundary of its own (100 % Rust + WGSL); its extension API is the set of
+ * `add_*_to_graph` routine methods whose node bodies record wgpu work.  This header is the
+ * boundary those node bodies would call instead.  Each entry point cites the reference
+ * interface it replaces; INTEGRATION.md shows the Rust `extern "C"` block and the adaptor
+ * structs (BaseRenderGraph / GpuCuller / ForwardRoutine / HiZRoutine / TonemappingRoutine)
+ * a maintainer would add on the rend3 side.
+ *
+ * Conventions
+ *   - opaque context, one HIP device + one HIP stream per context;
+ *   - every call returns 0 on success, <0 on error (never unwinds); r3n_last_error() has text;
+ *   - the caller owns every host pointer for the duration of the call only; the context owns
+ *     all device memory; all calls are asynchronous on the context's stream except r3n_readback_*,
+ *     r3n_sync and calls documented as synchronising;
+ *   - byte layouts are rend3's own (encase std430), restated in SURVEY.md App. A and checked by
+ *     static_asserts in rend3_amd/csrc/layouts.h;
+ *   - calls are made from one thread at a time (the reference holds the data_core mutex for the
+ *     whole graph execution, rend3/src/graph/graph.rs:265).
+ */
+#ifndef R3N_H
+#define R3N_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3N_OK 0
+#define R3N_ERR_INVALID_ARG (-1)
+#define R3N_ERR_HIP (-2)
+#define R3N_ERR_NO_DEVICE (-3)
+#define R3N_ERR_STATE (-4)
+#define R3N_ERR_UNSUPPORTED (-5)
+
+/* CameraSpecifier (rend3-routine/src/common/camera.rs:3-35): shadow index, or R3N_CAMERA_VIEWPORT
+ * (== CameraSpecifier::Viewport.to_shader_index() == u32::MAX). */
+typedef uint32_t r3n_camera;
+#define R3N_CAMERA_VIEWPORT 0xFFFFFFFFu
+#define R3N_MAX_SHADOW_VIEWS 64u
+
+/* RoutineType (rend3-routine/src/forward.rs:40-44) */
+#define R3N_PASS_DEPTH 0u
+#define R3N_PASS_FORWARD 1u
+/* CullingSource (rend3-routine/src/forward.rs:64-70) */
+#define R3N_SOURCE_PREDICTED 0u
+#define R3N_SOURCE_RESIDUAL 1u
+/* Material::key() of PbrMaterial = TransparencyType (rend3-routine/src/pbr/material.rs:383-392,497-499) */
+#define R3N_KEY_OPAQUE 0u
+#define R3N_KEY_CUTOUT 1u
+#define R3N_KEY_BLEND 2u
+
+typedef struct r3n_ctx r3n_ctx;
+
+/* ShaderObject<PbrMaterial>, 128 B (rend3/src/managers/object.rs:23-36) */
+typedef struct r3n_object128 {
+    float transform[16];
+    float bounding_sphere_center[3];
+    float bounding_sphere_radius;
+    uint32_t first_index;
+    uint32_t index_count;
+    uint32_t material_index;
+    uint32_t vertex_attribute_start_offsets[6];
+    uint32_t enabled;
+    uint32_t _pad[2];
+} r3n_object128;
+
+/* GpuPoweredShaderWrapper<PbrMaterial> = 10 texture ids + ShaderMaterial, 208 B
+ * (rend3/src/managers/material.rs:25-29, rend3-routine/src/pbr/material.rs:526-543) */
+typedef struct r3n_material208 {
+    uint32_t textures[10];
+    uint32_t _pad[2];
+    float uv_transform0[12];
+    float uv_transform1[12];
+    float albedo[4];
+    float emissive[3];
+    float roughness;
+    float metallic;
+    float reflectance;
+    float clear_coat;
+    float clear_coat_roughness;
+    float anisotropy;
+    float ambient_occlusion;
+    float alpha_cutout;
+    uint32_t flags;
+} r3n_material208;
+
+/* PerCameraUniform header, 240 B (rend3-routine/src/culling/culler.rs:158-175) */
+typedef struct r3n_camera_header240 {
+    float view[16];
+    float view_proj[16];
+    uint32_t shadow_index;
+    uint32_t _pad[3];
+    float frustum[20];
+    float resolution[2];
+    uint32_t flags; /* bit0 positive area visible, bit1 multisampled (culler.rs:151-156) */
+    uint32_t object_count;
+} r3n_camera_header240;
+
+/* FrameUniforms, 496 B (rend3-routine/src/uniforms.rs:17-27) */
+typedef struct r3n_frame_uniforms496 {
+    float view[16];
+    float view_proj[16];
+    float origin_view_proj[16];
+    float inv_view[16];
+    float inv_view_proj[16];
+    float inv_origin_view_proj[16];
+    float frustum[20];
+    float ambient[4];
+    uint32_t resolution[2];
+    uint32_t _pad[2];
+} r3n_frame_uniforms496;
+
+/* wgpu DrawIndexedIndirect as written by cull.wgsl:47-61 (structures.wgsl:20-26), 20 B.
+ * One per region; here a region is one material key. */
+typedef struct r3n_indirect_call {
+    uint32_t vertex_count;
+    uint32_t instance_count;
+    uint32_t base_index;
+    int32_t vertex_offset;
+    uint32_t base_instance;
+} r3n_indirect_call;
+
+typedef struct r3n_config {
+    uint32_t struct_size;      /* sizeof(r3n_config) */
+    uint32_t max_big_items;    /* raster work-queue capacity (0 = default 4 Mi items) */
+    uint64_t reserved[3];
+} r3n_config;
+
+/* ---- lifetime (replaces rend3::create_iad + BaseRenderGraph::new / PbrRoutine::new state:
+ *      rend3-routine/src/base.rs:111-124, culling/culler.rs:198-425) */
+r3n_ctx *r3n_create(int hip_device, const r3n_config *config);
+void r3n_destroy(r3n_ctx *ctx);
+const char *r3n_last_error(const r3n_ctx *ctx);
+/* text of the last error of a failed r3n_create (ctx == NULL) */
+const char *r3n_create_error(void);
+int r3n_sync(r3n_ctx *ctx);
+/* the context's hipStream_t, so callers (torch, RCCL) can order work against it */
+void *r3n_stream(r3n_ctx *ctx);
+
+/* ---- world data uploads (the managers' GPU buffers the hot path reads)
+ *      MeshManager::add upload, rend3/src/managers/mesh.rs:123-184 (layout: SoA attribute runs + u32 indices) */
+int r3n_mesh_buffer_write(r3n_ctx *ctx, uint64_t byte_offset, const void *data, uint64_t bytes);
+/*      ObjectManager::evaluate scatter upload, rend3/src/managers/object.rs:344-364.
+ *      `capacity` = object-buffer capacity in records (FreelistDerivedBuffer, util/freelist/buffer.rs:48-52);
+ *      growing it preserves existing records, new records are zero (enabled == 0). */
+int r3n_objects_write(r3n_ctx *ctx, const uint32_t *slots, const r3n_object128 *records, uint32_t n,
+                      uint32_t capacity);
+/*      MaterialManager::evaluate, rend3/src/managers/material.rs:202-227.  `keys[i]` = Material::key()
+ *      (R3N_KEY_*), which is host-side state in the reference (not part of the 208-byte record). */
+int r3n_materials_write(r3n_ctx *ctx, const uint32_t *slots, const r3n_material208 *records,
+                        const uint8_t *keys, uint32_t n);
+/*      DirectionalLightManager / PointLightManager buffers, byte-identical:
+ *      u32 count @0, array @16 (stride 128 / 32): rend3/src/managers/directional.rs:31-53,135-153, point.rs:14-74 */
+int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t directional_bytes,
+                     const void *point_buffer, uint64_t point_bytes);
+
+/* ---- frame (node order of BaseRenderGraph::add_to_graph, rend3-routine/src/base.rs:135-185)
+ * r3n_frame_begin: create_frame_uniforms (uniforms.rs:73-125) + render-target setup (base.rs:224-264) +
+ * clear_shadow_buffers (clear.rs:4-20).  Clears colour to `clear_color`, depth and the shadow atlas to 0.0. */
+int r3n_frame_begin(r3n_ctx *ctx, const r3n_frame_uniforms496 *uniforms, uint32_t width, uint32_t height,
+                    uint32_t samples, const float clear_color[4], uint32_t shadow_atlas_width,
+                    uint32_t shadow_atlas_height);
+/* GpuCuller::object_uniform_upload (culler.rs:427-529) + uniform_prep.wgsl */
+int r3n_uniform_bake(r3n_ctx *ctx, r3n_camera camera, const r3n_camera_header240 *header);
+/* GpuCuller::add_culling_to_graph (culler.rs:682-713) = batch_objects (batching.rs:120-250, frustum cull +
+ * slot assignment, done on the GPU here) + GpuCuller::cull (culler.rs:531-659) + cull.wgsl.
+ * Owns the per-camera temporal state (previous-invocation map, ping-pong result bits, predicted lists). */
+int r3n_cull(r3n_ctx *ctx, r3n_camera camera);
+/* HiZRoutine::add_hi_z_to_graph (hi_z.rs:161-234) + hi_z.wgsl: pyramid from the viewport depth so far */
+int r3n_hi_z(r3n_ctx *ctx);
+/* Shadow viewport of a shadow camera inside the atlas (base.rs:369: ViewportRect(desc.map.offset, size)) */
+int r3n_shadow_viewport(r3n_ctx *ctx, r3n_camera shadow_camera, uint32_t x, uint32_t y, uint32_t size);
+/* ForwardRoutine::add_forward_to_graph (forward.rs:192-315) for one (camera, routine type, culling source,
+ * material key): rasterises that draw-call range with depth test GreaterEqual + write (forward.rs:347-351).
+ * FORWARD colour is resolved per pixel by r3n_resolve_opaque (each pixel shaded once, for its nearest fragment). */
+int r3n_forward(r3n_ctx *ctx, r3n_camera camera, uint32_t pass, uint32_t source, uint32_t material_key);
+/* Evaluates opaque.wgsl (VS :91-135 + FS :203-551) for the nearest fragment of every pixel -> Rgba16Float HDR.
+ * Must follow the last FORWARD r3n_forward of the frame (base.rs:172) and precede r3n_tonemap. */
+int r3n_resolve_opaque(r3n_ctx *ctx);
+/* TonemappingRoutine::add_to_graph (tonemapping.rs:108-147) + blit.wgsl into an Rgba8UnormSrgb target.
+ * If `host_rgba8` is non-NULL the image is also copied out (synchronises), `pitch_bytes` per row. */
+int r3n_tonemap(r3n_ctx *ctx, void *host_rgba8, uint64_t pitch_bytes);
+/* Marks the end of the frame: swaps the temporal state (InputOutputBuffer::swap, culling/suballoc.rs:164-214). */
+int r3n_frame_end(r3n_ctx *ctx);
+
+/* ---- multi-GPU support: object-range sharding (not in the reference).
+ * Only objects with slot in [begin, end) are culled/drawn by this context; buffers stay replicated. */
+int r3n_set_object_range(r3n_ctx *ctx, uint32_t begin, uint32_t end);
+/* Device pointers + sizes of the exchange buffers, for RCCL (all-reduce MAX over ranks):
+ * the 64-bit visibility/depth keys (width*height u64, as int64 non-negative) and the f32 shadow atlas. */
+int r3n_exchange_buffers(r3n_ctx *ctx, void **visibility_keys, uint64_t *visibility_count,
+                         void **shadow_atlas, uint64_t *shadow_atlas_count);
+/* Device pointer of the tonemapped Rgba8 image (width*height*4 bytes) and the rows [row_begin,row_end) this
+ * rank resolves/tonemaps when screen-space work is split after the exchange. */
+int r3n_set_row_range(r3n_ctx *ctx, uint32_t row_begin, uint32_t row_end);
+int r3n_output_buffer(r3n_ctx *ctx, void **rgba8, uint64_t *bytes);
+
+/* ---- parity / debug taps (not in the reference; synchronise) */
+/* L1 set: flags[i] = 1 iff object slot i survived the frustum test of `camera`'s last r3n_cull */
+int r3n_readback_visible_objects(r3n_ctx *ctx, r3n_camera camera, uint8_t *flags, uint32_t capacity);
+/* L2 set in canonical layout: bit for (object o, triangle t) at index tri_base[o] + t, where tri_base is the
+ * exclusive scan of (enabled ? index_count/3 : 0) over object slots.  pass = execute_culling result
+ * (cull.wgsl:264-324); residual = newly visible (cull.wgsl:366-371).  `n` = total triangle count. */
+int r3n_readback_triangle_sets(r3n_ctx *ctx, r3n_camera camera, uint8_t *pass, uint8_t *residual, uint64_t n);
+/* per-region IndirectCall as cull.wgsl leaves it: calls[0..3) predicted, calls[3..6) residual (by material key) */
+int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call calls[6]);
+int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
+int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height */
+int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys */
+int r3n_readback_hiz(r3n_ctx *ctx, float *pyramid, uint64_t count); /* all mips, mip0 first */
+int r3n_readback_shadow_atlas(r3n_ctx *ctx, float *atlas);  /* atlas_w*atlas_h */
+int r3n_readback_hdr(r3n_ctx *ctx, uint16_t *rgba16f);      /* width*height*4 half bits */
+int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* either may be NULL */
+
+/* ---- timing taps for bench.py: HIP events recorded on the context's stream around every kernel launch of a
+ * named stage.  r3n_stage_times returns accumulated milliseconds and launch counts since the last reset. */
+#define R3N_STAGE_BAKE 0
+#define R3N_STAGE_OBJECT_CULL 1
+#define R3N_STAGE_TRIANGLE_CULL 2
+#define R3N_STAGE_HIZ 3
+#define R3N_STAGE_RASTER 4
+#define R3N_STAGE_SHADE 5
+#define R3N_STAGE_TONEMAP 6
+#define R3N_STAGE_CLEAR 7
+#define R3N_STAGE_COUNT 8
+int r3n_timing_enable(r3n_ctx *ctx, int enable);
+int r3n_stage_times(r3n_ctx *ctx, double ms[R3N_STAGE_COUNT], uint64_t launches[R3N_STAGE_COUNT], int reset);
+
+/* ---- host-side mirror of the reference's CPU math on the path (rend3_amd/csrc/host.cpp).
+ * In a real integration these stay in Rust (rend3 core); they exist here so the standalone harness, the
+ * bench and the parity tests can build the boundary inputs without the oracle.  Matrices are column-major f32[16]. */
+/* glam Mat4 mul / inverse as used by camera.rs:64-73, uniforms.rs:41-43 */
+void r3n_host_mat4_mul(const float *a, const float *b, float *out);
+void r3n_host_mat4_inverse(const float *m, float *out);
+/* glam look_at_{lh,rh} (shadow_camera.rs:12-14,28); rh != 0 selects the right-handed form */
+void r3n_host_look_at(const float eye[3], const float center[3], const float up[3], int rh, float *out);
+/* camera.rs:88-107: kind 0 = Orthographic{size[3]}, 1 = Perspective{vfov_deg = params[0], near = params[1]} */
+void r3n_host_projection(int kind, const float *params, int rh, float aspect_ratio, float *out);
+/* Frustum::from_matrix, rend3/src/util/frustum.rs:96-145: 5 planes x vec4 */
+void r3n_host_frustum_from_matrix(const float *m, float *planes20);
+int r3n_host_frustum_contains_sphere(const float *planes20, const float center[3], float radius);
+/* BoundingSphere::{from_mesh, apply_transform}, frustum.rs:15-56 */
+void r3n_host_bounding_sphere_from_mesh(const float *positions, uint64_t vertex_count, float out_center[3],
+                                        float *out_radius);
+void r3n_host_bounding_sphere_apply_transform(const float center[3], float radius, const float *m,
+                                              float out_center[3], float *out_radius);
+/* Mesh::calculate_normals_for_buffers, rend3-types/src/lib.rs:662-704 */
+void r3n_host_calculate_normals(const float *positions, uint64_t vertex_count, const uint32_t *indices,
+                                uint64_t index_count, int left_handed, float *normals);
+/* shadow_camera, rend3/src/managers/directional/shadow_camera.rs:6-33: outputs the shadow view matrix and its
+ * orthographic projection */
+void r3n_host_shadow_camera(const float direction[3], float distance, uint32_t resolution,
+                            const float camera_location[3], int rh, float *out_view, float *out_proj);
+/* allocate_shadow_atlas, rend3/src/managers/directional/shadow_alloc.rs:59-136.  Returns the number of maps
+ * written (0 when there is nothing to allocate); out_maps[i] = {offset_x, offset_y, size, handle}. */
+uint32_t r3n_host_allocate_shadow_atlas(const uint32_t *handles, const uint16_t *resolutions, uint32_t n,
+                                        uint32_t max_dimension, uint32_t out_dimensions[2],
+                                        uint32_t *out_maps /* 4*n */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3N_H */

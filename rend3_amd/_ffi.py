@@ -1,0 +1,109 @@
+"""ctypes binding of librend3_amd.so (include/r3n.h).  The library is built in-tree by rend3_amd/build.py;
+if it is missing and cannot be built this module raises -- there is no CPU fallback for the product path."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+vp = ctypes.c_void_p
+u32 = ctypes.c_uint32
+u64 = ctypes.c_uint64
+cint = ctypes.c_int
+cfloat = ctypes.c_float
+
+CAMERA_VIEWPORT = 0xFFFFFFFF
+PASS_DEPTH, PASS_FORWARD = 0, 1
+SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
+KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
+STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear"]
+
+# every symbol include/r3n.h declares: (restype, argtypes)
+SIGNATURES = {
+    "r3n_create": (vp, [cint, vp]),
+    "r3n_destroy": (None, [vp]),
+    "r3n_last_error": (ctypes.c_char_p, [vp]),
+    "r3n_create_error": (ctypes.c_char_p, []),
+    "r3n_sync": (cint, [vp]),
+    "r3n_stream": (vp, [vp]),
+    "r3n_mesh_buffer_write": (cint, [vp, u64, vp, u64]),
+    "r3n_objects_write": (cint, [vp, vp, vp, u32, u32]),
+    "r3n_materials_write": (cint, [vp, vp, vp, vp, u32]),
+    "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
+    "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
+    "r3n_uniform_bake": (cint, [vp, u32, vp]),
+    "r3n_cull": (cint, [vp, u32]),
+    "r3n_hi_z": (cint, [vp]),
+    "r3n_shadow_viewport": (cint, [vp, u32, u32, u32, u32]),
+    "r3n_forward": (cint, [vp, u32, u32, u32, u32]),
+    "r3n_resolve_opaque": (cint, [vp]),
+    "r3n_tonemap": (cint, [vp, vp, u64]),
+    "r3n_frame_end": (cint, [vp]),
+    "r3n_set_object_range": (cint, [vp, u32, u32]),
+    "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
+    "r3n_set_row_range": (cint, [vp, u32, u32]),
+    "r3n_output_buffer": (cint, [vp, vp, vp]),
+    "r3n_readback_visible_objects": (cint, [vp, u32, vp, u32]),
+    "r3n_readback_triangle_sets": (cint, [vp, u32, vp, vp, u64]),
+    "r3n_readback_draw_calls": (cint, [vp, u32, vp]),
+    "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
+    "r3n_readback_visibility": (cint, [vp, vp]),
+    "r3n_readback_depth": (cint, [vp, vp]),
+    "r3n_readback_hiz": (cint, [vp, vp, u64]),
+    "r3n_readback_shadow_atlas": (cint, [vp, vp]),
+    "r3n_readback_hdr": (cint, [vp, vp]),
+    "r3n_readback_output": (cint, [vp, vp, vp]),
+    "r3n_timing_enable": (cint, [vp, cint]),
+    "r3n_stage_times": (cint, [vp, vp, vp, cint]),
+    "r3n_host_mat4_mul": (None, [vp, vp, vp]),
+    "r3n_host_mat4_inverse": (None, [vp, vp]),
+    "r3n_host_look_at": (None, [vp, vp, vp, cint, vp]),
+    "r3n_host_projection": (None, [cint, vp, cint, cfloat, vp]),
+    "r3n_host_frustum_from_matrix": (None, [vp, vp]),
+    "r3n_host_frustum_contains_sphere": (cint, [vp, vp, cfloat]),
+    "r3n_host_bounding_sphere_from_mesh": (None, [vp, u64, vp, vp]),
+    "r3n_host_bounding_sphere_apply_transform": (None, [vp, cfloat, vp, vp, vp]),
+    "r3n_host_calculate_normals": (None, [vp, u64, vp, u64, cint, vp]),
+    "r3n_host_shadow_camera": (None, [vp, cfloat, u32, vp, cint, vp, vp]),
+    "r3n_host_allocate_shadow_atlas": (u32, [vp, vp, u32, u32, vp, vp]),
+}
+
+_LIB = None
+
+
+def library_path():
+    return _build.SO
+
+
+def lib():
+    """Loads (building first if needed) the native library.  Raises if that is impossible."""
+    global _LIB
+    if _LIB is None:
+        path = _build.build()
+        if not os.path.exists(path):
+            raise RuntimeError("librend3_amd.so is missing and could not be built; the HIP path has no fallback")
+        l = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError here == the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def ptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], "need a contiguous ndarray"
+    return a.ctypes.data_as(vp)
+
+
+class R3nError(RuntimeError):
+    pass
+
+
+def check(ctx, code, what):
+    if code != 0:
+        msg = lib().r3n_last_error(ctx)
+        raise R3nError(f"{what} failed ({code}): {msg.decode() if msg else ''}")

@@ -1,0 +1,152 @@
+// device_math.h -- f32 helpers shared by the kernels.  Every expression is written with an explicit
+// operation order and the TU is built with -ffp-contract=off, so each op rounds once (no FMA) and the
+// results are bit-identical to the arithmetic contract in DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layouts.h"
+
+#define R3N_DEV __device__ __forceinline__
+
+// m * (x,y,z,w), column-major m: ((c0*x + c1*y) + c2*z) + c3*w
+R3N_DEV void mul_vec4(const float *__restrict__ m, float x, float y, float z, float w, float o[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+// position variant: w == 1 still multiplies (keeps the op sequence identical to the contract)
+R3N_DEV void mul_point(const float *__restrict__ m, const float v[3], float o[4]) { mul_vec4(m, v[0], v[1], v[2], 1.0f, o); }
+
+R3N_DEV float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+R3N_DEV float sat(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+R3N_DEV void normalize3(float v[3]) {
+    float r = 1.0f / sqrtf(dot3(v, v));
+    v[0] *= r; v[1] *= r; v[2] *= r;
+}
+R3N_DEV void mat3_mul_vec3(const float *__restrict__ c0, const float *__restrict__ c1, const float *__restrict__ c2,
+                           const float v[3], float o[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o[r] = (c0[r] * v[0] + c1[r] * v[1]) + c2[r] * v[2];
+}
+
+// determinant(mat3x3(p0.xyw, p1.xyw, p2.xyw)) -- cull.wgsl:272
+R3N_DEV float det3_xyw(const float p0[4], const float p1[4], const float p2[4]) {
+    float ax = p0[0], ay = p0[1], az = p0[3];
+    float bx = p1[0], by = p1[1], bz = p1[3];
+    float cx = p2[0], cy = p2[1], cz = p2[3];
+    return (ax * (by * cz - cy * bz) - bx * (ay * cz - cy * az)) + cx * (ay * bz - by * az);
+}
+
+// ceil(log2(max(x,1))) from the exponent bits: exact, unlike ceil(log2f(x)) (cull.wgsl:314)
+R3N_DEV uint32_t ceil_log2_ge1(float x) {
+    x = fmaxf(x, 1.0f);  // NaN -> 1
+    uint32_t b = __float_as_uint(x);
+    uint32_t e = (b >> 23) & 0xFFu;
+    if (e == 0xFFu) return 1000u;  // +inf
+    uint32_t l = e - 127u;
+    return (b & 0x7FFFFFu) ? l + 1u : l;
+}
+
+// float -> texel index, NaN / out of range made deterministic
+R3N_DEV uint32_t clamp_texel(float v, uint32_t dim) {
+    if (!(v >= 0.0f)) return 0u;
+    float top = (float)(dim - 1u);
+    if (v >= top) return dim - 1u;
+    return (uint32_t)v;
+}
+
+R3N_DEV uint32_t mip_dim(uint32_t d, uint32_t k) {
+    uint32_t v = d >> k;
+    return v ? v : 1u;
+}
+
+// vertex_attributes.wgsl:51-58
+R3N_DEV void fetch_vec3(const uint32_t *__restrict__ mesh, uint32_t byte_off, uint32_t vtx, float o[3]) {
+    const uint32_t w = byte_off / 4u + vtx * 3u;
+    o[0] = __uint_as_float(mesh[w]);
+    o[1] = __uint_as_float(mesh[w + 1u]);
+    o[2] = __uint_as_float(mesh[w + 2u]);
+}
+
+// ---- homogeneous triangle setup (DESIGN.md "Rasteriser contract") --------------------------------
+struct TriSetup {
+    float e[3][3];  // oriented edge functions (A,B,C), inside >= 0
+    float z[3];     // clip-space z per vertex
+    float det;      // oriented determinant (> 0 when valid)
+    bool valid;
+};
+
+// p[k] = clip-space position of vertex k.  Pixel-space homogeneous coords: Xh = (x + w) * W/2,
+// Yh = (w - y) * H/2 (y down), third coordinate w.  e0 = v1 x v2, e1 = v2 x v0, e2 = v0 x v1.
+R3N_DEV void setup_triangle(const float p[3][4], float half_w, float half_h, bool positive_visible, TriSetup &ts) {
+    float h[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        h[k][0] = (p[k][0] + p[k][3]) * half_w;
+        h[k][1] = (p[k][3] - p[k][1]) * half_h;
+        h[k][2] = p[k][3];
+        ts.z[k] = p[k][2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float *a = h[(i + 1) % 3], *b = h[(i + 2) % 3];
+        ts.e[i][0] = a[1] * b[2] - a[2] * b[1];
+        ts.e[i][1] = a[2] * b[0] - a[0] * b[2];
+        ts.e[i][2] = a[0] * b[1] - a[1] * b[0];
+    }
+    float det = (h[0][0] * ts.e[0][0] + h[0][1] * ts.e[0][1]) + h[0][2] * ts.e[0][2];
+    ts.valid = positive_visible ? (det < 0.0f) : (det > 0.0f);
+    if (det < 0.0f) {
+        det = -det;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ts.e[i][c] = -ts.e[i][c];
+    }
+    ts.det = det;
+}
+
+// Edge functions at a pixel centre; true when covered under the top-left rule.
+R3N_DEV bool edge_eval(const TriSetup &ts, float px, float py, float E[3]) {
+    bool in = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float A = ts.e[i][0], B = ts.e[i][1];
+        const float v = (A * px + B * py) + ts.e[i][2];
+        E[i] = v;
+        const bool ok = (v > 0.0f) || (v == 0.0f && (A > 0.0f || (A == 0.0f && B > 0.0f)));
+        in = in && ok;
+    }
+    return in;
+}
+
+R3N_DEV float frag_depth(const TriSetup &ts, const float E[3]) {
+    float z = ((E[0] * ts.z[0] + E[1] * ts.z[1]) + E[2] * ts.z[2]) / ts.det;
+    return z;
+}
+
+// Conservative integer pixel bounds inside a (vw x vh) viewport; empty when x1 < x0 or y1 < y0.
+R3N_DEV void tri_bounds(const float p[3][4], float half_w, float half_h, int vw, int vh, int &x0, int &y0, int &x1,
+                        int &y1) {
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    bool all_front = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!(p[k][3] > 0.0f)) all_front = false;
+        const float sx = (p[k][0] / p[k][3] + 1.0f) * half_w;
+        const float sy = (1.0f - p[k][1] / p[k][3]) * half_h;
+        mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx);
+        mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+    }
+    // fminf/fmaxf drop NaNs, so test the inputs for NaN through the results' finiteness instead
+    const bool finite = (mnx - mnx == 0.0f) && (mny - mny == 0.0f) && (mxx - mxx == 0.0f) && (mxy - mxy == 0.0f);
+    if (!all_front || !finite) {
+        x0 = 0; y0 = 0; x1 = vw - 1; y1 = vh - 1;
+        return;
+    }
+    const float fx0 = floorf(mnx) - 1.0f, fy0 = floorf(mny) - 1.0f, fx1 = ceilf(mxx) + 1.0f, fy1 = ceilf(mxy) + 1.0f;
+    const float wm = (float)(vw - 1), hm = (float)(vh - 1);
+    x0 = fx0 < 0.0f ? 0 : (fx0 > wm ? vw : (int)fx0);
+    y0 = fy0 < 0.0f ? 0 : (fy0 > hm ? vh : (int)fy0);
+    x1 = fx1 < 0.0f ? -1 : (fx1 > wm ? vw - 1 : (int)fx1);
+    y1 = fy1 < 0.0f ? -1 : (fy1 > hm ? vh - 1 : (int)fy1);
+}

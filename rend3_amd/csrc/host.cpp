@@ -1,0 +1,336 @@
+// host.cpp -- host-side mirror of the reference's CPU math on the hot path (the r3n_host_* half of
+// include/r3n.h).  In a real rend3 integration this stays in Rust (rend3 core + glam); it exists so the
+// standalone harness and bench can build the C-ABI's inputs.  f32 throughout, fixed operation order,
+// built with -ffp-contract=off (DESIGN.md "Arithmetic contract").
+//
+// Follows (reference file:line):
+//   CameraState / compute_projection_matrix   rend3/src/managers/camera.rs:23-114
+//   Frustum::from_matrix, contains_sphere     rend3/src/util/frustum.rs:96-161
+//   BoundingSphere                            rend3/src/util/frustum.rs:15-56
+//   shadow_camera                             rend3/src/managers/directional/shadow_camera.rs:6-33
+//   allocate_shadow_atlas                     rend3/src/managers/directional/shadow_alloc.rs:59-136
+//   calculate_normals_for_buffers             rend3-types/src/lib.rs:662-704
+//   glam 0.25 (un-vendored, rend3/Cargo.toml:43): look_at_*, orthographic_*,
+//   perspective_infinite_reverse_*, Mat4 mul/inverse -- restated from its documented conventions
+//   (SURVEY.md App. E).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "../../include/r3n.h"
+
+namespace {
+
+inline void mul_vec4(const float *m, float x, float y, float z, float w, float *o) {
+    for (int r = 0; r < 4; ++r) o[r] = ((m[r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline void cross3(const float *a, const float *b, float *o) {
+    float x = a[1] * b[2] - a[2] * b[1];
+    float y = a[2] * b[0] - a[0] * b[2];
+    float z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+inline void normalize3(float *v) {
+    float r = 1.0f / std::sqrt(dot3(v, v));
+    v[0] *= r; v[1] *= r; v[2] *= r;
+}
+
+// glam look_to_{lh,rh}
+void look_to(const float *eye, const float *fwd, const float *up, int rh, float *m) {
+    float f[3] = {fwd[0], fwd[1], fwd[2]};
+    normalize3(f);
+    float s[3], u[3];
+    if (rh) {
+        cross3(f, up, s);
+        normalize3(s);
+        cross3(s, f, u);
+        float cols[16] = {s[0], u[0], -f[0], 0, s[1], u[1], -f[1], 0, s[2], u[2], -f[2], 0,
+                          -dot3(eye, s), -dot3(eye, u), dot3(eye, f), 1};
+        std::memcpy(m, cols, sizeof cols);
+    } else {
+        cross3(up, f, s);
+        normalize3(s);
+        cross3(f, s, u);
+        float cols[16] = {s[0], u[0], f[0], 0, s[1], u[1], f[1], 0, s[2], u[2], f[2], 0,
+                          -dot3(eye, s), -dot3(eye, u), -dot3(eye, f), 1};
+        std::memcpy(m, cols, sizeof cols);
+    }
+}
+
+void orthographic(float l, float r, float b, float t, float n, float f, int rh, float *m) {
+    float rw = 1.0f / (r - l);
+    float rhh = 1.0f / (t - b);
+    float rd = rh ? 1.0f / (n - f) : 1.0f / (f - n);
+    std::memset(m, 0, 16 * sizeof(float));
+    m[0] = rw + rw;
+    m[5] = rhh + rhh;
+    m[10] = rd;
+    m[12] = -(l + r) * rw;
+    m[13] = -(t + b) * rhh;
+    m[14] = rh ? rd * n : -rd * n;
+    m[15] = 1.0f;
+}
+
+}  // namespace
+
+extern "C" {
+
+void r3n_host_mat4_mul(const float *a, const float *b, float *out) {
+    float tmp[16];
+    for (int c = 0; c < 4; ++c) mul_vec4(a, b[4 * c], b[4 * c + 1], b[4 * c + 2], b[4 * c + 3], tmp + 4 * c);
+    std::memcpy(out, tmp, sizeof tmp);
+}
+
+void r3n_host_mat4_inverse(const float *m, float *out) {
+    // cofactor expansion; m[4*c + r]
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+    const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+    const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+    const float m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
+    const float c00 = m22 * m33 - m32 * m23;
+    const float c02 = m12 * m33 - m32 * m13;
+    const float c03 = m12 * m23 - m22 * m13;
+    const float c04 = m21 * m33 - m31 * m23;
+    const float c06 = m11 * m33 - m31 * m13;
+    const float c07 = m11 * m23 - m21 * m13;
+    const float c08 = m21 * m32 - m31 * m22;
+    const float c10 = m11 * m32 - m31 * m12;
+    const float c11 = m11 * m22 - m21 * m12;
+    const float c12 = m20 * m33 - m30 * m23;
+    const float c14 = m10 * m33 - m30 * m13;
+    const float c15 = m10 * m23 - m20 * m13;
+    const float c16 = m20 * m32 - m30 * m22;
+    const float c18 = m10 * m32 - m30 * m12;
+    const float c19 = m10 * m22 - m20 * m12;
+    const float c20 = m20 * m31 - m30 * m21;
+    const float c22 = m10 * m31 - m30 * m11;
+    const float c23 = m10 * m21 - m20 * m11;
+    const float i00 = (m11 * c00 - m12 * c04) + m13 * c08;
+    const float i01 = -((m01 * c00 - m02 * c04) + m03 * c08);
+    const float i02 = (m01 * c02 - m02 * c06) + m03 * c10;
+    const float i03 = -((m01 * c03 - m02 * c07) + m03 * c11);
+    const float i10 = -((m10 * c00 - m12 * c12) + m13 * c16);
+    const float i11 = (m00 * c00 - m02 * c12) + m03 * c16;
+    const float i12 = -((m00 * c02 - m02 * c14) + m03 * c18);
+    const float i13 = (m00 * c03 - m02 * c15) + m03 * c19;
+    const float i20 = (m10 * c04 - m11 * c12) + m13 * c20;
+    const float i21 = -((m00 * c04 - m01 * c12) + m03 * c20);
+    const float i22 = (m00 * c06 - m01 * c14) + m03 * c22;
+    const float i23 = -((m00 * c07 - m01 * c15) + m03 * c23);
+    const float i30 = -((m10 * c08 - m11 * c16) + m12 * c20);
+    const float i31 = (m00 * c08 - m01 * c16) + m02 * c20;
+    const float i32 = -((m00 * c10 - m01 * c18) + m02 * c22);
+    const float i33 = (m00 * c11 - m01 * c19) + m02 * c23;
+    const float det = ((m00 * i00 + m01 * i10) + m02 * i20) + m03 * i30;
+    const float rdet = 1.0f / det;
+    const float inv[16] = {i00, i01, i02, i03, i10, i11, i12, i13, i20, i21, i22, i23, i30, i31, i32, i33};
+    for (int k = 0; k < 16; ++k) out[k] = inv[k] * rdet;
+}
+
+void r3n_host_look_at(const float eye[3], const float center[3], const float up[3], int rh, float *out) {
+    float dir[3] = {center[0] - eye[0], center[1] - eye[1], center[2] - eye[2]};
+    look_to(eye, dir, up, rh, out);
+}
+
+void r3n_host_projection(int kind, const float *params, int rh, float aspect_ratio, float *out) {
+    if (kind == 0) {
+        // camera.rs:90-97: near = +half.z, far = -half.z  => reverse-Z
+        float hx = params[0] * 0.5f, hy = params[1] * 0.5f, hz = params[2] * 0.5f;
+        orthographic(-hx, hx, -hy, hy, hz, -hz, rh, out);
+    } else {
+        // glam perspective_infinite_reverse_{lh,rh}; sin/cos evaluated in double, rounded once
+        float fov = params[0] * 0.017453292519943295f;
+        float half = 0.5f * fov;
+        float s = (float)std::sin((double)half), c = (float)std::cos((double)half);
+        float h = c / s;
+        float w = h / aspect_ratio;
+        std::memset(out, 0, 16 * sizeof(float));
+        out[0] = w;
+        out[5] = h;
+        out[11] = rh ? -1.0f : 1.0f;
+        out[14] = params[1];
+    }
+}
+
+void r3n_host_frustum_from_matrix(const float *m, float *planes) {
+    const float sgn[5] = {1.0f, -1.0f, -1.0f, 1.0f, -1.0f};
+    const int row[5] = {0, 0, 1, 1, 2};
+    for (int p = 0; p < 5; ++p) {
+        float a = m[3] + sgn[p] * m[row[p]];
+        float b = m[7] + sgn[p] * m[4 + row[p]];
+        float c = m[11] + sgn[p] * m[8 + row[p]];
+        float d = m[15] + sgn[p] * m[12 + row[p]];
+        float mag = std::sqrt((a * a + b * b) + c * c);
+        planes[4 * p + 0] = a / mag;
+        planes[4 * p + 1] = b / mag;
+        planes[4 * p + 2] = c / mag;
+        planes[4 * p + 3] = d / mag;
+    }
+}
+
+int r3n_host_frustum_contains_sphere(const float *planes, const float center[3], float radius) {
+    float neg_radius = -radius;
+    for (int p = 0; p < 5; ++p) {
+        float dist = dot3(planes + 4 * p, center) + planes[4 * p + 3];
+        if (!(dist >= neg_radius)) return 0;
+    }
+    return 1;
+}
+
+void r3n_host_bounding_sphere_from_mesh(const float *positions, uint64_t n, float out_center[3], float *out_radius) {
+    if (n == 0) {
+        out_center[0] = out_center[1] = out_center[2] = 0.0f;
+        *out_radius = 0.0f;
+        return;
+    }
+    float mx[3] = {positions[0], positions[1], positions[2]}, mn[3] = {positions[0], positions[1], positions[2]};
+    for (uint64_t i = 1; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            mx[c] = std::max(mx[c], positions[3 * i + c]);
+            mn[c] = std::min(mn[c], positions[3 * i + c]);
+        }
+    for (int c = 0; c < 3; ++c) out_center[c] = (mx[c] + mn[c]) / 2.0f;
+    float r = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) {
+        float d[3] = {positions[3 * i] - out_center[0], positions[3 * i + 1] - out_center[1],
+                      positions[3 * i + 2] - out_center[2]};
+        r = std::max(r, std::sqrt(dot3(d, d)));
+    }
+    *out_radius = r;
+}
+
+void r3n_host_bounding_sphere_apply_transform(const float center[3], float radius, const float *m, float out_center[3],
+                                              float *out_radius) {
+    float l0 = dot3(m, m), l1 = dot3(m + 4, m + 4), l2 = dot3(m + 8, m + 8);
+    float max_scale = std::sqrt(std::max(l0, std::max(l1, l2)));
+    float c[4];
+    mul_vec4(m, center[0], center[1], center[2], 1.0f, c);
+    out_center[0] = c[0]; out_center[1] = c[1]; out_center[2] = c[2];
+    *out_radius = max_scale * radius;
+}
+
+void r3n_host_calculate_normals(const float *positions, uint64_t vertex_count, const uint32_t *indices,
+                                uint64_t index_count, int left_handed, float *normals) {
+    std::memset(normals, 0, sizeof(float) * 3 * vertex_count);
+    for (uint64_t t = 0; t + 2 < index_count; t += 3) {
+        const float *p1 = positions + 3 * (uint64_t)indices[t];
+        const float *p2 = positions + 3 * (uint64_t)indices[t + 1];
+        const float *p3 = positions + 3 * (uint64_t)indices[t + 2];
+        float e1[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+        float e2[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]};
+        float n[3];
+        if (left_handed) cross3(e1, e2, n); else cross3(e2, e1, n);
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) normals[3 * (uint64_t)indices[t + k] + c] += n[c];
+    }
+    for (uint64_t i = 0; i < vertex_count; ++i) {
+        float *n = normals + 3 * i;
+        float rcp = 1.0f / std::sqrt(dot3(n, n));  // glam normalize_or_zero
+        if (std::isfinite(rcp) && rcp > 0.0f) { n[0] *= rcp; n[1] *= rcp; n[2] *= rcp; }
+        else { n[0] = n[1] = n[2] = 0.0f; }
+    }
+}
+
+void r3n_host_shadow_camera(const float direction[3], float distance, uint32_t resolution,
+                            const float camera_location[3], int rh, float *out_view, float *out_proj) {
+    const float zero[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+    float texel = distance / (float)resolution;
+    float origin_view[16];
+    look_to(zero, direction, up, rh, origin_view);
+    float cov[4];
+    mul_vec4(origin_view, camera_location[0], camera_location[1], camera_location[2], 1.0f, cov);
+    float off[2] = {std::fmod(cov[0], texel), std::fmod(cov[1], texel)};  // Rust f32 `%`
+    float shadow_loc[3] = {cov[0] - off[0], cov[1] - off[1], cov[2] - 0.0f};
+    float inv_origin_view[16];
+    r3n_host_mat4_inverse(origin_view, inv_origin_view);
+    float nl[4];
+    mul_vec4(inv_origin_view, shadow_loc[0], shadow_loc[1], shadow_loc[2], 1.0f, nl);
+    float centre[3] = {nl[0] + direction[0], nl[1] + direction[1], nl[2] + direction[2]};
+    r3n_host_look_at(nl, centre, up, rh, out_view);
+    float size[3] = {distance, distance, distance};
+    r3n_host_projection(0, size, rh, 1.0f, out_proj);
+}
+
+uint32_t r3n_host_allocate_shadow_atlas(const uint32_t *handles, const uint16_t *resolutions, uint32_t n,
+                                        uint32_t max_dimension, uint32_t out_dimensions[2], uint32_t *out_maps) {
+    if (n == 0 || max_dimension == 0) return 0;
+    struct Map { uint32_t handle; uint16_t res; };
+    std::vector<Map> maps(n);
+    for (uint32_t i = 0; i < n; ++i) maps[i] = {handles[i], resolutions[i]};
+    std::stable_sort(maps.begin(), maps.end(), [](const Map &a, const Map &b) { return a.res > b.res; });
+    auto lz16 = [](uint16_t v) { uint32_t k = 0; for (int b = 15; b >= 0 && !((v >> b) & 1); --b) ++k; return k; };
+
+    enum Kind { Vacant, Leaf, Children };
+    struct Node { Kind kind; uint32_t handle; uint32_t child[4]; };
+    std::vector<Node> nodes;
+    std::vector<uint32_t> roots;
+    nodes.push_back({Vacant, 0, {0, 0, 0, 0}});
+    roots.push_back(0);
+    struct Alloc {
+        std::vector<Node> &nodes;
+        bool run(uint32_t idx, uint32_t order, uint32_t handle) {
+            Kind k = nodes[idx].kind;
+            if (k == Vacant) {
+                if (order == 0) { nodes[idx].kind = Leaf; nodes[idx].handle = handle; return true; }
+                uint32_t base = (uint32_t)nodes.size();
+                nodes[idx].kind = Children;
+                for (uint32_t c = 0; c < 4; ++c) nodes[idx].child[c] = base + c;
+                for (uint32_t c = 0; c < 4; ++c) nodes.push_back({Vacant, 0, {0, 0, 0, 0}});
+                return run(idx, order, handle);
+            }
+            if (k == Leaf) return false;
+            if (order == 0) return false;
+            for (uint32_t c = 0; c < 4; ++c) {
+                uint32_t ch = nodes[idx].child[c];
+                if (run(ch, order - 1, handle)) return true;
+            }
+            return false;
+        }
+    } alloc{nodes};
+
+    uint32_t root_size = maps[0].res;
+    uint32_t min_lz = lz16((uint16_t)root_size);
+    for (const Map &m : maps) {
+        uint32_t order = lz16(m.res) - min_lz;
+        for (;;) {
+            if (alloc.run(roots.back(), order, m.handle)) break;
+            nodes.push_back({Vacant, 0, {0, 0, 0, 0}});
+            roots.push_back((uint32_t)nodes.size() - 1);
+        }
+    }
+    uint32_t available_columns = max_dimension / root_size;
+    float root_count = (float)roots.size();
+    float rows_needed = std::ceil(root_count / (float)available_columns);
+    uint32_t columns_needed = (uint32_t)std::ceil(root_count / rows_needed);
+    out_dimensions[0] = columns_needed * root_size;
+    out_dimensions[1] = (uint32_t)rows_needed * root_size;
+
+    struct Visit { uint32_t div, ox, oy, node; };
+    std::deque<Visit> queue;
+    for (uint32_t i = 0; i < roots.size(); ++i)
+        queue.push_back({1, (i % columns_needed) * root_size, (i / columns_needed) * root_size, roots[i]});
+    uint32_t written = 0;
+    while (!queue.empty()) {
+        Visit v = queue.front();
+        queue.pop_front();
+        uint32_t size = root_size / v.div, half = size / 2;
+        const Node &nd = nodes[v.node];
+        if (nd.kind == Leaf) {
+            out_maps[4 * written + 0] = v.ox;
+            out_maps[4 * written + 1] = v.oy;
+            out_maps[4 * written + 2] = size;
+            out_maps[4 * written + 3] = nd.handle;
+            ++written;
+        } else if (nd.kind == Children) {
+            for (uint32_t c = 0; c < 4; ++c)
+                queue.push_back({v.div * 2, v.ox + half * (c % 2), v.oy + half * (c / 2), nd.child[c]});
+        }
+    }
+    return written;
+}
+
+}  // extern "C"

@@ -1,0 +1,434 @@
+// kernels_cull.h -- uniform bake (K1), object-level frustum cull + device-side slot assignment (B1 moved
+// to the GPU), per-triangle cull + LDS-staged compaction into per-region indirect calls (K2).
+//
+// Reference behaviour restated (file:line):
+//   uniform_prep.wgsl:9-27, culler.rs:427-529          k_uniform_bake
+//   batching.rs:134-170,191-236, frustum.rs:148-161    k_object_count / k_object_scan / k_object_scatter
+//   cull.wgsl:264-324 (execute_culling), :326-390      k_triangle_cull
+//
+// Shape changes vs. the reference (results identical): no 256-object batches, no CPU sort,
+// one launch per camera; objects own whole wavefronts (64 triangle slots) so matrices are wave-uniform;
+// compaction = wave ballot + popcount, staged through LDS per 4096-slot chunk, one global atomic per
+// (chunk, list, region) instead of one per triangle.
+#pragma once
+#include "device_math.h"
+
+// ------------------------------------------------------------------------------------------------ K1
+// 4 threads per object: thread c bakes column c of model_view and model_view_proj.  Consecutive threads
+// read consecutive 16-byte columns (fully coalesced) and write two 16-byte columns.
+__global__ __launch_bounds__(256) void k_uniform_bake(const r3n_camera_header240 *__restrict__ hdr,
+                                                      const r3n_object128 *__restrict__ objects,
+                                                      r3n_baked128 *__restrict__ baked) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t obj = gid >> 2, c = gid & 3u;
+    if (obj >= hdr->object_count) return;            // uniform_prep.wgsl:15-17
+    if (objects[obj].enabled == 0u) return;          // :18-20 (stale matrices stay, App. D.2)
+    const float4 col = reinterpret_cast<const float4 *>(objects[obj].transform)[c];
+    float mv[4], mvp[4];
+    mul_vec4(hdr->view, col.x, col.y, col.z, col.w, mv);
+    mul_vec4(hdr->view_proj, col.x, col.y, col.z, col.w, mvp);
+    reinterpret_cast<float4 *>(baked[obj].model_view)[c] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    reinterpret_cast<float4 *>(baked[obj].model_view_proj)[c] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ object pass
+struct ObjBlockSums {
+    uint32_t visible, waves, tris_all, key_tris[3];
+};
+
+R3N_DEV uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Pass A: frustum test (batching.rs:146, frustum.rs:148-161) + per-block totals.
+__global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240 *__restrict__ hdr,
+                                                      const r3n_object128 *__restrict__ objects,
+                                                      const uint8_t *__restrict__ material_keys, uint32_t n_materials,
+                                                      uint32_t range_begin, uint32_t range_end,
+                                                      uint8_t *__restrict__ vis_flags,
+                                                      ObjBlockSums *__restrict__ block_sums) {
+    __shared__ uint32_t red[4][6];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t cap = hdr->object_count;
+    uint32_t flag = 0, ntri_all = 0, ntri_vis = 0, key = 0;
+    if (i < cap) {
+        const r3n_object128 *o = &objects[i];
+        const uint32_t enabled = o->enabled;
+        const uint32_t ntri = enabled ? o->index_count / 3u : 0u;
+        ntri_all = ntri;
+        if (ntri > 0u && i >= range_begin && i < range_end) {
+            const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
+            const float c[3] = {sph.x, sph.y, sph.z};
+            const float neg_radius = -sph.w;
+            bool inside = true;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
+                inside = inside && (d >= neg_radius);
+            }
+            flag = inside ? 1u : 0u;
+        }
+        if (flag) {
+            ntri_vis = ntri;
+            const uint32_t mi = o->material_index;
+            key = mi < n_materials ? material_keys[mi] : 0u;
+            if (key > 2u) key = 2u;
+        }
+        vis_flags[i] = (uint8_t)flag;
+    }
+    uint32_t vals[6] = {flag, flag ? (ntri_vis + 63u) / 64u : 0u, ntri_all, key == 0u ? ntri_vis : 0u,
+                        key == 1u ? ntri_vis : 0u, key == 2u ? ntri_vis : 0u};
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t s = wave_reduce_add(vals[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t k = threadIdx.x;
+        const uint32_t s = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&block_sums[blockIdx.x]);
+        dst[k] = s;
+    }
+}
+
+struct ObjBlockOffsets {
+    uint32_t visible, waves, tris_all;
+};
+
+// Pass B: one block scans the per-block totals, derives region bases and resets the indirect calls
+// (culler.rs:642 clear_buffer + cull.wgsl:47-61 init_draw_calls).
+__global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__restrict__ block_sums, uint32_t nblocks,
+                                                      ObjBlockOffsets *__restrict__ block_off,
+                                                      r3n_cull_counts *__restrict__ counts,
+                                                      r3n_vis_entry *__restrict__ vis_list,
+                                                      r3n_indirect_call *__restrict__ calls /* [6] */) {
+    __shared__ uint32_t sh[3][1024];
+    __shared__ uint32_t carry[3];
+    __shared__ uint32_t ktot[3];
+    const uint32_t t = threadIdx.x;
+    if (t < 3) { carry[t] = 0; ktot[t] = 0; }
+    __syncthreads();
+    uint32_t kacc[3] = {0, 0, 0};
+    for (uint32_t base = 0; base < nblocks; base += 1024u) {
+        const uint32_t b = base + t;
+        uint32_t v[3] = {0, 0, 0};
+        if (b < nblocks) {
+            v[0] = block_sums[b].visible; v[1] = block_sums[b].waves; v[2] = block_sums[b].tris_all;
+            kacc[0] += block_sums[b].key_tris[0]; kacc[1] += block_sums[b].key_tris[1]; kacc[2] += block_sums[b].key_tris[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sh[k][t] = v[k];
+        __syncthreads();
+        // Hillis-Steele inclusive scan over 1024 entries (tiny: one block, runs once per camera)
+        for (uint32_t off = 1; off < 1024u; off <<= 1) {
+            uint32_t add[3] = {0, 0, 0};
+            if (t >= off) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) add[k] = sh[k][t - off];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sh[k][t] += add[k];
+            __syncthreads();
+        }
+        if (b < nblocks) {
+            block_off[b].visible = carry[0] + sh[0][t] - v[0];
+            block_off[b].waves = carry[1] + sh[1][t] - v[1];
+            block_off[b].tris_all = carry[2] + sh[2][t] - v[2];
+        }
+        __syncthreads();
+        if (t < 3) carry[t] += sh[t][1023];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (kacc[k]) atomicAdd(&ktot[k], kacc[k]);
+    __syncthreads();
+    if (t == 0) {
+        counts->visible_objects = carry[0];
+        counts->total_waves = carry[1];
+        counts->total_triangles = carry[2];
+        uint32_t base = 0;
+        for (int k = 0; k < 3; ++k) {
+            counts->key_triangles[k] = ktot[k];
+            counts->region_base[k] = base;
+            for (int list = 0; list < 2; ++list) {
+                r3n_indirect_call *c = &calls[list * 3 + k];
+                c->vertex_count = 0;
+                c->instance_count = 1;
+                c->base_index = base * 3u;  // cull.wgsl:53 base_index = first slot * 3
+                c->vertex_offset = 0;
+                c->base_instance = 0;
+            }
+            base += ktot[k];
+        }
+        vis_list[carry[0]].object = R3N_INVALID;  // sentinel
+        vis_list[carry[0]].wave_start = carry[1];
+    }
+}
+
+R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o, 64);
+        if (lane >= (uint32_t)o) v += n;
+    }
+    return v;
+}
+
+// Pass C: scatter visible objects into the work list (object-slot order => deterministic layout).
+// slot_base[i] = first triangle slot of object i in this frame's result bitmask, or INVALID when the object
+// was not batched (== "not in current_invocation_map", batching.rs:226,230).  tri_base[i] = canonical base.
+__global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header240 *__restrict__ hdr,
+                                                        const r3n_object128 *__restrict__ objects,
+                                                        const uint8_t *__restrict__ vis_flags,
+                                                        const ObjBlockOffsets *__restrict__ block_off,
+                                                        r3n_vis_entry *__restrict__ vis_list,
+                                                        uint32_t *__restrict__ slot_base,
+                                                        uint32_t *__restrict__ tri_base) {
+    __shared__ uint32_t wtot[4][3];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t cap = hdr->object_count;
+    uint32_t flag = 0, nw = 0, ntri = 0;
+    if (i < cap) {
+        flag = vis_flags[i];
+        ntri = objects[i].enabled ? objects[i].index_count / 3u : 0u;
+        nw = flag ? (ntri + 63u) / 64u : 0u;
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t s0 = wave_inclusive_scan(flag, lane);
+    const uint32_t s1 = wave_inclusive_scan(nw, lane);
+    const uint32_t s2 = wave_inclusive_scan(ntri, lane);
+    if (lane == 63u) { wtot[wave][0] = s0; wtot[wave][1] = s1; wtot[wave][2] = s2; }
+    __syncthreads();
+    uint32_t p0 = block_off[blockIdx.x].visible, p1 = block_off[blockIdx.x].waves, p2 = block_off[blockIdx.x].tris_all;
+    for (uint32_t w = 0; w < wave; ++w) { p0 += wtot[w][0]; p1 += wtot[w][1]; p2 += wtot[w][2]; }
+    if (i < cap) {
+        const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
+        if (flag) {
+            vis_list[e].object = i;
+            vis_list[e].wave_start = ws;
+        }
+        slot_base[i] = flag ? ws * 64u : R3N_INVALID;
+        if (tri_base != nullptr) tri_base[i] = p2 + s2 - ntri;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+struct HizView {
+    const float *__restrict__ data;
+    r3n_hiz_desc d;
+};
+
+// cull.wgsl:243-262 (textureSampleMin) on the linear f32 pyramid
+R3N_DEV float hiz_sample_min(const HizView &hz, float u, float v, uint32_t mip) {
+    const uint32_t mw = mip_dim(hz.d.width, mip), mh = mip_dim(hz.d.height, mip);
+    const float *tex = hz.data + hz.d.offset[mip];
+    const float px = u * (float)mw - 0.5f;
+    const float py = v * (float)mh - 0.5f;
+    const uint32_t lx = clamp_texel(fmaxf(floorf(px), 0.0f), mw);
+    const uint32_t ly = clamp_texel(fmaxf(floorf(py), 0.0f), mh);
+    const uint32_t hx = clamp_texel(fminf(ceilf(px), (float)mw - 1.0f), mw);
+    const uint32_t hy = clamp_texel(fminf(ceilf(py), (float)mh - 1.0f), mh);
+    float m = tex[ly * mw + lx];
+    m = fminf(m, tex[ly * mw + hx]);
+    m = fminf(m, tex[hy * mw + lx]);
+    m = fminf(m, tex[hy * mw + hx]);
+    return m;
+}
+
+// cull.wgsl:264-324
+R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3], uint32_t flags, bool shadow,
+                             float res_x, float res_y, const HizView &hz) {
+    float p[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mul_point(mvp, v[k], p[k]);
+    const float det = det3_xyw(p[0], p[1], p[2]);
+    if (flags & R3N_PCU_POSITIVE_AREA_VISIBLE) {
+        if (det <= 0.0f) return false;
+    } else {
+        if (det >= 0.0f) return false;
+    }
+    float ndc[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ndc[k][c] = p[k][c] / p[k][3];
+    float mn[2], mx[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        mn[c] = fminf(ndc[0][c], fminf(ndc[1][c], ndc[2][c]));
+        mx[c] = fmaxf(ndc[0][c], fmaxf(ndc[1][c], ndc[2][c]));
+    }
+    const float half_res[2] = {res_x / 2.0f, res_y / 2.0f};
+    float smin[2], smax[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        smin[c] = (mn[c] + 1.0f) * half_res[c];
+        smax[c] = (mx[c] + 1.0f) * half_res[c];
+    }
+    if (!(flags & R3N_PCU_MULTISAMPLED)) {
+        // WGSL round() is ties-to-even == v_rndne_f32
+        if (rintf(smin[0]) == rintf(smax[0]) || rintf(smin[1]) == rintf(smax[1])) return false;
+    }
+    if (shadow) return true;  // cull.wgsl:300-303
+
+    float mintc[2] = {(mn[0] + 1.0f) / 2.0f, (mn[1] + 1.0f) / 2.0f};
+    float maxtc[2] = {(mx[0] + 1.0f) / 2.0f, (mx[1] + 1.0f) / 2.0f};
+    mintc[1] = 1.0f - mintc[1];
+    maxtc[1] = 1.0f - maxtc[1];
+    const float uv[2] = {(maxtc[0] + mintc[0]) / 2.0f, (maxtc[1] + mintc[1]) / 2.0f};
+    const float longest = fmaxf(smax[0] - smin[0], smax[1] - smin[1]);
+    uint32_t mip = ceil_log2_ge1(longest);
+    if (mip > hz.d.mips - 1u) mip = hz.d.mips - 1u;  // App. D.1: clamp to the last level
+    const float depth = fmaxf(fmaxf(ndc[0][2], ndc[1][2]), ndc[2][2]);
+    const float occ = hiz_sample_min(hz, uv[0], uv[1], mip);
+    if (depth < occ) return false;
+    return true;
+}
+
+#define R3N_CHUNK_ITERS 16u                      // wave slots per wavefront per chunk
+#define R3N_CHUNK_WAVES (4u * R3N_CHUNK_ITERS)   // wave slots per 256-thread block per chunk (4096 triangles)
+
+struct TriCullArgs {
+    const r3n_camera_header240 *hdr;
+    const r3n_object128 *objects;
+    const uint32_t *mesh;
+    const r3n_baked128 *baked;
+    const uint8_t *material_keys;
+    uint32_t n_materials;
+    const r3n_vis_entry *vis_list;
+    const r3n_cull_counts *counts;
+    const uint32_t *prev_slot_base;       // per object, INVALID when absent last frame; may be null
+    const unsigned long long *prev_mask;  // may be null
+    unsigned long long *mask;             // one u64 per wave slot
+    r3n_tri_ref *predicted;
+    r3n_tri_ref *residual;                // null for shadow cameras
+    r3n_indirect_call *calls;             // [0..3) predicted, [3..6) residual
+    HizView hiz;
+};
+
+// Persistent kernel: block b processes chunks b, b+grid, ... ; within a chunk wavefront w owns
+// R3N_CHUNK_ITERS consecutive wave slots.  Per-iteration ballots are staged in LDS, then one thread per
+// (list, region) reserves output space for the whole 4096-slot chunk with a single global atomic.
+__global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
+    __shared__ unsigned long long s_pass[4][R3N_CHUNK_ITERS];
+    __shared__ unsigned long long s_resid[4][R3N_CHUNK_ITERS];
+    __shared__ uint32_t s_obj[4][R3N_CHUNK_ITERS];
+    __shared__ uint32_t s_tri0[4][R3N_CHUNK_ITERS];
+    __shared__ uint32_t s_key[4][R3N_CHUNK_ITERS];
+    __shared__ uint32_t cnt[4][6];    // per wave: [list*3 + key] passing triangles in this chunk
+    __shared__ uint32_t base[4][6];   // per wave: first output entry for (list,key)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = a.counts->total_waves;
+    const uint32_t nvis = a.counts->visible_objects;
+    const uint32_t nchunks = (total_waves + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
+    const uint32_t flags = a.hdr->flags;
+    const bool shadow = a.hdr->shadow_index != R3N_INVALID;
+    const float res_x = a.hdr->resolution[0], res_y = a.hdr->resolution[1];
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint32_t region_base[3] = {a.counts->region_base[0], a.counts->region_base[1], a.counts->region_base[2]};
+
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t w0 = chunk * R3N_CHUNK_WAVES + wave * R3N_CHUNK_ITERS;
+        // locate the entry owning wave slot w0: last e with wave_start[e] <= w0 (wave-uniform binary search)
+        uint32_t e = 0, next_start = 0;
+        if (w0 < total_waves) {
+            uint32_t lo = 0, hi = nvis;
+            while (hi - lo > 1u) {
+                const uint32_t mid = lo + (hi - lo) / 2u;
+                if (a.vis_list[mid].wave_start <= w0) lo = mid; else hi = mid;
+            }
+            e = lo;
+            next_start = a.vis_list[e + 1u].wave_start;
+        }
+        uint32_t c_p0 = 0, c_p1 = 0, c_p2 = 0, c_r0 = 0, c_r1 = 0, c_r2 = 0;
+
+#pragma unroll 1
+        for (uint32_t it = 0; it < R3N_CHUNK_ITERS; ++it) {
+            const uint32_t w = w0 + it;
+            unsigned long long ballot = 0, resid = 0;
+            uint32_t obj = 0, wrel = 0, key = 0;
+            if (w < total_waves) {
+                while (w >= next_start) { ++e; next_start = a.vis_list[e + 1u].wave_start; }
+                obj = __builtin_amdgcn_readfirstlane(a.vis_list[e].object);
+                wrel = w - __builtin_amdgcn_readfirstlane(a.vis_list[e].wave_start);
+                const r3n_object128 *ob = &a.objects[obj];
+                const uint32_t ntri = ob->index_count / 3u;
+                const uint32_t tri = wrel * 64u + lane;
+                bool pass = false;
+                if (tri < ntri) {
+                    const uint32_t first = ob->first_index + tri * 3u;
+                    const uint32_t pos_off = ob->vertex_attribute_start_offsets[0];
+                    float v[3][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, pos_off, a.mesh[first + (uint32_t)k], v[k]);
+                    pass = execute_culling(a.baked[obj].model_view_proj, v, flags, shadow, res_x, res_y, a.hiz);
+                }
+                ballot = __ballot(pass);
+                if (!shadow) {
+                    unsigned long long prev = 0;
+                    if (a.prev_slot_base != nullptr) {
+                        const uint32_t pb = a.prev_slot_base[obj];
+                        if (pb != R3N_INVALID) prev = a.prev_mask[pb / 64u + wrel];  // cull.wgsl:152-160
+                    }
+                    resid = ballot & ~prev;
+                }
+                if (lane == 0) a.mask[w] = ballot;  // cull.wgsl:229-240: result bits, 64 per wave slot
+                const uint32_t mi = ob->material_index;
+                key = mi < a.n_materials ? a.material_keys[mi] : 0u;
+                key = key > 2u ? 2u : key;
+                const uint32_t np = (uint32_t)__popcll(ballot), nr = (uint32_t)__popcll(resid);
+                c_p0 += key == 0u ? np : 0u; c_p1 += key == 1u ? np : 0u; c_p2 += key == 2u ? np : 0u;
+                c_r0 += key == 0u ? nr : 0u; c_r1 += key == 1u ? nr : 0u; c_r2 += key == 2u ? nr : 0u;
+            }
+            if (lane == 0) {
+                s_pass[wave][it] = ballot; s_resid[wave][it] = resid;
+                s_obj[wave][it] = obj; s_tri0[wave][it] = wrel * 64u; s_key[wave][it] = key;
+            }
+        }
+
+        // ---- LDS-staged compaction: one global atomic per (chunk, list, region)
+        if (lane == 0) {
+            cnt[wave][0] = c_p0; cnt[wave][1] = c_p1; cnt[wave][2] = c_p2;
+            cnt[wave][3] = c_r0; cnt[wave][4] = c_r1; cnt[wave][5] = c_r2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6u) {
+            const uint32_t k = threadIdx.x;
+            const uint32_t c0 = cnt[0][k], c1 = cnt[1][k], c2 = cnt[2][k], c3 = cnt[3][k];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            uint32_t start = 0;
+            if (tot) start = atomicAdd(&a.calls[k].vertex_count, tot * 3u) / 3u;  // cull.wgsl:63-73
+            base[0][k] = start; base[1][k] = start + c0; base[2][k] = start + c0 + c1; base[3][k] = start + c0 + c1 + c2;
+        }
+        __syncthreads();
+        uint32_t run_p[3] = {base[wave][0], base[wave][1], base[wave][2]};
+        uint32_t run_r[3] = {base[wave][3], base[wave][4], base[wave][5]};
+#pragma unroll 1
+        for (uint32_t it = 0; it < R3N_CHUNK_ITERS; ++it) {
+            const unsigned long long pb = s_pass[wave][it];
+            if (pb == 0ull) continue;
+            const unsigned long long rb = s_resid[wave][it];
+            const uint32_t key = s_key[wave][it];
+            const r3n_tri_ref ref = {s_obj[wave][it], s_tri0[wave][it] + lane};
+            const uint32_t np = (uint32_t)__popcll(pb), nr = (uint32_t)__popcll(rb);
+            const uint32_t rp = key == 0u ? run_p[0] : (key == 1u ? run_p[1] : run_p[2]);
+            const uint32_t rr = key == 0u ? run_r[0] : (key == 1u ? run_r[1] : run_r[2]);
+            const uint32_t region = key == 0u ? region_base[0] : (key == 1u ? region_base[1] : region_base[2]);
+            if ((pb >> lane) & 1ull) a.predicted[region + rp + (uint32_t)__popcll(pb & lane_lt)] = ref;
+            if ((rb >> lane) & 1ull) a.residual[region + rr + (uint32_t)__popcll(rb & lane_lt)] = ref;
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) {
+                run_p[k] += key == k ? np : 0u;
+                run_r[k] += key == k ? nr : 0u;
+            }
+        }
+        __syncthreads();  // LDS staging reused by the next chunk
+    }
+}

@@ -1,0 +1,559 @@
+// kernels_raster.h -- software rasteriser (K5/K6 coverage + depth), Hi-Z pyramid (K3), deferred PBR
+// resolve (K6 shading) and tonemap (K7).
+//
+// Reference behaviour restated (file:line):
+//   forward.rs:318-371  pipeline state: cull Back (forward) / Front (depth), depth GreaterEqual + write
+//   depth.wgsl:51-127, opaque.wgsl:91-135 (VS), :203-551 (FS), math/brdf.wgsl, shadow/pcf.wgsl
+//   hi_z.wgsl:19-32, hi_z.rs:161-234
+//   blit.wgsl:22-31, tonemapping.rs:44 (Rgba8UnormSrgb target => exact sRGB OETF)
+//
+// Design: a 64-bit visibility buffer (depth bits << 32 | canonical triangle slot + 1) written
+// with 64-bit atomic max -- reverse-Z GreaterEqual + depth write is exactly "max" -- so opaque shading
+// runs once per pixel for the nearest fragment instead of once per rasterised fragment.  Triangles up to
+// 8x8 px are scanned by one thread; larger ones are split into <=64x64 px work items scanned by one
+// wavefront each (8x8 pixel blocks per step).
+#pragma once
+#include "device_math.h"
+
+struct RasterArgs {
+    const r3n_camera_header240 *hdr;
+    const r3n_object128 *objects;
+    const uint32_t *mesh;
+    const r3n_baked128 *baked;
+    const r3n_material208 *materials;
+    const uint8_t *material_keys;
+    uint32_t n_materials;
+    const uint32_t *tri_base;              // canonical slot base per object (forward only)
+    const r3n_tri_ref *list;               // compacted triangle list of this camera/source
+    const r3n_cull_counts *counts;         // region bases of that list
+    const r3n_indirect_call *calls;        // [3] calls of that list: vertex_count/3 triangles per region
+    uint32_t key;                          // region to draw
+    uint32_t vp_x, vp_y, vp_w, vp_h;       // viewport inside the target
+    uint32_t target_pitch;                 // elements per row of the target
+    unsigned long long *vis;               // forward target (u64 per pixel) or null
+    uint32_t *depth;                       // depth-only target (f32 bits per pixel) or null
+    r3n_big_item *big_items;
+    uint32_t *big_count;
+    uint32_t big_capacity;
+};
+
+R3N_DEV float cutout_alpha(const r3n_material208 &m, float vertex_alpha) {
+    float alpha = 1.0f;
+    if ((m.flags & R3N_FLAGS_ALBEDO_ACTIVE) && (m.flags & R3N_FLAGS_ALBEDO_BLEND)) alpha *= vertex_alpha;
+    alpha *= m.albedo[3];
+    return alpha;
+}
+
+R3N_DEV float fetch_color_alpha(const r3n_object128 &ob, const uint32_t *__restrict__ mesh, uint32_t vtx) {
+    const uint32_t off = ob.vertex_attribute_start_offsets[5];
+    if (off == R3N_INVALID) return 1.0f;
+    const uint32_t w = mesh[off / 4u + vtx];
+    return (float)((w >> 24) & 0xFFu) / 255.0f;
+}
+
+// Everything needed to scan one triangle.
+struct TriWork {
+    TriSetup ts;
+    float va[3];
+    const r3n_material208 *mat;
+    uint32_t slot1;  // canonical slot + 1 (forward)
+    bool cutout;
+    int x0, y0, x1, y1;
+};
+
+template <bool DEPTH_ONLY>
+R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, bool positive_visible, TriWork &tw) {
+    const r3n_object128 &ob = a.objects[obj];
+    if (ob.enabled == 0u) return false;  // opaque.wgsl:104-112 / depth.wgsl:64-72
+    const uint32_t first = ob.first_index + tri * 3u;
+    const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
+    uint32_t idx[3];
+    float p[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        idx[k] = a.mesh[first + (uint32_t)k];
+        float v[3];
+        fetch_vec3(a.mesh, pos_off, idx[k], v);
+        mul_point(a.baked[obj].model_view_proj, v, p[k]);
+    }
+    const float half_w = (float)a.vp_w / 2.0f, half_h = (float)a.vp_h / 2.0f;
+    setup_triangle(p, half_w, half_h, positive_visible, tw.ts);
+    if (!tw.ts.valid) return false;
+    tri_bounds(p, half_w, half_h, (int)a.vp_w, (int)a.vp_h, tw.x0, tw.y0, tw.x1, tw.y1);
+    if (tw.x1 < tw.x0 || tw.y1 < tw.y0) return false;
+    tw.cutout = a.key == R3N_KEY_CUTOUT;
+    tw.mat = &a.materials[ob.material_index < a.n_materials ? ob.material_index : 0u];
+    tw.va[0] = tw.va[1] = tw.va[2] = 1.0f;
+    if (tw.cutout) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tw.va[k] = fetch_color_alpha(ob, a.mesh, idx[k]);
+    }
+    if (!DEPTH_ONLY) tw.slot1 = a.tri_base[obj] + tri + 1u;
+    return true;
+}
+
+template <bool DEPTH_ONLY>
+R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
+    float E[3];
+    if (!edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
+    float z = frag_depth(tw.ts, E);
+    if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
+    if (z == 0.0f) z = 0.0f;                // canonicalise -0
+    if (tw.cutout) {
+        const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+        const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+        if (cutout_alpha(*tw.mat, al) < tw.mat->alpha_cutout) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
+    }
+    const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
+    const uint32_t zb = __float_as_uint(z);
+    if (DEPTH_ONLY) {
+        if (zb >= a.depth[pix]) atomicMax(&a.depth[pix], zb);
+    } else {
+        const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
+        if (key > a.vis[pix]) atomicMax(&a.vis[pix], key);
+    }
+}
+
+#define R3N_SMALL_MAX 8
+
+// Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
+// <=64x64 px items for stage 2.
+template <bool DEPTH_ONLY>
+__global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
+    const uint32_t n = a.calls[a.key].vertex_count / 3u;
+    const uint32_t region = a.counts->region_base[a.key];
+    const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const r3n_tri_ref ref = a.list[region + i];
+        TriWork tw;
+        if (!prepare_triangle<DEPTH_ONLY>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
+        const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
+        if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
+            for (int y = tw.y0; y <= tw.y1; ++y)
+                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+        } else {
+            const uint32_t tx = (uint32_t)(bw + 63) / 64u, ty = (uint32_t)(bh + 63) / 64u;
+            const uint32_t cnt = tx * ty;
+            const uint32_t start = atomicAdd(a.big_count, cnt);
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const uint32_t ix = t % tx, iy = t / tx;
+                const int rx0 = tw.x0 + (int)ix * 64, ry0 = tw.y0 + (int)iy * 64;
+                const int rx1 = min(rx0 + 63, tw.x1), ry1 = min(ry0 + 63, tw.y1);
+                if (start + t < a.big_capacity) {
+                    r3n_big_item it = {ref.object, ref.triangle, (uint32_t)rx0 | ((uint32_t)ry0 << 16),
+                                       (uint32_t)rx1 | ((uint32_t)ry1 << 16)};
+                    a.big_items[start + t] = it;
+                } else {
+                    // queue full: never drop work -- scan the region here (slow path)
+                    for (int y = ry0; y <= ry1; ++y)
+                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+                }
+            }
+        }
+    }
+}
+
+// Stage 2: one wavefront per item, lanes tile an 8x8 pixel block, stepping through the item's region.
+template <bool DEPTH_ONLY>
+__global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * 4u;
+    uint32_t n = *a.big_count;
+    n = n < a.big_capacity ? n : a.big_capacity;
+    const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
+    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    for (uint32_t i = wave_global; i < n; i += nwaves) {
+        const r3n_big_item it = a.big_items[i];
+        TriWork tw;
+        if (!prepare_triangle<DEPTH_ONLY>(a, it.object, it.triangle, positive_visible, tw)) continue;
+        const int rx0 = (int)(it.xy0 & 0xFFFFu), ry0 = (int)(it.xy0 >> 16);
+        const int rx1 = (int)(it.xy1 & 0xFFFFu), ry1 = (int)(it.xy1 >> 16);
+        for (int by = ry0; by <= ry1; by += 8)
+            for (int bx = rx0; bx <= rx1; bx += 8) {
+                const int x = bx + lx, y = by + ly;
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ clears
+__global__ __launch_bounds__(256) void k_fill_u64(unsigned long long *__restrict__ p, unsigned long long v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ K3 Hi-Z
+// Level 0: depth plane = high 32 bits of the visibility keys (background 0.0 = infinitely far).
+__global__ __launch_bounds__(256) void k_hiz_mip0(const unsigned long long *__restrict__ vis, float *__restrict__ mip0,
+                                                  size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u)
+        mip0[i] = __uint_as_float((uint32_t)(vis[i] >> 32));
+}
+
+// hi_z.wgsl:19-32: dst = min over the 2x2 (3 wide/high when the source dimension is odd) source texels;
+// out-of-range source loads read 0.0.
+__global__ __launch_bounds__(256) void k_hiz_downsample(const float *__restrict__ src, float *__restrict__ dst,
+                                                        uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh) {
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+    const uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
+    if (x >= dw || y >= dh) return;
+    const uint32_t nx = 2u + (sw & 1u), ny = 2u + (sh & 1u);
+    float nearest = 1.0f;
+    for (uint32_t ix = 0; ix < nx; ++ix)
+        for (uint32_t iy = 0; iy < ny; ++iy) {
+            const uint32_t sx = 2u * x + ix, sy = 2u * y + iy;
+            const float v = (sx < sw && sy < sh) ? src[(size_t)sy * sw + sx] : 0.0f;
+            nearest = fminf(nearest, v);
+        }
+    dst[(size_t)y * dw + x] = nearest;
+}
+
+// ------------------------------------------------------------------------------------------------ K6 resolve
+struct ShadeArgs {
+    const unsigned long long *vis;
+    uint32_t width, height, row_begin, row_end;
+    const r3n_frame_uniforms496 *fu;
+    const r3n_camera_header240 *hdr;
+    const r3n_object128 *objects;
+    const uint32_t *mesh;
+    const r3n_baked128 *baked;
+    const r3n_material208 *materials;
+    uint32_t n_materials;
+    const uint32_t *tri_base;
+    const uint8_t *dir_buf;    // count @0, records @16
+    const uint8_t *point_buf;  // count @0, records @16
+    const float *atlas;
+    uint32_t atlas_w, atlas_h;
+    float clear[4];
+    ushort4 *hdr_out;          // Rgba16Float
+};
+
+struct LdsDirLight {
+    float m[16];      // light.view_proj * uniforms.inv_view (opaque.wgsl:491)
+    float l[3];       // normalize(view_mat3 * -direction)   (opaque.wgsl:519)
+    float color[3];
+    float inv_res[2], offset[2], size[2];
+};
+struct LdsPointLight {
+    float vpos[3];    // (uniforms.view * position).xyz (opaque.wgsl:528)
+    float color[3];
+    float radius;
+};
+
+// shadow/pcf.wgsl + comparison sampler (samplers.rs:24,42-57): bilinear, GreaterEqual, Repeat
+R3N_DEV float sample_compare(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref,
+                             int ox, int oy) {
+    const float tx = (u * (float)aw - 0.5f) + (float)ox;
+    const float ty = (v * (float)ah - 0.5f) + (float)oy;
+    const float fx0 = floorf(tx), fy0 = floorf(ty);
+    float fx = tx - fx0, fy = ty - fy0;
+    const long long ix = (fx0 == fx0 && fabsf(fx0) < 1e9f) ? (long long)fx0 : 0ll;
+    const long long iy = (fy0 == fy0 && fabsf(fy0) < 1e9f) ? (long long)fy0 : 0ll;
+    if (!(fx == fx)) fx = 0.0f;
+    if (!(fy == fy)) fy = 0.0f;
+    const long long w = (long long)aw, h = (long long)ah;
+    const uint32_t x0 = (uint32_t)(((ix % w) + w) % w), x1 = (uint32_t)((((ix + 1) % w) + w) % w);
+    const uint32_t y0 = (uint32_t)(((iy % h) + h) % h), y1 = (uint32_t)((((iy + 1) % h) + h) % h);
+    const float c00 = ref >= atlas[(size_t)y0 * aw + x0] ? 1.0f : 0.0f;
+    const float c10 = ref >= atlas[(size_t)y0 * aw + x1] ? 1.0f : 0.0f;
+    const float c01 = ref >= atlas[(size_t)y1 * aw + x0] ? 1.0f : 0.0f;
+    const float c11 = ref >= atlas[(size_t)y1 * aw + x1] ? 1.0f : 0.0f;
+    const float top = c00 * (1.0f - fx) + c10 * fx;
+    const float bot = c01 * (1.0f - fx) + c11 * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
+    float r = 0.0f;
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, 0);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, 1);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, -1);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, 1, 0);
+    r = r + sample_compare(atlas, aw, ah, u, v, ref, -1, 0);
+    return r * 0.2f;
+}
+
+struct PixelData {
+    float albedo[4], diffuse[3], roughness, normal[3], f0[3], emissive[3], ao;
+};
+
+#define R3N_PI 3.14159265359f
+
+// opaque.wgsl:440-468
+R3N_DEV void surface_shading(const float l[3], const float intensity[3], const PixelData &px, const float v[3],
+                             float occlusion, float out[3]) {
+    float h[3] = {v[0] + l[0], v[1] + l[1], v[2] + l[2]};
+    normalize3(h);
+    const float nov = fabsf(dot3(px.normal, v)) + 0.00001f;
+    const float nol = sat(dot3(px.normal, l));
+    const float noh = sat(dot3(px.normal, h));
+    const float loh = sat(dot3(l, h));
+    const float c165[3] = {16.5f, 16.5f, 16.5f};
+    const float f90 = sat(dot3(px.f0, c165));
+    const float a = px.roughness, a2 = a * a;
+    const float f = (noh * a2 - noh) * noh + 1.0f;
+    const float d = a2 / ((R3N_PI * f) * f);
+    const float x = 1.0f - loh, x2 = x * x, x5 = (x2 * x2) * x;
+    const float ggxl = nov * sqrtf((-nol * a2 + nol) * nol + a2);
+    const float ggxv = nol * sqrtf((-nov * a2 + nov) * nov + a2);
+    const float vis = 0.5f / (ggxl + ggxv);
+    const float k = nol * occlusion;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float fres = px.f0[c] + (f90 - px.f0[c]) * x5;
+        const float fr = (d * vis) * fres;
+        const float fd = px.diffuse[c] * (1.0f / R3N_PI);
+        const float color = fd + fr;
+        out[c] = (color * intensity[c]) * k;
+    }
+}
+
+R3N_DEV float srgb_to_linear(float e) { return e > 0.04045f ? powf((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f; }
+
+R3N_DEV ushort4 pack_half4(const float v[4]) {
+    ushort4 o;
+    // float -> half conversion rounds to nearest even (v_cvt_f16_f32)
+    o.x = __builtin_bit_cast(unsigned short, (_Float16)v[0]);
+    o.y = __builtin_bit_cast(unsigned short, (_Float16)v[1]);
+    o.z = __builtin_bit_cast(unsigned short, (_Float16)v[2]);
+    o.w = __builtin_bit_cast(unsigned short, (_Float16)v[3]);
+    return o;
+}
+
+// One thread per pixel, 16x16 pixel tiles; the light list is transformed once per workgroup and staged in LDS.
+__global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
+    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
+    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    const uint32_t n_dir = min(*reinterpret_cast<const uint32_t *>(a.dir_buf), (uint32_t)R3N_MAX_DIR_LIGHTS);
+    const uint32_t n_point = min(*reinterpret_cast<const uint32_t *>(a.point_buf), (uint32_t)R3N_MAX_POINT_LIGHTS);
+    const r3n_dir_light128 *dirs = reinterpret_cast<const r3n_dir_light128 *>(a.dir_buf + 16);
+    const r3n_point_light32 *points = reinterpret_cast<const r3n_point_light32 *>(a.point_buf + 16);
+    for (uint32_t i = threadIdx.x; i < n_dir * 4u; i += 256u) {
+        const uint32_t li = i >> 2, c = i & 3u;
+        const float *col = a.fu->inv_view + 4 * c;  // column c of (view_proj * inv_view)
+        float o[4];
+        mul_vec4(dirs[li].view_proj, col[0], col[1], col[2], col[3], o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_dir[li].m[4 * c + r] = o[r];
+        if (c == 0) {
+            const float nd[3] = {-dirs[li].direction[0], -dirs[li].direction[1], -dirs[li].direction[2]};
+            float l[3];
+            mat3_mul_vec3(a.fu->view, a.fu->view + 4, a.fu->view + 8, nd, l);
+            normalize3(l);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { s_dir[li].l[r] = l[r]; s_dir[li].color[r] = dirs[li].color[r]; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                s_dir[li].inv_res[r] = dirs[li].inv_resolution[r];
+                s_dir[li].offset[r] = dirs[li].atlas_offset[r];
+                s_dir[li].size[r] = dirs[li].atlas_size[r];
+            }
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n_point; i += 256u) {
+        float o[4];
+        mul_vec4(a.fu->view, points[i].position[0], points[i].position[1], points[i].position[2], points[i].position[3], o);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { s_point[i].vpos[r] = o[r]; s_point[i].color[r] = points[i].color[r]; }
+        s_point[i].radius = points[i].radius;
+    }
+    __syncthreads();
+
+    const uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+    const uint32_t y = a.row_begin + blockIdx.y * 16u + (threadIdx.x >> 4);
+    if (x >= a.width || y >= a.row_end) return;
+    const size_t pix = (size_t)y * a.width + x;
+    const unsigned long long key = a.vis[pix];
+    const uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
+    if (id == 0u) {
+        a.hdr_out[pix] = pack_half4(a.clear);
+        return;
+    }
+    const uint32_t slot = id - 1u;
+    uint32_t lo = 0, hi = a.hdr->object_count;
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (a.tri_base[mid] <= slot) lo = mid; else hi = mid;
+    }
+    const uint32_t obj = lo, tri = slot - a.tri_base[obj];
+    const r3n_object128 &ob = a.objects[obj];
+    const r3n_material208 &mat = a.materials[ob.material_index < a.n_materials ? ob.material_index : 0u];
+    const float *mv = a.baked[obj].model_view;
+
+    // vertex stage for the 3 vertices (opaque.wgsl:114-134)
+    uint32_t idx[3];
+    float p[3][4], vp[3][4], vn[3][3], vc[3][4];
+    const float inv_s2[3] = {1.0f / dot3(mv, mv), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
+    const uint32_t first = ob.first_index + tri * 3u;
+    const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
+    const uint32_t nrm_off = ob.vertex_attribute_start_offsets[1];
+    const uint32_t col_off = ob.vertex_attribute_start_offsets[5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        idx[k] = a.mesh[first + (uint32_t)k];
+        float v[3];
+        fetch_vec3(a.mesh, pos_off, idx[k], v);
+        mul_point(a.baked[obj].model_view_proj, v, p[k]);
+        mul_point(mv, v, vp[k]);
+        float nm[3] = {0.0f, 0.0f, 0.0f};
+        if (nrm_off != R3N_INVALID) fetch_vec3(a.mesh, nrm_off, idx[k], nm);
+        const float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
+        mat3_mul_vec3(mv, mv + 4, mv + 8, sn, vn[k]);
+        normalize3(vn[k]);
+        if (col_off != R3N_INVALID) {
+            const uint32_t cw = a.mesh[col_off / 4u + idx[k]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vc[k][c] = 1.0f;
+        }
+    }
+    TriSetup ts;
+    setup_triangle(p, (float)a.width / 2.0f, (float)a.height / 2.0f,
+                   (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u, ts);
+    float E[3];
+    (void)edge_eval(ts, (float)x + 0.5f, (float)y + 0.5f, E);
+    const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+    const float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
+    float vpos[4], nrm[3], col[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
+
+    // fragment stage (opaque.wgsl:203-424, untextured paths)
+    PixelData px;
+    const uint32_t mflags = mat.flags;
+    if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
+        if (mflags & R3N_FLAGS_ALBEDO_BLEND) {
+            if (mflags & R3N_FLAGS_ALBEDO_VERTEX_SRGB) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
+                px.albedo[3] *= col[3];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) px.albedo[c] *= col[c];
+            }
+        }
+    } else {
+        px.albedo[0] = px.albedo[1] = px.albedo[2] = 0.0f;
+        px.albedo[3] = 1.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) px.albedo[c] *= mat.albedo[c];
+
+    float out[4];
+    if (mflags & R3N_FLAGS_UNLIT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
+        normalize3(px.normal);
+        float pr = mat.roughness;
+        const float metallic = mat.metallic, cc = mat.clear_coat, ccpr = mat.clear_coat_roughness;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            px.emissive[c] = mat.emissive[c];
+            px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
+        }
+        const float refl = (0.16f * mat.reflectance) * mat.reflectance;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
+        if (cc != 0.0f) {
+            const float base_pr = fmaxf(pr, ccpr);
+            pr = pr * (1.0f - cc) + base_pr * cc;
+        }
+        px.roughness = pr * pr;
+        px.ao = mat.ambient_occlusion;
+
+        float vv[3] = {vpos[0], vpos[1], vpos[2]};
+        normalize3(vv);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
+        float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
+        for (uint32_t i = 0; i < n_dir; ++i) {
+            const LdsDirLight &L = s_dir[i];
+            float sn[4];
+            mul_vec4(L.m, vpos[0], vpos[1], vpos[2], vpos[3], sn);
+            const float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
+            const float local[2] = {fl[0], 1.0f - fl[1]};
+            float tl[2] = {L.offset[0], L.offset[1]};
+            float tr[2] = {tl[0] + L.size[0], tl[1] + L.size[1]};
+            const float coords[2] = {tl[0] * (1.0f - local[0]) + tr[0] * local[0],
+                                     tl[1] * (1.0f - local[1]) + tr[1] * local[1]};
+            const float border[2] = {L.inv_res[0] * 1.5f, L.inv_res[1] * 1.5f};
+            tl[0] += border[0]; tl[1] += border[1];
+            tr[0] -= border[0]; tr[1] -= border[1];
+            float shadow = 1.0f;
+            // opaque.wgsl:509-514 (quirk: `any`, un-atlased coords vs atlas-space bounds -- reproduced)
+            if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f)
+                shadow = shadow_pcf5(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], sn[2]);
+            float res[3];
+            surface_shading(L.l, L.color, px, vv, shadow * px.ao, res);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) color[c] += res[c];
+        }
+        for (uint32_t i = 0; i < n_point; ++i) {
+            const LdsPointLight &P = s_point[i];
+            const float delta[3] = {P.vpos[0] - vpos[0], P.vpos[1] - vpos[1], P.vpos[2] - vpos[2]};
+            const float d = sqrtf(dot3(delta, delta));
+            const float s = sat(d / P.radius);
+            const float s2 = s * s, is2 = 1.0f - s2;
+            const float att = is2 * is2 / (1.0f + s2);
+            const float inten[3] = {P.color[0] * att, P.color[1] * att, P.color[2] * att};
+            const float l[3] = {delta[0] / d, delta[1] / d, delta[2] / d};
+            float res[3];
+            surface_shading(l, inten, px, vv, px.ao, res);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) color[c] += (res[c] > 0.0f ? res[c] : 0.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = fmaxf(a.fu->ambient[c] * px.albedo[c], color[c]);
+        out[3] = fmaxf(a.fu->ambient[3] * px.albedo[3], px.albedo[3]);
+    }
+    a.hdr_out[pix] = pack_half4(out);
+}
+
+// ------------------------------------------------------------------------------------------------ K7 tonemap
+R3N_DEV float srgb_oetf(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    if (x <= 0.0031308f) return x * 12.92f;
+    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+}
+
+// 2 pixels per thread: one 16-byte load, one 8-byte store.
+__global__ __launch_bounds__(256) void k_tonemap(const ushort4 *__restrict__ hdr, uchar4 *__restrict__ out,
+                                                 float4 *__restrict__ out_f32, size_t first_pixel, size_t n_pixels) {
+    const size_t pair = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t i0 = first_pixel + pair * 2u;
+    if (pair * 2u >= n_pixels) return;
+    const bool two = pair * 2u + 1u < n_pixels;
+    ushort4 h[2];
+    if (two && (i0 & 1u) == 0u) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(hdr + i0);
+        h[0] = make_ushort4(raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu, raw.y >> 16);
+        h[1] = make_ushort4(raw.z & 0xFFFFu, raw.z >> 16, raw.w & 0xFFFFu, raw.w >> 16);
+    } else {
+        h[0] = hdr[i0];
+        h[1] = two ? hdr[i0 + 1u] : make_ushort4(0, 0, 0, 0);
+    }
+    uchar4 o8[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float r = (float)__builtin_bit_cast(_Float16, h[k].x), g = (float)__builtin_bit_cast(_Float16, h[k].y);
+        const float b = (float)__builtin_bit_cast(_Float16, h[k].z), al = (float)__builtin_bit_cast(_Float16, h[k].w);
+        const float e[4] = {srgb_oetf(r), srgb_oetf(g), srgb_oetf(b), (!(al > 0.0f)) ? 0.0f : (al >= 1.0f ? 1.0f : al)};
+        o8[k] = make_uchar4((unsigned char)(e[0] * 255.0f + 0.5f), (unsigned char)(e[1] * 255.0f + 0.5f),
+                            (unsigned char)(e[2] * 255.0f + 0.5f), (unsigned char)(e[3] * 255.0f + 0.5f));
+        if (out_f32 != nullptr && (k == 0 || two)) out_f32[i0 + (size_t)k] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    out[i0] = o8[0];
+    if (two) out[i0 + 1u] = o8[1];
+}

@@ -1,0 +1,795 @@
+// r3n.hip -- context, device-memory management and the extern "C" entry points of include/r3n.h.
+// All device work is enqueued on the context's stream; nothing on the frame path reads back to the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels_cull.h"
+#include "kernels_raster.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct CamState {
+    r3n_camera_header240 hdr{};
+    bool has_hdr = false;
+    bool has_prev = false;       // results of a previous frame's cull exist in index 1-cur
+    bool culled = false;         // culled during the current frame
+    int cur = 0;                 // ping-pong index written by this frame's cull
+    int last = -1;               // index holding the most recent cull results (for readbacks)
+    uint32_t vp_x = 0, vp_y = 0, vp_size = 0;
+    DevBuf d_hdr, baked, vis_flags, vis_list, block_sums, block_off;
+    DevBuf slot_base[2], mask[2], predicted[2], calls[2], counts[2];
+    DevBuf residual;
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct r3n_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // world data
+    DevBuf mesh, objects, materials, material_keys, dir_buf, point_buf, fu;
+    uint32_t capacity = 0, n_materials = 0;
+    std::vector<uint32_t> h_ntri;  // host mirror: triangles per enabled object slot
+    uint64_t total_tris = 0;
+    bool tri_base_dirty = true;
+    DevBuf tri_base;
+    CamState canon;  // scratch camera used to (re)build the canonical tri_base scan
+    // frame targets
+    uint32_t width = 0, height = 0, samples = 1, atlas_w = 0, atlas_h = 0;
+    float clear[4] = {0, 0, 0, 0};
+    bool in_frame = false;
+    DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
+    r3n_hiz_desc hizd{};
+    DevBuf big_items, big_count;
+    uint32_t big_capacity = 4u << 20;
+    CamState viewport;
+    std::map<uint32_t, CamState> shadows;
+    uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
+    uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
+    // timing taps
+    bool timing = false;
+    struct Span { hipEvent_t a, b; int stage; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double stage_ms[R3N_STAGE_COUNT] = {0};
+    uint64_t stage_launches[R3N_STAGE_COUNT] = {0};
+};
+
+namespace {
+
+int fail(r3n_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail((c), R3N_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+// Grow-only device buffer.  preserve: keep old contents; fill: byte value for the newly allocated tail.
+int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
+    if (bytes <= b.bytes && b.p) return R3N_OK;
+    size_t want = std::max<size_t>(bytes, 256);
+    if (b.bytes) want = std::max(want, b.bytes + b.bytes / 2);  // amortised growth
+    void *np = nullptr;
+    HIP_TRY(c, hipMalloc(&np, want));
+    size_t kept = 0;
+    if (preserve && b.p && b.bytes) {
+        HIP_TRY(c, hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, c->stream));
+        kept = b.bytes;
+    }
+    if (fill >= 0) HIP_TRY(c, hipMemsetAsync(static_cast<char *>(np) + kept, fill, want - kept, c->stream));
+    if (b.p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(b.p));
+    }
+    b.p = np;
+    b.bytes = want;
+    return R3N_OK;
+}
+
+#define TRY(expr)                      \
+    do {                               \
+        int _r = (expr);               \
+        if (_r != R3N_OK) return _r;   \
+    } while (0)
+
+struct Timed {
+    r3n_ctx *c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(r3n_ctx *ctx, int st) : c(ctx), stage(st) {
+        c->stage_launches[stage]++;
+        if (!c->timing) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = get(); b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Timed() {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->spans.push_back({a, b, stage});
+    }
+};
+
+int check_launch(r3n_ctx *c, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, R3N_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return R3N_OK;
+}
+
+CamState *find_cam(r3n_ctx *c, r3n_camera cam, bool create) {
+    if (cam == R3N_CAMERA_VIEWPORT) return &c->viewport;
+    if (cam >= R3N_MAX_SHADOW_VIEWS) return nullptr;
+    auto it = c->shadows.find(cam);
+    if (it != c->shadows.end()) return &it->second;
+    if (!create) return nullptr;
+    return &c->shadows[cam];
+}
+
+void free_cam(CamState &s) {
+    DevBuf *bufs[] = {&s.d_hdr, &s.baked, &s.vis_flags, &s.vis_list, &s.block_sums, &s.block_off, &s.slot_base[0],
+                      &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.calls[0],
+                      &s.calls[1], &s.counts[0], &s.counts[1], &s.residual};
+    for (DevBuf *b : bufs)
+        if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
+}
+
+uint32_t max_waves(const r3n_ctx *c) { return (uint32_t)(c->total_tris / 64u) + c->capacity + 1u; }
+
+// Object pass for one camera state (frustum cull + slot assignment); range (0,0) builds only tri_base.
+int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint32_t range_end, uint32_t *tri_base) {
+    const uint32_t cap = c->capacity;
+    const uint32_t nblocks = (cap + 255u) / 256u;
+    TRY(ensure(c, s.vis_flags, cap, false, -1));
+    TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
+    TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
+    TRY(ensure(c, s.block_off, (size_t)nblocks * sizeof(ObjBlockOffsets), false, -1));
+    TRY(ensure(c, s.slot_base[idx], (size_t)cap * 4u, true, 0xFF));
+    TRY(ensure(c, s.calls[idx], 6 * sizeof(r3n_indirect_call), false, 0));
+    TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
+    Timed t(c, R3N_STAGE_OBJECT_CULL);
+    hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, c->stream, s.d_hdr.as<r3n_camera_header240>(),
+                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin,
+                       range_end, s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
+    hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(1024), 0, c->stream, s.block_sums.as<ObjBlockSums>(), nblocks,
+                       s.block_off.as<ObjBlockOffsets>(), s.counts[idx].as<r3n_cull_counts>(),
+                       s.vis_list.as<r3n_vis_entry>(), s.calls[idx].as<r3n_indirect_call>());
+    hipLaunchKernelGGL(k_object_scatter, dim3(nblocks), dim3(256), 0, c->stream,
+                       s.d_hdr.as<r3n_camera_header240>(), c->objects.as<r3n_object128>(), s.vis_flags.as<uint8_t>(),
+                       s.block_off.as<ObjBlockOffsets>(), s.vis_list.as<r3n_vis_entry>(),
+                       s.slot_base[idx].as<uint32_t>(), tri_base);
+    return check_launch(c, "object pass");
+}
+
+int refresh_tri_base(r3n_ctx *c) {
+    if (!c->tri_base_dirty) return R3N_OK;
+    if (c->capacity == 0) { c->tri_base_dirty = false; return R3N_OK; }
+    TRY(ensure(c, c->tri_base, (size_t)c->capacity * 4u, false, 0));
+    r3n_camera_header240 h{};
+    h.object_count = c->capacity;
+    h.shadow_index = 0;
+    TRY(ensure(c, c->canon.d_hdr, sizeof h, false, -1));
+    HIP_TRY(c, hipMemcpyAsync(c->canon.d_hdr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
+    TRY(run_object_pass(c, c->canon, 0, 0, 0, c->tri_base.as<uint32_t>()));
+    c->tri_base_dirty = false;
+    return R3N_OK;
+}
+
+void build_hiz_desc(r3n_hiz_desc &d, uint32_t w, uint32_t h) {
+    d.width = w; d.height = h;
+    uint32_t m = std::max(w, h), n = 0;
+    while (m) { ++n; m >>= 1; }
+    d.mips = std::min<uint32_t>(n, R3N_MAX_HIZ_MIPS);
+    uint32_t off = 0;
+    for (uint32_t k = 0; k < R3N_MAX_HIZ_MIPS; ++k) {
+        d.offset[k] = off;
+        if (k < d.mips) off += std::max(1u, w >> k) * std::max(1u, h >> k);
+    }
+}
+size_t hiz_elements(const r3n_hiz_desc &d) {
+    size_t n = 0;
+    for (uint32_t k = 0; k < d.mips; ++k) n += (size_t)std::max(1u, d.width >> k) * std::max(1u, d.height >> k);
+    return n;
+}
+
+int drain_timing(r3n_ctx *c) {
+    if (c->spans.empty()) return R3N_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) c->stage_ms[s.stage] += ms;
+        c->event_pool.push_back(s.a);
+        c->event_pool.push_back(s.b);
+    }
+    c->spans.clear();
+    return R3N_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *r3n_create_error(void) { return g_create_error.c_str(); }
+
+r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (hip_device < 0 || hip_device >= n) { g_create_error = "hip_device out of range"; return nullptr; }
+    e = hipSetDevice(hip_device);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, hip_device);
+    if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return nullptr; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("this build targets gfx950 (MI355X) only; device is ") + prop.gcnArchName;
+        return nullptr;
+    }
+    r3n_ctx *c = new r3n_ctx();
+    c->device = hip_device;
+    if (config && config->struct_size >= sizeof(r3n_config) && config->max_big_items) c->big_capacity = config->max_big_items;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete c;
+        return nullptr;
+    }
+    // empty light buffers: count = 0
+    if (ensure(c, c->dir_buf, 16, false, 0) != R3N_OK || ensure(c, c->point_buf, 16, false, 0) != R3N_OK ||
+        ensure(c, c->material_keys, 256, false, 0) != R3N_OK || ensure(c, c->materials, sizeof(r3n_material208), false, 0) != R3N_OK ||
+        ensure(c, c->big_count, 4, false, 0) != R3N_OK ||
+        ensure(c, c->big_items, (size_t)c->big_capacity * sizeof(r3n_big_item), false, -1) != R3N_OK) {
+        g_create_error = c->err;
+        r3n_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void r3n_destroy(r3n_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
+                      &c->tri_base, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->big_items,
+                      &c->big_count};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    free_cam(c->canon);
+    free_cam(c->viewport);
+    for (auto &kv : c->shadows) free_cam(kv.second);
+    for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *r3n_last_error(const r3n_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int r3n_sync(r3n_ctx *c) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
+
+void *r3n_stream(r3n_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ uploads
+int r3n_mesh_buffer_write(r3n_ctx *c, uint64_t byte_offset, const void *data, uint64_t bytes) {
+    if (!c || (!data && bytes) || (byte_offset & 3u) || (bytes & 3u)) return fail(c, R3N_ERR_INVALID_ARG, "mesh write: bad args");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure(c, c->mesh, byte_offset + bytes, true, 0));
+    if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(c->mesh.p) + byte_offset, data, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns `data` only for the duration of the call
+    }
+    return R3N_OK;
+}
+
+int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *records, uint32_t n, uint32_t capacity) {
+    if (!c || (n && (!slots || !records))) return fail(c, R3N_ERR_INVALID_ARG, "objects write: null");
+    if (capacity < c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "objects write: capacity cannot shrink");
+    for (uint32_t i = 0; i < n; ++i)
+        if (slots[i] >= capacity) return fail(c, R3N_ERR_INVALID_ARG, "objects write: slot >= capacity");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure(c, c->objects, (size_t)capacity * sizeof(r3n_object128), true, 0));
+    if (capacity != c->capacity) {
+        c->capacity = capacity;
+        c->h_ntri.resize(capacity, 0);
+        c->tri_base_dirty = true;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_TRY(c, hipMemcpyAsync(c->objects.as<r3n_object128>() + slots[i], records + i, sizeof(r3n_object128),
+                                  hipMemcpyHostToDevice, c->stream));
+        const uint32_t nt = records[i].enabled ? records[i].index_count / 3u : 0u;
+        c->total_tris = c->total_tris - c->h_ntri[slots[i]] + nt;
+        c->h_ntri[slots[i]] = nt;
+    }
+    if (n) c->tri_base_dirty = true;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
+
+int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208 *records, const uint8_t *keys, uint32_t n) {
+    if (!c || (n && (!slots || !records || !keys))) return fail(c, R3N_ERR_INVALID_ARG, "materials write: null");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t need = c->n_materials;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (keys[i] > R3N_KEY_BLEND) return fail(c, R3N_ERR_INVALID_ARG, "materials write: bad key");
+        need = std::max(need, slots[i] + 1u);
+    }
+    TRY(ensure(c, c->materials, (size_t)need * sizeof(r3n_material208), true, 0));
+    TRY(ensure(c, c->material_keys, need, true, 0));
+    c->n_materials = need;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_TRY(c, hipMemcpyAsync(c->materials.as<r3n_material208>() + slots[i], records + i, sizeof(r3n_material208),
+                                  hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->material_keys.as<uint8_t>() + slots[i], keys + i, 1, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
+
+int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void *point, uint64_t point_bytes) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto upload = [&](DevBuf &b, const void *src, uint64_t bytes, uint32_t stride, uint32_t cap) -> int {
+        if (!src || bytes < 16) {
+            HIP_TRY(c, hipMemsetAsync(b.p, 0, 16, c->stream));
+            return R3N_OK;
+        }
+        uint32_t count;
+        std::memcpy(&count, src, 4);
+        if ((uint64_t)count * stride + 16 > bytes) return fail(c, R3N_ERR_INVALID_ARG, "lights write: count exceeds buffer");
+        if (count > cap) return fail(c, R3N_ERR_UNSUPPORTED, "lights write: more lights than the LDS light list holds");
+        TRY(ensure(c, b, bytes, false, -1));
+        HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return R3N_OK;
+    };
+    TRY(upload(c->dir_buf, dir, dir_bytes, 128, R3N_MAX_DIR_LIGHTS));
+    TRY(upload(c->point_buf, point, point_bytes, 32, R3N_MAX_POINT_LIGHTS));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ frame
+int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint32_t h, uint32_t samples,
+                    const float clear_color[4], uint32_t atlas_w, uint32_t atlas_h) {
+    if (!c || !u || !clear_color || !w || !h) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: bad args");
+    if (samples != 1) return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: MSAA (SampleCount::Four) is not built yet (row N4)");
+    if (w > 65535 || h > 65535) return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: target larger than 65535");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (w != c->width || h != c->height) {
+        // resolution change invalidates the temporal history exactly like a new CullingBufferMap entry would
+        c->viewport.has_prev = false;
+    }
+    c->width = w; c->height = h; c->samples = samples; c->atlas_w = atlas_w; c->atlas_h = atlas_h;
+    std::memcpy(c->clear, clear_color, 16);
+    const size_t npix = (size_t)w * h;
+    TRY(ensure(c, c->fu, sizeof *u, false, -1));
+    HIP_TRY(c, hipMemcpyAsync(c->fu.p, u, sizeof *u, hipMemcpyHostToDevice, c->stream));
+    TRY(ensure(c, c->vis, npix * 8, false, -1));
+    TRY(ensure(c, c->hdr16, npix * 8, false, -1));
+    TRY(ensure(c, c->out8, npix * 4, false, -1));
+    build_hiz_desc(c->hizd, w, h);
+    TRY(ensure(c, c->hiz, hiz_elements(c->hizd) * 4, false, -1));
+    const size_t apix = (size_t)std::max(1u, atlas_w) * std::max(1u, atlas_h);
+    TRY(ensure(c, c->atlas, apix * 4, false, -1));
+    {
+        Timed t(c, R3N_STAGE_CLEAR);
+        // depth clear 0.0 / no triangle (base.rs:259-263) and shadow atlas clear 0.0 (clear.rs:4-20)
+        HIP_TRY(c, hipMemsetAsync(c->vis.p, 0, npix * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->atlas.p, 0, apix * 4, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `u` is caller-owned
+    TRY(refresh_tri_base(c));
+    c->in_frame = true;
+    c->viewport.culled = false;
+    for (auto &kv : c->shadows) kv.second.culled = false;
+    return R3N_OK;
+}
+
+int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr) {
+    if (!c || !hdr) return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: null");
+    CamState *s = find_cam(c, cam, true);
+    if (!s) return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: bad camera");
+    if (hdr->object_count != c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: header.object_count != object capacity");
+    if ((cam == R3N_CAMERA_VIEWPORT) != (hdr->shadow_index == R3N_INVALID) || (cam != R3N_CAMERA_VIEWPORT && hdr->shadow_index != cam))
+        return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: header.shadow_index does not match camera");
+    HIP_TRY(c, hipSetDevice(c->device));
+    s->hdr = *hdr;
+    s->has_hdr = true;
+    if (c->capacity == 0) return R3N_OK;  // culler.rs:449-451
+    TRY(ensure(c, s->d_hdr, sizeof *hdr, false, -1));
+    HIP_TRY(c, hipMemcpyAsync(s->d_hdr.p, &s->hdr, sizeof *hdr, hipMemcpyHostToDevice, c->stream));
+    // per-camera buffer regrow preserves old matrices (disabled slots keep stale data, App. D.2)
+    TRY(ensure(c, s->baked, (size_t)c->capacity * sizeof(r3n_baked128), true, 0));
+    Timed t(c, R3N_STAGE_BAKE);
+    const uint32_t threads = c->capacity * 4u;
+    hipLaunchKernelGGL(k_uniform_bake, dim3((threads + 255u) / 256u), dim3(256), 0, c->stream,
+                       s->d_hdr.as<r3n_camera_header240>(), c->objects.as<r3n_object128>(), s->baked.as<r3n_baked128>());
+    return check_launch(c, "k_uniform_bake");
+}
+
+int r3n_cull(r3n_ctx *c, r3n_camera cam) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    CamState *s = find_cam(c, cam, false);
+    if (!s || !s->has_hdr) return fail(c, R3N_ERR_STATE, "cull: camera has no baked uniforms (culler.rs:572 panics here)");
+    if (!c->in_frame) return fail(c, R3N_ERR_STATE, "cull: outside frame_begin/frame_end");
+    if (c->capacity == 0) return R3N_OK;  // culler.rs:705-707
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool viewport = cam == R3N_CAMERA_VIEWPORT;
+    const int cur = s->cur, prev = 1 - cur;
+    TRY(run_object_pass(c, *s, cur, c->range_begin, c->range_end, nullptr));
+    const size_t list_bytes = (size_t)std::max<uint64_t>(c->total_tris, 1) * sizeof(r3n_tri_ref);
+    const uint32_t mw = max_waves(c);
+    TRY(ensure(c, s->mask[cur], (size_t)mw * 8u, false, -1));
+    TRY(ensure(c, s->predicted[cur], list_bytes, false, -1));
+    if (viewport) TRY(ensure(c, s->residual, list_bytes, false, -1));
+    TriCullArgs a{};
+    a.hdr = s->d_hdr.as<r3n_camera_header240>();
+    a.objects = c->objects.as<r3n_object128>();
+    a.mesh = c->mesh.as<uint32_t>();
+    a.baked = s->baked.as<r3n_baked128>();
+    a.material_keys = c->material_keys.as<uint8_t>();
+    a.n_materials = c->n_materials;
+    a.vis_list = s->vis_list.as<r3n_vis_entry>();
+    a.counts = s->counts[cur].as<r3n_cull_counts>();
+    a.prev_slot_base = (viewport && s->has_prev) ? s->slot_base[prev].as<uint32_t>() : nullptr;
+    a.prev_mask = (viewport && s->has_prev) ? s->mask[prev].as<unsigned long long>() : nullptr;
+    a.mask = s->mask[cur].as<unsigned long long>();
+    a.predicted = s->predicted[cur].as<r3n_tri_ref>();
+    a.residual = viewport ? s->residual.as<r3n_tri_ref>() : nullptr;
+    a.calls = s->calls[cur].as<r3n_indirect_call>();
+    a.hiz.data = c->hiz.as<float>();
+    a.hiz.d = c->hizd;
+    const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
+    const uint32_t grid = std::max(1u, std::min(chunks, 2048u));
+    {
+        Timed t(c, R3N_STAGE_TRIANGLE_CULL);
+        hipLaunchKernelGGL(k_triangle_cull, dim3(grid), dim3(256), 0, c->stream, a);
+    }
+    TRY(check_launch(c, "k_triangle_cull"));
+    s->culled = true;
+    s->last = cur;
+    return R3N_OK;
+}
+
+int r3n_hi_z(r3n_ctx *c) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "hi_z: outside a frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    Timed t(c, R3N_STAGE_HIZ);
+    const size_t npix = (size_t)c->width * c->height;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((npix + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_hiz_mip0, dim3(blocks), dim3(256), 0, c->stream, c->vis.as<unsigned long long>(), c->hiz.as<float>(), npix);
+    for (uint32_t k = 1; k < c->hizd.mips; ++k) {
+        const uint32_t sw = std::max(1u, c->width >> (k - 1)), sh = std::max(1u, c->height >> (k - 1));
+        const uint32_t dw = std::max(1u, c->width >> k), dh = std::max(1u, c->height >> k);
+        hipLaunchKernelGGL(k_hiz_downsample, dim3((dw + 15u) / 16u, (dh + 15u) / 16u), dim3(256), 0, c->stream,
+                           c->hiz.as<float>() + c->hizd.offset[k - 1], c->hiz.as<float>() + c->hizd.offset[k], sw, sh, dw, dh);
+    }
+    return check_launch(c, "hi_z");
+}
+
+int r3n_shadow_viewport(r3n_ctx *c, r3n_camera cam, uint32_t x, uint32_t y, uint32_t size) {
+    if (!c || cam == R3N_CAMERA_VIEWPORT) return fail(c, R3N_ERR_INVALID_ARG, "shadow_viewport: needs a shadow camera");
+    CamState *s = find_cam(c, cam, true);
+    if (!s) return fail(c, R3N_ERR_INVALID_ARG, "shadow_viewport: bad camera");
+    s->vp_x = x; s->vp_y = y; s->vp_size = size;
+    return R3N_OK;
+}
+
+int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint32_t key) {
+    if (!c || pass > R3N_PASS_FORWARD || source > R3N_SOURCE_RESIDUAL || key > R3N_KEY_BLEND)
+        return fail(c, R3N_ERR_INVALID_ARG, "forward: bad args");
+    if (!c->in_frame) return fail(c, R3N_ERR_STATE, "forward: outside a frame");
+    if (key == R3N_KEY_BLEND) return fail(c, R3N_ERR_UNSUPPORTED, "forward: blend routine is not built yet (row N3)");
+    CamState *s = find_cam(c, cam, false);
+    if (!s || !s->has_hdr || c->capacity == 0) return R3N_OK;  // nothing baked / culled yet: forward.rs:214-242
+    const bool viewport = cam == R3N_CAMERA_VIEWPORT;
+    if ((pass == R3N_PASS_FORWARD) != viewport) return fail(c, R3N_ERR_UNSUPPORTED, "forward: FORWARD needs the viewport, DEPTH a shadow camera");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int idx;
+    const r3n_tri_ref *list;
+    const r3n_indirect_call *calls;
+    if (source == R3N_SOURCE_PREDICTED) {
+        // last frame's predicted triangles, this frame's matrices (forward.rs:224-232, App. D.8)
+        if (!s->has_prev) return R3N_OK;
+        idx = 1 - s->cur;
+        list = s->predicted[idx].as<r3n_tri_ref>();
+        calls = s->calls[idx].as<r3n_indirect_call>();
+    } else {
+        if (!s->culled) return R3N_OK;
+        idx = s->cur;
+        // residual && viewport -> residual list; otherwise the list written this frame (forward.rs:234,251)
+        list = viewport ? s->residual.as<r3n_tri_ref>() : s->predicted[idx].as<r3n_tri_ref>();
+        calls = s->calls[idx].as<r3n_indirect_call>() + (viewport ? 3 : 0);
+    }
+    RasterArgs a{};
+    a.hdr = s->d_hdr.as<r3n_camera_header240>();
+    a.objects = c->objects.as<r3n_object128>();
+    a.mesh = c->mesh.as<uint32_t>();
+    a.baked = s->baked.as<r3n_baked128>();
+    a.materials = c->materials.as<r3n_material208>();
+    a.material_keys = c->material_keys.as<uint8_t>();
+    a.n_materials = c->n_materials;
+    a.tri_base = c->tri_base.as<uint32_t>();
+    a.list = list;
+    a.counts = s->counts[idx].as<r3n_cull_counts>();
+    a.calls = calls;
+    a.key = key;
+    a.big_items = c->big_items.as<r3n_big_item>();
+    a.big_count = c->big_count.as<uint32_t>();
+    a.big_capacity = c->big_capacity;
+    const uint32_t small_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->total_tris + 255) / 256, 2048));
+    Timed t(c, R3N_STAGE_RASTER);
+    HIP_TRY(c, hipMemsetAsync(c->big_count.p, 0, 4, c->stream));
+    if (viewport) {
+        a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
+        a.vis = c->vis.as<unsigned long long>();
+        hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_raster_big<false>, dim3(1024), dim3(256), 0, c->stream, a);
+    } else {
+        if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
+            return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
+        a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
+        a.depth = c->atlas.as<uint32_t>();
+        hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_raster_big<true>, dim3(1024), dim3(256), 0, c->stream, a);
+    }
+    return check_launch(c, "raster");
+}
+
+int r3n_resolve_opaque(r3n_ctx *c) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "resolve_opaque: outside a frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t r0 = std::min(c->row_begin, c->height), r1 = std::min(c->row_end, c->height);
+    if (r1 <= r0) return R3N_OK;
+    CamState &s = c->viewport;
+    if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
+    ShadeArgs a{};
+    a.vis = c->vis.as<unsigned long long>();
+    a.width = c->width; a.height = c->height; a.row_begin = r0; a.row_end = r1;
+    a.fu = c->fu.as<r3n_frame_uniforms496>();
+    a.hdr = s.d_hdr.as<r3n_camera_header240>();
+    a.objects = c->objects.as<r3n_object128>();
+    a.mesh = c->mesh.as<uint32_t>();
+    a.baked = s.baked.as<r3n_baked128>();
+    a.materials = c->materials.as<r3n_material208>();
+    a.n_materials = c->n_materials;
+    a.tri_base = c->tri_base.as<uint32_t>();
+    a.dir_buf = c->dir_buf.as<uint8_t>();
+    a.point_buf = c->point_buf.as<uint8_t>();
+    a.atlas = c->atlas.as<float>();
+    a.atlas_w = std::max(1u, c->atlas_w); a.atlas_h = std::max(1u, c->atlas_h);
+    std::memcpy(a.clear, c->clear, 16);
+    a.hdr_out = c->hdr16.as<ushort4>();
+    Timed t(c, R3N_STAGE_SHADE);
+    hipLaunchKernelGGL(k_resolve_opaque, dim3((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u), dim3(256), 0, c->stream, a);
+    return check_launch(c, "k_resolve_opaque");
+}
+
+static int launch_tonemap(r3n_ctx *c, float4 *f32_out) {
+    const uint32_t r0 = std::min(c->row_begin, c->height), r1 = std::min(c->row_end, c->height);
+    if (r1 <= r0) return R3N_OK;
+    const size_t first = (size_t)r0 * c->width, n = (size_t)(r1 - r0) * c->width;
+    Timed t(c, R3N_STAGE_TONEMAP);
+    const size_t pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, c->stream, c->hdr16.as<ushort4>(),
+                       c->out8.as<uchar4>(), f32_out, first, n);
+    return check_launch(c, "k_tonemap");
+}
+
+int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "tonemap: outside a frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(launch_tonemap(c, nullptr));
+    if (host_rgba8) {
+        if (pitch < (uint64_t)c->width * 4) return fail(c, R3N_ERR_INVALID_ARG, "tonemap: pitch too small");
+        HIP_TRY(c, hipMemcpy2DAsync(host_rgba8, pitch, c->out8.p, (size_t)c->width * 4, (size_t)c->width * 4, c->height,
+                                    hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return R3N_OK;
+}
+
+int r3n_frame_end(r3n_ctx *c) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "frame_end: no frame in flight");
+    auto flip = [](CamState &s) {
+        if (s.culled) { s.cur = 1 - s.cur; s.has_prev = true; }
+        s.culled = false;
+    };
+    flip(c->viewport);
+    for (auto &kv : c->shadows) flip(kv.second);
+    c->in_frame = false;
+    return R3N_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+int r3n_set_object_range(r3n_ctx *c, uint32_t begin, uint32_t end) {
+    if (!c || begin > end) return fail(c, R3N_ERR_INVALID_ARG, "set_object_range: begin > end");
+    c->range_begin = begin; c->range_end = end;
+    return R3N_OK;
+}
+int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atlas, uint64_t *atlas_count) {
+    if (!c || !c->vis.p) return fail(c, R3N_ERR_STATE, "exchange_buffers: no frame targets yet");
+    if (vis) *vis = c->vis.p;
+    if (vis_count) *vis_count = (uint64_t)c->width * c->height;
+    if (atlas) *atlas = c->atlas.p;
+    if (atlas_count) *atlas_count = (uint64_t)c->atlas_w * c->atlas_h;
+    return R3N_OK;
+}
+int r3n_set_row_range(r3n_ctx *c, uint32_t b, uint32_t e) {
+    if (!c || b > e) return fail(c, R3N_ERR_INVALID_ARG, "set_row_range: begin > end");
+    c->row_begin = b; c->row_end = e;
+    return R3N_OK;
+}
+int r3n_output_buffer(r3n_ctx *c, void **rgba8, uint64_t *bytes) {
+    if (!c || !c->out8.p) return fail(c, R3N_ERR_STATE, "output_buffer: no frame targets yet");
+    if (rgba8) *rgba8 = c->out8.p;
+    if (bytes) *bytes = (uint64_t)c->width * c->height * 4;
+    return R3N_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ readbacks
+static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
+
+int r3n_readback_visible_objects(r3n_ctx *c, r3n_camera cam, uint8_t *flags, uint32_t capacity) {
+    CamState *s = c ? find_cam(c, cam, false) : nullptr;
+    if (!s || s->last < 0 || !flags) return fail(c, R3N_ERR_STATE, "readback_visible_objects: camera never culled");
+    if (capacity < c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "readback_visible_objects: buffer too small");
+    return d2h(c, flags, s->vis_flags.p, c->capacity);
+}
+
+int r3n_readback_draw_calls(r3n_ctx *c, r3n_camera cam, r3n_indirect_call calls[6]) {
+    CamState *s = c ? find_cam(c, cam, false) : nullptr;
+    if (!s || s->last < 0) return fail(c, R3N_ERR_STATE, "readback_draw_calls: camera never culled");
+    return d2h(c, calls, s->calls[s->last].p, 6 * sizeof(r3n_indirect_call));
+}
+
+int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_t *residual, uint64_t n) {
+    CamState *s = c ? find_cam(c, cam, false) : nullptr;
+    if (!s || s->last < 0) return fail(c, R3N_ERR_STATE, "readback_triangle_sets: camera never culled");
+    if (n < c->total_tris) return fail(c, R3N_ERR_INVALID_ARG, "readback_triangle_sets: buffer too small");
+    const int idx = s->last;
+    const uint32_t cap = c->capacity;
+    r3n_cull_counts counts;
+    TRY(d2h(c, &counts, s->counts[idx].p, sizeof counts));
+    std::vector<uint32_t> slot_base(cap), tri_base(cap);
+    TRY(d2h(c, slot_base.data(), s->slot_base[idx].p, (size_t)cap * 4));
+    TRY(d2h(c, tri_base.data(), c->tri_base.p, (size_t)cap * 4));
+    std::vector<unsigned long long> mask(std::max(1u, counts.total_waves));
+    if (counts.total_waves) TRY(d2h(c, mask.data(), s->mask[idx].p, (size_t)counts.total_waves * 8));
+    if (pass) {
+        std::memset(pass, 0, n);
+        for (uint32_t o = 0; o < cap; ++o) {
+            if (slot_base[o] == R3N_INVALID) continue;
+            for (uint32_t t = 0; t < c->h_ntri[o]; ++t) {
+                const uint64_t bit = (uint64_t)slot_base[o] + t;
+                pass[(uint64_t)tri_base[o] + t] = (uint8_t)((mask[bit / 64] >> (bit % 64)) & 1ull);
+            }
+        }
+    }
+    if (residual) {
+        std::memset(residual, 0, n);
+        if (cam == R3N_CAMERA_VIEWPORT) {
+            r3n_indirect_call calls[6];
+            TRY(d2h(c, calls, s->calls[idx].p, sizeof calls));
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t cnt = calls[3 + k].vertex_count / 3u;
+                if (!cnt) continue;
+                std::vector<r3n_tri_ref> refs(cnt);
+                TRY(d2h(c, refs.data(), s->residual.as<r3n_tri_ref>() + counts.region_base[k], (size_t)cnt * sizeof(r3n_tri_ref)));
+                for (const auto &r : refs) residual[(uint64_t)tri_base[r.object] + r.triangle] = 1;
+            }
+        }
+    }
+    return R3N_OK;
+}
+
+int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity) {
+    CamState *s = c ? find_cam(c, cam, false) : nullptr;
+    if (!s || !s->baked.p || !out) return fail(c, R3N_ERR_STATE, "readback_baked: camera never baked");
+    if (capacity < c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "readback_baked: buffer too small");
+    return d2h(c, out, s->baked.p, (size_t)c->capacity * sizeof(r3n_baked128));
+}
+
+int r3n_readback_visibility(r3n_ctx *c, uint64_t *keys) {
+    if (!c || !c->vis.p || !keys) return fail(c, R3N_ERR_STATE, "readback_visibility: no frame");
+    return d2h(c, keys, c->vis.p, (size_t)c->width * c->height * 8);
+}
+
+int r3n_readback_depth(r3n_ctx *c, float *depth) {
+    if (!c || !c->vis.p || !depth) return fail(c, R3N_ERR_STATE, "readback_depth: no frame");
+    const size_t n = (size_t)c->width * c->height;
+    std::vector<uint64_t> keys(n);
+    TRY(d2h(c, keys.data(), c->vis.p, n * 8));
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t zb = (uint32_t)(keys[i] >> 32);
+        std::memcpy(depth + i, &zb, 4);
+    }
+    return R3N_OK;
+}
+
+int r3n_readback_hiz(r3n_ctx *c, float *pyr, uint64_t count) {
+    if (!c || !c->hiz.p || !pyr) return fail(c, R3N_ERR_STATE, "readback_hiz: no frame");
+    if (count < hiz_elements(c->hizd)) return fail(c, R3N_ERR_INVALID_ARG, "readback_hiz: buffer too small");
+    return d2h(c, pyr, c->hiz.p, hiz_elements(c->hizd) * 4);
+}
+
+int r3n_readback_shadow_atlas(r3n_ctx *c, float *atlas) {
+    if (!c || !c->atlas.p || !atlas) return fail(c, R3N_ERR_STATE, "readback_shadow_atlas: no frame");
+    return d2h(c, atlas, c->atlas.p, (size_t)c->atlas_w * c->atlas_h * 4);
+}
+
+int r3n_readback_hdr(r3n_ctx *c, uint16_t *rgba16f) {
+    if (!c || !c->hdr16.p || !rgba16f) return fail(c, R3N_ERR_STATE, "readback_hdr: no frame");
+    return d2h(c, rgba16f, c->hdr16.p, (size_t)c->width * c->height * 8);
+}
+
+int r3n_readback_output(r3n_ctx *c, uint8_t *rgba8, float *rgba_f32) {
+    if (!c || !c->out8.p) return fail(c, R3N_ERR_STATE, "readback_output: no frame");
+    const size_t n = (size_t)c->width * c->height;
+    if (rgba_f32) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        TRY(ensure(c, c->out_f32, n * 16, false, -1));
+        TRY(launch_tonemap(c, c->out_f32.as<float4>()));
+        TRY(d2h(c, rgba_f32, c->out_f32.p, n * 16));
+    }
+    if (rgba8) TRY(d2h(c, rgba8, c->out8.p, n * 4));
+    return R3N_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+int r3n_timing_enable(r3n_ctx *c, int enable) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    TRY(drain_timing(c));
+    c->timing = enable != 0;
+    return R3N_OK;
+}
+
+int r3n_stage_times(r3n_ctx *c, double ms[R3N_STAGE_COUNT], uint64_t launches[R3N_STAGE_COUNT], int reset) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    TRY(drain_timing(c));
+    for (int i = 0; i < R3N_STAGE_COUNT; ++i) {
+        if (ms) ms[i] = c->stage_ms[i];
+        if (launches) launches[i] = c->stage_launches[i];
+        if (reset) { c->stage_ms[i] = 0; c->stage_launches[i] = 0; }
+    }
+    return R3N_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,506 @@
+"""Host-side mirror of the reference's routine interface for the hot path, driving the HIP kernels through
+the C ABI (include/r3n.h).  Names, argument meaning and the node order follow the reference:
+
+  Renderer (world edits the path consumes)         rend3/src/renderer/mod.rs:126-424
+  RenderGraph / node closures                      rend3/src/graph/graph.rs:81-519, graph/node.rs:59-213
+  BaseRenderGraph::{new, add_to_graph}             rend3-routine/src/base.rs:110-186
+  GpuCuller::{add_object_uniform_upload_to_graph,
+              add_culling_to_graph}                rend3-routine/src/culling/culler.rs:661-713
+  ForwardRoutine::add_forward_to_graph             rend3-routine/src/forward.rs:192-315
+  PbrRoutine (5 forward routines + hi-z)           rend3-routine/src/pbr/routine.rs:35-133
+  HiZRoutine::add_hi_z_to_graph                    rend3-routine/src/hi_z.rs:161-234
+  TonemappingRoutine::add_to_graph                 rend3-routine/src/tonemapping.rs:108-147
+
+The graph here is the fixed schedule only (the render-graph machinery itself is
+out of scope); nodes are closures executed in declaration order by RenderGraph.execute.
+This module never imports the oracle; without the native library it raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi, host
+
+f32 = np.float32
+INVALID = 0xFFFFFFFF
+OPAQUE, CUTOUT, BLEND = 0, 1, 2
+
+# rend3-routine/shaders/src/material.wgsl:1-15
+FLAGS_ALBEDO_ACTIVE = 0x0001
+FLAGS_ALBEDO_BLEND = 0x0002
+FLAGS_ALBEDO_VERTEX_SRGB = 0x0004
+FLAGS_AOMR_SPLIT = 0x0100
+FLAGS_CC_GLTF_COMBINED = 0x0400
+FLAGS_UNLIT = 0x2000
+
+
+def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, roughness=0.0, metallic=0.0,
+                    reflectance=0.5, emissive=(0, 0, 0), ao=1.0, clear_coat=0.0, clear_coat_roughness=0.0,
+                    cutout=None, vertex_srgb=True):
+    """ShaderMaterial::from_material (rend3-routine/src/pbr/material.rs:548-583) for untextured PbrMaterials,
+    behind the 48-byte texture-id prefix (rend3/src/managers/material.rs:25-29).  208 bytes as f32[52]."""
+    rec = np.zeros(52, dtype=f32)
+    ru = rec.view(np.uint32)
+    for base in (12, 24):  # uv_transform0/1 = identity mat3 (3 x vec4 columns)
+        rec[base + 0] = rec[base + 5] = rec[base + 10] = 1.0
+    flags = FLAGS_AOMR_SPLIT | FLAGS_CC_GLTF_COMBINED
+    if albedo_mode == "none":
+        alb = (0.0, 0.0, 0.0, 1.0)
+    elif albedo_mode == "vertex":
+        flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
+        alb = (1.0, 1.0, 1.0, 1.0)
+    elif albedo_mode == "value":
+        flags |= FLAGS_ALBEDO_ACTIVE
+        alb = albedo
+    elif albedo_mode == "value_vertex":
+        flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
+        alb = albedo
+    else:
+        raise ValueError(albedo_mode)
+    if unlit:
+        flags |= FLAGS_UNLIT
+    rec[36:40] = alb
+    rec[40:43] = emissive
+    rec[43], rec[44], rec[45], rec[46], rec[47] = roughness, metallic, reflectance, clear_coat, clear_coat_roughness
+    rec[49] = ao
+    rec[50] = 0.0 if cutout is None else cutout
+    ru[51] = flags
+    return rec
+
+
+class CameraSpecifier:
+    """rend3-routine/src/common/camera.rs:3-35"""
+    VIEWPORT = _ffi.CAMERA_VIEWPORT
+
+    @staticmethod
+    def shadow(i):
+        assert i != 0xFFFFFFFF
+        return i
+
+
+class _Mesh:
+    __slots__ = ("attr_off", "first_index", "index_count", "centre", "radius")
+
+
+class EvalOutput:
+    """What Renderer::evaluate_instructions hands the graph (rend3/src/renderer/eval.rs:157-187), path subset."""
+
+    def __init__(self, shadows, shadow_target_size):
+        self.shadows = shadows
+        self.shadow_target_size = shadow_target_size
+
+
+class Renderer:
+    """World bookkeeping feeding the object/mesh/material/light buffers of the C ABI."""
+
+    def __init__(self, handedness=host.LEFT, aspect_ratio=None, device=0):
+        self.lib = _ffi.lib()
+        self.ctx = self.lib.r3n_create(device, None)
+        if not self.ctx:
+            raise _ffi.R3nError("r3n_create failed: " + self.lib.r3n_create_error().decode())
+        self.handedness = handedness
+        self.aspect_ratio = aspect_ratio
+        self.mesh_cursor = 0  # in u32 words
+        self.meshes = []
+        self.materials = []
+        self.capacity = 16  # FreelistDerivedBuffer::STARTING_SIZE
+        self.object_meta = {}
+        self.free_handles, self.pending_free, self.deferred_removals = [], [], []
+        self.next_handle = 0
+        self.dirty_objects = {}
+        self.dir_lights, self.point_lights = [], []
+        self.camera = host.CameraState(host.identity(), ("raw", host.identity()), handedness, aspect_ratio)
+        self.object_range = None
+        self._write_objects([], force_capacity=True)
+
+    def close(self):
+        if self.ctx:
+            self.lib.r3n_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, code, what):
+        _ffi.check(self.ctx, code, what)
+
+    # ------------------------------------------------------------------ world edits
+    def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT):
+        positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
+        if indices is None:
+            indices = np.arange(len(positions), dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        if normals is None:  # MeshBuilder::build (rend3-types/src/lib.rs:501-504)
+            normals = host.calculate_normals(positions, indices, mesh_handedness == host.LEFT)
+        normals = np.ascontiguousarray(normals, dtype=f32).reshape(-1, 3)
+        m = _Mesh()
+        m.attr_off = [INVALID] * 6
+        chunks = []
+        cursor = self.mesh_cursor
+
+        def push(words):
+            nonlocal cursor
+            start = cursor
+            chunks.append(np.ascontiguousarray(words))
+            cursor += len(words)
+            return start
+
+        m.attr_off[0] = 4 * push(positions.view(np.uint32).reshape(-1))
+        m.attr_off[1] = 4 * push(normals.view(np.uint32).reshape(-1))
+        if colors is not None:
+            colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 4)
+            m.attr_off[5] = 4 * push(colors.view(np.uint32).reshape(-1))
+        m.first_index = push(indices)
+        m.index_count = len(indices)
+        blob = np.concatenate(chunks)
+        self._check(self.lib.r3n_mesh_buffer_write(self.ctx, 4 * self.mesh_cursor, _ffi.ptr(blob), blob.nbytes),
+                    "r3n_mesh_buffer_write")
+        self.mesh_cursor = cursor
+        m.centre, m.radius = host.bounding_sphere_from_mesh(positions)
+        self.meshes.append(m)
+        return len(self.meshes) - 1
+
+    def add_material(self, record, key=OPAQUE):
+        idx = len(self.materials)
+        self.materials.append((np.asarray(record, dtype=f32), key))
+        slots = np.array([idx], dtype=np.uint32)
+        rec = np.ascontiguousarray(record, dtype=f32).reshape(1, 52)
+        keys = np.array([key], dtype=np.uint8)
+        self._check(self.lib.r3n_materials_write(self.ctx, _ffi.ptr(slots), _ffi.ptr(rec), _ffi.ptr(keys), 1),
+                    "r3n_materials_write")
+        return idx
+
+    def _alloc_handle(self):
+        if self.free_handles:
+            return self.free_handles.pop(0)
+        h = self.next_handle
+        self.next_handle += 1
+        return h
+
+    def _use_index(self, idx):
+        cap = self.capacity
+        if idx > cap:  # freelist/buffer.rs:48-52
+            cap = 1 << (int(idx) - 1).bit_length()
+        while cap <= idx:
+            cap *= 2
+        self.capacity = cap
+
+    def _object_record(self, h):
+        meta = self.object_meta[h]
+        mesh = self.meshes[meta["mesh"]]
+        rec = np.zeros(32, dtype=np.uint32)
+        rf = rec.view(f32)
+        rf[0:16] = meta["transform"]
+        c, r = host.bounding_sphere_apply_transform(mesh.centre, mesh.radius, meta["transform"])
+        rf[16:19] = c
+        rf[19] = r
+        rec[20], rec[21], rec[22] = mesh.first_index, mesh.index_count, meta["material"]
+        rec[23:29] = mesh.attr_off
+        rec[29] = 1 if meta["enabled"] else 0
+        return rec
+
+    def _mark(self, h, rec):
+        self._use_index(h)
+        self.dirty_objects[h] = rec
+
+    def _write_objects(self, items, force_capacity=False):
+        if not items and not force_capacity:
+            return
+        slots = np.array([h for h, _ in items], dtype=np.uint32)
+        recs = np.ascontiguousarray(np.stack([r for _, r in items]) if items else np.zeros((0, 32), dtype=np.uint32))
+        self._check(self.lib.r3n_objects_write(self.ctx, _ffi.ptr(slots) if len(slots) else None,
+                                               _ffi.ptr(recs) if len(slots) else None, len(slots), self.capacity),
+                    "r3n_objects_write")
+
+    def add_object(self, mesh, material, transform):
+        h = self._alloc_handle()
+        self.object_meta[h] = dict(mesh=mesh, material=material, transform=np.asarray(transform, dtype=f32).copy(),
+                                   enabled=True)
+        self._mark(h, self._object_record(h))
+        return h
+
+    def set_object_transform(self, h, transform):
+        self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
+        self._mark(h, self._object_record(h))
+
+    def remove_object(self, h):
+        self.object_meta[h]["enabled"] = False  # object.rs:330-342: disabled now, removed next frame
+        self._mark(h, self._object_record(h))
+        self.deferred_removals.append(h)
+
+    def add_directional_light(self, color=(1, 1, 1), intensity=1.0, direction=(0, -1, 0), distance=100.0,
+                              resolution=2048):
+        self.dir_lights.append(dict(color=color, intensity=intensity, direction=direction, distance=distance,
+                                    resolution=resolution))
+        return len(self.dir_lights) - 1
+
+    def add_point_light(self, position, color=(1, 1, 1), intensity=1.0, radius=1.0):
+        self.point_lights.append(dict(position=position, color=color, intensity=intensity, radius=radius))
+        return len(self.point_lights) - 1
+
+    def set_camera_data(self, view, projection):
+        self.camera = host.CameraState(view, projection, self.handedness, self.aspect_ratio)
+
+    def set_object_range(self, begin, end):
+        """Multi-GPU sharding (not in the reference): this rank culls/draws object slots [begin, end)."""
+        self._check(self.lib.r3n_set_object_range(self.ctx, begin, end), "r3n_set_object_range")
+
+    # ------------------------------------------------------------------ per-frame evaluation
+    def evaluate_instructions(self):
+        """Renderer::evaluate_instructions (rend3/src/renderer/eval.rs:9-187), path subset: flush dirty objects,
+        evaluate lights -> shadow cameras + atlas + light buffers."""
+        for h in self.pending_free:
+            self.dirty_objects[h] = np.zeros(32, dtype=np.uint32)  # unwrap_or_default(), object.rs:363
+            self.object_meta.pop(h, None)
+            self.free_handles.append(h)
+        self.pending_free = self.deferred_removals
+        self.deferred_removals = []
+        self._write_objects(sorted(self.dirty_objects.items()), force_capacity=True)
+        self.dirty_objects = {}
+        size, shadows, dir_buf = host.evaluate_directional_lights(self.dir_lights, self.camera)
+        point_buf = host.point_light_buffer(self.point_lights)
+        self._check(self.lib.r3n_lights_write(self.ctx, _ffi.ptr(dir_buf), dir_buf.nbytes, _ffi.ptr(point_buf),
+                                              point_buf.nbytes), "r3n_lights_write")
+        self._dir_buf, self._point_buf = dir_buf, point_buf
+        return EvalOutput(shadows, size)
+
+    # ------------------------------------------------------------------ convenience: one whole frame
+    def render(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0), readback=True,
+               base=None, exchange=None):
+        """The reference's per-frame driver (rend3-test/src/runner.rs:121-169): evaluate, build the graph with
+        BaseRenderGraph::add_to_graph, execute.  `readback` additionally pulls the parity taps."""
+        eval_output = self.evaluate_instructions()
+        base = base or BaseRenderGraph(self)
+        graph = RenderGraph()
+        inputs = BaseRenderGraphInputs(eval_output, base.default_routines(), (width, height), samples)
+        base.add_to_graph(graph, inputs, BaseRenderGraphSettings(ambient, clear_color), exchange=exchange)
+        graph.execute(self, eval_output)
+        if not readback:
+            return None
+        return self.readback_frame(eval_output, width, height)
+
+    def readback_frame(self, eval_output, width, height):
+        lib, ctx = self.lib, self.ctx
+        cap = self.capacity
+        out = {"capacity": cap, "shadows": []}
+        total = int(sum(self.meshes[m["mesh"]].index_count // 3 for m in self.object_meta.values() if m["enabled"]))
+
+        def cam_sets(cam):
+            visible = np.zeros(cap, dtype=np.uint8)
+            self._check(lib.r3n_readback_visible_objects(ctx, cam, _ffi.ptr(visible), cap), "readback_visible_objects")
+            p = np.zeros(max(total, 1), dtype=np.uint8)
+            r = np.zeros(max(total, 1), dtype=np.uint8)
+            self._check(lib.r3n_readback_triangle_sets(ctx, cam, _ffi.ptr(p), _ffi.ptr(r), len(p)), "readback_triangle_sets")
+            calls = np.zeros((6, 5), dtype=np.uint32)
+            self._check(lib.r3n_readback_draw_calls(ctx, cam, _ffi.ptr(calls)), "readback_draw_calls")
+            baked = np.zeros((cap, 32), dtype=f32)
+            self._check(lib.r3n_readback_baked(ctx, cam, _ffi.ptr(baked), cap), "readback_baked")
+            return dict(visible=visible, residual=r, draw_calls=calls, baked=baked, **{"pass": p})
+
+        if cap and self.object_meta:
+            for si in range(len(eval_output.shadows)):
+                out["shadows"].append(cam_sets(si))
+            out.update(cam_sets(_ffi.CAMERA_VIEWPORT))
+        vis = np.zeros((height, width), dtype=np.uint64)
+        self._check(lib.r3n_readback_visibility(ctx, _ffi.ptr(vis)), "readback_visibility")
+        aw, ah = eval_output.shadow_target_size
+        atlas = np.zeros((ah, aw), dtype=f32)
+        self._check(lib.r3n_readback_shadow_atlas(ctx, _ffi.ptr(atlas)), "readback_shadow_atlas")
+        hdr16 = np.zeros((height, width, 4), dtype=np.uint16)
+        self._check(lib.r3n_readback_hdr(ctx, _ffi.ptr(hdr16)), "readback_hdr")
+        rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
+        rgba_f = np.zeros((height, width, 4), dtype=f32)
+        self._check(lib.r3n_readback_output(ctx, _ffi.ptr(rgba8), _ffi.ptr(rgba_f)), "readback_output")
+        out.update(vis=vis, atlas=atlas, atlas_size=(aw, ah), hdr16=hdr16, rgba8=rgba8, rgba_f32=rgba_f)
+        return out
+
+    def readback_hiz(self, width, height):
+        n = 0
+        k = 0
+        m = max(width, height)
+        while m:
+            n += max(1, width >> k) * max(1, height >> k)
+            k += 1
+            m >>= 1
+        pyr = np.zeros(n, dtype=f32)
+        self._check(self.lib.r3n_readback_hiz(self.ctx, _ffi.ptr(pyr), n), "readback_hiz")
+        return pyr
+
+    # ------------------------------------------------------------------ timing taps
+    def timing_enable(self, on=True):
+        self._check(self.lib.r3n_timing_enable(self.ctx, 1 if on else 0), "r3n_timing_enable")
+
+    def stage_times(self, reset=True):
+        ms = np.zeros(len(_ffi.STAGES), dtype=np.float64)
+        n = np.zeros(len(_ffi.STAGES), dtype=np.uint64)
+        self._check(self.lib.r3n_stage_times(self.ctx, _ffi.ptr(ms), _ffi.ptr(n), 1 if reset else 0), "r3n_stage_times")
+        return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(_ffi.STAGES)}
+
+    def sync(self):
+        self._check(self.lib.r3n_sync(self.ctx), "r3n_sync")
+
+
+# ---------------------------------------------------------------------------------------------------- graph
+class RenderGraph:
+    """Fixed-order stand-in for rend3::graph::RenderGraph: nodes are (name, closure) run in declaration order."""
+
+    def __init__(self):
+        self.nodes = []
+
+    def add_node(self, name, body):
+        self.nodes.append((name, body))
+
+    def execute(self, renderer, eval_output):
+        for _name, body in self.nodes:
+            body(renderer, eval_output)
+
+
+class BaseRenderGraphSettings:
+    """rend3-routine/src/base.rs:94-98"""
+
+    def __init__(self, ambient_color=(0, 0, 0, 0), clear_color=(0, 0, 0, 0)):
+        self.ambient_color = ambient_color
+        self.clear_color = clear_color
+
+
+class BaseRenderGraphInputs:
+    """rend3-routine/src/base.rs:72-92 (eval_output, routines, target{resolution, samples})"""
+
+    def __init__(self, eval_output, routines, resolution, samples=1):
+        self.eval_output = eval_output
+        self.routines = routines
+        self.resolution = resolution
+        self.samples = samples
+
+
+class GpuCuller:
+    """rend3-routine/src/culling/culler.rs:185-714"""
+
+    def add_object_uniform_upload_to_graph(self, graph, camera_specifier, resolution, samples, name):
+        def body(r, ev):
+            cam = r.camera if camera_specifier == CameraSpecifier.VIEWPORT else ev.shadows[camera_specifier]["camera"]
+            hdr = host.camera_header(cam, None if camera_specifier == CameraSpecifier.VIEWPORT else camera_specifier,
+                                     resolution, samples, r.capacity)
+            r._check(r.lib.r3n_uniform_bake(r.ctx, camera_specifier, _ffi.ptr(hdr)), "r3n_uniform_bake")
+
+        graph.add_node(name, body)
+
+    def add_culling_to_graph(self, graph, camera_specifier, name):
+        graph.add_node(name, lambda r, ev: r._check(r.lib.r3n_cull(r.ctx, camera_specifier), "r3n_cull"))
+
+
+class ForwardRoutine:
+    """rend3-routine/src/forward.rs:135-316: one (routine type, material key) pipeline."""
+
+    def __init__(self, routine_type, material_key):
+        self.routine_type = routine_type
+        self.material_key = material_key
+
+    def add_forward_to_graph(self, graph, label, camera, culling_source):
+        def body(r, ev):
+            r._check(r.lib.r3n_forward(r.ctx, camera, self.routine_type, culling_source, self.material_key), "r3n_forward")
+
+        graph.add_node(label, body)
+
+
+class HiZRoutine:
+    """rend3-routine/src/hi_z.rs:18-235"""
+
+    def add_hi_z_to_graph(self, graph):
+        graph.add_node("HiZ", lambda r, ev: r._check(r.lib.r3n_hi_z(r.ctx), "r3n_hi_z"))
+
+
+class PbrRoutine:
+    """rend3-routine/src/pbr/routine.rs:17-133"""
+
+    def __init__(self):
+        self.opaque_depth = ForwardRoutine(_ffi.PASS_DEPTH, OPAQUE)
+        self.cutout_depth = ForwardRoutine(_ffi.PASS_DEPTH, CUTOUT)
+        self.opaque_routine = ForwardRoutine(_ffi.PASS_FORWARD, OPAQUE)
+        self.cutout_routine = ForwardRoutine(_ffi.PASS_FORWARD, CUTOUT)
+        self.blend_routine = ForwardRoutine(_ffi.PASS_FORWARD, BLEND)
+        self.hi_z = HiZRoutine()
+
+
+class TonemappingRoutine:
+    """rend3-routine/src/tonemapping.rs:29-148"""
+
+    def add_to_graph(self, graph):
+        def body(r, ev):
+            r._check(r.lib.r3n_resolve_opaque(r.ctx), "r3n_resolve_opaque")
+            r._check(r.lib.r3n_tonemap(r.ctx, None, 0), "r3n_tonemap")
+
+        graph.add_node("Tonemapping", body)
+
+
+class BaseRenderGraphRoutines:
+    def __init__(self, pbr, tonemapping, skybox=None):
+        self.pbr, self.tonemapping, self.skybox = pbr, tonemapping, skybox
+
+
+class BaseRenderGraph:
+    """rend3-routine/src/base.rs:103-186: owns the culler; add_to_graph declares the frame's nodes in order."""
+
+    def __init__(self, renderer):
+        self.renderer = renderer
+        self.gpu_culler = GpuCuller()
+
+    def default_routines(self):
+        return BaseRenderGraphRoutines(PbrRoutine(), TonemappingRoutine())
+
+    def add_to_graph(self, graph, inputs, settings, exchange=None):
+        """Node order == base.rs:135-185.  `exchange` (multi-GPU only, not in the reference) is called with
+        ("shadow" | "pass1" | "pass2", renderer) at the points where ranks must merge their depth keys."""
+        ev = inputs.eval_output
+        w, h = inputs.resolution
+        pbr = inputs.routines.pbr
+        VP = CameraSpecifier.VIEWPORT
+
+        # clear_shadow_buffers + create_frame_uniforms (base.rs:139,142)
+        def begin(r, _ev):
+            fu = host.frame_uniforms(r.camera, settings.ambient_color, (w, h))
+            clear = np.asarray(settings.clear_color, dtype=f32)
+            aw, ah = ev.shadow_target_size
+            r._check(r.lib.r3n_frame_begin(r.ctx, _ffi.ptr(fu), w, h, inputs.samples, _ffi.ptr(clear), aw, ah),
+                     "r3n_frame_begin")
+            for si, sh in enumerate(ev.shadows):
+                r._check(r.lib.r3n_shadow_viewport(r.ctx, si, sh["offset"][0], sh["offset"][1], sh["size"]),
+                         "r3n_shadow_viewport")
+
+        graph.add_node("Frame Uniforms", begin)
+        # skinning (base.rs:145): row S1, not built
+        # shadow_object_uniform_upload (base.rs:148)
+        for si, sh in enumerate(ev.shadows):
+            self.gpu_culler.add_object_uniform_upload_to_graph(graph, si, (sh["size"], sh["size"]), 1, f"Shadow Culling S{si}")
+        # pbr_shadow_culling (base.rs:150)
+        for si in range(len(ev.shadows)):
+            self.gpu_culler.add_culling_to_graph(graph, si, f"Shadow Culling S{si}")
+        # pbr_shadow_rendering (base.rs:153,366-396)
+        for si in range(len(ev.shadows)):
+            for routine in (pbr.opaque_depth, pbr.cutout_depth):
+                routine.add_forward_to_graph(graph, f"pbr shadow renderering S{si}", si, _ffi.SOURCE_RESIDUAL)
+        if exchange is not None and len(ev.shadows):
+            graph.add_node("exchange shadow atlas", lambda r, _ev: exchange("shadow", r))
+        # object_uniform_upload (base.rs:156)
+        self.gpu_culler.add_object_uniform_upload_to_graph(graph, VP, (w, h), inputs.samples, "Uniform Bake")
+        # pbr_render_opaque_predicted_triangles (base.rs:159)
+        for routine in (pbr.opaque_routine, pbr.cutout_routine):
+            routine.add_forward_to_graph(graph, "PBR Forward Pass 1", VP, _ffi.SOURCE_PREDICTED)
+        if exchange is not None:
+            graph.add_node("exchange pass-1 depth", lambda r, _ev: exchange("pass1", r))
+        # hi_z (base.rs:162)
+        pbr.hi_z.add_hi_z_to_graph(graph)
+        # pbr_culling (base.rs:169)
+        self.gpu_culler.add_culling_to_graph(graph, VP, "Primary Culling")
+        # pbr_render_opaque_residual_triangles (base.rs:172)
+        for routine in (pbr.opaque_routine, pbr.cutout_routine):
+            routine.add_forward_to_graph(graph, "PBR Forward Pass 2", VP, _ffi.SOURCE_RESIDUAL)
+        if exchange is not None:
+            graph.add_node("exchange pass-2 keys", lambda r, _ev: exchange("pass2", r))
+        # skybox (base.rs:175): out of scope.  pbr_forward_rendering_transparent (base.rs:181): row N3, not built
+        # tonemapping (base.rs:184)
+        inputs.routines.tonemapping.add_to_graph(graph)
+        graph.add_node("Frame End", lambda r, _ev: r._check(r.lib.r3n_frame_end(r.ctx), "r3n_frame_end"))
