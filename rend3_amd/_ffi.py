@@ -80,6 +80,13 @@ def lib():
     """Loads (building first if needed) the native library.  Raises if that is impossible."""
     global _LIB
     if _LIB is None:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/HSA runtime, and two HSA
+        # runtimes cannot both open the KFD.  Importing torch first makes this library bind to the runtime
+        # torch already loaded (torch is the plumbing for streams / torch.distributed in this harness).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = _build.build()
         if not os.path.exists(path):
             raise RuntimeError("librend3_amd.so is missing and could not be built; the HIP path has no fallback")

@@ -61,6 +61,13 @@ struct r3n_ctx {
     std::map<uint32_t, CamState> shadows;
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
+    // pinned staging ring for small per-frame uploads (headers, uniforms, light buffers): the caller owns its
+    // pointers only for the duration of a call, and the frame path must not synchronise with the GPU.
+    static constexpr uint32_t kStageSlots = 256, kStageSlotBytes = 4096;
+    uint8_t *stage = nullptr;
+    uint32_t stage_next = 0;
+    hipEvent_t stage_half_done[2] = {nullptr, nullptr};
+    bool stage_half_pending[2] = {false, false};
     // timing taps
     bool timing = false;
     struct Span { hipEvent_t a, b; int stage; };
@@ -103,6 +110,32 @@ int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
     }
     b.p = np;
     b.bytes = want;
+    return R3N_OK;
+}
+
+// Asynchronous small upload through the pinned ring; falls back to a synchronous copy for large payloads.
+int upload_small(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes > r3n_ctx::kStageSlotBytes || !c->stage) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return R3N_OK;
+    }
+    const uint32_t half_slots = r3n_ctx::kStageSlots / 2;
+    const uint32_t slot = c->stage_next;
+    const uint32_t half = slot / half_slots;
+    if (slot % half_slots == 0 && c->stage_half_pending[half]) {
+        // entering a half of the ring: every copy previously issued from it must have executed
+        HIP_TRY(c, hipEventSynchronize(c->stage_half_done[half]));
+        c->stage_half_pending[half] = false;
+    }
+    uint8_t *h = c->stage + (size_t)slot * r3n_ctx::kStageSlotBytes;
+    std::memcpy(h, src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, c->stream));
+    c->stage_next = (slot + 1) % r3n_ctx::kStageSlots;
+    if (c->stage_next % half_slots == 0) {
+        HIP_TRY(c, hipEventRecord(c->stage_half_done[half], c->stream));
+        c->stage_half_pending[half] = true;
+    }
     return R3N_OK;
 }
 
@@ -262,6 +295,13 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         delete c;
         return nullptr;
     }
+    if (hipHostMalloc((void **)&c->stage, (size_t)r3n_ctx::kStageSlots * r3n_ctx::kStageSlotBytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->stage_half_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->stage_half_done[1], hipEventDisableTiming) != hipSuccess) {
+        g_create_error = "pinned staging ring allocation failed";
+        r3n_destroy(c);
+        return nullptr;
+    }
     // empty light buffers: count = 0
     if (ensure(c, c->dir_buf, 16, false, 0) != R3N_OK || ensure(c, c->point_buf, 16, false, 0) != R3N_OK ||
         ensure(c, c->material_keys, 256, false, 0) != R3N_OK || ensure(c, c->materials, sizeof(r3n_material208), false, 0) != R3N_OK ||
@@ -288,6 +328,9 @@ void r3n_destroy(r3n_ctx *c) {
     for (auto &kv : c->shadows) free_cam(kv.second);
     for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->stage) (void)hipHostFree(c->stage);
+    for (auto e : c->stage_half_done)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -371,12 +414,10 @@ int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void
         if ((uint64_t)count * stride + 16 > bytes) return fail(c, R3N_ERR_INVALID_ARG, "lights write: count exceeds buffer");
         if (count > cap) return fail(c, R3N_ERR_UNSUPPORTED, "lights write: more lights than the LDS light list holds");
         TRY(ensure(c, b, bytes, false, -1));
-        HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
-        return R3N_OK;
+        return upload_small(c, b.p, src, bytes);
     };
     TRY(upload(c->dir_buf, dir, dir_bytes, 128, R3N_MAX_DIR_LIGHTS));
     TRY(upload(c->point_buf, point, point_bytes, 32, R3N_MAX_POINT_LIGHTS));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return R3N_OK;
 }
 
@@ -395,7 +436,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     std::memcpy(c->clear, clear_color, 16);
     const size_t npix = (size_t)w * h;
     TRY(ensure(c, c->fu, sizeof *u, false, -1));
-    HIP_TRY(c, hipMemcpyAsync(c->fu.p, u, sizeof *u, hipMemcpyHostToDevice, c->stream));
+    TRY(upload_small(c, c->fu.p, u, sizeof *u));
     TRY(ensure(c, c->vis, npix * 8, false, -1));
     TRY(ensure(c, c->hdr16, npix * 8, false, -1));
     TRY(ensure(c, c->out8, npix * 4, false, -1));
@@ -409,7 +450,6 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
         HIP_TRY(c, hipMemsetAsync(c->vis.p, 0, npix * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->atlas.p, 0, apix * 4, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `u` is caller-owned
     TRY(refresh_tri_base(c));
     c->in_frame = true;
     c->viewport.culled = false;
@@ -429,7 +469,7 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     s->has_hdr = true;
     if (c->capacity == 0) return R3N_OK;  // culler.rs:449-451
     TRY(ensure(c, s->d_hdr, sizeof *hdr, false, -1));
-    HIP_TRY(c, hipMemcpyAsync(s->d_hdr.p, &s->hdr, sizeof *hdr, hipMemcpyHostToDevice, c->stream));
+    TRY(upload_small(c, s->d_hdr.p, hdr, sizeof *hdr));
     // per-camera buffer regrow preserves old matrices (disabled slots keep stale data, App. D.2)
     TRY(ensure(c, s->baked, (size_t)c->capacity * sizeof(r3n_baked128), true, 0));
     Timed t(c, R3N_STAGE_BAKE);

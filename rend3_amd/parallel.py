@@ -1,0 +1,109 @@
+"""Multi-GPU object-range sharding (the reference is single-device, so this layer is new).
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests).  Every rank holds
+the full mesh/object/material buffers and culls + rasterises only its contiguous object-slot range.  The path has
+three real exchange steps per frame, all element-wise MAX all-reduces (reverse-Z: nearest == max; the 64-bit
+visibility key orders by depth first, so MAX of keys is exactly the depth-tested composite):
+
+  "shadow": the f32 shadow atlas                  (after the shadow depth draws)
+  "pass1" : the 64-bit visibility keys            (before Hi-Z: every rank culls against the GLOBAL pass-1 depth,
+                                                   which keeps the per-triangle visible set bit-exact)
+  "pass2" : the 64-bit visibility keys            (before the resolve)
+
+After "pass2" every rank holds the full keys; screen rows are split across ranks for resolve + tonemap and the
+Rgba8 rows are all-gathered.
+"""
+import numpy as np
+
+
+def partition_objects(tri_counts, world_size):
+    """Contiguous object-slot ranges balanced by triangle count (prefix sum of index_count/3).
+    Returns [(begin, end)] * world_size covering [0, len(tri_counts))."""
+    tri_counts = np.asarray(tri_counts, dtype=np.int64)
+    n = len(tri_counts)
+    if world_size <= 1:
+        return [(0, n)]
+    prefix = np.concatenate([[0], np.cumsum(tri_counts + 1)])  # +1: empty objects still cost a slot
+    total = prefix[-1]
+    cuts = [0]
+    for r in range(1, world_size):
+        cuts.append(int(np.searchsorted(prefix, total * r / world_size, side="left")))
+    cuts.append(n)
+    cuts = [min(max(c, 0), n) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[i], cuts[i + 1]) for i in range(world_size)]
+
+
+def row_ranges(height, world_size):
+    base, rem = divmod(height, world_size)
+    out, y = [], 0
+    for r in range(world_size):
+        h = base + (1 if r < rem else 0)
+        out.append((y, y + h))
+        y += h
+    return out
+
+
+class _DevArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, count, dtype_str, device):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, (int(count),), dtype_str), device=device)
+
+
+class Exchange:
+    """The callable BaseRenderGraph.add_to_graph(exchange=...) expects, over torch.distributed."""
+
+    def __init__(self, renderer, device, group=None):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch, self.group = dist, torch, group
+        self.r = renderer
+        self.device = device
+        self.stream = torch.cuda.ExternalStream(renderer.lib.r3n_stream(renderer.ctx), device=device)
+        self._ct = ctypes
+
+    def _buffers(self):
+        ct = self._ct
+        vis, vis_n, atlas, atlas_n = ct.c_void_p(), ct.c_uint64(), ct.c_void_p(), ct.c_uint64()
+        r = self.r
+        r._check(r.lib.r3n_exchange_buffers(r.ctx, ct.byref(vis), ct.byref(vis_n), ct.byref(atlas), ct.byref(atlas_n)),
+                 "r3n_exchange_buffers")
+        return vis.value, vis_n.value, atlas.value, atlas_n.value
+
+    def __call__(self, what, renderer):
+        dist, torch = self.dist, self.torch
+        vis, vis_n, atlas, atlas_n = self._buffers()
+        # the context's stream is made torch's current stream, so the collective is ordered after the kernels
+        # already enqueued on it and the kernels enqueued next wait for the collective
+        with torch.cuda.stream(self.stream):
+            if what == "shadow":
+                if atlas_n:
+                    t = device_tensor(atlas, atlas_n, "<f4", self.device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            else:
+                # keys are depth_bits << 32 | slot with depth in [0,1]: the top bit is never set, so signed MAX == unsigned MAX
+                t = device_tensor(vis, vis_n, "<i8", self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
+    def gather_rows(self, width, height, world_size):
+        """All-gather the Rgba8 rows each rank tonemapped (equal row counts required)."""
+        import ctypes
+        dist, torch = self.dist, self.torch
+        assert height % world_size == 0
+        out, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+        r = self.r
+        r._check(r.lib.r3n_output_buffer(r.ctx, ctypes.byref(out), ctypes.byref(nbytes)), "r3n_output_buffer")
+        with torch.cuda.stream(self.stream):
+            full = device_tensor(out.value, nbytes.value, "|u1", self.device)
+            rank = dist.get_rank(self.group)
+            chunk = nbytes.value // world_size
+            mine = full[rank * chunk:(rank + 1) * chunk].clone()
+            dist.all_gather_into_tensor(full, mine, group=self.group)

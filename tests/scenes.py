@@ -48,80 +48,7 @@ def lit(r, mk, color):
     return r.add_material(mk(albedo=color, albedo_mode="value", unlit=False), OPAQUE)
 
 
-# ------------------------------------------------------------------ procedural meshes for synthetic scenes
-def icosphere(subdiv):
-    t = (1.0 + math.sqrt(5.0)) / 2.0
-    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
-         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
-    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
-         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
-         (8, 6, 7), (9, 8, 1)]
-    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
-    for _ in range(subdiv):
-        cache = {}
-        nf = []
-
-        def mid(a, b):
-            key = (min(a, b), max(a, b))
-            if key not in cache:
-                m = v[a] + v[b]
-                v.append(m / np.linalg.norm(m))
-                cache[key] = len(v) - 1
-            return cache[key]
-
-        for a, b, c in f:
-            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
-            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
-        f = nf
-    pos = np.array(v, dtype=f32)
-    idx = np.array(f, dtype=np.uint32).reshape(-1)
-    return pos, idx, pos.copy()  # unit sphere: normal == position
-
-
-def box(sx=1.0, sy=1.0, sz=1.0):
-    pos = np.array(CUBE_POS, dtype=f32) * np.array([sx, sy, sz], dtype=f32)
-    nrm = np.repeat(np.array([(0, 0, 1), (0, 0, -1), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0)], dtype=f32), 4, 0)
-    return pos, np.array(CUBE_IDX, dtype=np.uint32), nrm
-
-
-def grid_plane(n, size=1.0):
-    """(n x n) quads in the XZ plane facing +Y, CW-from-above winding for a LH renderer."""
-    xs = np.linspace(-size, size, n + 1, dtype=f32)
-    pos = np.array([(x, 0.0, z) for z in xs for x in xs], dtype=f32)
-    idx = []
-    for j in range(n):
-        for i in range(n):
-            a = j * (n + 1) + i
-            b = a + 1
-            c = a + n + 1
-            d = c + 1
-            idx += [a, c, b, b, c, d]
-    nrm = np.tile(np.array([0, 1, 0], dtype=f32), (len(pos), 1))
-    return pos, np.array(idx, dtype=np.uint32), nrm
-
-
-class Pcg32:
-    """PCG32 (O'Neill), the generator SURVEY.md section 8d names for the synthetic configs."""
-
-    def __init__(self, seed, seq=54):
-        self.state = 0
-        self.inc = ((seq << 1) | 1) & 0xFFFFFFFFFFFFFFFF
-        self.next_u32()
-        self.state = (self.state + seed) & 0xFFFFFFFFFFFFFFFF
-        self.next_u32()
-
-    def next_u32(self):
-        old = self.state
-        self.state = (old * 6364136223846793005 + self.inc) & 0xFFFFFFFFFFFFFFFF
-        xorshifted = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
-        rot = old >> 59
-        return ((xorshifted >> rot) | (xorshifted << ((-rot) & 31))) & 0xFFFFFFFF
-
-    def uniform(self, lo=0.0, hi=1.0):
-        return lo + (hi - lo) * (self.next_u32() / 4294967296.0)
-
-    def randint(self, n):
-        return self.next_u32() % n
+from rend3_amd.scenes import Pcg32, box, grid_plane, icosphere  # noqa: E402,F401  (input generators, shared with bench.py)
 
 
 def random_rotation(rng, hm):

@@ -277,27 +277,36 @@ def test_empty_and_degenerate_inputs(r3):
 
 
 # ------------------------------------------------------------------ full-size properties (oracle too slow there)
-def test_large_scene_properties(r3):
-    """4K, 20k objects: size-independent properties.  (a) static camera: frame N+1 has an empty residual set and
-    its image equals frame N's; (b) re-rendering is deterministic; (c) the pass set is a subset of the triangles
-    of L1-visible objects; (d) predicted call counts == popcount of the pass set."""
+def _large(r3):
     p = r3.Renderer(oh.LEFT, f32(3840) / f32(2160))
     scenes.build_random_scene(p, r3.host, r3.material_record, 20000, 0xB157, extent=(120.0, 20.0, 120.0), lights=1,
                               shadow_res=1024, shadow_distance=200.0)
     p.set_camera_data(oh.look_at_lh((0, 3, -10), (0, 0, 40), (0, 1, 0)), ("perspective", 60.0, 0.1))
-    f0 = p.render(3840, 2160, ambient=(0.1, 0.1, 0.1, 1))
-    f1 = p.render(3840, 2160, ambient=(0.1, 0.1, 0.1, 1))
-    f2 = p.render(3840, 2160, ambient=(0.1, 0.1, 0.1, 1))
-    assert f0["residual"].sum() == f0["pass"].sum() > 0            # frame 0: no history -> all residual
-    assert f2["residual"].sum() == 0                                # steady state: nothing newly visible
-    assert np.array_equal(f1["rgba8"], f2["rgba8"]) and np.array_equal(f1["vis"], f2["vis"])
-    assert np.array_equal(f1["pass"], f2["pass"])
-    assert f1["pass"].sum() <= f0["pass"].sum()                     # occlusion can only remove triangles
-    for k in range(3):
-        assert f2["draw_calls"][k][0] % 3 == 0
+    return p
+
+
+def test_large_scene_properties(r3):
+    """4K, 20k objects (oracle too slow): size-independent properties.
+    (a) frame 0 has no history: residual == pass; a static camera reaches residual == 0;
+    (b) the whole pipeline is deterministic: a second context fed the same inputs produces bit-identical sets,
+        visibility keys and image on every frame (the compaction ORDER may differ, the sets may not);
+    (c) occlusion only removes triangles: pass(f1) is a subset of pass(f0);
+    (d) predicted IndirectCall counts == 3 * popcount(pass);
+    (e) every pixel's nearest fragment in frame 2 comes from a triangle of pass(f1) + residual(f2)."""
+    p, q = _large(r3), _large(r3)
+    fp = [p.render(3840, 2160, ambient=(0.1, 0.1, 0.1, 1)) for _ in range(3)]
+    fq = [q.render(3840, 2160, ambient=(0.1, 0.1, 0.1, 1)) for _ in range(3)]
+    f0, f1, f2 = fp
+    assert f0["residual"].sum() == f0["pass"].sum() > 0
+    assert f2["residual"].sum() == 0
+    for a, b in zip(fp, fq):
+        for k in ("visible", "pass", "residual", "vis", "rgba8", "hdr16"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a["atlas"].view(np.uint32), b["atlas"].view(np.uint32))
+    assert not (f1["pass"].astype(bool) & ~f0["pass"].astype(bool)).any()
+    assert f1["pass"].sum() < f0["pass"].sum()
     assert sum(int(f2["draw_calls"][k][0]) for k in range(3)) == 3 * int(f2["pass"].sum())
-    # every pixel's nearest fragment belongs to a triangle in pass(f1) (drawn as predicted in f2)
     ids = (f2["vis"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     ids = ids[ids > 0] - 1
-    assert f1["pass"][ids].all()
-    p.close()
+    assert (f1["pass"][ids].astype(bool) | f2["residual"][ids].astype(bool)).all()
+    p.close(); q.close()
