@@ -207,6 +207,9 @@ int r3n_readback_visible_objects(r3n_ctx *ctx, r3n_camera camera, uint8_t *flags
 int r3n_readback_triangle_sets(r3n_ctx *ctx, r3n_camera camera, uint8_t *pass, uint8_t *residual, uint64_t n);
 /* per-region IndirectCall as cull.wgsl leaves it: calls[0..3) predicted, calls[3..6) residual (by material key) */
 int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call calls[6]);
+/* work-queue occupancy of the rasteriser: big_items[i] = number of >8x8 px work items the i-th r3n_forward call of
+ * the last frame produced (performance diagnostics only) */
+int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height */
 int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys */

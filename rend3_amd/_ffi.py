@@ -47,6 +47,7 @@ SIGNATURES = {
     "r3n_readback_visible_objects": (cint, [vp, u32, vp, u32]),
     "r3n_readback_triangle_sets": (cint, [vp, u32, vp, vp, u64]),
     "r3n_readback_draw_calls": (cint, [vp, u32, vp]),
+    "r3n_readback_raster_stats": (cint, [vp, vp]),
     "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
     "r3n_readback_visibility": (cint, [vp, vp]),
     "r3n_readback_depth": (cint, [vp, vp]),

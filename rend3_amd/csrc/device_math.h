@@ -124,24 +124,62 @@ R3N_DEV float frag_depth(const TriSetup &ts, const float E[3]) {
     return z;
 }
 
-// Conservative integer pixel bounds inside a (vw x vh) viewport; empty when x1 < x0 or y1 < y0.
-R3N_DEV void tri_bounds(const float p[3][4], float half_w, float half_h, int vw, int vh, int &x0, int &y0, int &x1,
+// Conservative integer pixel bounds inside a (vw x vh) viewport.  Returns false when no pixel can be covered.
+// Bounds only limit the scan (coverage is decided per pixel by edge_eval + the depth clip), so any conservative
+// box gives identical results.  Triangles that cross the depth-clip planes (0 <= z <= w, which also implies
+// w >= 0) are clipped for the purpose of the box: without this a triangle with a vertex behind the camera would
+// be scanned over the whole viewport.
+R3N_DEV bool tri_bounds(const float p[3][4], float half_w, float half_h, int vw, int vh, int &x0, int &y0, int &x1,
                         int &y1) {
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-    bool all_front = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (!(p[k][3] > 0.0f)) all_front = false;
-        const float sx = (p[k][0] / p[k][3] + 1.0f) * half_w;
-        const float sy = (1.0f - p[k][1] / p[k][3]) * half_h;
+    bool ok = true;      // false -> fall back to the whole viewport
+    bool any = false;    // some point contributes
+    auto add = [&](float x, float y, float w) {
+        if (!(w > 1e-30f)) { ok = false; return; }
+        const float sx = (x / w + 1.0f) * half_w;
+        const float sy = (1.0f - y / w) * half_h;
+        if (!(sx - sx == 0.0f) || !(sy - sy == 0.0f)) { ok = false; return; }  // inf / NaN
         mnx = fminf(mnx, sx); mxx = fmaxf(mxx, sx);
         mny = fminf(mny, sy); mxy = fmaxf(mxy, sy);
+        any = true;
+    };
+    const bool all_front = p[0][3] > 0.0f && p[1][3] > 0.0f && p[2][3] > 0.0f;
+    if (all_front) {
+        // projecting every vertex is conservative whether or not the depth clip removes part of the triangle
+#pragma unroll
+        for (int k = 0; k < 3; ++k) add(p[k][0], p[k][1], p[k][3]);
+    } else {
+        float dA[3], dB[3];
+        bool crossA = false, crossB = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dA[k] = p[k][2];            // z >= 0
+            dB[k] = p[k][3] - p[k][2];  // z <= w
+            crossA = crossA || !(dA[k] >= 0.0f);
+            crossB = crossB || !(dB[k] >= 0.0f);
+        }
+        if (crossA && crossB) {
+            ok = false;  // crosses both planes: rare, scan everything
+        } else if (!crossA && !crossB) {
+            ok = false;  // some w <= 0 yet inside both planes: only degenerate / NaN input
+        } else {
+            const float *d = crossA ? dA : dB;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int n = (k + 1) % 3;
+                if (d[k] >= 0.0f) add(p[k][0], p[k][1], p[k][3]);
+                if ((d[k] >= 0.0f) != (d[n] >= 0.0f)) {
+                    const float t = d[k] / (d[k] - d[n]);
+                    add(p[k][0] + t * (p[n][0] - p[k][0]), p[k][1] + t * (p[n][1] - p[k][1]),
+                        p[k][3] + t * (p[n][3] - p[k][3]));
+                }
+            }
+            if (ok && !any) return false;  // entirely outside the depth range: nothing can pass the depth clip
+        }
     }
-    // fminf/fmaxf drop NaNs, so test the inputs for NaN through the results' finiteness instead
-    const bool finite = (mnx - mnx == 0.0f) && (mny - mny == 0.0f) && (mxx - mxx == 0.0f) && (mxy - mxy == 0.0f);
-    if (!all_front || !finite) {
+    if (!ok) {
         x0 = 0; y0 = 0; x1 = vw - 1; y1 = vh - 1;
-        return;
+        return true;
     }
     const float fx0 = floorf(mnx) - 1.0f, fy0 = floorf(mny) - 1.0f, fx1 = ceilf(mxx) + 1.0f, fy1 = ceilf(mxy) + 1.0f;
     const float wm = (float)(vw - 1), hm = (float)(vh - 1);
@@ -149,4 +187,5 @@ R3N_DEV void tri_bounds(const float p[3][4], float half_w, float half_h, int vw,
     y0 = fy0 < 0.0f ? 0 : (fy0 > hm ? vh : (int)fy0);
     x1 = fx1 < 0.0f ? -1 : (fx1 > wm ? vw - 1 : (int)fx1);
     y1 = fy1 < 0.0f ? -1 : (fy1 > hm ? vh - 1 : (int)fy1);
+    return x1 >= x0 && y1 >= y0;
 }

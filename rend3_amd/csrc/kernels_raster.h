@@ -79,8 +79,7 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     const float half_w = (float)a.vp_w / 2.0f, half_h = (float)a.vp_h / 2.0f;
     setup_triangle(p, half_w, half_h, positive_visible, tw.ts);
     if (!tw.ts.valid) return false;
-    tri_bounds(p, half_w, half_h, (int)a.vp_w, (int)a.vp_h, tw.x0, tw.y0, tw.x1, tw.y1);
-    if (tw.x1 < tw.x0 || tw.y1 < tw.y0) return false;
+    if (!tri_bounds(p, half_w, half_h, (int)a.vp_w, (int)a.vp_h, tw.x0, tw.y0, tw.x1, tw.y1)) return false;
     tw.cutout = a.key == R3N_KEY_CUTOUT;
     tw.mat = &a.materials[ob.material_index < a.n_materials ? ob.material_index : 0u];
     tw.va[0] = tw.va[1] = tw.va[2] = 1.0f;
@@ -153,7 +152,25 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
     }
 }
 
-// Stage 2: one wavefront per item, lanes tile an 8x8 pixel block, stepping through the item's region.
+// Upper bound of edge function i over the pixel centres of an 8x8 block whose first pixel is (bx,by).  Each
+// f32 operation is monotone, so evaluating the same expression at the extreme corner gives the exact maximum of
+// the per-pixel values: a block with a negative maximum holds no covered pixel.
+R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry1) {
+    const float x_lo = (float)bx + 0.5f, x_hi = (float)min(bx + 7, rx1) + 0.5f;
+    const float y_lo = (float)by + 0.5f, y_hi = (float)min(by + 7, ry1) + 0.5f;
+    bool may = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float A = ts.e[i][0], B = ts.e[i][1];
+        const float px = A > 0.0f ? x_hi : x_lo, py = B > 0.0f ? y_hi : y_lo;
+        const float v = (A * px + B * py) + ts.e[i][2];
+        may = may && !(v < 0.0f);  // NaN keeps the block (per-pixel evaluation rejects it)
+    }
+    return may;
+}
+
+// Stage 2: one wavefront per item (<= 64x64 px).  Lane b first tests 8x8 block b of the item against the three
+// edge functions; the ballot is the list of candidate blocks, and only those are scanned (lane = pixel).
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -169,11 +186,15 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
         if (!prepare_triangle<DEPTH_ONLY>(a, it.object, it.triangle, positive_visible, tw)) continue;
         const int rx0 = (int)(it.xy0 & 0xFFFFu), ry0 = (int)(it.xy0 >> 16);
         const int rx1 = (int)(it.xy1 & 0xFFFFu), ry1 = (int)(it.xy1 >> 16);
-        for (int by = ry0; by <= ry1; by += 8)
-            for (int bx = rx0; bx <= rx1; bx += 8) {
-                const int x = bx + lx, y = by + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
-            }
+        const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
+        const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover(tw.ts, cbx, cby, rx1, ry1);
+        unsigned long long blocks = __ballot(cand);
+        while (blocks) {
+            const int b = __builtin_ctzll(blocks);
+            blocks &= blocks - 1ull;
+            const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
+            if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+        }
     }
 }
 

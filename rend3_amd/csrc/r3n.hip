@@ -57,6 +57,7 @@ struct r3n_ctx {
     r3n_hiz_desc hizd{};
     DevBuf big_items, big_count;
     uint32_t big_capacity = 4u << 20;
+    uint32_t forward_index = 0;  // r3n_forward calls so far this frame (each gets its own work-queue counter)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
@@ -305,7 +306,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     // empty light buffers: count = 0
     if (ensure(c, c->dir_buf, 16, false, 0) != R3N_OK || ensure(c, c->point_buf, 16, false, 0) != R3N_OK ||
         ensure(c, c->material_keys, 256, false, 0) != R3N_OK || ensure(c, c->materials, sizeof(r3n_material208), false, 0) != R3N_OK ||
-        ensure(c, c->big_count, 4, false, 0) != R3N_OK ||
+        ensure(c, c->big_count, 64 * 4, false, 0) != R3N_OK ||
         ensure(c, c->big_items, (size_t)c->big_capacity * sizeof(r3n_big_item), false, -1) != R3N_OK) {
         g_create_error = c->err;
         r3n_destroy(c);
@@ -452,6 +453,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     }
     TRY(refresh_tri_base(c));
     c->in_frame = true;
+    c->forward_index = 0;
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
@@ -587,11 +589,12 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.calls = calls;
     a.key = key;
     a.big_items = c->big_items.as<r3n_big_item>();
-    a.big_count = c->big_count.as<uint32_t>();
+    const uint32_t fwd = std::min(c->forward_index++, 63u);
+    a.big_count = c->big_count.as<uint32_t>() + fwd;
     a.big_capacity = c->big_capacity;
     const uint32_t small_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->total_tris + 255) / 256, 2048));
     Timed t(c, R3N_STAGE_RASTER);
-    HIP_TRY(c, hipMemsetAsync(c->big_count.p, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, 4, c->stream));
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
@@ -758,6 +761,11 @@ int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_
         }
     }
     return R3N_OK;
+}
+
+int r3n_readback_raster_stats(r3n_ctx *c, uint32_t big_items[64]) {
+    if (!c || !big_items) return R3N_ERR_INVALID_ARG;
+    return d2h(c, big_items, c->big_count.p, 64 * 4);
 }
 
 int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity) {
