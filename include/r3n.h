@@ -224,11 +224,14 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_OBJECT_CULL 1
 #define R3N_STAGE_TRIANGLE_CULL 2
 #define R3N_STAGE_HIZ 3
-#define R3N_STAGE_RASTER 4
+#define R3N_STAGE_RASTER 4          /* viewport: per-triangle pass (small triangles + work-item emission) */
 #define R3N_STAGE_SHADE 5
 #define R3N_STAGE_TONEMAP 6
 #define R3N_STAGE_CLEAR 7
-#define R3N_STAGE_COUNT 8
+#define R3N_STAGE_RASTER_BIG 8      /* viewport: wave-cooperative pass over the large-triangle work items */
+#define R3N_STAGE_SHADOW_RASTER 9   /* shadow views: per-triangle pass */
+#define R3N_STAGE_SHADOW_RASTER_BIG 10
+#define R3N_STAGE_COUNT 11
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
 int r3n_stage_times(r3n_ctx *ctx, double ms[R3N_STAGE_COUNT], uint64_t launches[R3N_STAGE_COUNT], int reset);
 

@@ -17,7 +17,8 @@ CAMERA_VIEWPORT = 0xFFFFFFFF
 PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
-STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear"]
+STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
+          "shadow_raster", "shadow_raster_big"]
 
 # every symbol include/r3n.h declares: (restype, argtypes)
 SIGNATURES = {

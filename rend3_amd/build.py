@@ -33,8 +33,9 @@ def up_to_date():
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return SO
+    extra = os.environ.get("R3N_EXTRA_CXXFLAGS", "").split()
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", SO] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", "-o", SO] + extra + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)

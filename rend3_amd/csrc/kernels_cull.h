@@ -9,7 +9,7 @@
 // Shape changes vs. the reference (results identical): no 256-object batches, no CPU sort,
 // one launch per camera; objects own whole wavefronts (64 triangle slots) so matrices are wave-uniform;
 // compaction = wave ballot + popcount, staged through LDS per 4096-slot chunk, one global atomic per
-// (chunk, list, region) instead of one per triangle.
+// (chunk, list, region) instead of one per triangle, spread over R3N_SUBQ sub-lists per region.
 #pragma once
 #include "device_math.h"
 
@@ -99,18 +99,19 @@ struct ObjBlockOffsets {
     uint32_t visible, waves, tris_all;
 };
 
-// Pass B: one block scans the per-block totals, derives region bases and resets the indirect calls
+// Pass B: one block scans the per-block totals, derives region bases and resets the append counters
 // (culler.rs:642 clear_buffer + cull.wgsl:47-61 init_draw_calls).
 __global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__restrict__ block_sums, uint32_t nblocks,
                                                       ObjBlockOffsets *__restrict__ block_off,
                                                       r3n_cull_counts *__restrict__ counts,
                                                       r3n_vis_entry *__restrict__ vis_list,
-                                                      r3n_indirect_call *__restrict__ calls /* [6] */) {
+                                                      r3n_sub_counts *__restrict__ sub_counts) {
     __shared__ uint32_t sh[3][1024];
     __shared__ uint32_t carry[3];
     __shared__ uint32_t ktot[3];
     const uint32_t t = threadIdx.x;
     if (t < 3) { carry[t] = 0; ktot[t] = 0; }
+    if (t < 2u * 3u * R3N_SUBQ) (&sub_counts->n[0][0][0])[t] = 0u;
     __syncthreads();
     uint32_t kacc[3] = {0, 0, 0};
     for (uint32_t base = 0; base < nblocks; base += 1024u) {
@@ -156,14 +157,6 @@ __global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__rest
         for (int k = 0; k < 3; ++k) {
             counts->key_triangles[k] = ktot[k];
             counts->region_base[k] = base;
-            for (int list = 0; list < 2; ++list) {
-                r3n_indirect_call *c = &calls[list * 3 + k];
-                c->vertex_count = 0;
-                c->instance_count = 1;
-                c->base_index = base * 3u;  // cull.wgsl:53 base_index = first slot * 3
-                c->vertex_offset = 0;
-                c->base_instance = 0;
-            }
             base += ktot[k];
         }
         vis_list[carry[0]].object = R3N_INVALID;  // sentinel
@@ -291,7 +284,7 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
     return true;
 }
 
-#define R3N_CHUNK_ITERS 16u                      // wave slots per wavefront per chunk
+#define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
 #define R3N_CHUNK_WAVES (4u * R3N_CHUNK_ITERS)   // wave slots per 256-thread block per chunk (4096 triangles)
 
 struct TriCullArgs {
@@ -308,7 +301,8 @@ struct TriCullArgs {
     unsigned long long *mask;             // one u64 per wave slot
     r3n_tri_ref *predicted;
     r3n_tri_ref *residual;                // null for shadow cameras
-    r3n_indirect_call *calls;             // [0..3) predicted, [3..6) residual
+    r3n_sub_counts *sub_counts;           // append counters of this cull
+    uint32_t subcap;                      // entries reserved per (material key, sub-list) in each list
     HizView hiz;
 };
 
@@ -332,7 +326,6 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
     const bool shadow = a.hdr->shadow_index != R3N_INVALID;
     const float res_x = a.hdr->resolution[0], res_y = a.hdr->resolution[1];
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const uint32_t region_base[3] = {a.counts->region_base[0], a.counts->region_base[1], a.counts->region_base[2]};
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t w0 = chunk * R3N_CHUNK_WAVES + wave * R3N_CHUNK_ITERS;
@@ -404,7 +397,8 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
             const uint32_t c0 = cnt[0][k], c1 = cnt[1][k], c2 = cnt[2][k], c3 = cnt[3][k];
             const uint32_t tot = c0 + c1 + c2 + c3;
             uint32_t start = 0;
-            if (tot) start = atomicAdd(&a.calls[k].vertex_count, tot * 3u) / 3u;  // cull.wgsl:63-73
+            // cull.wgsl:63-73 (atomicAdd on the region's vertex_count), one add per chunk and per sub-list
+            if (tot) start = atomicAdd(&(&a.sub_counts->n[0][0][0])[k * R3N_SUBQ + (chunk % R3N_SUBQ)], tot);
             base[0][k] = start; base[1][k] = start + c0; base[2][k] = start + c0 + c1; base[3][k] = start + c0 + c1 + c2;
         }
         __syncthreads();
@@ -420,7 +414,7 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
             const uint32_t np = (uint32_t)__popcll(pb), nr = (uint32_t)__popcll(rb);
             const uint32_t rp = key == 0u ? run_p[0] : (key == 1u ? run_p[1] : run_p[2]);
             const uint32_t rr = key == 0u ? run_r[0] : (key == 1u ? run_r[1] : run_r[2]);
-            const uint32_t region = key == 0u ? region_base[0] : (key == 1u ? region_base[1] : region_base[2]);
+            const uint32_t region = (key * R3N_SUBQ + (chunk % R3N_SUBQ)) * a.subcap;
             if ((pb >> lane) & 1ull) a.predicted[region + rp + (uint32_t)__popcll(pb & lane_lt)] = ref;
             if ((rb >> lane) & 1ull) a.residual[region + rr + (uint32_t)__popcll(rb & lane_lt)] = ref;
 #pragma unroll

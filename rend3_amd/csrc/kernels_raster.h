@@ -25,15 +25,15 @@ struct RasterArgs {
     uint32_t n_materials;
     const uint32_t *tri_base;              // canonical slot base per object (forward only)
     const r3n_tri_ref *list;               // compacted triangle list of this camera/source
-    const r3n_cull_counts *counts;         // region bases of that list
-    const r3n_indirect_call *calls;        // [3] calls of that list: vertex_count/3 triangles per region
+    const uint32_t *sub_counts;            // [3][R3N_SUBQ] triangles per (material key, sub-list) of that list
+    uint32_t subcap;                       // entries reserved per (material key, sub-list)
     uint32_t key;                          // region to draw
     uint32_t vp_x, vp_y, vp_w, vp_h;       // viewport inside the target
     uint32_t target_pitch;                 // elements per row of the target
     unsigned long long *vis;               // forward target (u64 per pixel) or null
     uint32_t *depth;                       // depth-only target (f32 bits per pixel) or null
-    r3n_big_item *big_items;
-    uint32_t *big_count;
+    r3n_big_item *big_items;               // R3N_BIGQ sub-queues of big_capacity entries each
+    uint32_t *big_count;                   // [R3N_BIGQ]
     uint32_t big_capacity;
 };
 
@@ -91,7 +91,16 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     return true;
 }
 
-template <bool DEPTH_ONLY>
+#ifndef R3N_PREREAD_SMALL
+#define R3N_PREREAD_SMALL 0
+#endif
+#ifndef R3N_PREREAD_BIG
+#define R3N_PREREAD_BIG 0
+#endif
+// PREREAD: plain load + compare before the atomic.  It filters occluded fragments cheaply (the load may be
+// stale, which is only conservative because keys grow monotonically) but puts a dependent load in front of every
+// atomic; without it the atomic is fire-and-forget.
+template <bool DEPTH_ONLY, bool PREREAD>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     float E[3];
     if (!edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
@@ -106,34 +115,44 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
     const uint32_t zb = __float_as_uint(z);
     if (DEPTH_ONLY) {
-        if (zb >= a.depth[pix]) atomicMax(&a.depth[pix], zb);
+        if (!PREREAD || zb > a.depth[pix]) atomicMax(&a.depth[pix], zb);
     } else {
         const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
-        if (key > a.vis[pix]) atomicMax(&a.vis[pix], key);
+        if (!PREREAD || key > a.vis[pix]) atomicMax(&a.vis[pix], key);
     }
 }
 
+#ifndef R3N_SMALL_MAX
 #define R3N_SMALL_MAX 8
+#endif
 
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
 template <bool DEPTH_ONLY>
 __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
-    const uint32_t n = a.calls[a.key].vertex_count / 3u;
-    const uint32_t region = a.counts->region_base[a.key];
+    // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
+    const uint32_t q = blockIdx.x % R3N_SUBQ;
+    const uint32_t n = a.sub_counts[a.key * R3N_SUBQ + q];
+    const r3n_tri_ref *list = a.list + (size_t)(a.key * R3N_SUBQ + q) * a.subcap;
+    // producer side of the work queue: the sub-queue is chosen per WAVE.  readfirstlane makes the counter address
+    // provably wave-uniform, which is what lets the compiler fold a wave's appends into ONE atomic (with a
+    // per-lane address every lane issues its own returning atomic -- measured 4x slower kernels)
+    const uint32_t bq = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) % R3N_BIGQ);
     const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const r3n_tri_ref ref = a.list[region + i];
+    const uint32_t stride = (gridDim.x / R3N_SUBQ) * 256u;
+    for (uint32_t i = (blockIdx.x / R3N_SUBQ) * 256u + threadIdx.x; i < n; i += stride) {
+        const r3n_tri_ref ref = list[i];
         TriWork tw;
         if (!prepare_triangle<DEPTH_ONLY>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
-                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0>(a, tw, x, y);
         } else {
             const uint32_t tx = (uint32_t)(bw + 63) / 64u, ty = (uint32_t)(bh + 63) / 64u;
             const uint32_t cnt = tx * ty;
-            const uint32_t start = atomicAdd(a.big_count, cnt);
+            const uint32_t start = atomicAdd(&a.big_count[bq], cnt);
+            r3n_big_item *big = a.big_items + (size_t)bq * a.big_capacity;
             for (uint32_t t = 0; t < cnt; ++t) {
                 const uint32_t ix = t % tx, iy = t / tx;
                 const int rx0 = tw.x0 + (int)ix * 64, ry0 = tw.y0 + (int)iy * 64;
@@ -141,11 +160,11 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
                 if (start + t < a.big_capacity) {
                     r3n_big_item it = {ref.object, ref.triangle, (uint32_t)rx0 | ((uint32_t)ry0 << 16),
                                        (uint32_t)rx1 | ((uint32_t)ry1 << 16)};
-                    a.big_items[start + t] = it;
+                    big[start + t] = it;
                 } else {
                     // queue full: never drop work -- scan the region here (slow path)
                     for (int y = ry0; y <= ry1; ++y)
-                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0>(a, tw, x, y);
                 }
             }
         }
@@ -169,19 +188,77 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
     return may;
 }
 
-// Stage 2: one wavefront per item (<= 64x64 px).  Lane b first tests 8x8 block b of the item against the three
-// edge functions; the ballot is the list of candidate blocks, and only those are scanned (lane = pixel).
-template <bool DEPTH_ONLY>
+// Stage 2: scan of the work items (<= 64x64 px each), lane = 8x8 block for rejection, then lane = pixel.
+// COOP: each lane first loads and sets up a DIFFERENT item (64 independent gather chains in flight per wave instead
+// of one, no redundant setup arithmetic); the wave then walks the 64 prepared items, broadcasting one item's setup
+// across the wave.  Batches are strided through the queue so neighbouring entries (tiles of one large triangle,
+// equally expensive) land in different batches.  !COOP: one item per wave, every lane repeats the setup.
+// Measured on the Bistro-like scene (ms per frame): shadow views 0.51 (COOP) vs 0.87; viewport 0.36 (COOP) vs 0.22
+// -- many medium triangles favour COOP, few very large ones the finer per-item distribution -- so the depth-only
+// passes use COOP and the forward pass does not.
+template <bool DEPTH_ONLY, bool COOP>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_global = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t nwaves = gridDim.x * 4u;
-    uint32_t n = *a.big_count;
+    // wave w serves sub-queue (w % R3N_BIGQ); within it waves are strided
+    const uint32_t wave_all = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t bq = wave_all % R3N_BIGQ;
+    const uint32_t wave_global = wave_all / R3N_BIGQ;
+    const uint32_t nwaves = (gridDim.x * 4u) / R3N_BIGQ;
+    uint32_t n = a.big_count[bq];
     n = n < a.big_capacity ? n : a.big_capacity;
+    const r3n_big_item *big = a.big_items + (size_t)bq * a.big_capacity;
     const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    if (COOP) {
+    // batch b takes items {b + lane * nbatches}: neighbouring queue entries (tiles of one large triangle, equally
+    // expensive) land in different batches, which evens out the per-wave work
+    const uint32_t nbatches = (n + 63u) / 64u;
+    for (uint32_t batch = wave_global; batch < nbatches; batch += nwaves) {
+        TriWork tw;
+        uint32_t xy0 = 0, xy1 = 0;
+        bool valid = false;
+        const uint32_t item_index = batch + lane * nbatches;
+        if (item_index < n) {
+            const r3n_big_item it = big[item_index];
+            xy0 = it.xy0; xy1 = it.xy1;
+            valid = prepare_triangle<DEPTH_ONLY>(a, it.object, it.triangle, positive_visible, tw);
+        }
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            TriWork w;  // lane k's item, broadcast (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) w.ts.e[i][c] = __shfl(tw.ts.e[i][c], k, 64);
+                w.ts.z[i] = __shfl(tw.ts.z[i], k, 64);
+                w.va[i] = __shfl(tw.va[i], k, 64);
+            }
+            w.ts.det = __shfl(tw.ts.det, k, 64);
+            w.ts.valid = true;
+            w.slot1 = DEPTH_ONLY ? 0u : (uint32_t)__shfl((int)tw.slot1, k, 64);
+            w.cutout = a.key == R3N_KEY_CUTOUT;  // launch-uniform
+            const unsigned long long mp = (unsigned long long)tw.mat;
+            w.mat = (const r3n_material208 *)(((unsigned long long)(uint32_t)__shfl((int)(mp >> 32), k, 64) << 32) |
+                                              (unsigned long long)(uint32_t)__shfl((int)(mp & 0xFFFFFFFFull), k, 64));
+            const uint32_t kxy0 = (uint32_t)__shfl((int)xy0, k, 64), kxy1 = (uint32_t)__shfl((int)xy1, k, 64);
+            const int rx0 = (int)(kxy0 & 0xFFFFu), ry0 = (int)(kxy0 >> 16);
+            const int rx1 = (int)(kxy1 & 0xFFFFu), ry1 = (int)(kxy1 >> 16);
+            const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
+            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover(w.ts, cbx, cby, rx1, ry1);
+            unsigned long long blocks = __ballot(cand);
+            while (blocks) {
+                const int b = __builtin_ctzll(blocks);
+                blocks &= blocks - 1ull;
+                const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0>(a, w, x, y);
+            }
+        }
+    }
+    } else {
     for (uint32_t i = wave_global; i < n; i += nwaves) {
-        const r3n_big_item it = a.big_items[i];
+        const r3n_big_item it = big[i];
         TriWork tw;
         if (!prepare_triangle<DEPTH_ONLY>(a, it.object, it.triangle, positive_visible, tw)) continue;
         const int rx0 = (int)(it.xy0 & 0xFFFFu), ry0 = (int)(it.xy0 >> 16);
@@ -193,8 +270,9 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
             const int b = __builtin_ctzll(blocks);
             blocks &= blocks - 1ull;
             const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-            if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY>(a, tw, x, y);
+            if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0>(a, tw, x, y);
         }
+    }
     }
 }
 

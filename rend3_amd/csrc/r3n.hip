@@ -29,7 +29,8 @@ struct CamState {
     int last = -1;               // index holding the most recent cull results (for readbacks)
     uint32_t vp_x = 0, vp_y = 0, vp_size = 0;
     DevBuf d_hdr, baked, vis_flags, vis_list, block_sums, block_off;
-    DevBuf slot_base[2], mask[2], predicted[2], calls[2], counts[2];
+    DevBuf slot_base[2], mask[2], predicted[2], sub_counts[2], counts[2];
+    uint32_t subcap[2] = {0, 0};  // list entries reserved per (material key, sub-list)
     DevBuf residual;
 };
 
@@ -45,6 +46,10 @@ struct r3n_ctx {
     DevBuf mesh, objects, materials, material_keys, dir_buf, point_buf, fu;
     uint32_t capacity = 0, n_materials = 0;
     std::vector<uint32_t> h_ntri;  // host mirror: triangles per enabled object slot
+    std::vector<uint32_t> h_material;  // host mirror: material index per object slot
+    std::vector<uint8_t> h_material_key;  // host mirror: Material::key() per material slot
+    bool key_census_dirty = true;
+    uint64_t key_objects[3] = {0, 0, 0};  // enabled objects per material key
     uint64_t total_tris = 0;
     bool tri_base_dirty = true;
     DevBuf tri_base;
@@ -56,7 +61,7 @@ struct r3n_ctx {
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
     DevBuf big_items, big_count;
-    uint32_t big_capacity = 4u << 20;
+    uint32_t big_capacity = (4u << 20) / R3N_BIGQ;  // entries per work sub-queue (R3N_BIGQ of them)
     uint32_t forward_index = 0;  // r3n_forward calls so far this frame (each gets its own work-queue counter)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
@@ -186,8 +191,8 @@ CamState *find_cam(r3n_ctx *c, r3n_camera cam, bool create) {
 
 void free_cam(CamState &s) {
     DevBuf *bufs[] = {&s.d_hdr, &s.baked, &s.vis_flags, &s.vis_list, &s.block_sums, &s.block_off, &s.slot_base[0],
-                      &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.calls[0],
-                      &s.calls[1], &s.counts[0], &s.counts[1], &s.residual};
+                      &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.sub_counts[0],
+                      &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual};
     for (DevBuf *b : bufs)
         if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
 }
@@ -203,7 +208,7 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
     TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
     TRY(ensure(c, s.block_off, (size_t)nblocks * sizeof(ObjBlockOffsets), false, -1));
     TRY(ensure(c, s.slot_base[idx], (size_t)cap * 4u, true, 0xFF));
-    TRY(ensure(c, s.calls[idx], 6 * sizeof(r3n_indirect_call), false, 0));
+    TRY(ensure(c, s.sub_counts[idx], sizeof(r3n_sub_counts), false, 0));
     TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
     Timed t(c, R3N_STAGE_OBJECT_CULL);
     hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, c->stream, s.d_hdr.as<r3n_camera_header240>(),
@@ -211,7 +216,7 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
                        range_end, s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
     hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(1024), 0, c->stream, s.block_sums.as<ObjBlockSums>(), nblocks,
                        s.block_off.as<ObjBlockOffsets>(), s.counts[idx].as<r3n_cull_counts>(),
-                       s.vis_list.as<r3n_vis_entry>(), s.calls[idx].as<r3n_indirect_call>());
+                       s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>());
     hipLaunchKernelGGL(k_object_scatter, dim3(nblocks), dim3(256), 0, c->stream,
                        s.d_hdr.as<r3n_camera_header240>(), c->objects.as<r3n_object128>(), s.vis_flags.as<uint8_t>(),
                        s.block_off.as<ObjBlockOffsets>(), s.vis_list.as<r3n_vis_entry>(),
@@ -289,7 +294,8 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     }
     r3n_ctx *c = new r3n_ctx();
     c->device = hip_device;
-    if (config && config->struct_size >= sizeof(r3n_config) && config->max_big_items) c->big_capacity = config->max_big_items;
+    if (config && config->struct_size >= sizeof(r3n_config) && config->max_big_items)
+        c->big_capacity = std::max(1024u, config->max_big_items / R3N_BIGQ);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -306,8 +312,8 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     // empty light buffers: count = 0
     if (ensure(c, c->dir_buf, 16, false, 0) != R3N_OK || ensure(c, c->point_buf, 16, false, 0) != R3N_OK ||
         ensure(c, c->material_keys, 256, false, 0) != R3N_OK || ensure(c, c->materials, sizeof(r3n_material208), false, 0) != R3N_OK ||
-        ensure(c, c->big_count, 64 * 4, false, 0) != R3N_OK ||
-        ensure(c, c->big_items, (size_t)c->big_capacity * sizeof(r3n_big_item), false, -1) != R3N_OK) {
+        ensure(c, c->big_count, 64 * R3N_BIGQ * 4, false, 0) != R3N_OK ||
+        ensure(c, c->big_items, (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) != R3N_OK) {
         g_create_error = c->err;
         r3n_destroy(c);
         return nullptr;
@@ -368,6 +374,7 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
     if (capacity != c->capacity) {
         c->capacity = capacity;
         c->h_ntri.resize(capacity, 0);
+        c->h_material.resize(capacity, 0);
         c->tri_base_dirty = true;
     }
     for (uint32_t i = 0; i < n; ++i) {
@@ -376,6 +383,8 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
         const uint32_t nt = records[i].enabled ? records[i].index_count / 3u : 0u;
         c->total_tris = c->total_tris - c->h_ntri[slots[i]] + nt;
         c->h_ntri[slots[i]] = nt;
+        c->h_material[slots[i]] = records[i].material_index;
+        c->key_census_dirty = true;
     }
     if (n) c->tri_base_dirty = true;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -393,6 +402,9 @@ int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208
     TRY(ensure(c, c->materials, (size_t)need * sizeof(r3n_material208), true, 0));
     TRY(ensure(c, c->material_keys, need, true, 0));
     c->n_materials = need;
+    c->h_material_key.resize(need, 0);
+    for (uint32_t i = 0; i < n; ++i) c->h_material_key[slots[i]] = keys[i];
+    c->key_census_dirty = true;
     for (uint32_t i = 0; i < n; ++i) {
         HIP_TRY(c, hipMemcpyAsync(c->materials.as<r3n_material208>() + slots[i], records + i, sizeof(r3n_material208),
                                   hipMemcpyHostToDevice, c->stream));
@@ -491,8 +503,12 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     const int cur = s->cur, prev = 1 - cur;
     TRY(run_object_pass(c, *s, cur, c->range_begin, c->range_end, nullptr));
-    const size_t list_bytes = (size_t)std::max<uint64_t>(c->total_tris, 1) * sizeof(r3n_tri_ref);
     const uint32_t mw = max_waves(c);
+    const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
+    // every chunk appends to sub-list (chunk % R3N_SUBQ); worst case all of its slots pass and share one key
+    const uint32_t subcap = ((chunks + R3N_SUBQ - 1u) / R3N_SUBQ) * (R3N_CHUNK_WAVES * 64u);
+    const size_t list_bytes = (size_t)3 * R3N_SUBQ * subcap * sizeof(r3n_tri_ref);
+    s->subcap[cur] = subcap;
     TRY(ensure(c, s->mask[cur], (size_t)mw * 8u, false, -1));
     TRY(ensure(c, s->predicted[cur], list_bytes, false, -1));
     if (viewport) TRY(ensure(c, s->residual, list_bytes, false, -1));
@@ -510,11 +526,11 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     a.mask = s->mask[cur].as<unsigned long long>();
     a.predicted = s->predicted[cur].as<r3n_tri_ref>();
     a.residual = viewport ? s->residual.as<r3n_tri_ref>() : nullptr;
-    a.calls = s->calls[cur].as<r3n_indirect_call>();
+    a.sub_counts = s->sub_counts[cur].as<r3n_sub_counts>();
+    a.subcap = subcap;
     a.hiz.data = c->hiz.as<float>();
     a.hiz.d = c->hizd;
-    const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
-    const uint32_t grid = std::max(1u, std::min(chunks, 2048u));
+    const uint32_t grid = std::max(1u, std::min(chunks, 4096u));
     {
         Timed t(c, R3N_STAGE_TRIANGLE_CULL);
         hipLaunchKernelGGL(k_triangle_cull, dim3(grid), dim3(256), 0, c->stream, a);
@@ -556,24 +572,36 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     if (key == R3N_KEY_BLEND) return fail(c, R3N_ERR_UNSUPPORTED, "forward: blend routine is not built yet (row N3)");
     CamState *s = find_cam(c, cam, false);
     if (!s || !s->has_hdr || c->capacity == 0) return R3N_OK;  // nothing baked / culled yet: forward.rs:214-242
+    if (c->key_census_dirty) {
+        c->key_objects[0] = c->key_objects[1] = c->key_objects[2] = 0;
+        for (uint32_t o = 0; o < c->capacity; ++o)
+            if (c->h_ntri[o]) {
+                const uint32_t mi = c->h_material[o];
+                c->key_objects[mi < c->h_material_key.size() ? std::min<uint32_t>(c->h_material_key[mi], 2) : 0]++;
+            }
+        c->key_census_dirty = false;
+    }
+    // no object carries this material key: the draw-call range is empty ("no draw calls for this material",
+    // forward.rs:285-288) -- known on the host, so no launch at all
+    if (c->key_objects[key] == 0) return R3N_OK;
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     if ((pass == R3N_PASS_FORWARD) != viewport) return fail(c, R3N_ERR_UNSUPPORTED, "forward: FORWARD needs the viewport, DEPTH a shadow camera");
     HIP_TRY(c, hipSetDevice(c->device));
     int idx;
     const r3n_tri_ref *list;
-    const r3n_indirect_call *calls;
+    const uint32_t *sub_counts;
     if (source == R3N_SOURCE_PREDICTED) {
         // last frame's predicted triangles, this frame's matrices (forward.rs:224-232, App. D.8)
         if (!s->has_prev) return R3N_OK;
         idx = 1 - s->cur;
         list = s->predicted[idx].as<r3n_tri_ref>();
-        calls = s->calls[idx].as<r3n_indirect_call>();
+        sub_counts = &s->sub_counts[idx].as<r3n_sub_counts>()->n[0][0][0];
     } else {
         if (!s->culled) return R3N_OK;
         idx = s->cur;
         // residual && viewport -> residual list; otherwise the list written this frame (forward.rs:234,251)
         list = viewport ? s->residual.as<r3n_tri_ref>() : s->predicted[idx].as<r3n_tri_ref>();
-        calls = s->calls[idx].as<r3n_indirect_call>() + (viewport ? 3 : 0);
+        sub_counts = &s->sub_counts[idx].as<r3n_sub_counts>()->n[viewport ? 1 : 0][0][0];
     }
     RasterArgs a{};
     a.hdr = s->d_hdr.as<r3n_camera_header240>();
@@ -585,28 +613,27 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.n_materials = c->n_materials;
     a.tri_base = c->tri_base.as<uint32_t>();
     a.list = list;
-    a.counts = s->counts[idx].as<r3n_cull_counts>();
-    a.calls = calls;
+    a.sub_counts = sub_counts;
+    a.subcap = s->subcap[idx];
     a.key = key;
     a.big_items = c->big_items.as<r3n_big_item>();
     const uint32_t fwd = std::min(c->forward_index++, 63u);
-    a.big_count = c->big_count.as<uint32_t>() + fwd;
+    a.big_count = c->big_count.as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
     a.big_capacity = c->big_capacity;
-    const uint32_t small_grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->total_tris + 255) / 256, 2048));
-    Timed t(c, R3N_STAGE_RASTER);
-    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, 4, c->stream));
+    const uint32_t small_grid = 2048;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
+    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, c->stream));
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
-        hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, c->stream, a);
-        hipLaunchKernelGGL(k_raster_big<false>, dim3(1024), dim3(256), 0, c->stream, a);
+        { Timed t(c, R3N_STAGE_RASTER); hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, c->stream, a); }
+        { Timed t(c, R3N_STAGE_RASTER_BIG); hipLaunchKernelGGL((k_raster_big<false, false>), dim3(1024), dim3(256), 0, c->stream, a); }
     } else {
         if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
             return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
         a.depth = c->atlas.as<uint32_t>();
-        hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, c->stream, a);
-        hipLaunchKernelGGL(k_raster_big<true>, dim3(1024), dim3(256), 0, c->stream, a);
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER); hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, c->stream, a); }
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG); hipLaunchKernelGGL((k_raster_big<true, true>), dim3(1024), dim3(256), 0, c->stream, a); }
     }
     return check_launch(c, "raster");
 }
@@ -720,7 +747,18 @@ int r3n_readback_visible_objects(r3n_ctx *c, r3n_camera cam, uint8_t *flags, uin
 int r3n_readback_draw_calls(r3n_ctx *c, r3n_camera cam, r3n_indirect_call calls[6]) {
     CamState *s = c ? find_cam(c, cam, false) : nullptr;
     if (!s || s->last < 0) return fail(c, R3N_ERR_STATE, "readback_draw_calls: camera never culled");
-    return d2h(c, calls, s->calls[s->last].p, 6 * sizeof(r3n_indirect_call));
+    r3n_sub_counts sc;
+    r3n_cull_counts counts;
+    TRY(d2h(c, &sc, s->sub_counts[s->last].p, sizeof sc));
+    TRY(d2h(c, &counts, s->counts[s->last].p, sizeof counts));
+    for (int list = 0; list < 2; ++list)
+        for (int k = 0; k < 3; ++k) {
+            uint32_t n = 0;
+            for (uint32_t q = 0; q < R3N_SUBQ; ++q) n += sc.n[list][k][q];
+            // cull.wgsl:47-73: vertex_count = 3 per appended triangle, instance_count 1, base_index = first slot * 3
+            calls[list * 3 + k] = {n * 3u, 1u, counts.region_base[k] * 3u, 0, 0u};
+        }
+    return R3N_OK;
 }
 
 int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_t *residual, uint64_t n) {
@@ -749,15 +787,17 @@ int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_
     if (residual) {
         std::memset(residual, 0, n);
         if (cam == R3N_CAMERA_VIEWPORT) {
-            r3n_indirect_call calls[6];
-            TRY(d2h(c, calls, s->calls[idx].p, sizeof calls));
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t cnt = calls[3 + k].vertex_count / 3u;
-                if (!cnt) continue;
-                std::vector<r3n_tri_ref> refs(cnt);
-                TRY(d2h(c, refs.data(), s->residual.as<r3n_tri_ref>() + counts.region_base[k], (size_t)cnt * sizeof(r3n_tri_ref)));
-                for (const auto &r : refs) residual[(uint64_t)tri_base[r.object] + r.triangle] = 1;
-            }
+            r3n_sub_counts sc;
+            TRY(d2h(c, &sc, s->sub_counts[idx].p, sizeof sc));
+            for (uint32_t k = 0; k < 3; ++k)
+                for (uint32_t q = 0; q < R3N_SUBQ; ++q) {
+                    const uint32_t cnt = sc.n[1][k][q];
+                    if (!cnt) continue;
+                    std::vector<r3n_tri_ref> refs(cnt);
+                    TRY(d2h(c, refs.data(), s->residual.as<r3n_tri_ref>() + (size_t)(k * R3N_SUBQ + q) * s->subcap[idx],
+                            (size_t)cnt * sizeof(r3n_tri_ref)));
+                    for (const auto &r : refs) residual[(uint64_t)tri_base[r.object] + r.triangle] = 1;
+                }
         }
     }
     return R3N_OK;
@@ -765,7 +805,13 @@ int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_
 
 int r3n_readback_raster_stats(r3n_ctx *c, uint32_t big_items[64]) {
     if (!c || !big_items) return R3N_ERR_INVALID_ARG;
-    return d2h(c, big_items, c->big_count.p, 64 * 4);
+    std::vector<uint32_t> raw(64 * R3N_BIGQ);
+    TRY(d2h(c, raw.data(), c->big_count.p, raw.size() * 4));
+    for (int f = 0; f < 64; ++f) {
+        big_items[f] = 0;
+        for (int q = 0; q < R3N_BIGQ; ++q) big_items[f] += raw[f * R3N_BIGQ + q];
+    }
+    return R3N_OK;
 }
 
 int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity) {
