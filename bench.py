@@ -135,9 +135,9 @@ def main():
         launches = {s: n / n_inst for s, (_ms, n) in stages.items()}
         cull_ms = stage_ms["bake"] + stage_ms["object_cull"] + stage_ms["triangle_cull"]
         tri_cull_ms_per_launch = stage_ms["triangle_cull"] / max(launches["triangle_cull"], 1)
-        # algorithmic bytes of the triangle cull (SURVEY.md section 8d / BASELINE.md section 5):
-        #   48 B in + 12 B * pass_rate + 12 B * new_rate + 0.25 B out per triangle SLOT processed by the launch
-        roof = None
+        # roofline objects: algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 5) / average launch duration
+        # from HIP events recorded on the context's stream around that kernel's launches (instrumented pass above)
+        roof = roof_cull = None
         if last is not None:
             vis_tris = 0
             per_launch = []
@@ -149,14 +149,25 @@ def main():
                 t_in = int(counts[c["visible"].astype(bool)].sum())
                 n_pass = int(c["pass"].sum())
                 n_new = int(c["residual"].sum())
+                # triangle cull: 48 B in + 12 B * pass + 12 B * new + 0.25 B out per triangle slot the launch processes
                 per_launch.append(48.0 * t_in + 12.0 * n_pass + 12.0 * n_new + 0.25 * t_in)
                 vis_tris += t_in
             bytes_per_launch = float(np.mean(per_launch))
             achieved = bytes_per_launch / (tri_cull_ms_per_launch * 1e-3) / 1e9
-            roof = {"kernel": "k_triangle_cull", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(tri_cull_ms_per_launch, 5),
-                    "triangles_per_launch": vis_tris // len(cams)}
+            roof_cull = {"kernel": "k_triangle_cull", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(tri_cull_ms_per_launch, 5),
+                         "triangles_per_launch": vis_tris // len(cams)}
+        # dominant kernel by GPU time: the deferred PBR resolve (one launch per frame).  Its HBM floor is 8 B key read +
+        # 8 B Rgba16Float write per pixel (">= 16 B / shaded pixel"); it is VALU/gather-latency bound,
+        # not HBM-bound, so the fraction of the HBM roofline is small by construction.
+        shade_ms = stage_ms["shade"] / max(launches["shade"], 1)
+        shade_bytes = 16.0 * WIDTH * HEIGHT / world
+        ach = shade_bytes / (shade_ms * 1e-3) / 1e9
+        roof = {"kernel": "k_resolve_opaque", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "bytes_per_launch": int(shade_bytes),
+                "ms_per_launch": round(shade_ms, 5),
+                "note": "dominant kernel by time; VALU + gather-latency bound (4 lights x 5-tap PCF + GGX per pixel), see DESIGN.md"}
         result = {
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,6 +183,7 @@ def main():
             "stage_ms_per_frame": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_launches_per_frame": launches,
             "roofline": roof,
+            "roofline_triangle_cull": roof_cull,
         }
 
     # ---------------------------------------------------------------- CPU baseline: the oracle ("port"), rank 0, N=1 only

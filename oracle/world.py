@@ -98,6 +98,7 @@ class OracleRenderer:
         self.camera = host.CameraState(host.identity(), ("raw", host.identity()), handedness, aspect_ratio)
         self.cam_state = {}  # camera specifier -> temporal state
         self.frame_index = 0
+        self.object_range = None
 
     # ------------------------------------------------------------------ world edits
     def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT):
@@ -224,6 +225,10 @@ class OracleRenderer:
         cap = self.capacity
         visible = np.zeros(cap, dtype=np.uint8)
         lib.r3o_frustum_cull(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(visible))
+        if self.object_range is not None:  # multi-rank sharding: this rank owns object slots [begin, end)
+            b, e = self.object_range
+            visible[:b] = 0
+            visible[e:] = 0
         tri_base, total = self.tri_base()
         pass_bits = np.zeros(max(total, 1), dtype=np.uint8)
         residual = np.zeros(max(total, 1), dtype=np.uint8)
@@ -250,7 +255,9 @@ class OracleRenderer:
         return np.ascontiguousarray(obj), np.ascontiguousarray(tri)
 
     # ------------------------------------------------------------------ frame
-    def render(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0)):
+    def render(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0), exchange=None):
+        """exchange(what, ndarray) -- multi-rank only: element-wise MAX all-reduce of the shadow atlas ("shadow") and of
+        the visibility keys ("pass1", "pass2") at the points DESIGN.md section 6 names."""
         assert samples == 1, "MSAA is row N4 (not built)"
         lib = self.lib
         # Renderer::evaluate_instructions (renderer/eval.rs): last frame's removals become real
@@ -283,6 +290,8 @@ class OracleRenderer:
                                  lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(lo), lib.ptr(lt), len(lo),
                                  lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"])
             out["shadows"].append(dict(header=hdr, visible=visible, tri_base=tri_base, **{"pass": pass_bits}))
+        if exchange is not None and shadows:
+            exchange("shadow", atlas)
 
         # 7. viewport bake
         hdr = host.camera_header(cam, None, (width, height), samples, cap, lib)
@@ -303,6 +312,8 @@ class OracleRenderer:
             lo, lt = predicted
             keep = lo < cap
             draw(np.ascontiguousarray(lo[keep]), np.ascontiguousarray(lt[keep]))
+        if exchange is not None:
+            exchange("pass1", vis)
         # 9. Hi-Z from pass-1 depth (hi_z.rs:161-234)
         nm = lib.r3o_hiz_mip_count(width, height)
         pyr = np.zeros(int(lib.r3o_hiz_mip_offset(width, height, nm)), dtype=f32)
@@ -316,6 +327,8 @@ class OracleRenderer:
         # 11. pass 2: residual triangles
         draw(*self._list_from_bits(residual, tri_base))
         self.cam_state["predicted_list"] = self._list_from_bits(pass_bits, tri_base)
+        if exchange is not None:
+            exchange("pass2", vis)
 
         # opaque shading of the nearest fragment + 14. tonemap
         hdr16 = np.zeros((height, width, 4), dtype=np.uint16)

@@ -211,6 +211,21 @@ __global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header2
     }
 }
 
+// slot_table[b] = last object o with tri_base[o] <= (b << R3N_SLOT_TABLE_SHIFT): accelerates the slot -> object
+// lookup of the resolve pass.  Rebuilt only when the object set changes.
+__global__ __launch_bounds__(256) void k_build_slot_table(const uint32_t *__restrict__ tri_base, uint32_t capacity,
+                                                          uint32_t *__restrict__ table, uint32_t table_size) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= table_size) return;
+    const uint32_t slot = b << R3N_SLOT_TABLE_SHIFT;
+    uint32_t lo = 0, hi = capacity;
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (tri_base[mid] <= slot) lo = mid; else hi = mid;
+    }
+    table[b] = lo;
+}
+
 // ------------------------------------------------------------------------------------------------ K2
 struct HizView {
     const float *__restrict__ data;

@@ -319,6 +319,8 @@ struct ShadeArgs {
     const r3n_material208 *materials;
     uint32_t n_materials;
     const uint32_t *tri_base;
+    const uint32_t *slot_table;  // slot_table[b] = object owning canonical slot b << R3N_SLOT_TABLE_SHIFT
+    uint32_t slot_table_size;
     const uint8_t *dir_buf;    // count @0, records @16
     const uint8_t *point_buf;  // count @0, records @16
     const float *atlas;
@@ -362,13 +364,62 @@ R3N_DEV float sample_compare(const float *__restrict__ atlas, uint32_t aw, uint3
     return top * (1.0f - fy) + bot * fy;
 }
 
+// Texel coordinates + bilinear weights of one comparison tap, exactly as sample_compare derives them.
+struct PcfTap {
+    long long ix, iy;
+    float fx, fy;
+};
+R3N_DEV PcfTap pcf_tap(uint32_t aw, uint32_t ah, float u, float v, int ox, int oy) {
+    const float tx = (u * (float)aw - 0.5f) + (float)ox;
+    const float ty = (v * (float)ah - 0.5f) + (float)oy;
+    const float fx0 = floorf(tx), fy0 = floorf(ty);
+    PcfTap t;
+    t.fx = tx - fx0; t.fy = ty - fy0;
+    t.ix = (fx0 == fx0 && fabsf(fx0) < 1e9f) ? (long long)fx0 : 0ll;
+    t.iy = (fy0 == fy0 && fabsf(fy0) < 1e9f) ? (long long)fy0 : 0ll;
+    if (!(t.fx == t.fx)) t.fx = 0.0f;
+    if (!(t.fy == t.fy)) t.fy = 0.0f;
+    return t;
+}
+R3N_DEV float pcf_texel_cmp(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, long long x, long long y, float ref) {
+    const long long w = (long long)aw, h = (long long)ah;
+    const uint32_t xw = (uint32_t)(((x % w) + w) % w), yw = (uint32_t)(((y % h) + h) % h);
+    return ref >= atlas[(size_t)yw * aw + xw] ? 1.0f : 0.0f;
+}
+
+// shadow/pcf.wgsl: mean of 5 bilinear comparison taps (centre, +-1 texel in x and y).  The 5 taps touch 20 texels
+// of which only 12 are distinct (a 4x4 block without its corners): the comparisons are fetched once and every tap
+// then applies its own weights -- same values, same operation order as five independent sample_compare calls.
 R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
+    const PcfTap c = pcf_tap(aw, ah, u, v, 0, 0);
+    // cmp[dy][dx] for texel (c.ix - 1 + dx, c.iy - 1 + dy); corners are never needed on the regular path
+    float cmp[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const bool corner = (dx == 0 || dx == 3) && (dy == 0 || dy == 3);
+            cmp[dy][dx] = corner ? 0.0f : pcf_texel_cmp(atlas, aw, ah, c.ix - 1 + dx, c.iy - 1 + dy, ref);
+        }
+    const int offs[5][2] = {{0, 0}, {0, 1}, {0, -1}, {1, 0}, {-1, 0}};
     float r = 0.0f;
-    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, 0);
-    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, 1);
-    r = r + sample_compare(atlas, aw, ah, u, v, ref, 0, -1);
-    r = r + sample_compare(atlas, aw, ah, u, v, ref, 1, 0);
-    r = r + sample_compare(atlas, aw, ah, u, v, ref, -1, 0);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const PcfTap t = k == 0 ? c : pcf_tap(aw, ah, u, v, offs[k][0], offs[k][1]);
+        const long long rx = t.ix - c.ix + 1, ry = t.iy - c.iy + 1;
+        float c00, c10, c01, c11;
+        // regular case: the tap's 2x2 footprint lies inside the fetched block (and off its corners)
+        if (rx == offs[k][0] + 1 && ry == offs[k][1] + 1) {
+            c00 = cmp[offs[k][1] + 1][offs[k][0] + 1]; c10 = cmp[offs[k][1] + 1][offs[k][0] + 2];
+            c01 = cmp[offs[k][1] + 2][offs[k][0] + 1]; c11 = cmp[offs[k][1] + 2][offs[k][0] + 2];
+        } else {  // adding the integer offset rounded across a texel boundary (or NaN input): fetch directly
+            c00 = pcf_texel_cmp(atlas, aw, ah, t.ix, t.iy, ref);     c10 = pcf_texel_cmp(atlas, aw, ah, t.ix + 1, t.iy, ref);
+            c01 = pcf_texel_cmp(atlas, aw, ah, t.ix, t.iy + 1, ref); c11 = pcf_texel_cmp(atlas, aw, ah, t.ix + 1, t.iy + 1, ref);
+        }
+        const float top = c00 * (1.0f - t.fx) + c10 * t.fx;
+        const float bot = c01 * (1.0f - t.fx) + c11 * t.fx;
+        r = r + (top * (1.0f - t.fy) + bot * t.fy);
+    }
     return r * 0.2f;
 }
 
@@ -469,7 +520,11 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
         return;
     }
     const uint32_t slot = id - 1u;
-    uint32_t lo = 0, hi = a.hdr->object_count;
+    // object = last o with tri_base[o] <= slot; the coarse table narrows the binary search to the objects that
+    // start inside one 256-slot bucket (usually zero or one step instead of log2(capacity))
+    const uint32_t bucket = slot >> R3N_SLOT_TABLE_SHIFT;
+    uint32_t lo = a.slot_table[bucket];
+    uint32_t hi = bucket + 1u < a.slot_table_size ? a.slot_table[bucket + 1u] + 1u : a.hdr->object_count;
     while (hi - lo > 1u) {
         const uint32_t mid = lo + (hi - lo) / 2u;
         if (a.tri_base[mid] <= slot) lo = mid; else hi = mid;
@@ -578,6 +633,14 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
         float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
         for (uint32_t i = 0; i < n_dir; ++i) {
             const LdsDirLight &L = s_dir[i];
+            // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
+            // (D <= 1/(pi a^2), V <= 0.5/(nov a), nov >= 1e-5), so the light adds exactly +0: skip the shadow lookup
+            // and the BRDF.  `+= 0.0f` keeps the -0 -> +0 behaviour of the full expression.
+            if (px.roughness > 0.0f && sat(dot3(px.normal, L.l)) == 0.0f) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) color[c] += 0.0f;
+                continue;
+            }
             float sn[4];
             mul_vec4(L.m, vpos[0], vpos[1], vpos[2], vpos[3], sn);
             const float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};

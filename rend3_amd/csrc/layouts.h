@@ -109,6 +109,8 @@ struct r3n_sub_counts {
     uint32_t n[2][3][R3N_SUBQ];  // [predicted|residual][material key][sub-list] = triangles appended
 };
 
+#define R3N_SLOT_TABLE_SHIFT 8  // canonical triangle slots per bucket of the slot -> object table
+
 #define R3N_MAX_HIZ_MIPS 16
 struct r3n_hiz_desc {
     uint32_t width, height, mips, _pad;

@@ -52,7 +52,8 @@ struct r3n_ctx {
     uint64_t key_objects[3] = {0, 0, 0};  // enabled objects per material key
     uint64_t total_tris = 0;
     bool tri_base_dirty = true;
-    DevBuf tri_base;
+    DevBuf tri_base, slot_table;
+    uint32_t slot_table_size = 0;
     CamState canon;  // scratch camera used to (re)build the canonical tri_base scan
     // frame targets
     uint32_t width = 0, height = 0, samples = 1, atlas_w = 0, atlas_h = 0;
@@ -235,6 +236,11 @@ int refresh_tri_base(r3n_ctx *c) {
     HIP_TRY(c, hipMemcpyAsync(c->canon.d_hdr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
     TRY(run_object_pass(c, c->canon, 0, 0, 0, c->tri_base.as<uint32_t>()));
+    c->slot_table_size = (uint32_t)(c->total_tris >> R3N_SLOT_TABLE_SHIFT) + 1u;
+    TRY(ensure(c, c->slot_table, (size_t)c->slot_table_size * 4u, false, -1));
+    hipLaunchKernelGGL(k_build_slot_table, dim3((c->slot_table_size + 255u) / 256u), dim3(256), 0, c->stream,
+                       c->tri_base.as<uint32_t>(), c->capacity, c->slot_table.as<uint32_t>(), c->slot_table_size);
+    TRY(check_launch(c, "k_build_slot_table"));
     c->tri_base_dirty = false;
     return R3N_OK;
 }
@@ -326,7 +332,7 @@ void r3n_destroy(r3n_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
-                      &c->tri_base, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->big_items,
+                      &c->tri_base, &c->slot_table, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->big_items,
                       &c->big_count};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -656,6 +662,8 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     a.materials = c->materials.as<r3n_material208>();
     a.n_materials = c->n_materials;
     a.tri_base = c->tri_base.as<uint32_t>();
+    a.slot_table = c->slot_table.as<uint32_t>();
+    a.slot_table_size = c->slot_table_size;
     a.dir_buf = c->dir_buf.as<uint8_t>();
     a.point_buf = c->point_buf.as<uint8_t>();
     a.atlas = c->atlas.as<float>();

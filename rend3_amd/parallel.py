@@ -45,6 +45,28 @@ def row_ranges(height, world_size):
     return out
 
 
+def allreduce_max_(tensor, group=None):
+    """In-place element-wise MAX all-reduce (the only data-path collective of the pipeline).  Visibility keys are
+    passed as int64: depth lies in [0,1] so bit 63 is never set and signed MAX equals unsigned MAX."""
+    import torch.distributed as dist
+    dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+    return tensor
+
+
+def allgather_rows_(full, rank, world_size, group=None):
+    """`full` is the whole flat image; rank r has valid data in its r-th equal chunk.  Gathers every chunk in place."""
+    import torch.distributed as dist
+    assert full.numel() % world_size == 0
+    chunk = full.numel() // world_size
+    mine = full[rank * chunk:(rank + 1) * chunk].clone()
+    if hasattr(dist, "all_gather_into_tensor") and full.is_cuda:
+        dist.all_gather_into_tensor(full, mine, group=group)
+    else:
+        parts = [full[r * chunk:(r + 1) * chunk] for r in range(world_size)]
+        dist.all_gather(parts, mine, group=group)
+    return full
+
+
 class _DevArray:
     """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
 
@@ -86,12 +108,9 @@ class Exchange:
         with torch.cuda.stream(self.stream):
             if what == "shadow":
                 if atlas_n:
-                    t = device_tensor(atlas, atlas_n, "<f4", self.device)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                    allreduce_max_(device_tensor(atlas, atlas_n, "<f4", self.device), self.group)
             else:
-                # keys are depth_bits << 32 | slot with depth in [0,1]: the top bit is never set, so signed MAX == unsigned MAX
-                t = device_tensor(vis, vis_n, "<i8", self.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                allreduce_max_(device_tensor(vis, vis_n, "<i8", self.device), self.group)
 
     def gather_rows(self, width, height, world_size):
         """All-gather the Rgba8 rows each rank tonemapped (equal row counts required)."""
@@ -103,7 +122,4 @@ class Exchange:
         r._check(r.lib.r3n_output_buffer(r.ctx, ctypes.byref(out), ctypes.byref(nbytes)), "r3n_output_buffer")
         with torch.cuda.stream(self.stream):
             full = device_tensor(out.value, nbytes.value, "|u1", self.device)
-            rank = dist.get_rank(self.group)
-            chunk = nbytes.value // world_size
-            mine = full[rank * chunk:(rank + 1) * chunk].clone()
-            dist.all_gather_into_tensor(full, mine, group=self.group)
+            allgather_rows_(full, dist.get_rank(self.group), world_size, self.group)
