@@ -127,6 +127,12 @@ def main():
     last = frame(args.warmup + args.steps + n_inst, readback=(world == 1))
 
     result = None
+    traffic = {}
+    try:  # HBM bytes per launch from the committed PMC passes (collected separately, see profiles/r01_summary.md)
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh).get("bytes_per_launch", {})
+    except OSError:
+        pass
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mpix = WIDTH * HEIGHT * args.steps / elapsed / 1e6
@@ -155,7 +161,8 @@ def main():
             bytes_per_launch = float(np.mean(per_launch))
             achieved = bytes_per_launch / (tri_cull_ms_per_launch * 1e-3) / 1e9
             roof_cull = {"kernel": "k_triangle_cull", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic.get("k_triangle_cull") if world == 1 else None,
                          "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(tri_cull_ms_per_launch, 5),
                          "triangles_per_launch": vis_tris // len(cams)}
         # dominant kernel by GPU time: the deferred PBR resolve (one launch per frame).  Its HBM floor is 8 B key read +
@@ -165,7 +172,8 @@ def main():
         shade_bytes = 16.0 * WIDTH * HEIGHT / world
         ach = shade_bytes / (shade_ms * 1e-3) / 1e9
         roof = {"kernel": "k_resolve_opaque", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "bytes_per_launch": int(shade_bytes),
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get("k_resolve_opaque") if world == 1 else None,
+                "bytes_per_launch": int(shade_bytes),
                 "ms_per_launch": round(shade_ms, 5),
                 "note": "dominant kernel by time; VALU + gather-latency bound (4 lights x 5-tap PCF + GGX per pixel), see DESIGN.md"}
         result = {
