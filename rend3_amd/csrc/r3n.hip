@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -38,9 +39,20 @@ std::string g_create_error;
 
 }  // namespace
 
+#define R3N_AUX_STREAMS 4
+
 struct r3n_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // main stream: uploads, viewport chain, resolve, tonemap, collectives
+    // Shadow views are independent of each other and of the viewport's pass-1 / Hi-Z / cull chain until the
+    // resolve reads the atlas, and their kernels are latency-bound rather than throughput-bound: each shadow camera
+    // runs on its own auxiliary stream (forked after the frame's clears, joined before the resolve) so the five
+    // chains overlap and the launch gaps of one hide behind the work of the others.
+    hipStream_t aux[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t join_ev[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    bool aux_used[R3N_AUX_STREAMS] = {false, false, false, false};
+    bool multi_stream = true;
     std::string err;
     // world data
     DevBuf mesh, objects, materials, material_keys, dir_buf, point_buf, fu;
@@ -61,9 +73,9 @@ struct r3n_ctx {
     bool in_frame = false;
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
-    DevBuf big_items, big_count;
+    DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
+    uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {0, 0, 0, 0, 0};
     uint32_t big_capacity = (4u << 20) / R3N_BIGQ;  // entries per work sub-queue (R3N_BIGQ of them)
-    uint32_t forward_index = 0;  // r3n_forward calls so far this frame (each gets its own work-queue counter)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
@@ -98,6 +110,8 @@ int fail(r3n_ctx *c, int code, const std::string &msg) {
             return fail((c), R3N_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
+int sync_all(r3n_ctx *c);
+
 // Grow-only device buffer.  preserve: keep old contents; fill: byte value for the newly allocated tail.
 int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
     if (bytes <= b.bytes && b.p) return R3N_OK;
@@ -112,7 +126,8 @@ int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
     }
     if (fill >= 0) HIP_TRY(c, hipMemsetAsync(static_cast<char *>(np) + kept, fill, want - kept, c->stream));
     if (b.p) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int r = sync_all(c);  // any stream may still be reading the old allocation
+        if (r != R3N_OK) return r;
         HIP_TRY(c, hipFree(b.p));
     }
     b.p = np;
@@ -155,8 +170,9 @@ int upload_small(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
 struct Timed {
     r3n_ctx *c;
     int stage;
+    hipStream_t stream;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(r3n_ctx *ctx, int st) : c(ctx), stage(st) {
+    Timed(r3n_ctx *ctx, int st, hipStream_t on = nullptr) : c(ctx), stage(st), stream(on ? on : ctx->stream) {
         c->stage_launches[stage]++;
         if (!c->timing) return;
         auto get = [&]() {
@@ -166,14 +182,47 @@ struct Timed {
             return e;
         };
         a = get(); b = get();
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, stream);
     }
     ~Timed() {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, stream);
         c->spans.push_back({a, b, stage});
     }
 };
+
+// stream lane of a camera: 0 = main stream, 1 + k = auxiliary stream k
+int cam_lane(const r3n_ctx *c, r3n_camera cam) {
+    if (cam == R3N_CAMERA_VIEWPORT || !c->multi_stream) return 0;
+    return 1 + (int)(cam % R3N_AUX_STREAMS);
+}
+hipStream_t lane_stream(const r3n_ctx *c, int lane) { return lane == 0 ? c->stream : c->aux[lane - 1]; }
+
+// Order the lane's stream after everything enqueued on the main stream so far (clears, uploads).
+int fork_lane(r3n_ctx *c, int lane) {
+    if (lane == 0) return R3N_OK;
+    const int k = lane - 1;
+    HIP_TRY(c, hipEventRecord(c->fork_ev[k], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->aux[k], c->fork_ev[k], 0));
+    c->aux_used[k] = true;
+    return R3N_OK;
+}
+// Order the main stream after everything enqueued on the auxiliary streams so far.
+int join_lanes(r3n_ctx *c) {
+    for (int k = 0; k < R3N_AUX_STREAMS; ++k)
+        if (c->aux_used[k]) {
+            HIP_TRY(c, hipEventRecord(c->join_ev[k], c->aux[k]));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->join_ev[k], 0));
+            c->aux_used[k] = false;
+        }
+    return R3N_OK;
+}
+int sync_all(r3n_ctx *c) {
+    int r = join_lanes(c);
+    if (r != R3N_OK) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
 
 int check_launch(r3n_ctx *c, const char *what) {
     hipError_t e = hipGetLastError();
@@ -201,7 +250,8 @@ void free_cam(CamState &s) {
 uint32_t max_waves(const r3n_ctx *c) { return (uint32_t)(c->total_tris / 64u) + c->capacity + 1u; }
 
 // Object pass for one camera state (frustum cull + slot assignment); range (0,0) builds only tri_base.
-int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint32_t range_end, uint32_t *tri_base) {
+int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint32_t range_end, uint32_t *tri_base,
+                    hipStream_t stream) {
     const uint32_t cap = c->capacity;
     const uint32_t nblocks = (cap + 255u) / 256u;
     TRY(ensure(c, s.vis_flags, cap, false, -1));
@@ -211,14 +261,14 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
     TRY(ensure(c, s.slot_base[idx], (size_t)cap * 4u, true, 0xFF));
     TRY(ensure(c, s.sub_counts[idx], sizeof(r3n_sub_counts), false, 0));
     TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
-    Timed t(c, R3N_STAGE_OBJECT_CULL);
-    hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, c->stream, s.d_hdr.as<r3n_camera_header240>(),
+    Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
+    hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
                        c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin,
                        range_end, s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
-    hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(1024), 0, c->stream, s.block_sums.as<ObjBlockSums>(), nblocks,
+    hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(1024), 0, stream, s.block_sums.as<ObjBlockSums>(), nblocks,
                        s.block_off.as<ObjBlockOffsets>(), s.counts[idx].as<r3n_cull_counts>(),
                        s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>());
-    hipLaunchKernelGGL(k_object_scatter, dim3(nblocks), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_object_scatter, dim3(nblocks), dim3(256), 0, stream,
                        s.d_hdr.as<r3n_camera_header240>(), c->objects.as<r3n_object128>(), s.vis_flags.as<uint8_t>(),
                        s.block_off.as<ObjBlockOffsets>(), s.vis_list.as<r3n_vis_entry>(),
                        s.slot_base[idx].as<uint32_t>(), tri_base);
@@ -235,7 +285,7 @@ int refresh_tri_base(r3n_ctx *c) {
     TRY(ensure(c, c->canon.d_hdr, sizeof h, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->canon.d_hdr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
-    TRY(run_object_pass(c, c->canon, 0, 0, 0, c->tri_base.as<uint32_t>()));
+    TRY(run_object_pass(c, c->canon, 0, 0, 0, c->tri_base.as<uint32_t>(), c->stream));
     c->slot_table_size = (uint32_t)(c->total_tris >> R3N_SLOT_TABLE_SHIFT) + 1u;
     TRY(ensure(c, c->slot_table, (size_t)c->slot_table_size * 4u, false, -1));
     hipLaunchKernelGGL(k_build_slot_table, dim3((c->slot_table_size + 255u) / 256u), dim3(256), 0, c->stream,
@@ -264,7 +314,7 @@ size_t hiz_elements(const r3n_hiz_desc &d) {
 
 int drain_timing(r3n_ctx *c) {
     if (c->spans.empty()) return R3N_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(sync_all(c));
     for (auto &s : c->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) c->stage_ms[s.stage] += ms;
@@ -315,11 +365,22 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         r3n_destroy(c);
         return nullptr;
     }
+    if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
+    for (int k = 0; k < R3N_AUX_STREAMS; ++k)
+        if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->fork_ev[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->join_ev[k], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "auxiliary stream creation failed";
+            r3n_destroy(c);
+            return nullptr;
+        }
     // empty light buffers: count = 0
-    if (ensure(c, c->dir_buf, 16, false, 0) != R3N_OK || ensure(c, c->point_buf, 16, false, 0) != R3N_OK ||
-        ensure(c, c->material_keys, 256, false, 0) != R3N_OK || ensure(c, c->materials, sizeof(r3n_material208), false, 0) != R3N_OK ||
-        ensure(c, c->big_count, 64 * R3N_BIGQ * 4, false, 0) != R3N_OK ||
-        ensure(c, c->big_items, (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) != R3N_OK) {
+    bool ok = ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
+              ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
+    for (int lane = 0; ok && lane < 1 + R3N_AUX_STREAMS; ++lane)
+        ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
+             ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK;
+    if (!ok) {
         g_create_error = c->err;
         r3n_destroy(c);
         return nullptr;
@@ -331,9 +392,13 @@ void r3n_destroy(r3n_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < R3N_AUX_STREAMS; ++k)
+        if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
+    for (int lane = 0; lane < 1 + R3N_AUX_STREAMS; ++lane)
+        for (DevBuf *b : {&c->big_items[lane], &c->big_count[lane]})
+            if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
-                      &c->tri_base, &c->slot_table, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->big_items,
-                      &c->big_count};
+                      &c->tri_base, &c->slot_table, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -341,6 +406,11 @@ void r3n_destroy(r3n_ctx *c) {
     for (auto &kv : c->shadows) free_cam(kv.second);
     for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < R3N_AUX_STREAMS; ++k) {
+        if (c->fork_ev[k]) (void)hipEventDestroy(c->fork_ev[k]);
+        if (c->join_ev[k]) (void)hipEventDestroy(c->join_ev[k]);
+        if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+    }
     if (c->stage) (void)hipHostFree(c->stage);
     for (auto e : c->stage_half_done)
         if (e) (void)hipEventDestroy(e);
@@ -352,8 +422,7 @@ const char *r3n_last_error(const r3n_ctx *c) { return c ? c->err.c_str() : g_cre
 
 int r3n_sync(r3n_ctx *c) {
     if (!c) return R3N_ERR_INVALID_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return R3N_OK;
+    return sync_all(c);
 }
 
 void *r3n_stream(r3n_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -375,6 +444,7 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
     if (capacity < c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "objects write: capacity cannot shrink");
     for (uint32_t i = 0; i < n; ++i)
         if (slots[i] >= capacity) return fail(c, R3N_ERR_INVALID_ARG, "objects write: slot >= capacity");
+    if (n == 0 && capacity == c->capacity) return R3N_OK;  // nothing dirty: no upload, no synchronisation
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(ensure(c, c->objects, (size_t)capacity * sizeof(r3n_object128), true, 0));
     if (capacity != c->capacity) {
@@ -471,7 +541,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     }
     TRY(refresh_tri_base(c));
     c->in_frame = true;
-    c->forward_index = 0;
+    for (auto &f : c->forward_index_lane) f = 0;
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
@@ -492,9 +562,12 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     TRY(upload_small(c, s->d_hdr.p, hdr, sizeof *hdr));
     // per-camera buffer regrow preserves old matrices (disabled slots keep stale data, App. D.2)
     TRY(ensure(c, s->baked, (size_t)c->capacity * sizeof(r3n_baked128), true, 0));
-    Timed t(c, R3N_STAGE_BAKE);
+    const int lane = cam_lane(c, cam);
+    TRY(fork_lane(c, lane));  // after the header upload (main stream)
+    hipStream_t stream = lane_stream(c, lane);
+    Timed t(c, R3N_STAGE_BAKE, stream);
     const uint32_t threads = c->capacity * 4u;
-    hipLaunchKernelGGL(k_uniform_bake, dim3((threads + 255u) / 256u), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_uniform_bake, dim3((threads + 255u) / 256u), dim3(256), 0, stream,
                        s->d_hdr.as<r3n_camera_header240>(), c->objects.as<r3n_object128>(), s->baked.as<r3n_baked128>());
     return check_launch(c, "k_uniform_bake");
 }
@@ -508,7 +581,19 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     HIP_TRY(c, hipSetDevice(c->device));
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     const int cur = s->cur, prev = 1 - cur;
-    TRY(run_object_pass(c, *s, cur, c->range_begin, c->range_end, nullptr));
+    const int lane = cam_lane(c, cam);
+    hipStream_t stream = lane_stream(c, lane);
+    // (re)allocations below run on the main stream: size everything first, then fork
+    {
+        const uint32_t cap0 = c->capacity, nblocks0 = (cap0 + 255u) / 256u;
+        TRY(ensure(c, s->vis_flags, cap0, false, -1));
+        TRY(ensure(c, s->vis_list, (size_t)(cap0 + 1u) * sizeof(r3n_vis_entry), false, -1));
+        TRY(ensure(c, s->block_sums, (size_t)nblocks0 * sizeof(ObjBlockSums), false, -1));
+        TRY(ensure(c, s->block_off, (size_t)nblocks0 * sizeof(ObjBlockOffsets), false, -1));
+        TRY(ensure(c, s->slot_base[cur], (size_t)cap0 * 4u, true, 0xFF));
+        TRY(ensure(c, s->sub_counts[cur], sizeof(r3n_sub_counts), false, 0));
+        TRY(ensure(c, s->counts[cur], sizeof(r3n_cull_counts), false, 0));
+    }
     const uint32_t mw = max_waves(c);
     const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
     // every chunk appends to sub-list (chunk % R3N_SUBQ); worst case all of its slots pass and share one key
@@ -518,6 +603,8 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     TRY(ensure(c, s->mask[cur], (size_t)mw * 8u, false, -1));
     TRY(ensure(c, s->predicted[cur], list_bytes, false, -1));
     if (viewport) TRY(ensure(c, s->residual, list_bytes, false, -1));
+    TRY(fork_lane(c, lane));
+    TRY(run_object_pass(c, *s, cur, c->range_begin, c->range_end, nullptr, stream));
     TriCullArgs a{};
     a.hdr = s->d_hdr.as<r3n_camera_header240>();
     a.objects = c->objects.as<r3n_object128>();
@@ -538,8 +625,8 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     a.hiz.d = c->hizd;
     const uint32_t grid = std::max(1u, std::min(chunks, 4096u));
     {
-        Timed t(c, R3N_STAGE_TRIANGLE_CULL);
-        hipLaunchKernelGGL(k_triangle_cull, dim3(grid), dim3(256), 0, c->stream, a);
+        Timed t(c, R3N_STAGE_TRIANGLE_CULL, stream);
+        hipLaunchKernelGGL(k_triangle_cull, dim3(grid), dim3(256), 0, stream, a);
     }
     TRY(check_launch(c, "k_triangle_cull"));
     s->culled = true;
@@ -622,24 +709,27 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.sub_counts = sub_counts;
     a.subcap = s->subcap[idx];
     a.key = key;
-    a.big_items = c->big_items.as<r3n_big_item>();
-    const uint32_t fwd = std::min(c->forward_index++, 63u);
-    a.big_count = c->big_count.as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
+    const int lane = cam_lane(c, cam);
+    hipStream_t stream = lane_stream(c, lane);
+    a.big_items = c->big_items[lane].as<r3n_big_item>();
+    const uint32_t fwd = std::min(c->forward_index_lane[lane]++, 63u);
+    a.big_count = c->big_count[lane].as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
     a.big_capacity = c->big_capacity;
     const uint32_t small_grid = 2048;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
-    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, c->stream));
+    TRY(fork_lane(c, lane));
+    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
-        { Timed t(c, R3N_STAGE_RASTER); hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, c->stream, a); }
-        { Timed t(c, R3N_STAGE_RASTER_BIG); hipLaunchKernelGGL((k_raster_big<false, false>), dim3(1024), dim3(256), 0, c->stream, a); }
+        { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, stream, a); }
+        { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false, false>), dim3(1024), dim3(256), 0, stream, a); }
     } else {
         if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
             return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
         a.depth = c->atlas.as<uint32_t>();
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER); hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, c->stream, a); }
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG); hipLaunchKernelGGL((k_raster_big<true, true>), dim3(1024), dim3(256), 0, c->stream, a); }
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, stream, a); }
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, true>), dim3(1024), dim3(256), 0, stream, a); }
     }
     return check_launch(c, "raster");
 }
@@ -651,6 +741,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     if (r1 <= r0) return R3N_OK;
     CamState &s = c->viewport;
     if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
+    TRY(join_lanes(c));  // the shadow atlas must be complete
     ShadeArgs a{};
     a.vis = c->vis.as<unsigned long long>();
     a.width = c->width; a.height = c->height; a.row_begin = r0; a.row_end = r1;
@@ -701,6 +792,7 @@ int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
 
 int r3n_frame_end(r3n_ctx *c) {
     if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "frame_end: no frame in flight");
+    TRY(join_lanes(c));  // the next frame's clears (main stream) must not overtake this frame's shadow work
     auto flip = [](CamState &s) {
         if (s.culled) { s.cur = 1 - s.cur; s.has_prev = true; }
         s.culled = false;
@@ -719,6 +811,7 @@ int r3n_set_object_range(r3n_ctx *c, uint32_t begin, uint32_t end) {
 }
 int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atlas, uint64_t *atlas_count) {
     if (!c || !c->vis.p) return fail(c, R3N_ERR_STATE, "exchange_buffers: no frame targets yet");
+    TRY(join_lanes(c));  // collectives are ordered on the main stream
     if (vis) *vis = c->vis.p;
     if (vis_count) *vis_count = (uint64_t)c->width * c->height;
     if (atlas) *atlas = c->atlas.p;
@@ -740,6 +833,7 @@ int r3n_output_buffer(r3n_ctx *c, void **rgba8, uint64_t *bytes) {
 // ------------------------------------------------------------------------------------------------ readbacks
 static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(join_lanes(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return R3N_OK;
@@ -813,11 +907,14 @@ int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_
 
 int r3n_readback_raster_stats(r3n_ctx *c, uint32_t big_items[64]) {
     if (!c || !big_items) return R3N_ERR_INVALID_ARG;
+    // entries [0..16): main-stream lane (viewport) calls; [16 + 12*k ..): auxiliary lane k (shadow views)
     std::vector<uint32_t> raw(64 * R3N_BIGQ);
-    TRY(d2h(c, raw.data(), c->big_count.p, raw.size() * 4));
-    for (int f = 0; f < 64; ++f) {
-        big_items[f] = 0;
-        for (int q = 0; q < R3N_BIGQ; ++q) big_items[f] += raw[f * R3N_BIGQ + q];
+    for (int f = 0; f < 64; ++f) big_items[f] = 0;
+    for (int lane = 0; lane < 1 + R3N_AUX_STREAMS; ++lane) {
+        TRY(d2h(c, raw.data(), c->big_count[lane].p, raw.size() * 4));
+        const int base = lane == 0 ? 0 : 16 + 12 * (lane - 1), n = lane == 0 ? 16 : 12;
+        for (int f = 0; f < n; ++f)
+            for (int q = 0; q < R3N_BIGQ; ++q) big_items[base + f] += raw[f * R3N_BIGQ + q];
     }
     return R3N_OK;
 }
