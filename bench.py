@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--objects", type=int, default=3000)
     ap.add_argument("--tris", type=int, default=2_800_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-GPU exchange path (RCCL all-reduce / all-gather) even with one rank: plumbing check")
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     args = ap.parse_args()
 
@@ -64,8 +66,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    distributed = world > 1 or args.force_exchange
+    if distributed:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import rend3_amd as r3
     import rend3_amd.scenes  # noqa: F401
@@ -76,7 +82,7 @@ def main():
     info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=args.objects, target_tris=args.tris)
     view0 = info["camera"][0]
     exchange = None
-    if world > 1:
+    if distributed:
         counts = np.zeros(r.capacity, dtype=np.int64)
         for h, m in r.object_meta.items():
             counts[h] = r.meshes[m["mesh"]].index_count // 3
@@ -96,7 +102,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -109,7 +115,7 @@ def main():
         frame(args.warmup + k)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,7 +206,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     r.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -253,6 +253,12 @@ void r3n_host_bounding_sphere_from_mesh(const float *positions, uint64_t vertex_
                                         float *out_radius);
 void r3n_host_bounding_sphere_apply_transform(const float center[3], float radius, const float *m,
                                               float out_center[3], float *out_radius);
+/* ObjectManager::object_add_callback for `n` objects at once (rend3/src/managers/object.rs:236-300): fills the 128-byte
+ * records (world bounding sphere = mesh sphere transformed, object.rs:268-269; enabled = 1).
+ * mesh_desc[i] = {center.xyz, radius} as f32[4]; mesh_u32[i] = {first_index, index_count, attr_off[6]} as u32[8]. */
+void r3n_host_build_object_records(uint32_t n, const float *transforms /* 16 n */, const float *mesh_desc /* 4 n */,
+                                   const uint32_t *mesh_u32 /* 8 n */, const uint32_t *material_index /* n */,
+                                   r3n_object128 *out_records);
 /* Mesh::calculate_normals_for_buffers, rend3-types/src/lib.rs:662-704 */
 void r3n_host_calculate_normals(const float *positions, uint64_t vertex_count, const uint32_t *indices,
                                 uint64_t index_count, int left_handed, float *normals);

@@ -180,6 +180,10 @@ class OracleRenderer:
         self._write_object(h)
         return h
 
+    def add_objects_bulk(self, mesh_ids, material_ids, transforms):
+        transforms = np.ascontiguousarray(transforms, dtype=f32).reshape(len(mesh_ids), 16)
+        return [self.add_object(int(m), int(k), t) for m, k, t in zip(mesh_ids, material_ids, transforms)]
+
     def set_object_transform(self, h, transform):
         self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
         self._write_object(h)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "r3n_host_frustum_contains_sphere": (cint, [vp, vp, cfloat]),
     "r3n_host_bounding_sphere_from_mesh": (None, [vp, u64, vp, vp]),
     "r3n_host_bounding_sphere_apply_transform": (None, [vp, cfloat, vp, vp, vp]),
+    "r3n_host_build_object_records": (None, [u32, vp, vp, vp, vp, vp]),
     "r3n_host_calculate_normals": (None, [vp, u64, vp, u64, cint, vp]),
     "r3n_host_shadow_camera": (None, [vp, cfloat, u32, vp, cint, vp, vp]),
     "r3n_host_allocate_shadow_atlas": (u32, [vp, vp, u32, u32, vp, vp]),

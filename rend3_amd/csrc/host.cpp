@@ -213,6 +213,22 @@ void r3n_host_bounding_sphere_apply_transform(const float center[3], float radiu
     *out_radius = max_scale * radius;
 }
 
+void r3n_host_build_object_records(uint32_t n, const float *transforms, const float *mesh_desc, const uint32_t *mesh_u32,
+                                   const uint32_t *material_index, r3n_object128 *out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        r3n_object128 &o = out[i];
+        std::memset(&o, 0, sizeof o);
+        std::memcpy(o.transform, transforms + 16 * (size_t)i, 64);
+        r3n_host_bounding_sphere_apply_transform(mesh_desc + 4 * (size_t)i, mesh_desc[4 * (size_t)i + 3], o.transform,
+                                                 o.bounding_sphere_center, &o.bounding_sphere_radius);
+        o.first_index = mesh_u32[8 * (size_t)i];
+        o.index_count = mesh_u32[8 * (size_t)i + 1];
+        o.material_index = material_index[i];
+        for (int k = 0; k < 6; ++k) o.vertex_attribute_start_offsets[k] = mesh_u32[8 * (size_t)i + 2 + k];
+        o.enabled = 1;
+    }
+}
+
 void r3n_host_calculate_normals(const float *positions, uint64_t vertex_count, const uint32_t *indices,
                                 uint64_t index_count, int left_handed, float *normals) {
     std::memset(normals, 0, sizeof(float) * 3 * vertex_count);

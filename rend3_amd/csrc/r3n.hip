@@ -453,9 +453,14 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
         c->h_material.resize(capacity, 0);
         c->tri_base_dirty = true;
     }
-    for (uint32_t i = 0; i < n; ++i) {
-        HIP_TRY(c, hipMemcpyAsync(c->objects.as<r3n_object128>() + slots[i], records + i, sizeof(r3n_object128),
+    for (uint32_t i = 0; i < n;) {
+        uint32_t run = 1;  // consecutive slots upload as one copy
+        while (i + run < n && slots[i + run] == slots[i] + run) ++run;
+        HIP_TRY(c, hipMemcpyAsync(c->objects.as<r3n_object128>() + slots[i], records + i, (size_t)run * sizeof(r3n_object128),
                                   hipMemcpyHostToDevice, c->stream));
+        i += run;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
         const uint32_t nt = records[i].enabled ? records[i].index_count / 3u : 0u;
         c->total_tris = c->total_tris - c->h_ntri[slots[i]] + nt;
         c->h_ntri[slots[i]] = nt;

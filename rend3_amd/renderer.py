@@ -222,6 +222,28 @@ class Renderer:
         self._mark(h, self._object_record(h))
         return h
 
+    def add_objects_bulk(self, mesh_ids, material_ids, transforms):
+        """Vectorised add_object for large synthetic scenes (same records as add_object, built by the C++ host mirror)."""
+        n = len(mesh_ids)
+        transforms = np.ascontiguousarray(transforms, dtype=f32).reshape(n, 16)
+        desc = np.zeros((n, 4), dtype=f32)
+        mu = np.zeros((n, 8), dtype=np.uint32)
+        for i, mid in enumerate(mesh_ids):
+            m = self.meshes[mid]
+            desc[i, :3], desc[i, 3] = m.centre, m.radius
+            mu[i, 0], mu[i, 1] = m.first_index, m.index_count
+            mu[i, 2:8] = m.attr_off
+        mats = np.ascontiguousarray(material_ids, dtype=np.uint32)
+        recs = np.zeros((n, 32), dtype=np.uint32)
+        self.lib.r3n_host_build_object_records(n, _ffi.ptr(transforms), _ffi.ptr(desc), _ffi.ptr(mu), _ffi.ptr(mats), _ffi.ptr(recs))
+        handles = []
+        for i in range(n):
+            h = self._alloc_handle()
+            self.object_meta[h] = dict(mesh=int(mesh_ids[i]), material=int(material_ids[i]), transform=transforms[i], enabled=True)
+            self._mark(h, recs[i])
+            handles.append(h)
+        return handles
+
     def set_object_transform(self, h, transform):
         self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
         self._mark(h, self._object_record(h))

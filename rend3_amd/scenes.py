@@ -243,3 +243,132 @@ def _gauss(rng):
     u1 = max(rng.uniform(), 1e-12)
     u2 = rng.uniform()
     return math.sqrt(-2.0 * math.log(u1)) * math.cos(2.0 * math.pi * u2)
+
+
+def cylinder(seg, rings):
+    """Closed cylinder along Y, radius 1, height 2: 2*seg*rings side triangles + 2*(seg-2) cap triangles, LH-front winding."""
+    pos, nrm, idx = [], [], []
+    for r_ in range(rings + 1):
+        y = -1.0 + 2.0 * r_ / rings
+        for s_ in range(seg):
+            a = 2.0 * math.pi * s_ / seg
+            pos.append((math.cos(a), y, math.sin(a)))
+            nrm.append((math.cos(a), 0.0, math.sin(a)))
+    for r_ in range(rings):
+        for s_ in range(seg):
+            a0 = r_ * seg + s_
+            a1 = r_ * seg + (s_ + 1) % seg
+            b0, b1 = a0 + seg, a1 + seg
+            idx += [a0, b0, a1, a1, b0, b1]
+    for cap, y, ny in ((0, -1.0, -1.0), (1, 1.0, 1.0)):
+        base = len(pos)
+        for s_ in range(seg):
+            a = 2.0 * math.pi * s_ / seg
+            pos.append((math.cos(a), y, math.sin(a)))
+            nrm.append((0.0, ny, 0.0))
+        for s_ in range(1, seg - 1):
+            idx += [base, base + s_, base + s_ + 1] if cap == 0 else [base, base + s_ + 1, base + s_]
+    pos = np.array(pos, dtype=f32)
+    idx = np.array(idx, dtype=np.uint32)
+    # orient like the reference cube: cross(e1, e2) points outward
+    t = idx.reshape(-1, 3)
+    c = np.cross(pos[t[:, 1]] - pos[t[:, 0]], pos[t[:, 2]] - pos[t[:, 0]])
+    cen = (pos[t[:, 0]] + pos[t[:, 1]] + pos[t[:, 2]]) / 3.0
+    cen[:, 1] *= 0.25  # caps: outward is +-Y, sides: radial
+    flip = (c * cen).sum(axis=1) < 0
+    t[flip] = t[flip][:, ::-1]
+    return pos, t.reshape(-1), np.array(nrm, dtype=f32)
+
+
+def mesh_library_64(r, rh):
+    """64 procedural meshes, 12 ... 5 120 triangles (SURVEY.md section 8d cfg 2: icosphere / box / cylinder)."""
+    fix = _flip if rh else (lambda i: i)
+    lib = []
+    for n in range(1, 21):
+        p, i, nr = subdivided_box(n)
+        lib.append((12 * n * n, r.add_mesh(p, fix(i), normals=nr)))
+    for sub in range(0, 5):
+        p, i, nr = icosphere(sub)
+        lib.append((20 * 4 ** sub, r.add_mesh(p, fix(i), normals=nr)))
+    combos = [(s_, k) for s_ in (6, 8, 12, 16, 24, 32) for k in (1, 2, 4, 8, 16, 32, 64)]
+    for s_, k in combos[:39]:
+        p, i, nr = cylinder(s_, k)
+        lib.append((len(i) // 3, r.add_mesh(p, fix(i), normals=nr)))
+    assert len(lib) == 64
+    return lib
+
+
+def random_transforms(rng_np, n, extent, scale_lo, scale_hi):
+    """n random TRS matrices (column-major f32[16]): uniform positions in +-extent, uniform random rotations,
+    log-uniform scale.  Vectorised numpy; the SAME array is handed to every renderer that must agree."""
+    pos = (rng_np.random((n, 3)) * 2.0 - 1.0) * np.asarray(extent)
+    q = rng_np.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    x, y, z, w = q.T
+    R = np.empty((n, 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - z * w); R[:, 0, 2] = 2 * (x * z + y * w)
+    R[:, 1, 0] = 2 * (x * y + z * w); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - x * w)
+    R[:, 2, 0] = 2 * (x * z - y * w); R[:, 2, 1] = 2 * (y * z + x * w); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    s = np.exp(rng_np.uniform(math.log(scale_lo), math.log(scale_hi), size=n))
+    M = np.zeros((n, 16), dtype=f32)
+    for c in range(3):
+        for r_ in range(3):
+            M[:, 4 * c + r_] = (R[:, r_, c] * s).astype(f32)
+    M[:, 12:15] = pos.astype(f32)
+    M[:, 15] = 1.0
+    return M
+
+
+def scifi_like(r, hm, mk, n_objects=20000, seed=0xC0FFEE, n_materials=64, with_lights=False):
+    """BASELINE.json configs[1] stand-in (SURVEY.md section 8d cfg 2): 20 000 objects instancing 64 procedural meshes
+    (12 ... 5 120 triangles), uniform random positions in a 200 x 40 x 200 m box, random rotations, scale log-uniform
+    [0.25, 4]; right-handed, vfov 60, near 0.1, camera at the box centre looking down -Z; cull + compact only."""
+    rh = r.handedness == RIGHT
+    lib = mesh_library_64(r, rh)
+    rng = Pcg32(seed)
+    mats = [r.add_material(mk(albedo=(rng.uniform(0.2, 1), rng.uniform(0.2, 1), rng.uniform(0.2, 1), 1.0), albedo_mode="value",
+                              roughness=rng.uniform(0.2, 0.9), metallic=1.0 if rng.uniform() < 0.2 else 0.0), OPAQUE)
+            for _ in range(n_materials)]
+    rng_np = np.random.Generator(np.random.PCG64(seed))
+    xf = random_transforms(rng_np, n_objects, (100.0, 20.0, 100.0), 0.25, 4.0)
+    mesh_pick = rng_np.integers(0, 64, size=n_objects)
+    mat_pick = rng_np.integers(0, len(mats), size=n_objects)
+    r.add_objects_bulk([lib[k][1] for k in mesh_pick], [mats[k] for k in mat_pick], xf)
+    if with_lights:
+        r.add_directional_light(color=(1, 1, 1), intensity=3.0, direction=(0.3, -1.0, 0.2), distance=150.0, resolution=2048)
+    view = hm.identity()  # camera at the origin (box centre), looking down -Z (RH) / +Z (LH)
+    projection = ("perspective", 60.0, 0.1)
+    r.set_camera_data(view, projection)
+    return dict(objects=n_objects, triangles=int(sum(lib[k][0] for k in mesh_pick)), camera=(view, projection))
+
+
+def emerald_like(r, hm, mk, n_objects=1 << 20, seed=0xE5A0, n_materials=130, n_lights=0):
+    """BASELINE.json configs[3] stand-in (SURVEY.md section 8d cfg 4): 1 048 576 small objects (mean ~60 triangles) spread
+    over a 2 x 2 km district; used for the objects/s figure and for object-range sharding across GPUs."""
+    rh = r.handedness == RIGHT
+    fix = _flip if rh else (lambda i: i)
+    lib = []
+    for n in (1, 2, 3):
+        p, i, nr = subdivided_box(n)
+        lib.append((12 * n * n, r.add_mesh(p, fix(i), normals=nr)))
+    for sub in (0, 1, 2):
+        p, i, nr = icosphere(sub)
+        lib.append((20 * 4 ** sub, r.add_mesh(p, fix(i), normals=nr)))
+    rng = Pcg32(seed)
+    mats = [r.add_material(mk(albedo=(rng.uniform(0.2, 1), rng.uniform(0.2, 1), rng.uniform(0.2, 1), 1.0), albedo_mode="value",
+                              roughness=rng.uniform(0.2, 0.9), metallic=1.0 if rng.uniform() < 0.2 else 0.0), OPAQUE)
+            for _ in range(n_materials)]
+    rng_np = np.random.Generator(np.random.PCG64(seed))
+    xf = random_transforms(rng_np, n_objects, (1000.0, 30.0, 1000.0), 0.5, 6.0)
+    # triangle counts 12,48,108,20,80,320 with weights giving a mean near 60
+    mesh_pick = rng_np.choice(6, size=n_objects, p=[0.35, 0.2, 0.1, 0.2, 0.1, 0.05])
+    mat_pick = rng_np.integers(0, len(mats), size=n_objects)
+    r.add_objects_bulk([lib[k][1] for k in mesh_pick], [mats[k] for k in mat_pick], xf)
+    for k in range(n_lights):
+        ang = 0.5 * math.pi * k
+        r.add_directional_light(color=(1, 1, 1), intensity=4.0, direction=(math.cos(ang), -3.0, math.sin(ang)), distance=400.0,
+                                resolution=2048)
+    view = hm.mat4_mul(hm.rotation_x(0.25), hm.translation((0.0, -40.0, 0.0)))
+    projection = ("perspective", 60.0, 0.1)
+    r.set_camera_data(view, projection)
+    return dict(objects=n_objects, triangles=int(sum(lib[k][0] for k in mesh_pick)), camera=(view, projection))

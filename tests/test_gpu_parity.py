@@ -310,3 +310,60 @@ def test_large_scene_properties(r3):
     ids = ids[ids > 0] - 1
     assert (f1["pass"][ids].astype(bool) | f2["residual"][ids].astype(bool)).all()
     p.close(); q.close()
+
+
+def test_config2_scifi_full_size(r3):
+    """BASELINE.json configs[1] at FULL size: 20 000 objects / 19 M triangles, 1920x1080, right-handed, cull + compact:
+    visible-object set, per-triangle pass/residual sets and indirect-call counts bit-exact vs the oracle over three
+    frames (first frame without history, then a turning camera so predicted/residual/Hi-Z all engage)."""
+    import rend3_amd.scenes as S
+    o = OracleRenderer(oh.RIGHT, f32(1920) / f32(1080))
+    p = r3.Renderer(oh.RIGHT, f32(1920) / f32(1080))
+    io = S.scifi_like(o, oh, omk)
+    ip = S.scifi_like(p, r3.host, r3.material_record)
+    assert io["triangles"] == ip["triangles"] > 15_000_000
+    for f, yaw in enumerate((0.0, 0.1, 0.25)):
+        for r, hm in ((o, oh), (p, r3.host)):
+            r.set_camera_data(hm.rotation_y(yaw), io["camera"][1])
+        fo, fp = o.render(1920, 1080), p.render(1920, 1080)
+        compare_frames(fo, fp, f"cfg2 frame {f}")
+        assert fo["visible"].sum() > 1000 and fo["pass"].sum() > 1000
+    p.close()
+
+
+def test_config4_million_objects_properties(r3):
+    """BASELINE.json configs[3] shape: 1 048 576 objects (oracle too slow): properties only -- determinism across
+    contexts, residual(frame 0) == pass(frame 0), call counts == popcounts, every nearest fragment from a drawn triangle,
+    and object-range sharding: two half-range contexts produce L1/L2 sets whose union is the unsharded result."""
+    import rend3_amd.scenes as S
+    w, h = 1280, 720
+
+    def make(rng=None):
+        r = r3.Renderer(oh.LEFT, f32(w) / f32(h))
+        info = S.emerald_like(r, r3.host, r3.material_record)
+        if rng is not None:
+            r.evaluate_instructions()
+            r.set_object_range(*rng)
+        return r, info
+
+    a, info = make()
+    assert info["objects"] == 1 << 20
+    fa = [a.render(w, h) for _ in range(2)]
+    assert fa[0]["residual"].sum() == fa[0]["pass"].sum() > 0
+    assert sum(int(fa[1]["draw_calls"][k][0]) for k in range(3)) == 3 * int(fa[1]["pass"].sum())
+    ids = (fa[1]["vis"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    ids = ids[ids > 0] - 1
+    assert (fa[0]["pass"][ids].astype(bool) | fa[1]["residual"][ids].astype(bool)).all()
+    cap = a.capacity
+    a.close()
+    lo, _ = make((0, cap // 2))
+    flo = lo.render(w, h)
+    lo.close()
+    hi, _ = make((cap // 2, cap))
+    fhi = hi.render(w, h)
+    hi.close()
+    # frame 0 has no Hi-Z history, so sharded culling needs no exchange to be exact
+    assert np.array_equal(flo["visible"] | fhi["visible"], fa[0]["visible"])
+    assert not (flo["visible"] & fhi["visible"]).any()
+    assert np.array_equal(flo["pass"] | fhi["pass"], fa[0]["pass"])
+    assert np.array_equal(np.maximum(flo["vis"], fhi["vis"]), fa[0]["vis"])
