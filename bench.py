@@ -122,6 +122,9 @@ def main():
 
     # ---------------------------------------------------------------- instrumented pass (outside the timed region)
     # HIP events on the context's stream around every kernel launch of each stage (include/r3n.h R3N_STAGE_*)
+    # (single-stream here: a kernel's duration is inflated while kernels of other streams are co-resident)
+    r.sync()
+    r.set_multi_stream(False)
     r.timing_enable(True)
     r.stage_times(reset=True)
     n_inst = min(args.steps, 20)
@@ -130,6 +133,7 @@ def main():
     r.sync()
     stages = r.stage_times(reset=True)
     r.timing_enable(False)
+    r.set_multi_stream(True)
     last = frame(args.warmup + args.steps + n_inst, readback=(world == 1))
 
     result = None

@@ -123,6 +123,15 @@ typedef struct r3n_indirect_call {
     uint32_t base_instance;
 } r3n_indirect_call;
 
+/* GpuSkinningInput, 40 B (rend3-routine/src/skinning.rs:23-46, shaders/src/skinning.wgsl:3-25).  Offsets are byte
+ * offsets into the mesh buffer; 0xFFFFFFFF = attribute absent. */
+typedef struct r3n_skinning_input40 {
+    uint32_t base_position_offset, base_normal_offset, base_tangent_offset;
+    uint32_t joint_indices_offset, joint_weight_offset;
+    uint32_t updated_position_offset, updated_normal_offset, updated_tangent_offset;
+    uint32_t joint_matrix_base_offset, vertex_count;
+} r3n_skinning_input40;
+
 typedef struct r3n_config {
     uint32_t struct_size;      /* sizeof(r3n_config) */
     uint32_t max_big_items;    /* raster work-queue capacity (0 = default 4 Mi items) */
@@ -163,6 +172,12 @@ int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t dire
 int r3n_frame_begin(r3n_ctx *ctx, const r3n_frame_uniforms496 *uniforms, uint32_t width, uint32_t height,
                     uint32_t samples, const float clear_color[4], uint32_t shadow_atlas_width,
                     uint32_t shadow_atlas_height);
+/* skinning::add_skinning_to_graph (rend3-routine/src/skinning.rs:211-226): build_gpu_skinning_input_buffers (:54-139) +
+ * GpuSkinner::execute_pass (:142-199) + skinning.wgsl.  `inputs`: one record per skeleton, `joint_matrices`: all
+ * skeletons' joint matrices back to back (column-major mat4).  ONE launch covers every skeleton (the reference issues
+ * one dispatch + one dynamic-offset bind per skeleton).  Must precede the frame's bakes (base.rs:145). */
+int r3n_skinning(r3n_ctx *ctx, const r3n_skinning_input40 *inputs, uint32_t n_skeletons, const float *joint_matrices,
+                 uint32_t n_joint_matrices);
 /* GpuCuller::object_uniform_upload (culler.rs:427-529) + uniform_prep.wgsl */
 int r3n_uniform_bake(r3n_ctx *ctx, r3n_camera camera, const r3n_camera_header240 *header);
 /* GpuCuller::add_culling_to_graph (culler.rs:682-713) = batch_objects (batching.rs:120-250, frustum cull +
@@ -211,6 +226,7 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
  * the last frame produced (performance diagnostics only) */
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
+int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
 int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height */
 int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys */
 int r3n_readback_hiz(r3n_ctx *ctx, float *pyramid, uint64_t count); /* all mips, mip0 first */
@@ -231,8 +247,13 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_RASTER_BIG 8      /* viewport: wave-cooperative pass over the large-triangle work items */
 #define R3N_STAGE_SHADOW_RASTER 9   /* shadow views: per-triangle pass */
 #define R3N_STAGE_SHADOW_RASTER_BIG 10
-#define R3N_STAGE_COUNT 11
+#define R3N_STAGE_SKINNING 11
+#define R3N_STAGE_COUNT 12
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
+/* Shadow views normally run on auxiliary streams concurrently with the viewport chain; per-kernel durations measured
+ * while kernels of other streams are resident are inflated, so timing passes can serialise everything on the main
+ * stream (enable = 0).  Only between frames. */
+int r3n_set_multi_stream(r3n_ctx *ctx, int enable);
 int r3n_stage_times(r3n_ctx *ctx, double ms[R3N_STAGE_COUNT], uint64_t launches[R3N_STAGE_COUNT], int reset);
 
 /* ---- host-side mirror of the reference's CPU math on the path (rend3_amd/csrc/host.cpp).

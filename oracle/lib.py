@@ -60,6 +60,7 @@ class OracleLib:
             "r3o_shade": [vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp,
                           ctypes.c_uint32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp],
             "r3o_tonemap": [vp, ctypes.c_uint64, vp, vp],
+            "r3o_skinning": [vp, vp, ctypes.c_uint32, vp],
         }.items():
             fn = getattr(c, name)
             fn.restype = None

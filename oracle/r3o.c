@@ -897,3 +897,53 @@ void r3o_tonemap(const uint16_t *hdr_in, uint64_t npix, float *out_f32, uint8_t 
         }
     }
 }
+
+/* ------------------------------------------------------------------ K8: GPU skinning (row S1) */
+/* GpuSkinningInput, 40 B (rend3-routine/src/skinning.rs:23-46 / skinning.wgsl:3-25). */
+typedef struct {
+    uint32_t base_position_offset, base_normal_offset, base_tangent_offset;
+    uint32_t joint_indices_offset, joint_weight_offset;
+    uint32_t updated_position_offset, updated_normal_offset, updated_tangent_offset;
+    uint32_t joint_matrix_base_offset, vertex_count;
+} r3o_skinning_input;
+
+/* skinning.wgsl:37-94, one dispatch per skeleton in the reference (skinning.rs:181-198); sequential here.
+ * Writes the skinned position / normal / tangent runs into the mesh buffer. */
+void r3o_skinning(uint32_t *mesh, const r3o_skinning_input *inputs, uint32_t n_skeletons, const float *joint_matrices) {
+    for (uint32_t s = 0; s < n_skeletons; ++s) {
+        const r3o_skinning_input *in = &inputs[s];
+        for (uint32_t idx = 0; idx < in->vertex_count; ++idx) {
+            /* extract_attribute_vec4_u16 / vec4_f32 (vertex_attributes.wgsl:60-80) */
+            uint32_t j0 = mesh[in->joint_indices_offset / 4u + idx * 2u], j1 = mesh[in->joint_indices_offset / 4u + idx * 2u + 1u];
+            uint32_t ji[4] = {j0 & 0xFFFFu, (j0 >> 16) & 0xFFFFu, j1 & 0xFFFFu, (j1 >> 16) & 0xFFFFu};
+            float jw[4];
+            memcpy(jw, mesh + in->joint_weight_offset / 4u + idx * 4u, 16);
+            float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tan[3] = {0, 0, 0};
+            if (in->base_position_offset != R3O_INVALID) fetch_vec3(mesh, in->base_position_offset, idx, pos);
+            if (in->base_normal_offset != R3O_INVALID) fetch_vec3(mesh, in->base_normal_offset, idx, nrm);
+            if (in->base_tangent_offset != R3O_INVALID) fetch_vec3(mesh, in->base_tangent_offset, idx, tan);
+            float pa[3] = {0, 0, 0}, na[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int i = 0; i < 4; ++i) {
+                float w = jw[i];
+                if (w > 0.0f) {
+                    const float *jm = joint_matrices + 16 * (size_t)(in->joint_matrix_base_offset + ji[i]);
+                    float p4[4];
+                    mat4_mul_vec4(jm, pos[0], pos[1], pos[2], 1.0f, p4);
+                    for (int c = 0; c < 3; ++c) pa[c] += p4[c] * w;
+                    float inv_s2[3] = {1.0f / dot3(jm + 0, jm + 0), 1.0f / dot3(jm + 4, jm + 4), 1.0f / dot3(jm + 8, jm + 8)};
+                    float sn[3] = {inv_s2[0] * nrm[0], inv_s2[1] * nrm[1], inv_s2[2] * nrm[2]};
+                    float st[3] = {inv_s2[0] * tan[0], inv_s2[1] * tan[1], inv_s2[2] * tan[2]};
+                    float rn[3], rt[3];
+                    mat3_mul_vec3(jm + 0, jm + 4, jm + 8, sn, rn);
+                    mat3_mul_vec3(jm + 0, jm + 4, jm + 8, st, rt);
+                    for (int c = 0; c < 3; ++c) { na[c] += rn[c] * w; ta[c] += rt[c] * w; }
+                }
+            }
+            normalize3(na);
+            normalize3(ta);
+            if (in->updated_position_offset != R3O_INVALID) memcpy(mesh + in->updated_position_offset / 4u + idx * 3u, pa, 12);
+            if (in->updated_normal_offset != R3O_INVALID) memcpy(mesh + in->updated_normal_offset / 4u + idx * 3u, na, 12);
+            if (in->updated_tangent_offset != R3O_INVALID) memcpy(mesh + in->updated_tangent_offset / 4u + idx * 3u, ta, 12);
+        }
+    }
+}

@@ -75,7 +75,7 @@ def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, rough
 
 
 class _Mesh:
-    __slots__ = ("attr_off", "first_index", "index_count", "centre", "radius")
+    __slots__ = ("attr_off", "first_index", "index_count", "centre", "radius", "vertex_count", "joint_off", "weight_off")
 
 
 class OracleRenderer:
@@ -99,9 +99,38 @@ class OracleRenderer:
         self.cam_state = {}  # camera specifier -> temporal state
         self.frame_index = 0
         self.object_range = None
+        self.skeletons = []  # dict(mesh, out_off[3], matrices)
+
+    # ------------------------------------------------------------------ skeletons (rend3/src/managers/skeleton.rs:67-163)
+    def add_skeleton(self, mesh, joint_matrices):
+        m = self.meshes[mesh]
+        assert m.joint_off != INVALID, "Mesh must have joint indices to be used in a skeleton"
+        out_off = [INVALID] * 3
+        for a in range(3):  # position, normal, tangent copies private to the skeleton (skeleton.rs:110-113)
+            if m.attr_off[a] != INVALID:
+                out_off[a] = 4 * len(self.mesh_words)
+                self.mesh_words = np.concatenate([self.mesh_words, np.zeros(3 * m.vertex_count, dtype=np.uint32)])
+        self.skeletons.append(dict(mesh=mesh, out_off=out_off, matrices=np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)))
+        return len(self.skeletons) - 1
+
+    def set_skeleton_joint_matrices(self, sk, joint_matrices):
+        self.skeletons[sk]["matrices"] = np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)
+
+    def skinning_buffers(self):
+        """build_gpu_skinning_input_buffers, rend3-routine/src/skinning.rs:54-139"""
+        inputs = np.zeros((len(self.skeletons), 10), dtype=np.uint32)
+        mats, base = [], 0
+        for i, sk in enumerate(self.skeletons):
+            m = self.meshes[sk["mesh"]]
+            inputs[i] = [m.attr_off[0], m.attr_off[1], m.attr_off[2], m.joint_off, m.weight_off, sk["out_off"][0],
+                         sk["out_off"][1], sk["out_off"][2], base, m.vertex_count]
+            mats.append(sk["matrices"])
+            base += len(sk["matrices"])
+        return inputs, (np.ascontiguousarray(np.concatenate(mats)) if mats else np.zeros((0, 16), dtype=f32))
 
     # ------------------------------------------------------------------ world edits
-    def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT):
+    def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT, tangents=None,
+                 joint_indices=None, joint_weights=None):
         positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
         if indices is None:
             indices = np.arange(len(positions), dtype=np.uint32)
@@ -123,9 +152,16 @@ class OracleRenderer:
 
         m.attr_off[0] = 4 * push(positions.view(np.uint32).reshape(-1))
         m.attr_off[1] = 4 * push(normals.view(np.uint32).reshape(-1))
+        if tangents is not None:
+            m.attr_off[2] = 4 * push(np.ascontiguousarray(tangents, dtype=f32).reshape(-1).view(np.uint32))
         if colors is not None:
             colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 4)
             m.attr_off[5] = 4 * push(colors.view(np.uint32).reshape(-1))
+        m.vertex_count = len(positions)
+        m.joint_off = m.weight_off = INVALID
+        if joint_indices is not None:  # [u16; 4] per vertex, 8 bytes (rend3-types/src/attribute.rs:97-135)
+            m.joint_off = 4 * push(np.ascontiguousarray(joint_indices, dtype=np.uint16).reshape(-1, 4).view(np.uint32).reshape(-1))
+            m.weight_off = 4 * push(np.ascontiguousarray(joint_weights, dtype=f32).reshape(-1, 4).view(np.uint32).reshape(-1))
         m.first_index = push(indices)
         m.index_count = len(indices)
         self.mesh_words = np.concatenate(chunks)
@@ -169,14 +205,20 @@ class OracleRenderer:
         rec[21] = mesh.index_count
         rec[22] = meta["material"]
         rec[23:29] = mesh.attr_off
+        if meta.get("skeleton") is not None:  # object.rs:250-258: skeleton ranges override the mesh's
+            for a, off in enumerate(self.skeletons[meta["skeleton"]]["out_off"]):
+                if off != INVALID:
+                    rec[23 + a] = off
         rec[29] = 1 if meta["enabled"] else 0
         self._use_index(h)
         self.objects[h] = rec
 
-    def add_object(self, mesh, material, transform):
+    def add_object(self, mesh, material, transform, skeleton=None):
         h = self._alloc_handle()
+        if skeleton is not None:
+            mesh = self.skeletons[skeleton]["mesh"]
         self.object_meta[h] = dict(mesh=mesh, material=material, transform=np.asarray(transform, dtype=f32).copy(),
-                                   enabled=True)
+                                   enabled=True, skeleton=skeleton)
         self._write_object(h)
         return h
 
@@ -283,6 +325,10 @@ class OracleRenderer:
         atlas = np.zeros((atlas_size[1], atlas_size[0]), dtype=f32)
         # 2. frame uniforms (uniforms.rs)
         fu = host.frame_uniforms(cam, ambient, (width, height), lib)
+        # 3. skinning (base.rs:145, skinning.rs:211-226)
+        if self.skeletons:
+            sk_in, sk_m = self.skinning_buffers()
+            lib.r3o_skinning(lib.ptr(self.mesh_words), lib.ptr(sk_in), len(sk_in), lib.ptr(sk_m))
         # 4-6. shadow views: bake, cull, depth draw (base.rs:148-153)
         for si, sh in enumerate(shadows):
             hdr = host.camera_header(sh["camera"], si, (sh["size"], sh["size"]), 1, cap, lib)

@@ -18,7 +18,7 @@ PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
-          "shadow_raster", "shadow_raster_big"]
+          "shadow_raster", "shadow_raster_big", "skinning"]
 
 # every symbol include/r3n.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -33,6 +33,7 @@ SIGNATURES = {
     "r3n_materials_write": (cint, [vp, vp, vp, vp, u32]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
+    "r3n_skinning": (cint, [vp, vp, u32, vp, u32]),
     "r3n_uniform_bake": (cint, [vp, u32, vp]),
     "r3n_cull": (cint, [vp, u32]),
     "r3n_hi_z": (cint, [vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "r3n_readback_draw_calls": (cint, [vp, u32, vp]),
     "r3n_readback_raster_stats": (cint, [vp, vp]),
     "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
+    "r3n_readback_mesh": (cint, [vp, u64, vp, u64]),
     "r3n_readback_visibility": (cint, [vp, vp]),
     "r3n_readback_depth": (cint, [vp, vp]),
     "r3n_readback_hiz": (cint, [vp, vp, u64]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     "r3n_readback_output": (cint, [vp, vp, vp]),
     "r3n_timing_enable": (cint, [vp, cint]),
     "r3n_stage_times": (cint, [vp, vp, vp, cint]),
+    "r3n_set_multi_stream": (cint, [vp, cint]),
     "r3n_host_mat4_mul": (None, [vp, vp, vp]),
     "r3n_host_mat4_inverse": (None, [vp, vp]),
     "r3n_host_look_at": (None, [vp, vp, vp, cint, vp]),

@@ -211,6 +211,71 @@ __global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header2
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K8 skinning
+// skinning.wgsl:37-94.  One launch for all skeletons: wave slot w (64 vertices) belongs to skeleton wave_skeleton[w]
+// and covers its vertices [64 * (w - wave_first[skeleton]), +64): the skeleton record and its matrix base are
+// wave-uniform, positions / normals / tangents / weights are contiguous per wave (coalesced), outputs likewise.
+// HBM-bound: 60 B read + 36 B written per vertex against <= 272 flops -- plain f32 VALU with the
+// same operation order as the oracle; MFMA would change the rounding (fma chain) without moving the bound.
+__global__ __launch_bounds__(256) void k_skinning(uint32_t *__restrict__ mesh, const r3n_skinning_input40 *__restrict__ inputs,
+                                                  const float *__restrict__ joint_matrices,
+                                                  const uint32_t *__restrict__ wave_skeleton,
+                                                  const uint32_t *__restrict__ wave_first, uint32_t total_waves) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= total_waves) return;
+    const uint32_t sk = __builtin_amdgcn_readfirstlane(wave_skeleton[w]);
+    const r3n_skinning_input40 in = inputs[sk];
+    const uint32_t idx = (w - wave_first[sk]) * 64u + lane;
+    if (idx >= in.vertex_count) return;
+    const uint32_t j0 = mesh[in.joint_indices_offset / 4u + idx * 2u], j1 = mesh[in.joint_indices_offset / 4u + idx * 2u + 1u];
+    const uint32_t ji[4] = {j0 & 0xFFFFu, (j0 >> 16) & 0xFFFFu, j1 & 0xFFFFu, (j1 >> 16) & 0xFFFFu};
+    float jw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) jw[i] = __uint_as_float(mesh[in.joint_weight_offset / 4u + idx * 4u + (uint32_t)i]);
+    float pos[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f}, tan[3] = {0.0f, 0.0f, 0.0f};
+    if (in.base_position_offset != R3N_INVALID) fetch_vec3(mesh, in.base_position_offset, idx, pos);
+    if (in.base_normal_offset != R3N_INVALID) fetch_vec3(mesh, in.base_normal_offset, idx, nrm);
+    if (in.base_tangent_offset != R3N_INVALID) fetch_vec3(mesh, in.base_tangent_offset, idx, tan);
+    float pa[3] = {0.0f, 0.0f, 0.0f}, na[3] = {0.0f, 0.0f, 0.0f}, ta[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float wgt = jw[i];
+        if (wgt > 0.0f) {
+            const float *jm = joint_matrices + 16u * (size_t)(in.joint_matrix_base_offset + ji[i]);
+            float m[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m[k] = jm[k];
+            float p4[4];
+            mul_vec4(m, pos[0], pos[1], pos[2], 1.0f, p4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pa[c] += p4[c] * wgt;
+            const float inv_s2[3] = {1.0f / dot3(m, m), 1.0f / dot3(m + 4, m + 4), 1.0f / dot3(m + 8, m + 8)};
+            const float sn[3] = {inv_s2[0] * nrm[0], inv_s2[1] * nrm[1], inv_s2[2] * nrm[2]};
+            const float st[3] = {inv_s2[0] * tan[0], inv_s2[1] * tan[1], inv_s2[2] * tan[2]};
+            float rn[3], rt[3];
+            mat3_mul_vec3(m, m + 4, m + 8, sn, rn);
+            mat3_mul_vec3(m, m + 4, m + 8, st, rt);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { na[c] += rn[c] * wgt; ta[c] += rt[c] * wgt; }
+        }
+    }
+    normalize3(na);
+    normalize3(ta);
+    if (in.updated_position_offset != R3N_INVALID) {
+        const uint32_t o = in.updated_position_offset / 4u + idx * 3u;
+        mesh[o] = __float_as_uint(pa[0]); mesh[o + 1u] = __float_as_uint(pa[1]); mesh[o + 2u] = __float_as_uint(pa[2]);
+    }
+    if (in.updated_normal_offset != R3N_INVALID) {
+        const uint32_t o = in.updated_normal_offset / 4u + idx * 3u;
+        mesh[o] = __float_as_uint(na[0]); mesh[o + 1u] = __float_as_uint(na[1]); mesh[o + 2u] = __float_as_uint(na[2]);
+    }
+    if (in.updated_tangent_offset != R3N_INVALID) {
+        const uint32_t o = in.updated_tangent_offset / 4u + idx * 3u;
+        mesh[o] = __float_as_uint(ta[0]); mesh[o + 1u] = __float_as_uint(ta[1]); mesh[o + 2u] = __float_as_uint(ta[2]);
+    }
+}
+
 // slot_table[b] = last object o with tri_base[o] <= (b << R3N_SLOT_TABLE_SHIFT): accelerates the slot -> object
 // lookup of the resolve pass.  Rebuilt only when the object set changes.
 __global__ __launch_bounds__(256) void k_build_slot_table(const uint32_t *__restrict__ tri_base, uint32_t capacity,

@@ -65,6 +65,10 @@ struct r3n_ctx {
     uint64_t total_tris = 0;
     bool tri_base_dirty = true;
     DevBuf tri_base, slot_table;
+    // skinning (row S1): cached skeleton records + the wave -> skeleton map derived from them
+    DevBuf skin_inputs, skin_matrices, skin_wave_skeleton, skin_wave_first;
+    std::vector<r3n_skinning_input40> h_skin_inputs;
+    uint32_t skin_total_waves = 0;
     uint32_t slot_table_size = 0;
     CamState canon;  // scratch camera used to (re)build the canonical tri_base scan
     // frame targets
@@ -398,7 +402,8 @@ void r3n_destroy(r3n_ctx *c) {
         for (DevBuf *b : {&c->big_items[lane], &c->big_count[lane]})
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
-                      &c->tri_base, &c->slot_table, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz};
+                      &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -550,6 +555,53 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
+}
+
+int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, const float *joint_matrices, uint32_t n_joints) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    if (n == 0) return R3N_OK;  // skinning.rs:216-218: nothing to do without skeletons
+    if (!inputs || !joint_matrices || n_joints == 0) return fail(c, R3N_ERR_INVALID_ARG, "skinning: null inputs");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t mesh_words = c->mesh.bytes / 4;
+    for (uint32_t i = 0; i < n; ++i) {
+        const r3n_skinning_input40 &in = inputs[i];
+        if (in.joint_indices_offset == R3N_INVALID || in.joint_weight_offset == R3N_INVALID)
+            return fail(c, R3N_ERR_INVALID_ARG, "skinning: skeleton without joint indices / weights (SkeletonCreationError)");
+        if ((uint64_t)in.joint_weight_offset / 4 + (uint64_t)in.vertex_count * 4 > mesh_words)
+            return fail(c, R3N_ERR_INVALID_ARG, "skinning: attribute range outside the mesh buffer");
+        if (in.joint_matrix_base_offset >= n_joints) return fail(c, R3N_ERR_INVALID_ARG, "skinning: joint matrix base out of range");
+    }
+    // skeleton records change rarely: rebuild the wave -> skeleton map only when they do
+    const bool same = c->h_skin_inputs.size() == n && std::memcmp(c->h_skin_inputs.data(), inputs, (size_t)n * sizeof *inputs) == 0;
+    if (!same) {
+        c->h_skin_inputs.assign(inputs, inputs + n);
+        std::vector<uint32_t> wave_first(n + 1), wave_skel;
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            wave_first[i] = w;
+            const uint32_t nw = (inputs[i].vertex_count + 63u) / 64u;
+            wave_skel.insert(wave_skel.end(), nw, i);
+            w += nw;
+        }
+        wave_first[n] = w;
+        c->skin_total_waves = w;
+        TRY(ensure(c, c->skin_inputs, (size_t)n * sizeof *inputs, false, -1));
+        TRY(ensure(c, c->skin_wave_first, (size_t)(n + 1) * 4, false, -1));
+        TRY(ensure(c, c->skin_wave_skeleton, std::max<size_t>(w, 1) * 4, false, -1));
+        HIP_TRY(c, hipMemcpyAsync(c->skin_inputs.p, inputs, (size_t)n * sizeof *inputs, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->skin_wave_first.p, wave_first.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if (w) HIP_TRY(c, hipMemcpyAsync(c->skin_wave_skeleton.p, wave_skel.data(), (size_t)w * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors above are temporaries
+    }
+    TRY(ensure(c, c->skin_matrices, (size_t)n_joints * 64, false, -1));
+    HIP_TRY(c, hipMemcpyAsync(c->skin_matrices.p, joint_matrices, (size_t)n_joints * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns `joint_matrices` only for the duration of the call
+    if (c->skin_total_waves == 0) return R3N_OK;
+    Timed t(c, R3N_STAGE_SKINNING);
+    hipLaunchKernelGGL(k_skinning, dim3((c->skin_total_waves + 3u) / 4u), dim3(256), 0, c->stream, c->mesh.as<uint32_t>(),
+                       c->skin_inputs.as<r3n_skinning_input40>(), c->skin_matrices.as<float>(),
+                       c->skin_wave_skeleton.as<uint32_t>(), c->skin_wave_first.as<uint32_t>(), c->skin_total_waves);
+    return check_launch(c, "k_skinning");
 }
 
 int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr) {
@@ -931,6 +983,11 @@ int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity
     return d2h(c, out, s->baked.p, (size_t)c->capacity * sizeof(r3n_baked128));
 }
 
+int r3n_readback_mesh(r3n_ctx *c, uint64_t byte_offset, void *dst, uint64_t bytes) {
+    if (!c || !dst || byte_offset + bytes > c->mesh.bytes) return fail(c, R3N_ERR_INVALID_ARG, "readback_mesh: range outside the mesh buffer");
+    return d2h(c, dst, static_cast<char *>(c->mesh.p) + byte_offset, bytes);
+}
+
 int r3n_readback_visibility(r3n_ctx *c, uint64_t *keys) {
     if (!c || !c->vis.p || !keys) return fail(c, R3N_ERR_STATE, "readback_visibility: no frame");
     return d2h(c, keys, c->vis.p, (size_t)c->width * c->height * 8);
@@ -982,6 +1039,13 @@ int r3n_timing_enable(r3n_ctx *c, int enable) {
     if (!c) return R3N_ERR_INVALID_ARG;
     TRY(drain_timing(c));
     c->timing = enable != 0;
+    return R3N_OK;
+}
+
+int r3n_set_multi_stream(r3n_ctx *c, int enable) {
+    if (!c || c->in_frame) return fail(c, R3N_ERR_STATE, "set_multi_stream: only between frames");
+    TRY(sync_all(c));
+    c->multi_stream = enable != 0;
     return R3N_OK;
 }
 

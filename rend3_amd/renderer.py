@@ -79,7 +79,7 @@ class CameraSpecifier:
 
 
 class _Mesh:
-    __slots__ = ("attr_off", "first_index", "index_count", "centre", "radius")
+    __slots__ = ("attr_off", "first_index", "index_count", "centre", "radius", "vertex_count", "joint_off", "weight_off")
 
 
 class EvalOutput:
@@ -111,6 +111,7 @@ class Renderer:
         self.dir_lights, self.point_lights = [], []
         self.camera = host.CameraState(host.identity(), ("raw", host.identity()), handedness, aspect_ratio)
         self.object_range = None
+        self.skeletons = []
         self._write_objects([], force_capacity=True)
 
     def close(self):
@@ -128,7 +129,8 @@ class Renderer:
         _ffi.check(self.ctx, code, what)
 
     # ------------------------------------------------------------------ world edits
-    def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT):
+    def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT, tangents=None,
+                 joint_indices=None, joint_weights=None):
         positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
         if indices is None:
             indices = np.arange(len(positions), dtype=np.uint32)
@@ -150,9 +152,16 @@ class Renderer:
 
         m.attr_off[0] = 4 * push(positions.view(np.uint32).reshape(-1))
         m.attr_off[1] = 4 * push(normals.view(np.uint32).reshape(-1))
+        if tangents is not None:
+            m.attr_off[2] = 4 * push(np.ascontiguousarray(tangents, dtype=f32).reshape(-1).view(np.uint32))
         if colors is not None:
             colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 4)
             m.attr_off[5] = 4 * push(colors.view(np.uint32).reshape(-1))
+        m.vertex_count = len(positions)
+        m.joint_off = m.weight_off = INVALID
+        if joint_indices is not None:  # [u16; 4] per vertex + vec4<f32> weights (rend3-types/src/attribute.rs:97-135)
+            m.joint_off = 4 * push(np.ascontiguousarray(joint_indices, dtype=np.uint16).reshape(-1, 4).view(np.uint32).reshape(-1))
+            m.weight_off = 4 * push(np.ascontiguousarray(joint_weights, dtype=f32).reshape(-1, 4).view(np.uint32).reshape(-1))
         m.first_index = push(indices)
         m.index_count = len(indices)
         blob = np.concatenate(chunks)
@@ -162,6 +171,61 @@ class Renderer:
         m.centre, m.radius = host.bounding_sphere_from_mesh(positions)
         self.meshes.append(m)
         return len(self.meshes) - 1
+
+    # ---- skeletons (rend3/src/managers/skeleton.rs:67-163)
+    def add_skeleton(self, mesh, joint_matrices):
+        m = self.meshes[mesh]
+        if m.joint_off == INVALID:
+            raise ValueError("Mesh must have joint indices to be used in a skeleton")  # SkeletonCreationError
+        out_off = [INVALID] * 3
+        for a in range(3):  # private position / normal / tangent copies (skeleton.rs:110-113)
+            if m.attr_off[a] != INVALID:
+                out_off[a] = 4 * self.mesh_cursor
+                zeros = np.zeros(3 * m.vertex_count, dtype=np.uint32)
+                self._check(self.lib.r3n_mesh_buffer_write(self.ctx, out_off[a], _ffi.ptr(zeros), zeros.nbytes), "r3n_mesh_buffer_write")
+                self.mesh_cursor += len(zeros)
+        self.skeletons.append(dict(mesh=mesh, out_off=out_off, matrices=np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)))
+        self._skin_inputs = None
+        return len(self.skeletons) - 1
+
+    def add_skeletons_bulk(self, mesh, joint_matrices_per_skeleton):
+        """Many skeletons of one mesh (config 5): one zero-fill upload for all private output ranges."""
+        m = self.meshes[mesh]
+        n = len(joint_matrices_per_skeleton)
+        n_attr = sum(1 for a in range(3) if m.attr_off[a] != INVALID)
+        words = 3 * m.vertex_count
+        zeros = np.zeros(n * n_attr * words, dtype=np.uint32)
+        base = self.mesh_cursor
+        self._check(self.lib.r3n_mesh_buffer_write(self.ctx, 4 * base, _ffi.ptr(zeros), zeros.nbytes), "r3n_mesh_buffer_write")
+        self.mesh_cursor += len(zeros)
+        first = len(self.skeletons)
+        for i in range(n):
+            out_off, k = [INVALID] * 3, 0
+            for a in range(3):
+                if m.attr_off[a] != INVALID:
+                    out_off[a] = 4 * (base + (i * n_attr + k) * words)
+                    k += 1
+            self.skeletons.append(dict(mesh=mesh, out_off=out_off,
+                                       matrices=np.ascontiguousarray(joint_matrices_per_skeleton[i], dtype=f32).reshape(-1, 16)))
+        self._skin_inputs = None
+        return list(range(first, first + n))
+
+    def set_skeleton_joint_matrices(self, sk, joint_matrices):
+        self.skeletons[sk]["matrices"] = np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)
+
+    def skinning_buffers(self):
+        """build_gpu_skinning_input_buffers (rend3-routine/src/skinning.rs:54-139)"""
+        if getattr(self, "_skin_inputs", None) is None:
+            inputs = np.zeros((len(self.skeletons), 10), dtype=np.uint32)
+            base = 0
+            for i, sk in enumerate(self.skeletons):
+                m = self.meshes[sk["mesh"]]
+                inputs[i] = [m.attr_off[0], m.attr_off[1], m.attr_off[2], m.joint_off, m.weight_off, sk["out_off"][0],
+                             sk["out_off"][1], sk["out_off"][2], base, m.vertex_count]
+                base += len(sk["matrices"])
+            self._skin_inputs = inputs
+        mats = np.ascontiguousarray(np.concatenate([sk["matrices"] for sk in self.skeletons]))
+        return self._skin_inputs, mats
 
     def add_material(self, record, key=OPAQUE):
         idx = len(self.materials)
@@ -199,6 +263,10 @@ class Renderer:
         rf[19] = r
         rec[20], rec[21], rec[22] = mesh.first_index, mesh.index_count, meta["material"]
         rec[23:29] = mesh.attr_off
+        if meta.get("skeleton") is not None:  # object.rs:250-258: skeleton ranges override the mesh's
+            for a, off in enumerate(self.skeletons[meta["skeleton"]]["out_off"]):
+                if off != INVALID:
+                    rec[23 + a] = off
         rec[29] = 1 if meta["enabled"] else 0
         return rec
 
@@ -215,10 +283,12 @@ class Renderer:
                                                _ffi.ptr(recs) if len(slots) else None, len(slots), self.capacity),
                     "r3n_objects_write")
 
-    def add_object(self, mesh, material, transform):
+    def add_object(self, mesh, material, transform, skeleton=None):
         h = self._alloc_handle()
+        if skeleton is not None:
+            mesh = self.skeletons[skeleton]["mesh"]
         self.object_meta[h] = dict(mesh=mesh, material=material, transform=np.asarray(transform, dtype=f32).copy(),
-                                   enabled=True)
+                                   enabled=True, skeleton=skeleton)
         self._mark(h, self._object_record(h))
         return h
 
@@ -339,6 +409,11 @@ class Renderer:
         out.update(vis=vis, atlas=atlas, atlas_size=(aw, ah), hdr16=hdr16, rgba8=rgba8, rgba_f32=rgba_f)
         return out
 
+    def readback_mesh_words(self, byte_offset, n_words):
+        out = np.zeros(n_words, dtype=np.uint32)
+        self._check(self.lib.r3n_readback_mesh(self.ctx, byte_offset, _ffi.ptr(out), out.nbytes), "r3n_readback_mesh")
+        return out
+
     def readback_hiz(self, width, height):
         n = 0
         k = 0
@@ -354,6 +429,9 @@ class Renderer:
     # ------------------------------------------------------------------ timing taps
     def timing_enable(self, on=True):
         self._check(self.lib.r3n_timing_enable(self.ctx, 1 if on else 0), "r3n_timing_enable")
+
+    def set_multi_stream(self, on=True):
+        self._check(self.lib.r3n_set_multi_stream(self.ctx, 1 if on else 0), "r3n_set_multi_stream")
 
     def stage_times(self, reset=True):
         ms = np.zeros(len(_ffi.STAGES), dtype=np.float64)
@@ -493,7 +571,13 @@ class BaseRenderGraph:
                          "r3n_shadow_viewport")
 
         graph.add_node("Frame Uniforms", begin)
-        # skinning (base.rs:145): row S1, not built
+        # skinning (base.rs:145, skinning.rs:211-226)
+        def skin(r, _ev):
+            if r.skeletons:
+                sk_in, sk_m = r.skinning_buffers()
+                r._check(r.lib.r3n_skinning(r.ctx, _ffi.ptr(sk_in), len(sk_in), _ffi.ptr(sk_m), len(sk_m)), "r3n_skinning")
+
+        graph.add_node("Skinning", skin)
         # shadow_object_uniform_upload (base.rs:148)
         for si, sh in enumerate(ev.shadows):
             self.gpu_culler.add_object_uniform_upload_to_graph(graph, si, (sh["size"], sh["size"]), 1, f"Shadow Culling S{si}")

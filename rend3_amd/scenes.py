@@ -372,3 +372,29 @@ def emerald_like(r, hm, mk, n_objects=1 << 20, seed=0xE5A0, n_materials=130, n_l
     projection = ("perspective", 60.0, 0.1)
     r.set_camera_data(view, projection)
     return dict(objects=n_objects, triangles=int(sum(lib[k][0] for k in mesh_pick)), camera=(view, projection))
+
+
+def skinned_cylinder(joints, seg=16, rings=9):
+    """Cylinder along Y (radius 0.3, y in [0, 2]) rigged to `joints` bones spaced along the axis -- the shape of
+    examples/src/skinning/RiggedSimple.glb (160 vertices, 2 joints) with a variable joint count.  Every vertex blends
+    its two nearest bones; ring 0 adds a third and fourth influence, the last ring has a single weight of 1
+    (zero weights exercise skinning.wgsl:69).  Returns positions, indices, normals, tangents, joint_indices, weights."""
+    pos, idx, nrm = cylinder(seg, rings)
+    pos = pos.copy()
+    pos[:, 0] *= 0.3; pos[:, 2] *= 0.3; pos[:, 1] = pos[:, 1] + 1.0
+    tang = np.stack([-nrm[:, 2], np.zeros(len(nrm), dtype=f32), nrm[:, 0]], axis=1).astype(f32)
+    tang[np.abs(nrm[:, 1]) > 0.5] = (1.0, 0.0, 0.0)
+    ji = np.zeros((len(pos), 4), dtype=np.uint16)
+    jw = np.zeros((len(pos), 4), dtype=f32)
+    for v in range(len(pos)):
+        t = float(pos[v, 1]) / 2.0 * (joints - 1)
+        a = min(int(math.floor(t)), joints - 1)
+        b = min(a + 1, joints - 1)
+        fb = f32(t - a)
+        if pos[v, 1] >= 2.0 - 1e-6:
+            ji[v] = (joints - 1, 0, 0, 0); jw[v] = (1.0, 0.0, 0.0, 0.0)
+        elif pos[v, 1] <= 1e-6 and joints >= 4:
+            ji[v] = (0, 1, 2, 3); jw[v] = (0.5, 0.25, 0.125, 0.125)
+        else:
+            ji[v] = (a, b, 0, 0); jw[v] = (f32(1.0) - fb, fb, 0.0, 0.0)
+    return pos, idx, nrm, tang, ji, jw

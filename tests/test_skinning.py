@@ -1,0 +1,135 @@
+"""Row S1 (GPU skinning, rend3-routine/shaders/src/skinning.wgsl + skinning.rs): oracle known-answer tests on CPU,
+HIP-vs-oracle bit-exact parity and a config-5-shaped run (many instances, one launch) on the GPU."""
+import math
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import host as oh
+from oracle.world import OracleRenderer
+from oracle.world import material_record as omk
+from rend3_amd.scenes import Pcg32, skinned_cylinder
+
+f32 = np.float32
+
+
+def _rig(r, joints, mk, n_skeletons=1):
+    pos, idx, nrm, tang, ji, jw = skinned_cylinder(joints)
+    mesh = r.add_mesh(pos, idx, normals=nrm, tangents=tang, joint_indices=ji, joint_weights=jw)
+    mat = r.add_material(mk(albedo=(0.8, 0.6, 0.4, 1.0), albedo_mode="value", roughness=0.5), 0)
+    sks = [r.add_skeleton(mesh, np.tile(oh.identity(), (joints, 1))) for _ in range(n_skeletons)]
+    return mesh, mat, sks, pos, nrm
+
+
+def _pose(joints, seed, scale=True):
+    rng = Pcg32(seed)
+    mats = []
+    for j in range(joints):
+        m = oh.mat4_mul(oh.translation((rng.uniform(-0.2, 0.2), rng.uniform(-0.1, 0.1), rng.uniform(-0.2, 0.2))),
+                        scenes.random_rotation(rng, oh))
+        if scale:
+            m = oh.mat4_mul(m, oh.scale((rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0))))
+        mats.append(m)
+    return np.array(mats, dtype=f32)
+
+
+def _skinned_runs(r, sk):
+    s = r.skeletons[sk]
+    n = 3 * r.meshes[s["mesh"]].vertex_count
+    if hasattr(r, "mesh_words"):
+        return [r.mesh_words[o // 4:o // 4 + n].copy() for o in s["out_off"]]
+    return [r.readback_mesh_words(o, n) for o in s["out_off"]]
+
+
+# ------------------------------------------------------------------ CPU: oracle known answers
+def test_oracle_identity_pose_reproduces_bind_pose():
+    o = OracleRenderer(oh.LEFT)
+    _mesh, mat, (sk,), pos, nrm = _rig(o, 4, omk)
+    o.add_object(None, mat, oh.identity(), skeleton=sk)
+    o.set_camera_data(oh.look_at_lh((0, 1, -4), (0, 1, 0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    o.render(64, 64)
+    p, n, t = (a.view(f32).reshape(-1, 3) for a in _skinned_runs(o, sk))
+    # weights of each vertex sum to exactly 1 in f32 for this rig, identity matrices => bind pose back
+    assert np.allclose(p, pos, atol=1e-6) and np.allclose(n, nrm, atol=1e-6)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
+
+
+def test_oracle_translation_and_nonuniform_scale():
+    o = OracleRenderer(oh.LEFT)
+    _mesh, mat, (sk,), pos, nrm = _rig(o, 2, omk)
+    o.add_object(None, mat, oh.identity(), skeleton=sk)
+    o.set_camera_data(oh.look_at_lh((0, 1, -4), (0, 1, 0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    m = oh.mat4_mul(oh.translation((1.0, 2.0, 3.0)), oh.scale((2.0, 1.0, 0.5)))
+    o.set_skeleton_joint_matrices(sk, np.array([m, m], dtype=f32))
+    o.render(64, 64)
+    p, n, _t = (a.view(f32).reshape(-1, 3) for a in _skinned_runs(o, sk))
+    assert np.allclose(p, pos * np.array([2.0, 1.0, 0.5], dtype=f32) + np.array([1, 2, 3], dtype=f32), atol=1e-5)
+    # normals go through J3 * (inv_scale^2 o n) == inverse-transpose for a pure scale (skinning.wgsl:75-76)
+    expect = nrm / np.array([2.0, 1.0, 0.5], dtype=f32)
+    expect /= np.linalg.norm(expect, axis=1, keepdims=True)
+    assert np.allclose(n, expect, atol=1e-5)
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("joints", [2, 7, 34])
+def test_gpu_skinning_bit_exact_and_rendered(joints):
+    import torch
+    assert torch.cuda.is_available()
+    import rend3_amd as r3
+    from test_gpu_parity import compare_frames
+    o, p = OracleRenderer(oh.LEFT, f32(1.5)), r3.Renderer(oh.LEFT, f32(1.5))
+    rigs = []
+    for r, mk in ((o, omk), (p, r3.material_record)):
+        _mesh, mat, sks, _pos, _nrm = _rig(r, joints, mk, n_skeletons=3)
+        for i, sk in enumerate(sks):
+            r.add_object(None, mat, oh.translation((-1.2 + 1.2 * i, 0.0, 0.0)), skeleton=sk)
+        r.add_directional_light(color=(1, 1, 1), intensity=3.0, direction=(0.3, -1.0, 0.4), distance=10.0, resolution=256)
+        r.set_camera_data(oh.look_at_lh((0, 1.2, -4), (0, 1, 0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        rigs.append(sks)
+    for f in range(3):
+        for r, sks in zip((o, p), rigs):
+            for i, sk in enumerate(sks):
+                r.set_skeleton_joint_matrices(sk, _pose(joints, 100 * f + i, scale=(f != 1)))
+        fo, fp = o.render(192, 128, ambient=(0.1, 0.1, 0.1, 1)), p.render(192, 128, ambient=(0.1, 0.1, 0.1, 1))
+        for i in range(3):
+            for a, b in zip(_skinned_runs(o, rigs[0][i]), _skinned_runs(p, rigs[1][i])):
+                assert np.array_equal(a, b), f"skinned attribute run differs (frame {f}, skeleton {i})"
+        compare_frames(fo, fp, f"skinned frame {f}")
+        assert fo["pass"].sum() > 0
+    p.close()
+
+
+@pytest.mark.gpu
+def test_gpu_config5_shape_many_instances():
+    """BASELINE.json configs[4] shape, reduced instance count for test time: 5 000 skeletons x 160 vertices x 2 joints
+    skinned by ONE launch; every instance posed differently; spot-check 16 instances bit-exact against the oracle."""
+    import torch
+    assert torch.cuda.is_available()
+    import rend3_amd as r3
+    n = 5000
+    p = r3.Renderer(oh.LEFT, f32(16 / 9))
+    pos, idx, nrm, tang, ji, jw = skinned_cylinder(2)
+    assert len(pos) == 160 + 32 - 32 or len(pos) > 100
+    mesh = p.add_mesh(pos, idx, normals=nrm, tangents=tang, joint_indices=ji, joint_weights=jw)
+    mat = p.add_material(r3.material_record(albedo=(0.7, 0.7, 0.7, 1), albedo_mode="value", roughness=0.6), 0)
+    poses = [_pose(2, 7 + i) for i in range(n)]
+    sks = p.add_skeletons_bulk(mesh, poses)
+    rng = np.random.Generator(np.random.PCG64(5))
+    xf = np.tile(oh.identity(), (n, 1))
+    xf[:, 12] = rng.uniform(-60, 60, n); xf[:, 14] = rng.uniform(5, 120, n)
+    for i, sk in enumerate(sks):
+        p.add_object(None, mat, xf[i], skeleton=sk)
+    p.set_camera_data(oh.look_at_lh((0, 10, -10), (0, 0, 40), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    out = p.render(640, 360)
+    assert out["pass"].sum() > 0
+    o = OracleRenderer(oh.LEFT)
+    omesh = o.add_mesh(pos, idx, normals=nrm, tangents=tang, joint_indices=ji, joint_weights=jw)
+    for i in (0, 1, 2, 3, 17, 99, 1000, 1001, 2500, 3333, 4000, 4095, 4096, 4997, 4998, 4999):
+        osk = o.add_skeleton(omesh, poses[i])
+        sk_in, sk_m = o.skinning_buffers()
+        o.lib.r3o_skinning(o.lib.ptr(o.mesh_words), o.lib.ptr(sk_in), len(sk_in), o.lib.ptr(sk_m))
+        for a, b in zip(_skinned_runs(o, osk), _skinned_runs(p, sks[i])):
+            assert np.array_equal(a, b), i
+    p.close()
