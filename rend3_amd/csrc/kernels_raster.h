@@ -307,6 +307,81 @@ __global__ __launch_bounds__(256) void k_hiz_downsample(const float *__restrict_
     dst[(size_t)y * dw + x] = nearest;
 }
 
+// Fused head of the pyramid: one block reduces a 32x32 depth tile through mip0 .. mip`levels` (levels <= 4) in one
+// pass -- registers for the first 2x2, LDS for the rest.  Only used for levels whose SOURCE dimensions are even (then
+// hi_z.wgsl's window is a plain 2x2 and tiles are independent); the host picks `levels` accordingly.
+__global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__restrict__ vis, float *__restrict__ pyr,
+                                                  r3n_hiz_desc d, uint32_t levels) {
+    __shared__ float t[16][17];
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t x0 = (blockIdx.x * 16u + tx) * 2u, y0 = (blockIdx.y * 16u + ty) * 2u;
+    float q[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const uint32_t x = x0 + (uint32_t)dx, y = y0 + (uint32_t)dy;
+            float v = 0.0f;
+            if (x < d.width && y < d.height) {
+                v = __uint_as_float((uint32_t)(vis[(size_t)y * d.width + x] >> 32));
+                pyr[(size_t)y * d.width + x] = v;
+            }
+            q[dy][dx] = v;
+        }
+    if (levels == 0u) return;
+    // hi_z.wgsl:22-30 order: nearest = 1.0; x outer, y inner
+    float m = fminf(fminf(fminf(fminf(1.0f, q[0][0]), q[1][0]), q[0][1]), q[1][1]);
+    {
+        const uint32_t w1 = mip_dim(d.width, 1), h1 = mip_dim(d.height, 1), x = x0 >> 1, y = y0 >> 1;
+        if (x < w1 && y < h1) pyr[d.offset[1] + (size_t)y * w1 + x] = m;
+    }
+    t[ty][tx] = m;
+    for (uint32_t l = 2; l <= levels; ++l) {
+        __syncthreads();
+        const uint32_t n = 16u >> (l - 1u);  // tile edge at level l
+        float r = 0.0f;
+        const bool active = tx < n && ty < n;
+        if (active) {
+            const uint32_t s = 1u << (l - 2u);  // stride of level l-1 entries in the LDS tile
+            const float a = t[(2u * ty) * s][(2u * tx) * s], b = t[(2u * ty + 1u) * s][(2u * tx) * s];
+            const float c = t[(2u * ty) * s][(2u * tx + 1u) * s], e = t[(2u * ty + 1u) * s][(2u * tx + 1u) * s];
+            r = fminf(fminf(fminf(fminf(1.0f, a), b), c), e);
+        }
+        __syncthreads();
+        if (active) {
+            const uint32_t s = 1u << (l - 1u);
+            t[ty * s][tx * s] = r;
+            const uint32_t wl = mip_dim(d.width, l), hl = mip_dim(d.height, l);
+            const uint32_t x = blockIdx.x * n + tx, y = blockIdx.y * n + ty;
+            if (x < wl && y < hl) pyr[d.offset[l] + (size_t)y * wl + x] = r;
+        }
+    }
+}
+
+// Tail of the pyramid (levels first .. mips-1, at most a few thousand texels each): one block walks the levels,
+// generic odd-dimension windows, a barrier between levels.
+__global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {
+    for (uint32_t l = first; l < d.mips; ++l) {
+        const uint32_t sw = mip_dim(d.width, l - 1u), sh = mip_dim(d.height, l - 1u);
+        const uint32_t dw = mip_dim(d.width, l), dh = mip_dim(d.height, l);
+        const float *src = pyr + d.offset[l - 1u];
+        float *dst = pyr + d.offset[l];
+        const uint32_t nx = 2u + (sw & 1u), ny = 2u + (sh & 1u);
+        for (uint32_t i = threadIdx.x; i < dw * dh; i += 1024u) {
+            const uint32_t x = i % dw, y = i / dw;
+            float nearest = 1.0f;
+            for (uint32_t ix = 0; ix < nx; ++ix)
+                for (uint32_t iy = 0; iy < ny; ++iy) {
+                    const uint32_t sx = 2u * x + ix, sy = 2u * y + iy;
+                    const float v = (sx < sw && sy < sh) ? src[(size_t)sy * sw + sx] : 0.0f;
+                    nearest = fminf(nearest, v);
+                }
+            dst[i] = nearest;
+        }
+        __syncthreads();  // the next level reads what this one wrote (same workgroup, same CU)
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K6 resolve
 struct ShadeArgs {
     const unsigned long long *vis;
@@ -327,6 +402,7 @@ struct ShadeArgs {
     uint32_t atlas_w, atlas_h;
     float clear[4];
     ushort4 *hdr_out;          // Rgba16Float
+    uchar4 *ldr_out;           // Rgba8UnormSrgb: the tonemap blit fused into the resolve (one HDR round trip less)
 };
 
 struct LdsDirLight {
@@ -460,6 +536,21 @@ R3N_DEV void surface_shading(const float l[3], const float intensity[3], const P
 
 R3N_DEV float srgb_to_linear(float e) { return e > 0.04045f ? powf((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f; }
 
+R3N_DEV float srgb_oetf(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    if (x <= 0.0031308f) return x * 12.92f;
+    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+}
+// blit.wgsl fs_main_scene into an Rgba8UnormSrgb target: exact OETF of the Rgba16Float-rounded value
+R3N_DEV uchar4 tonemap_half4(ushort4 h) {
+    const float r = (float)__builtin_bit_cast(_Float16, h.x), g = (float)__builtin_bit_cast(_Float16, h.y);
+    const float b = (float)__builtin_bit_cast(_Float16, h.z), al = (float)__builtin_bit_cast(_Float16, h.w);
+    const float a = (!(al > 0.0f)) ? 0.0f : (al >= 1.0f ? 1.0f : al);
+    return make_uchar4((unsigned char)(srgb_oetf(r) * 255.0f + 0.5f), (unsigned char)(srgb_oetf(g) * 255.0f + 0.5f),
+                       (unsigned char)(srgb_oetf(b) * 255.0f + 0.5f), (unsigned char)(a * 255.0f + 0.5f));
+}
+
 R3N_DEV ushort4 pack_half4(const float v[4]) {
     ushort4 o;
     // float -> half conversion rounds to nearest even (v_cvt_f16_f32)
@@ -516,7 +607,9 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
     const unsigned long long key = a.vis[pix];
     const uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
     if (id == 0u) {
-        a.hdr_out[pix] = pack_half4(a.clear);
+        const ushort4 hc = pack_half4(a.clear);
+        a.hdr_out[pix] = hc;
+        a.ldr_out[pix] = tonemap_half4(hc);
         return;
     }
     const uint32_t slot = id - 1u;
@@ -679,17 +772,12 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
         for (int c = 0; c < 3; ++c) out[c] = fmaxf(a.fu->ambient[c] * px.albedo[c], color[c]);
         out[3] = fmaxf(a.fu->ambient[3] * px.albedo[3], px.albedo[3]);
     }
-    a.hdr_out[pix] = pack_half4(out);
+    const ushort4 ho = pack_half4(out);
+    a.hdr_out[pix] = ho;
+    a.ldr_out[pix] = tonemap_half4(ho);
 }
 
 // ------------------------------------------------------------------------------------------------ K7 tonemap
-R3N_DEV float srgb_oetf(float x) {
-    if (!(x > 0.0f)) return 0.0f;
-    if (x >= 1.0f) return 1.0f;
-    if (x <= 0.0031308f) return x * 12.92f;
-    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
-}
-
 // 2 pixels per thread: one 16-byte load, one 8-byte store.
 __global__ __launch_bounds__(256) void k_tonemap(const ushort4 *__restrict__ hdr, uchar4 *__restrict__ out,
                                                  float4 *__restrict__ out_f32, size_t first_pixel, size_t n_pixels) {

@@ -75,6 +75,7 @@ struct r3n_ctx {
     uint32_t width = 0, height = 0, samples = 1, atlas_w = 0, atlas_h = 0;
     float clear[4] = {0, 0, 0, 0};
     bool in_frame = false;
+    bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
@@ -552,6 +553,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     TRY(refresh_tri_base(c));
     c->in_frame = true;
     for (auto &f : c->forward_index_lane) f = 0;
+    c->resolved_this_frame = false;
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
@@ -695,15 +697,15 @@ int r3n_hi_z(r3n_ctx *c) {
     if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "hi_z: outside a frame");
     HIP_TRY(c, hipSetDevice(c->device));
     Timed t(c, R3N_STAGE_HIZ);
-    const size_t npix = (size_t)c->width * c->height;
-    const uint32_t blocks = (uint32_t)std::min<size_t>((npix + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_hiz_mip0, dim3(blocks), dim3(256), 0, c->stream, c->vis.as<unsigned long long>(), c->hiz.as<float>(), npix);
-    for (uint32_t k = 1; k < c->hizd.mips; ++k) {
-        const uint32_t sw = std::max(1u, c->width >> (k - 1)), sh = std::max(1u, c->height >> (k - 1));
-        const uint32_t dw = std::max(1u, c->width >> k), dh = std::max(1u, c->height >> k);
-        hipLaunchKernelGGL(k_hiz_downsample, dim3((dw + 15u) / 16u, (dh + 15u) / 16u), dim3(256), 0, c->stream,
-                           c->hiz.as<float>() + c->hizd.offset[k - 1], c->hiz.as<float>() + c->hizd.offset[k], sw, sh, dw, dh);
-    }
+    // head: mip0 + as many levels as have even source dimensions (<= 4), one launch; tail: one single-block launch
+    uint32_t levels = 0;
+    while (levels < 4u && levels + 1u < c->hizd.mips && ((c->width >> levels) % 2u == 0u) && ((c->height >> levels) % 2u == 0u) &&
+           (c->width >> levels) >= 2u && (c->height >> levels) >= 2u)
+        ++levels;
+    hipLaunchKernelGGL(k_hiz_head, dim3((c->width + 31u) / 32u, (c->height + 31u) / 32u), dim3(256), 0, c->stream,
+                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels);
+    if (levels + 1u < c->hizd.mips)
+        hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, c->stream, c->hiz.as<float>(), c->hizd, levels + 1u);
     return check_launch(c, "hi_z");
 }
 
@@ -818,6 +820,8 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     a.atlas_w = std::max(1u, c->atlas_w); a.atlas_h = std::max(1u, c->atlas_h);
     std::memcpy(a.clear, c->clear, 16);
     a.hdr_out = c->hdr16.as<ushort4>();
+    a.ldr_out = c->out8.as<uchar4>();
+    c->resolved_this_frame = true;
     Timed t(c, R3N_STAGE_SHADE);
     hipLaunchKernelGGL(k_resolve_opaque, dim3((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u), dim3(256), 0, c->stream, a);
     return check_launch(c, "k_resolve_opaque");
@@ -837,7 +841,9 @@ static int launch_tonemap(r3n_ctx *c, float4 *f32_out) {
 int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
     if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "tonemap: outside a frame");
     HIP_TRY(c, hipSetDevice(c->device));
-    TRY(launch_tonemap(c, nullptr));
+    // the blit is fused into r3n_resolve_opaque (same arithmetic on the Rgba16Float-rounded value); the separate
+    // kernel only runs when the HDR buffer was produced some other way
+    if (!c->resolved_this_frame) TRY(launch_tonemap(c, nullptr));
     if (host_rgba8) {
         if (pitch < (uint64_t)c->width * 4) return fail(c, R3N_ERR_INVALID_ARG, "tonemap: pitch too small");
         HIP_TRY(c, hipMemcpy2DAsync(host_rgba8, pitch, c->out8.p, (size_t)c->width * 4, (size_t)c->width * 4, c->height,

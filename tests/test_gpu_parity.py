@@ -367,3 +367,83 @@ def test_config4_million_objects_properties(r3):
     assert not (flo["visible"] & fhi["visible"]).any()
     assert np.array_equal(flo["pass"] | fhi["pass"], fa[0]["pass"])
     assert np.array_equal(np.maximum(flo["vis"], fhi["vis"]), fa[0]["vis"])
+
+
+def test_vertex_colour_and_cutout_alpha_paths(r3):
+    """Material paths of opaque.wgsl:213-235 / depth.wgsl:112-125 that the golden scenes do not reach: vertex-colour
+    albedo (linear and sRGB-decoded), cutout against an interpolated vertex alpha (forward and shadow passes).
+    The sRGB decode uses pow(), so the HDR buffer is compared to 2 f16 ulps instead of bit-exactly."""
+    o, p = both(r3, oh.LEFT, f32(1.5))
+    rng = scenes.Pcg32(11)
+    for r, mk in ((o, omk), (p, r3.material_record)):
+        rng = scenes.Pcg32(11)
+        pos, idx, nrm = scenes.grid_plane(8, 2.0)
+        cols = np.array([[rng.randint(256), rng.randint(256), rng.randint(256), rng.randint(256)] for _ in range(len(pos))], dtype=np.uint8)
+        mesh = r.add_mesh(pos, idx, normals=nrm, colors=cols)
+        m_lin = r.add_material(mk(albedo=(1, 1, 1, 1), albedo_mode="vertex", vertex_srgb=False, roughness=0.4), scenes.OPAQUE)
+        m_srgb = r.add_material(mk(albedo=(0.9, 0.8, 0.7, 1), albedo_mode="value_vertex", vertex_srgb=True, roughness=0.6), scenes.OPAQUE)
+        m_cut = r.add_material(mk(albedo=(0.2, 0.9, 0.3, 1.0), albedo_mode="value_vertex", vertex_srgb=False, roughness=0.5, cutout=0.5), scenes.CUTOUT)
+        m_cut_const = r.add_material(mk(albedo=(0.9, 0.2, 0.3, 0.3), albedo_mode="value", roughness=0.5, cutout=0.5), scenes.CUTOUT)
+        tilt = oh.rotation_x(-0.9)
+        r.add_object(mesh, m_lin, oh.mat4_mul(oh.translation((-2.2, 0.0, 5.0)), tilt))
+        r.add_object(mesh, m_srgb, oh.mat4_mul(oh.translation((2.2, 0.0, 5.0)), tilt))
+        r.add_object(mesh, m_cut, oh.mat4_mul(oh.translation((0.0, 1.5, 4.0)), tilt))       # holes where alpha < 0.5
+        r.add_object(mesh, m_cut_const, oh.mat4_mul(oh.translation((0.0, 3.0, 4.5)), tilt))  # alpha 0.3 < 0.5: fully discarded
+        floor = r.add_mesh(*scenes.grid_plane(2, 8.0)[:2], normals=scenes.grid_plane(2, 8.0)[2])
+        r.add_object(floor, scenes.lit(r, mk, (0.7, 0.7, 0.7, 1.0)), oh.translation((0.0, -1.5, 5.0)))
+        r.add_directional_light(color=(1, 1, 1), intensity=2.5, direction=(0.2, -1.0, 0.3), distance=20.0, resolution=512)
+        r.set_camera_data(oh.look_at_lh((0, 2.5, -3), (0, 0.5, 5), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    for f in range(2):
+        fo = o.render(240, 160, ambient=(0.05, 0.05, 0.05, 1), clear_color=(0.1, 0.1, 0.2, 1))
+        fp = p.render(240, 160, ambient=(0.05, 0.05, 0.05, 1), clear_color=(0.1, 0.1, 0.2, 1))
+        for k in ("visible", "pass", "residual", "vis"):
+            assert np.array_equal(fo[k], fp[k][: len(fo[k])] if fo[k].ndim == 1 else fp[k]), k
+        assert np.array_equal(fo["atlas"].view(np.uint32), fp["atlas"].view(np.uint32))  # cutout holes in the shadow map too
+        ho, hp = fo["hdr16"].astype(np.int32), fp["hdr16"].astype(np.int32)
+        assert np.abs(ho - hp).max() <= 2, np.abs(ho - hp).max()
+        assert np.abs(fo["rgba_f32"] - fp["rgba_f32"]).max() <= 1e-3
+    # the cutout object has holes: some of its bounding region shows what is behind it, and the constant-alpha one is gone
+    ids = (fo["vis"] & np.uint64(0xFFFFFFFF)).astype(np.int64) - 1
+    tri_obj = np.searchsorted(fo["tri_base"], ids[ids >= 0], side="right") - 1
+    assert (tri_obj == 2).any() and not (tri_obj == 3).any()
+
+
+def test_abi_error_behaviour(r3):
+    """Error convention of include/r3n.h: negative codes + message, never a crash; 'nothing to draw' is a silent success."""
+    from rend3_amd import _ffi
+    lib = _ffi.lib()
+    r = r3.Renderer(oh.LEFT)
+    ctx = r.ctx
+    fu = r3.host.frame_uniforms(r.camera, (0, 0, 0, 0), (64, 64))
+    clear = np.zeros(4, dtype=f32)
+    # outside a frame
+    assert lib.r3n_cull(ctx, _ffi.CAMERA_VIEWPORT) == -4 and b"baked" in lib.r3n_last_error(ctx)
+    assert lib.r3n_hi_z(ctx) == -4
+    assert lib.r3n_frame_end(ctx) == -4
+    # unsupported rows fail loudly
+    assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 64, 64, 4, _ffi.ptr(clear), 32, 32) == -5 and b"MSAA" in lib.r3n_last_error(ctx)
+    assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 0, 64, 1, _ffi.ptr(clear), 32, 32) == -1
+    assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 64, 64, 1, _ffi.ptr(clear), 32, 32) == 0
+    assert lib.r3n_forward(ctx, _ffi.CAMERA_VIEWPORT, _ffi.PASS_FORWARD, _ffi.SOURCE_RESIDUAL, _ffi.KEY_BLEND) == -5
+    assert lib.r3n_forward(ctx, _ffi.CAMERA_VIEWPORT, 7, 0, 0) == -1
+    # header / capacity mismatches
+    hdr = r3.host.camera_header(r.camera, None, (64, 64), 1, r.capacity + 1)
+    assert lib.r3n_uniform_bake(ctx, _ffi.CAMERA_VIEWPORT, _ffi.ptr(hdr)) == -1
+    hdr = r3.host.camera_header(r.camera, 3, (64, 64), 1, r.capacity)
+    assert lib.r3n_uniform_bake(ctx, _ffi.CAMERA_VIEWPORT, _ffi.ptr(hdr)) == -1
+    # empty world: every node is a silent no-op (culler.rs:449-451,705-707; forward.rs:214-242)
+    hdr = r3.host.camera_header(r.camera, None, (64, 64), 1, r.capacity)
+    assert lib.r3n_uniform_bake(ctx, _ffi.CAMERA_VIEWPORT, _ffi.ptr(hdr)) == 0
+    assert lib.r3n_forward(ctx, _ffi.CAMERA_VIEWPORT, _ffi.PASS_FORWARD, _ffi.SOURCE_PREDICTED, _ffi.KEY_OPAQUE) == 0
+    assert lib.r3n_hi_z(ctx) == 0 and lib.r3n_cull(ctx, _ffi.CAMERA_VIEWPORT) == 0
+    assert lib.r3n_resolve_opaque(ctx) == 0 and lib.r3n_tonemap(ctx, None, 0) == 0 and lib.r3n_frame_end(ctx) == 0
+    # too many lights for the LDS light list
+    big = np.zeros(16 + 128 * 17, dtype=np.uint8)
+    big[:4] = np.array([17], dtype=np.uint32).view(np.uint8)
+    assert lib.r3n_lights_write(ctx, _ffi.ptr(big), big.nbytes, None, 0) == -5
+    # object slot beyond capacity, shrinking capacity
+    rec = np.zeros((1, 32), dtype=np.uint32)
+    slot = np.array([r.capacity], dtype=np.uint32)
+    assert lib.r3n_objects_write(ctx, _ffi.ptr(slot), _ffi.ptr(rec), 1, r.capacity) == -1
+    assert lib.r3n_objects_write(ctx, None, None, 0, 1) == -1
+    r.close()
