@@ -201,6 +201,21 @@ def test_golden_cube_example(r3):
     assert diff.mean() <= 1.0 and (diff <= 3).mean() >= 0.995
 
 
+def test_golden_static_gltf_example(r3):
+    """examples/src/static_gltf/mod.rs at 1280x720: real asset through the GLB reader (row N1), HIP == oracle, and the
+    HIP image against the reference's screenshot."""
+    w, h = 1280, 720
+    o, p = both(r3, oh.LEFT, f32(w) / f32(h))
+    G.build_static_gltf(o, oh, omk)
+    G.build_static_gltf(p, r3.host, r3.material_record)
+    for f in range(2):
+        fo = o.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+        fp = p.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+        compare_frames(fo, fp, f"static_gltf frame {f}")
+    _gold, diff = G.golden_stats(fp["rgba8"], "static_gltf-screenshot.png")
+    assert diff.mean() <= 0.1 and (diff <= 1).mean() >= 0.998
+
+
 # ------------------------------------------------------------------ synthetic scenes: multi-frame temporal parity
 @pytest.mark.parametrize("handedness", [oh.LEFT, oh.RIGHT])
 def test_random_scene_multi_frame(r3, handedness):
