@@ -91,6 +91,7 @@ class OracleRenderer:
         self.object_meta = {}  # handle -> dict(mesh, mesh sphere)
         self.free_handles = []
         self.pending_free = []
+        self.skip_shadow_draw = False
         self.deferred_removals = []
         self.next_handle = 0
         self.dir_lights = []
@@ -336,6 +337,8 @@ class OracleRenderer:
             lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
             visible, tri_base, pass_bits, _ = self._cull(("shadow", si), hdr, baked, None, 0, 0)
             lo, lt = self._list_from_bits(pass_bits, tri_base)
+            if self.skip_shadow_draw:  # test probe only: leaves the atlas at its 0.0 clear, so every compare passes
+                lo, lt = lo[:0], lt[:0]
             lib.r3o_raster_depth(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words), lib.ptr(baked),
                                  lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(lo), lib.ptr(lt), len(lo),
                                  lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"])

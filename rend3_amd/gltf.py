@@ -94,3 +94,99 @@ class Gltf:
             return (1.0, 1.0, 1.0, 1.0)
         pbr = self.json["materials"][material].get("pbrMetallicRoughness", {})
         return tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0]))
+
+
+# ---------------------------------------------------------------------------------------------------- scene instancing
+def _node_local_matrix(node, hm):
+    """gltf::scene::Transform::matrix(): the node's `matrix`, or T * R * S from translation / rotation (xyzw) / scale."""
+    if "matrix" in node:
+        return np.asarray(node["matrix"], dtype=np.float32)
+    t = node.get("translation", [0.0, 0.0, 0.0])
+    q = np.asarray(node.get("rotation", [0.0, 0.0, 0.0, 1.0]), dtype=np.float32)
+    s = node.get("scale", [1.0, 1.0, 1.0])
+    x, y, z, w = (np.float32(v) for v in q)
+    one, two = np.float32(1.0), np.float32(2.0)
+    r = np.zeros(16, dtype=np.float32)
+    r[0], r[1], r[2] = one - two * (y * y + z * z), two * (x * y + z * w), two * (x * z - y * w)
+    r[4], r[5], r[6] = two * (x * y - z * w), one - two * (x * x + z * z), two * (y * z + x * w)
+    r[8], r[9], r[10] = two * (x * z + y * w), two * (y * z - x * w), one - two * (x * x + y * y)
+    r[15] = 1.0
+    return hm.mat4_mul(hm.mat4_mul(hm.translation(t), r), hm.scale(s))
+
+
+def material_from_gltf(g, index, mk):
+    """load_materials_and_textures (rend3-gltf/src/lib.rs:806-943) for materials WITHOUT textures: albedo =
+    ValueVertex{base_color_factor, srgb: false}, metallic / roughness factors (glTF defaults 1.0), emissive factor,
+    alpha mode -> transparency.  load_default_material (:777-800) when the primitive has no material.
+    Returns (record, material key)."""
+    if index is None:
+        return mk(albedo=(1.0, 1.0, 1.0, 1.0), albedo_mode="value", roughness=1.0, metallic=1.0, ao=1.0, clear_coat=1.0,
+                  clear_coat_roughness=1.0), 0
+    m = g.json["materials"][index]
+    pbr = m.get("pbrMetallicRoughness", {})
+    for key in ("baseColorTexture", "metallicRoughnessTexture"):
+        if key in pbr:
+            raise NotImplementedError("textured glTF materials are row N2 (not built)")
+    mode = m.get("alphaMode", "OPAQUE")
+    key = {"OPAQUE": 0, "MASK": 1, "BLEND": 2}[mode]
+    rec = mk(albedo=tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])), albedo_mode="value_vertex", vertex_srgb=False,
+             roughness=pbr.get("roughnessFactor", 1.0), metallic=pbr.get("metallicFactor", 1.0),
+             emissive=tuple(m.get("emissiveFactor", [0.0, 0.0, 0.0])),
+             cutout=(m.get("alphaCutoff", 0.5) if mode == "MASK" else None),
+             unlit="KHR_materials_unlit" in m.get("extensions", {}))
+    return rec, key
+
+
+def instance_scene(g, r, hm, mk, scale=1.0):
+    """load_gltf + instance_loaded_scene (rend3-gltf/src/lib.rs:335-379, 493-562): node transforms in topological order
+    under parent_transform = scale(s, s, -s for a left-handed renderer); one object per mesh primitive; a skeleton per
+    primitive of a skinned node (joint matrices start as identity, add_mesh_by_index :411-457); winding flipped for
+    left-handed renderers (load_meshes :628-634).  Returns dict(objects=[handles], skeletons=[handles],
+    inverse_bind_matrices=[per skin], node_transforms)."""
+    nodes = g.json.get("nodes", [])
+    lh = r.handedness == 0
+    parent_of = {}
+    for i, n in enumerate(nodes):
+        for ch in n.get("children", []):
+            parent_of[ch] = i
+    order, queue = [], [i for i in range(len(nodes)) if i not in parent_of]
+    while queue:
+        n = queue.pop(0)
+        order.append(n)
+        queue.extend(nodes[n].get("children", []))
+    s = np.float32(scale)
+    root = hm.scale((s, s, -s if lh else s))
+    meshes = {}
+    materials = {}
+    xf = [None] * len(nodes)
+    out = dict(objects=[], skeletons=[], inverse_bind_matrices=[], node_transforms=xf)
+    for sk in g.json.get("skins", []):
+        nj = len(sk["joints"])
+        ibm = g.accessor(sk["inverseBindMatrices"]).astype(np.float32) if "inverseBindMatrices" in sk else np.tile(hm.identity(), (nj, 1))
+        out["inverse_bind_matrices"].append(ibm)
+    for ni in order:
+        node = nodes[ni]
+        parent = xf[parent_of[ni]] if ni in parent_of else root
+        xf[ni] = hm.mat4_mul(parent, _node_local_matrix(node, hm))
+        if "mesh" not in node:
+            continue
+        mi = node["mesh"]
+        for pi in range(len(g.json["meshes"][mi]["primitives"])):
+            if (mi, pi) not in meshes:
+                p = g.primitive(mi, pi)
+                idx = p["indices"].reshape(-1, 3)[:, ::-1].reshape(-1) if lh else p["indices"]
+                meshes[(mi, pi)] = (r.add_mesh(p["positions"], idx, normals=p.get("normals"), tangents=p.get("tangents"),
+                                               joint_indices=p.get("joints"), joint_weights=p.get("weights"),
+                                               mesh_handedness=r.handedness), p["material"])
+            mesh, mat_index = meshes[(mi, pi)]
+            if mat_index not in materials:
+                rec, key = material_from_gltf(g, mat_index, mk)
+                materials[mat_index] = r.add_material(rec, key)
+            if "skin" in node:
+                nj = len(out["inverse_bind_matrices"][node["skin"]])
+                sk = r.add_skeleton(mesh, np.tile(hm.identity(), (nj, 1)))
+                out["skeletons"].append(sk)
+                out["objects"].append(r.add_object(None, materials[mat_index], xf[ni], skeleton=sk))
+            else:
+                out["objects"].append(r.add_object(mesh, materials[mat_index], xf[ni]))
+    return out

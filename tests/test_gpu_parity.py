@@ -216,6 +216,24 @@ def test_golden_static_gltf_example(r3):
     assert diff.mean() <= 0.1 and (diff <= 1).mean() >= 0.998
 
 
+def test_golden_skinning_example(r3):
+    """examples/src/skinning/mod.rs at 1280x720, three animation times: GLB skin -> k_skinning -> every pass; HIP ==
+    oracle bit for bit, and the t = 0 HIP image against the reference's screenshot (bounds: test_oracle_goldens)."""
+    w, h = 1280, 720
+    o, p = both(r3, oh.LEFT, f32(w) / f32(h))
+    io = G.build_skinning_example(o, oh, omk)
+    ip = G.build_skinning_example(p, r3.host, r3.material_record)
+    for f, t in enumerate((0.0, 0.11, 0.31)):
+        G.set_skinning_pose(o, oh, io, t)
+        G.set_skinning_pose(p, r3.host, ip, t)
+        fo = o.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+        fp = p.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+        compare_frames(fo, fp, f"skinning example t={t}")
+        if f == 0:
+            _gold, diff = G.golden_stats(fp["rgba8"], "skinning-screenshot.png")
+            assert diff.mean() <= 0.6 and (diff <= 1).mean() >= 0.97
+
+
 # ------------------------------------------------------------------ synthetic scenes: multi-frame temporal parity
 @pytest.mark.parametrize("handedness", [oh.LEFT, oh.RIGHT])
 def test_random_scene_multi_frame(r3, handedness):
