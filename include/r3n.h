@@ -198,6 +198,10 @@ int r3n_resolve_opaque(r3n_ctx *ctx);
 /* TonemappingRoutine::add_to_graph (tonemapping.rs:108-147) + blit.wgsl into an Rgba8UnormSrgb target.
  * If `host_rgba8` is non-NULL the image is also copied out (synchronises), `pitch_bytes` per row. */
 int r3n_tonemap(r3n_ctx *ctx, void *host_rgba8, uint64_t pitch_bytes);
+/* The routine's `src` is any Rgba16Float target (tonemapping.rs:108-116: `src: RenderTargetHandle`), not only the
+ * one r3n_resolve_opaque fills: this writes `n_pixels` RGBA half texels starting at `first_pixel` into the frame's HDR
+ * target.  A following r3n_tonemap then runs the stand-alone blit kernel over the whole target. */
+int r3n_hdr_write(r3n_ctx *ctx, const uint16_t *rgba16f, uint64_t first_pixel, uint64_t n_pixels);
 /* Marks the end of the frame: swaps the temporal state (InputOutputBuffer::swap, culling/suballoc.rs:164-214). */
 int r3n_frame_end(r3n_ctx *ctx);
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "r3n_forward": (cint, [vp, u32, u32, u32, u32]),
     "r3n_resolve_opaque": (cint, [vp]),
     "r3n_tonemap": (cint, [vp, vp, u64]),
+    "r3n_hdr_write": (cint, [vp, vp, u64, u64]),
     "r3n_frame_end": (cint, [vp]),
     "r3n_set_object_range": (cint, [vp, u32, u32]),
     "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
@@ -93,7 +94,8 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        path = _build.build()
+        # R3N_LIB: developer knob -- load another build of the same library (kernel experiments, tools/variants.py)
+        path = os.environ.get("R3N_LIB") or _build.build()
         if not os.path.exists(path):
             raise RuntimeError("librend3_amd.so is missing and could not be built; the HIP path has no fallback")
         l = ctypes.CDLL(path)

@@ -87,13 +87,20 @@ struct r3n_tri_ref {
     uint32_t triangle;
 };
 
-// Raster work item for triangles larger than 8x8 px: one wavefront scans a <=64x64 px region.
+// Raster work item for triangles larger than 8x8 px: one wavefront scans a <=64x64 px region.  The item carries
+// the finished triangle setup (the producer computed it to classify the triangle), so the consumer has no
+// dependent gather chain in front of its scan: one 80-byte record, broadcast through SGPRs.
 struct r3n_big_item {
-    uint32_t object;
-    uint32_t triangle;
-    uint32_t xy0;  // x0 | y0 << 16
-    uint32_t xy1;  // x1 | y1 << 16 (inclusive)
+    float e[3][3];      // oriented edge functions
+    float z[3];         // clip-space z per vertex
+    float det;
+    float va[3];        // vertex alpha (cutout key only)
+    uint32_t slot1;     // canonical slot + 1 (forward only)
+    uint32_t material;  // material index (cutout key only)
+    uint32_t xy0;       // x0 | y0 << 16
+    uint32_t xy1;       // x1 | y1 << 16 (inclusive)
 };
+static_assert(sizeof(r3n_big_item) == 80, "big item is 20 dwords");
 
 // Output lists and work queues are split into sub-queues so that appends do not serialise on one counter: a
 // returning atomic on a single address retires at only ~88 per microsecond on MI355X (MI355X_MICROARCH.md,
@@ -102,8 +109,8 @@ struct r3n_big_item {
 #define R3N_SUBQ 32   // sub-lists per (list, material key) of the cull output
 #endif
 #ifndef R3N_BIGQ
-#define R3N_BIGQ 1    // sub-queues of the rasteriser's large-triangle work queue (1: splitting it costs more in
-                      // consumer load imbalance than the single counter costs in atomics -- measured)
+#define R3N_BIGQ 32   // sub-queues of the rasteriser's large-triangle work queue; the consumers index their
+                      // concatenation, so the split only spreads the producers' counter traffic
 #endif
 struct r3n_sub_counts {
     uint32_t n[2][3][R3N_SUBQ];  // [predicted|residual][material key][sub-list] = triangles appended

@@ -78,9 +78,10 @@ struct r3n_ctx {
     bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
+    DevBuf srgb_lut;  // Rgba8UnormSrgb code of every half in [0, 1): kernels_raster.h k_build_srgb_lut
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
     uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {0, 0, 0, 0, 0};
-    uint32_t big_capacity = (4u << 20) / R3N_BIGQ;  // entries per work sub-queue (R3N_BIGQ of them)
+    uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (80 B) per work sub-queue (R3N_BIGQ of them)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
@@ -380,11 +381,17 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
             return nullptr;
         }
     // empty light buffers: count = 0
-    bool ok = ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
+    bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
               ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
     for (int lane = 0; ok && lane < 1 + R3N_AUX_STREAMS; ++lane)
         ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
              ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK;
+    if (ok) {
+        hipLaunchKernelGGL(k_build_srgb_lut, dim3((R3N_SRGB_LUT_SIZE + 255u) / 256u), dim3(256), 0, c->stream,
+                           c->srgb_lut.as<unsigned char>());
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        if (!ok) c->err = "k_build_srgb_lut failed";
+    }
     if (!ok) {
         g_create_error = c->err;
         r3n_destroy(c);
@@ -404,7 +411,7 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz};
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -774,6 +781,9 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     const uint32_t fwd = std::min(c->forward_index_lane[lane]++, 63u);
     a.big_count = c->big_count[lane].as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
     a.big_capacity = c->big_capacity;
+#ifndef R3N_BIG_GRID
+#define R3N_BIG_GRID 2048  // 8 waves per SIMD: the scan kernel needs 27 VGPRs
+#endif
     const uint32_t small_grid = 2048;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
     TRY(fork_lane(c, lane));
     HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
@@ -781,14 +791,14 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
         { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, stream, a); }
-        { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false, false>), dim3(1024), dim3(256), 0, stream, a); }
+        { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
     } else {
         if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
             return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
         a.depth = c->atlas.as<uint32_t>();
         { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, stream, a); }
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, true>), dim3(1024), dim3(256), 0, stream, a); }
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
     }
     return check_launch(c, "raster");
 }
@@ -821,6 +831,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     std::memcpy(a.clear, c->clear, 16);
     a.hdr_out = c->hdr16.as<ushort4>();
     a.ldr_out = c->out8.as<uchar4>();
+    a.srgb_lut = c->srgb_lut.as<unsigned char>();
     c->resolved_this_frame = true;
     Timed t(c, R3N_STAGE_SHADE);
     hipLaunchKernelGGL(k_resolve_opaque, dim3((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u), dim3(256), 0, c->stream, a);
@@ -834,8 +845,21 @@ static int launch_tonemap(r3n_ctx *c, float4 *f32_out) {
     Timed t(c, R3N_STAGE_TONEMAP);
     const size_t pairs = (n + 1) / 2;
     hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, c->stream, c->hdr16.as<ushort4>(),
-                       c->out8.as<uchar4>(), f32_out, first, n);
+                       c->out8.as<uchar4>(), f32_out, first, n, c->srgb_lut.as<unsigned char>());
     return check_launch(c, "k_tonemap");
+}
+
+int r3n_hdr_write(r3n_ctx *c, const uint16_t *rgba16f, uint64_t first_pixel, uint64_t n_pixels) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "hdr_write: outside a frame");
+    const uint64_t total = (uint64_t)c->width * c->height;
+    if (!rgba16f || first_pixel > total || n_pixels > total - first_pixel) return fail(c, R3N_ERR_INVALID_ARG, "hdr_write: range outside the target");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_pixels) {
+        HIP_TRY(c, hipMemcpyAsync(c->hdr16.as<uint16_t>() + first_pixel * 4u, rgba16f, n_pixels * 8u, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the source only for the duration of the call
+    }
+    c->resolved_this_frame = false;  // the fused blit no longer matches the HDR target
+    return R3N_OK;
 }
 
 int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {

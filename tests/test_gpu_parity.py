@@ -480,3 +480,33 @@ def test_abi_error_behaviour(r3):
     assert lib.r3n_objects_write(ctx, _ffi.ptr(slot), _ffi.ptr(rec), 1, r.capacity) == -1
     assert lib.r3n_objects_write(ctx, None, None, 0, 1) == -1
     r.close()
+
+
+def test_tonemap_every_half_value(r3):
+    """blit.wgsl + the Rgba8UnormSrgb store over EVERY Rgba16Float bit pattern (all 65536 halves in every channel,
+    NaN / inf / negative / denormal included): the device's sRGB table and the stand-alone blit kernel against the
+    oracle's direct evaluation, byte for byte; the float view within 1 ulp-scale tolerance of the same formula."""
+    from rend3_amd import _ffi
+    from oracle import lib as olib
+    lib = _ffi.lib()
+    r = r3.Renderer(oh.LEFT)
+    w = h = 256
+    fu = r3.host.frame_uniforms(r.camera, (0, 0, 0, 0), (w, h))
+    clear = np.zeros(4, dtype=f32)
+    assert lib.r3n_frame_begin(r.ctx, _ffi.ptr(fu), w, h, 1, _ffi.ptr(clear), 32, 32) == 0
+    halves = np.arange(65536, dtype=np.uint16)
+    hdr = np.stack([halves, halves[::-1], np.roll(halves, 12345), halves], axis=1).copy()
+    assert lib.r3n_hdr_write(r.ctx, _ffi.ptr(hdr), 0, w * h) == 0
+    assert lib.r3n_hdr_write(r.ctx, _ffi.ptr(hdr), 1, w * h) == -1  # range check
+    assert lib.r3n_tonemap(r.ctx, None, 0) == 0
+    got8 = np.zeros((w * h, 4), dtype=np.uint8)
+    gotf = np.zeros((w * h, 4), dtype=f32)
+    assert lib.r3n_readback_output(r.ctx, _ffi.ptr(got8), _ffi.ptr(gotf)) == 0
+    assert lib.r3n_frame_end(r.ctx) == 0
+    o = olib.get()
+    exp8 = np.zeros((w * h, 4), dtype=np.uint8)
+    expf = np.zeros((w * h, 4), dtype=f32)
+    o.r3o_tonemap(o.ptr(hdr), w * h, o.ptr(expf), o.ptr(exp8))
+    bad = np.nonzero((got8 != exp8).any(axis=1))[0]
+    assert len(bad) == 0, (len(bad), hdr[bad[:5]], got8[bad[:5]], exp8[bad[:5]])
+    assert np.allclose(gotf, expf, rtol=0, atol=2e-7)
