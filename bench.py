@@ -176,16 +176,17 @@ def main():
                          "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(tri_cull_ms_per_launch, 5),
                          "triangles_per_launch": vis_tris // len(cams)}
         # dominant kernel by GPU time: the deferred PBR resolve (one launch per frame).  Its HBM floor is 8 B key read +
-        # 8 B Rgba16Float write per pixel (">= 16 B / shaded pixel"); it is VALU/gather-latency bound,
-        # not HBM-bound, so the fraction of the HBM roofline is small by construction.
+        # 8 B Rgba16Float write per pixel (">= 16 B / shaded pixel") + 4 B for the Rgba8UnormSrgb
+        # blit fused into it.  The kernel is VALU-bound, not HBM-bound (SQ_ACTIVE_INST_VALU = the whole SIMD issue
+        # capacity of the launch, profiles/r01_summary.md), so the fraction of the HBM roofline is small by construction.
         shade_ms = stage_ms["shade"] / max(launches["shade"], 1)
-        shade_bytes = 16.0 * WIDTH * HEIGHT / world
+        shade_bytes = 20.0 * WIDTH * HEIGHT / world
         ach = shade_bytes / (shade_ms * 1e-3) / 1e9
         roof = {"kernel": "k_resolve_opaque", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get("k_resolve_opaque") if world == 1 else None,
                 "bytes_per_launch": int(shade_bytes),
                 "ms_per_launch": round(shade_ms, 5),
-                "note": "dominant kernel by time; VALU + gather-latency bound (4 lights x 5-tap PCF + GGX per pixel), see DESIGN.md"}
+                "note": "dominant kernel by time; VALU-bound (about 1500 vector instructions per pixel: vertex stage, 4 lights x (5-tap PCF + GGX), all IEEE div/sqrt), see DESIGN.md"}
         result = {
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -420,13 +420,23 @@ __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__re
 }
 
 // Tail of the pyramid (levels first .. mips-1, at most a few thousand texels each): one block walks the levels,
-// generic odd-dimension windows, a barrier between levels.
+// generic odd-dimension windows, a barrier between levels.  Every level is written to the pyramid in memory; a level
+// that fits is ALSO kept in LDS and the next level reads it from there, so the chain of ~10 dependent levels costs
+// LDS latencies instead of ~10 global-memory round trips (this kernel sits on the frame's critical path:
+// pass-1 raster -> Hi-Z -> cull -> pass-2 raster -> resolve).
+#define R3N_HIZ_LDS_A 8192u
+#define R3N_HIZ_LDS_B 2304u
 __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {
+    __shared__ float lds_a[R3N_HIZ_LDS_A];
+    __shared__ float lds_b[R3N_HIZ_LDS_B];
+    const float *src_lds = nullptr;  // previous level, when it was kept in LDS
+    bool to_a = true;
     for (uint32_t l = first; l < d.mips; ++l) {
         const uint32_t sw = mip_dim(d.width, l - 1u), sh = mip_dim(d.height, l - 1u);
         const uint32_t dw = mip_dim(d.width, l), dh = mip_dim(d.height, l);
         const float *src = pyr + d.offset[l - 1u];
         float *dst = pyr + d.offset[l];
+        float *dst_lds = dw * dh <= (to_a ? R3N_HIZ_LDS_A : R3N_HIZ_LDS_B) ? (to_a ? lds_a : lds_b) : nullptr;
         const uint32_t nx = 2u + (sw & 1u), ny = 2u + (sh & 1u);
         for (uint32_t i = threadIdx.x; i < dw * dh; i += 1024u) {
             const uint32_t x = i % dw, y = i / dw;
@@ -434,12 +444,16 @@ __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_
             for (uint32_t ix = 0; ix < nx; ++ix)
                 for (uint32_t iy = 0; iy < ny; ++iy) {
                     const uint32_t sx = 2u * x + ix, sy = 2u * y + iy;
-                    const float v = (sx < sw && sy < sh) ? src[(size_t)sy * sw + sx] : 0.0f;
+                    float v = 0.0f;
+                    if (sx < sw && sy < sh) v = src_lds ? src_lds[sy * sw + sx] : src[(size_t)sy * sw + sx];
                     nearest = fminf(nearest, v);
                 }
             dst[i] = nearest;
+            if (dst_lds) dst_lds[i] = nearest;
         }
         __syncthreads();  // the next level reads what this one wrote (same workgroup, same CU)
+        src_lds = dst_lds;
+        to_a = !to_a;
     }
 }
 
