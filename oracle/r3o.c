@@ -539,10 +539,21 @@ static float fetch_color_alpha(const r3o_object *ob, const uint32_t *mesh, uint3
  * forward.rs:347-351).  material_keys[material] : 0 opaque, 1 cutout, 2 blend (pbr/material.rs:497-499);
  * blend objects are skipped here (drawn by the transparent pass, base.rs:451-465).
  */
+/*
+ * Multisampling (row N4; forward.rs:358 MultisampleState{count}, base.rs:236-258): `samples` = 1 or 4.  The
+ * buffer holds `samples` keys per pixel (pixel-major).  Coverage and depth are evaluated at the standard sample
+ * positions (the D3D / Vulkan "standard sample locations" every wgpu backend uses for 4x); the fragment --
+ * here only its cutout alpha -- is evaluated once per pixel at the pixel centre, whether or not the centre is
+ * covered (no centroid / per-sample qualifier in opaque.wgsl).
+ */
+static const float SAMPLE_POS_1[1][2] = {{0.5f, 0.5f}};
+static const float SAMPLE_POS_4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}};
+
 void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
                            const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
                            const uint32_t *tri_base, const uint32_t *list_obj, const uint32_t *list_tri,
-                           uint64_t n, uint32_t w, uint32_t h, uint64_t *vis) {
+                           uint64_t n, uint32_t w, uint32_t h, uint32_t samples, uint64_t *vis) {
+    const float(*spos)[2] = samples == 4u ? SAMPLE_POS_4 : SAMPLE_POS_1;
     float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
     int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -567,19 +578,31 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
         uint32_t slot = tri_base[o] + t;
         for (int y = y0; y <= y1; ++y)
             for (int x = x0; x <= x1; ++x) {
-                float E[3];
-                if (!edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E)) continue;
-                float z = frag_depth(&ts, E);
-                if (!(z >= 0.0f && z <= 1.0f)) continue;
+                uint32_t mask = 0;
+                float zs[4];
+                for (uint32_t sm = 0; sm < samples; ++sm) {
+                    float E[3];
+                    if (!edge_eval(&ts, (float)x + spos[sm][0], (float)y + spos[sm][1], E)) continue;
+                    float z = frag_depth(&ts, E);
+                    if (!(z >= 0.0f && z <= 1.0f)) continue;
+                    zs[sm] = z;
+                    mask |= 1u << sm;
+                }
+                if (!mask) continue;
                 if (need_alpha) {
+                    float E[3];
+                    (void)edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E);
                     float rs = 1.0f / ((E[0] + E[1]) + E[2]);
                     float a = ((E[0] * rs) * va[0] + (E[1] * rs) * va[1]) + (E[2] * rs) * va[2];
                     if (material_alpha(mat, a) < mat->alpha_cutout) continue;
                 }
-                uint32_t zb; memcpy(&zb, &z, 4);
-                uint64_t k64 = ((uint64_t)zb << 32) | (uint64_t)(slot + 1u);
-                uint64_t *dst = &vis[(uint64_t)y * w + (uint64_t)x];
-                if (k64 > *dst) *dst = k64;
+                for (uint32_t sm = 0; sm < samples; ++sm) {
+                    if (!(mask & (1u << sm))) continue;
+                    uint32_t zb; memcpy(&zb, &zs[sm], 4);
+                    uint64_t k64 = ((uint64_t)zb << 32) | (uint64_t)(slot + 1u);
+                    uint64_t *dst = &vis[((uint64_t)y * w + (uint64_t)x) * samples + sm];
+                    if (k64 > *dst) *dst = k64;
+                }
             }
     }
 }
@@ -630,11 +653,22 @@ void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, c
     }
 }
 
-/* depth plane of a visibility buffer (high 32 bits), background = 0.0 */
-void r3o_vis_to_depth(const uint64_t *vis, uint64_t n, float *depth) {
+/* depth plane of a visibility buffer (high 32 bits), background = 0.0.  With multisampling the single-sample
+ * depth the Hi-Z pyramid starts from is resolve_depth_min.wgsl:19-27: nearest = 1.0, min over the samples. */
+void r3o_vis_to_depth(const uint64_t *vis, uint64_t n, uint32_t samples, float *depth) {
     for (uint64_t i = 0; i < n; ++i) {
-        uint32_t zb = (uint32_t)(vis[i] >> 32);
-        memcpy(&depth[i], &zb, 4);
+        if (samples == 1u) {
+            uint32_t zb = (uint32_t)(vis[i] >> 32);
+            memcpy(&depth[i], &zb, 4);
+        } else {
+            float nearest = 1.0f;
+            for (uint32_t sm = 0; sm < samples; ++sm) {
+                uint32_t zb = (uint32_t)(vis[i * samples + sm] >> 32);
+                float z; memcpy(&z, &zb, 4);
+                nearest = fminf(nearest, z);
+            }
+            depth[i] = nearest;
+        }
     }
 }
 
@@ -723,15 +757,172 @@ static float srgb_to_linear(float e) {
  * with r3o_mat4_mul; point_view_pos[i] = (uniforms.view * light.position).xyz (opaque.wgsl:528).
  * Output: Rgba16Float bits (base.rs:236-244).
  */
-void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, const r3o_frame_uniforms *fu,
+typedef struct {
+    uint32_t w, h;
+    const r3o_frame_uniforms *fu;
+    const r3o_camera_header *hdr;
+    const r3o_object *objects;
+    const uint32_t *mesh;
+    const r3o_baked *baked;
+    const r3o_material *materials;
+    const uint32_t *tri_base;
+    uint32_t n_dir;
+    const r3o_dir_light *dir;
+    uint32_t n_point;
+    const r3o_point_light *point;
+    const float *atlas;
+    uint32_t atlas_w, atlas_h;
+    const float *light_mats, *light_l, *pview;
+} shade_ctx;
+
+/* opaque.wgsl VS (:91-135) + FS (:203-551) for triangle slot `id - 1` at the centre of pixel (x, y) */
+static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_t y, float out[4]) {
+    const uint32_t w = sc->w, h = sc->h;
+    const r3o_frame_uniforms *fu = sc->fu;
+    const r3o_camera_header *hdr = sc->hdr;
+    const r3o_object *objects = sc->objects;
+    const uint32_t *mesh = sc->mesh;
+    const r3o_baked *baked = sc->baked;
+    const r3o_material *materials = sc->materials;
+    const uint32_t *tri_base = sc->tri_base;
+    const uint32_t n_dir = sc->n_dir, n_point = sc->n_point;
+    const r3o_dir_light *dir = sc->dir;
+    const r3o_point_light *point = sc->point;
+    const float *atlas = sc->atlas;
+    const uint32_t atlas_w = sc->atlas_w, atlas_h = sc->atlas_h;
+    const float *light_mats = sc->light_mats, *light_l = sc->light_l, *pview = sc->pview;
+    float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
+    int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+    uint32_t nobj = hdr->object_count;
+    uint32_t slot = id - 1u;
+    /* object = last slot o with tri_base[o] <= slot and a non-empty range */
+    uint32_t lo = 0, hi = nobj;
+    while (hi - lo > 1u) {
+        uint32_t mid = lo + (hi - lo) / 2u;
+        if (tri_base[mid] <= slot) lo = mid; else hi = mid;
+    }
+    uint32_t o = lo, t = slot - tri_base[o];
+    const r3o_object *ob = &objects[o];
+    const r3o_material *mat = &materials[ob->material_index];
+    uint32_t idx[3];
+    float v[3][3];
+    fetch_triangle(ob, mesh, t, idx, v);
+    tri_setup ts;
+    setup_triangle(baked[o].model_view_proj, v, half_w, half_h, positive_visible, &ts);
+    float E[3];
+    (void)edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E);
+    float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+    float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
+
+    /* vertex stage, opaque.wgsl:114-134 */
+    const float *mv = baked[o].model_view;
+    float inv_s2[3] = {1.0f / dot3(mv + 0, mv + 0), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
+    float vpos[4] = {0, 0, 0, 0}, nrm[3] = {0, 0, 0}, col[4] = {0, 0, 0, 0};
+    float vp[3][4], vn[3][3], vc[3][4];
+    for (int k = 0; k < 3; ++k) {
+        mat4_mul_vec4(mv, v[k][0], v[k][1], v[k][2], 1.0f, vp[k]);
+        float nm[3] = {0, 0, 0};
+        if (ob->attr_off[1] != R3O_INVALID) fetch_vec3(mesh, ob->attr_off[1], idx[k], nm);
+        float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
+        mat3_mul_vec3(mv + 0, mv + 4, mv + 8, sn, vn[k]);
+        normalize3(vn[k]);
+        if (ob->attr_off[5] != R3O_INVALID) {
+            uint32_t cw = mesh[ob->attr_off[5] / 4u + idx[k]];
+            for (int c = 0; c < 4; ++c) vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
+        } else
+            for (int c = 0; c < 4; ++c) vc[k][c] = 1.0f;
+    }
+    for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
+    for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
+    for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
+
+    /* fragment stage, opaque.wgsl:203-424 (untextured paths) */
+    pixel_data px;
+    if (mat->flags & FLAGS_ALBEDO_ACTIVE) {
+        for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
+        if (mat->flags & FLAGS_ALBEDO_BLEND) {
+            if (mat->flags & FLAGS_ALBEDO_VERTEX_SRGB) {
+                for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
+                px.albedo[3] *= col[3];
+            } else
+                for (int c = 0; c < 4; ++c) px.albedo[c] *= col[c];
+        }
+    } else {
+        px.albedo[0] = px.albedo[1] = px.albedo[2] = 0.0f;
+        px.albedo[3] = 1.0f;
+    }
+    for (int c = 0; c < 4; ++c) px.albedo[c] *= mat->albedo[c];
+
+    if (mat->flags & FLAGS_UNLIT) {
+        for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
+    } else {
+        for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
+        normalize3(px.normal);
+        float ao = mat->ambient_occlusion, pr = mat->roughness, metallic = mat->metallic;
+        float cc = mat->clear_coat, ccpr = mat->clear_coat_roughness;
+        for (int c = 0; c < 3; ++c) px.emissive[c] = mat->emissive[c];
+        for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
+        float refl = (0.16f * mat->reflectance) * mat->reflectance;
+        for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
+        if (cc != 0.0f) {
+            float base_pr = fmaxf(pr, ccpr);
+            pr = pr * (1.0f - cc) + base_pr * cc;
+        }
+        px.roughness = pr * pr;
+        px.ao = ao;
+
+        float vv[3] = {vpos[0], vpos[1], vpos[2]};
+        normalize3(vv);
+        for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
+        float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
+        for (uint32_t i = 0; i < n_dir; ++i) {
+            float sn[4];
+            mat4_mul_vec4(light_mats + 16 * i, vpos[0], vpos[1], vpos[2], vpos[3], sn);
+            float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
+            float local[2] = {fl[0], 1.0f - fl[1]};
+            float tl[2] = {dir[i].atlas_offset[0], dir[i].atlas_offset[1]};
+            float tr[2] = {tl[0] + dir[i].atlas_size[0], tl[1] + dir[i].atlas_size[1]};
+            float coords[2] = {tl[0] * (1.0f - local[0]) + tr[0] * local[0],
+                               tl[1] * (1.0f - local[1]) + tr[1] * local[1]};
+            float border[2] = {dir[i].inv_resolution[0] * 1.5f, dir[i].inv_resolution[1] * 1.5f};
+            tl[0] += border[0]; tl[1] += border[1];
+            tr[0] -= border[0]; tr[1] -= border[1];
+            float shadow = 1.0f;
+            if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f &&
+                sn[2] <= 1.0f)
+                shadow = shadow_pcf5(atlas, atlas_w, atlas_h, coords[0], coords[1], sn[2]);
+            float res[3];
+            surface_shading(light_l + 3 * i, dir[i].color, &px, vv, shadow * px.ao, res);
+            for (int c = 0; c < 3; ++c) color[c] += res[c];
+        }
+        for (uint32_t i = 0; i < n_point; ++i) {
+            float delta[3] = {pview[4 * i + 0] - vpos[0], pview[4 * i + 1] - vpos[1], pview[4 * i + 2] - vpos[2]};
+            float d = sqrtf(dot3(delta, delta));
+            float s = sat(d / point[i].radius);
+            float s2 = s * s, is2 = 1.0f - s2;
+            float att = is2 * is2 / (1.0f + s2);
+            float inten[3] = {point[i].color[0] * att, point[i].color[1] * att, point[i].color[2] * att};
+            float l[3] = {delta[0] / d, delta[1] / d, delta[2] / d};
+            float res[3];
+            surface_shading(l, inten, &px, vv, px.ao, res);
+            for (int c = 0; c < 3; ++c) color[c] += (res[c] > 0.0f ? res[c] : 0.0f);
+        }
+        for (int c = 0; c < 3; ++c) out[c] = fmaxf(fu->ambient[c] * px.albedo[c], color[c]);
+        out[3] = fmaxf(fu->ambient[3] * px.albedo[3], px.albedo[3]);
+    }
+}
+
+/*
+ * `samples` keys per pixel (pixel-major).  Every sample of the multisampled Rgba16Float target holds the
+ * half-rounded colour of its nearest fragment (or the clear colour); the render pass resolve
+ * (base.rs:245-258) is their box average, evaluated here as ((s0 + s1) + (s2 + s3)) * 0.25 in f32.
+ */
+void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, const r3o_frame_uniforms *fu,
                const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
                const r3o_baked *baked, const r3o_material *materials, const uint32_t *tri_base,
                uint32_t n_dir, const r3o_dir_light *dir, uint32_t n_point, const r3o_point_light *point,
                const float *atlas, uint32_t atlas_w, uint32_t atlas_h, const float *clear_color,
                uint16_t *hdr_out) {
-    float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
-    int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
-    uint32_t nobj = hdr->object_count;
     float *light_mats = (float *)malloc(sizeof(float) * 16 * (n_dir ? n_dir : 1));
     float *light_l = (float *)malloc(sizeof(float) * 3 * (n_dir ? n_dir : 1));
     float *pview = (float *)malloc(sizeof(float) * 4 * (n_point ? n_point : 1));
@@ -744,135 +935,38 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, const r3o_frame_unif
     for (uint32_t i = 0; i < n_point; ++i)
         mat4_mul_vec4(fu->view, point[i].position[0], point[i].position[1], point[i].position[2], point[i].position[3],
                       pview + 4 * i);
+    shade_ctx sc = {w, h, fu, hdr, objects, mesh, baked, materials, tri_base, n_dir, dir, n_point, point,
+                    atlas, atlas_w, atlas_h, light_mats, light_l, pview};
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (uint32_t y = 0; y < h; ++y)
         for (uint32_t x = 0; x < w; ++x) {
-            uint64_t key = vis[(uint64_t)y * w + x];
-            uint16_t *o16 = hdr_out + 4 * ((uint64_t)y * w + x);
-            float out[4];
-            uint32_t id = (uint32_t)(key & 0xFFFFFFFFu);
-            if (id == 0u) {
-                for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(clear_color[c]);
-                continue;
-            }
-            uint32_t slot = id - 1u;
-            /* object = last slot o with tri_base[o] <= slot and a non-empty range */
-            uint32_t lo = 0, hi = nobj;
-            while (hi - lo > 1u) {
-                uint32_t mid = lo + (hi - lo) / 2u;
-                if (tri_base[mid] <= slot) lo = mid; else hi = mid;
-            }
-            uint32_t o = lo, t = slot - tri_base[o];
-            const r3o_object *ob = &objects[o];
-            const r3o_material *mat = &materials[ob->material_index];
-            uint32_t idx[3];
-            float v[3][3];
-            fetch_triangle(ob, mesh, t, idx, v);
-            tri_setup ts;
-            setup_triangle(baked[o].model_view_proj, v, half_w, half_h, positive_visible, &ts);
-            float E[3];
-            (void)edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E);
-            float rs = 1.0f / ((E[0] + E[1]) + E[2]);
-            float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
-
-            /* vertex stage, opaque.wgsl:114-134 */
-            const float *mv = baked[o].model_view;
-            float inv_s2[3] = {1.0f / dot3(mv + 0, mv + 0), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
-            float vpos[4] = {0, 0, 0, 0}, nrm[3] = {0, 0, 0}, col[4] = {0, 0, 0, 0};
-            float vp[3][4], vn[3][3], vc[3][4];
-            for (int k = 0; k < 3; ++k) {
-                mat4_mul_vec4(mv, v[k][0], v[k][1], v[k][2], 1.0f, vp[k]);
-                float nm[3] = {0, 0, 0};
-                if (ob->attr_off[1] != R3O_INVALID) fetch_vec3(mesh, ob->attr_off[1], idx[k], nm);
-                float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
-                mat3_mul_vec3(mv + 0, mv + 4, mv + 8, sn, vn[k]);
-                normalize3(vn[k]);
-                if (ob->attr_off[5] != R3O_INVALID) {
-                    uint32_t cw = mesh[ob->attr_off[5] / 4u + idx[k]];
-                    for (int c = 0; c < 4; ++c) vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
-                } else
-                    for (int c = 0; c < 4; ++c) vc[k][c] = 1.0f;
-            }
-            for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
-            for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
-            for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
-
-            /* fragment stage, opaque.wgsl:203-424 (untextured paths) */
-            pixel_data px;
-            if (mat->flags & FLAGS_ALBEDO_ACTIVE) {
-                for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
-                if (mat->flags & FLAGS_ALBEDO_BLEND) {
-                    if (mat->flags & FLAGS_ALBEDO_VERTEX_SRGB) {
-                        for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
-                        px.albedo[3] *= col[3];
-                    } else
-                        for (int c = 0; c < 4; ++c) px.albedo[c] *= col[c];
+            const uint64_t pix = (uint64_t)y * w + x;
+            uint16_t *o16 = hdr_out + 4 * pix;
+            float half_s[4][4];
+            uint32_t last_id = 0xFFFFFFFFu;
+            uint32_t last_s = 0;
+            for (uint32_t sm = 0; sm < samples; ++sm) {
+                uint32_t id = (uint32_t)(vis[pix * samples + sm] & 0xFFFFFFFFu);
+                if (id == last_id) {  /* same triangle, same pixel centre: same value */
+                    for (int c = 0; c < 4; ++c) half_s[sm][c] = half_s[last_s][c];
+                    continue;
                 }
+                float out[4];
+                if (id == 0u)
+                    for (int c = 0; c < 4; ++c) out[c] = clear_color[c];
+                else
+                    shade_fragment(&sc, id, x, y, out);
+                for (int c = 0; c < 4; ++c) half_s[sm][c] = f16_to_f32(f32_to_f16(out[c]));
+                last_id = id;
+                last_s = sm;
+            }
+            if (samples == 1u) {
+                for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(half_s[0][c]);
             } else {
-                px.albedo[0] = px.albedo[1] = px.albedo[2] = 0.0f;
-                px.albedo[3] = 1.0f;
+                for (int c = 0; c < 4; ++c)
+                    o16[c] = f32_to_f16(((half_s[0][c] + half_s[1][c]) + (half_s[2][c] + half_s[3][c])) * 0.25f);
             }
-            for (int c = 0; c < 4; ++c) px.albedo[c] *= mat->albedo[c];
-
-            if (mat->flags & FLAGS_UNLIT) {
-                for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
-            } else {
-                for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
-                normalize3(px.normal);
-                float ao = mat->ambient_occlusion, pr = mat->roughness, metallic = mat->metallic;
-                float cc = mat->clear_coat, ccpr = mat->clear_coat_roughness;
-                for (int c = 0; c < 3; ++c) px.emissive[c] = mat->emissive[c];
-                for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
-                float refl = (0.16f * mat->reflectance) * mat->reflectance;
-                for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
-                if (cc != 0.0f) {
-                    float base_pr = fmaxf(pr, ccpr);
-                    pr = pr * (1.0f - cc) + base_pr * cc;
-                }
-                px.roughness = pr * pr;
-                px.ao = ao;
-
-                float vv[3] = {vpos[0], vpos[1], vpos[2]};
-                normalize3(vv);
-                for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
-                float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
-                for (uint32_t i = 0; i < n_dir; ++i) {
-                    float sn[4];
-                    mat4_mul_vec4(light_mats + 16 * i, vpos[0], vpos[1], vpos[2], vpos[3], sn);
-                    float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
-                    float local[2] = {fl[0], 1.0f - fl[1]};
-                    float tl[2] = {dir[i].atlas_offset[0], dir[i].atlas_offset[1]};
-                    float tr[2] = {tl[0] + dir[i].atlas_size[0], tl[1] + dir[i].atlas_size[1]};
-                    float coords[2] = {tl[0] * (1.0f - local[0]) + tr[0] * local[0],
-                                       tl[1] * (1.0f - local[1]) + tr[1] * local[1]};
-                    float border[2] = {dir[i].inv_resolution[0] * 1.5f, dir[i].inv_resolution[1] * 1.5f};
-                    tl[0] += border[0]; tl[1] += border[1];
-                    tr[0] -= border[0]; tr[1] -= border[1];
-                    float shadow = 1.0f;
-                    if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f &&
-                        sn[2] <= 1.0f)
-                        shadow = shadow_pcf5(atlas, atlas_w, atlas_h, coords[0], coords[1], sn[2]);
-                    float res[3];
-                    surface_shading(light_l + 3 * i, dir[i].color, &px, vv, shadow * px.ao, res);
-                    for (int c = 0; c < 3; ++c) color[c] += res[c];
-                }
-                for (uint32_t i = 0; i < n_point; ++i) {
-                    float delta[3] = {pview[4 * i + 0] - vpos[0], pview[4 * i + 1] - vpos[1], pview[4 * i + 2] - vpos[2]};
-                    float d = sqrtf(dot3(delta, delta));
-                    float s = sat(d / point[i].radius);
-                    float s2 = s * s, is2 = 1.0f - s2;
-                    float att = is2 * is2 / (1.0f + s2);
-                    float inten[3] = {point[i].color[0] * att, point[i].color[1] * att, point[i].color[2] * att};
-                    float l[3] = {delta[0] / d, delta[1] / d, delta[2] / d};
-                    float res[3];
-                    surface_shading(l, inten, &px, vv, px.ao, res);
-                    for (int c = 0; c < 3; ++c) color[c] += (res[c] > 0.0f ? res[c] : 0.0f);
-                }
-                for (int c = 0; c < 3; ++c) out[c] = fmaxf(fu->ambient[c] * px.albedo[c], color[c]);
-                out[3] = fmaxf(fu->ambient[3] * px.albedo[3], px.albedo[3]);
-            }
-            for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(out[c]);
         }
     free(light_mats);
     free(light_l);

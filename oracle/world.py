@@ -305,7 +305,7 @@ class OracleRenderer:
     def render(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0), exchange=None):
         """exchange(what, ndarray) -- multi-rank only: element-wise MAX all-reduce of the shadow atlas ("shadow") and of
         the visibility keys ("pass1", "pass2") at the points DESIGN.md section 6 names."""
-        assert samples == 1, "MSAA is row N4 (not built)"
+        assert samples in (1, 4), "SampleCount::One | SampleCount::Four (rend3-types/src/lib.rs SampleCount)"
         lib = self.lib
         # Renderer::evaluate_instructions (renderer/eval.rs): last frame's removals become real
         for h in self.pending_free:
@@ -350,14 +350,14 @@ class OracleRenderer:
         hdr = host.camera_header(cam, None, (width, height), samples, cap, lib)
         baked = np.zeros((cap, 32), dtype=f32)
         lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
-        vis = np.zeros((height, width), dtype=np.uint64)
+        vis = np.zeros((height, width) if samples == 1 else (height, width, samples), dtype=np.uint64)
         tri_base_now, _ = self.tri_base()
 
         def draw(lo, lt):
             if len(lo):
                 lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
                                           lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
-                                          lib.ptr(lo), lib.ptr(lt), len(lo), width, height, lib.ptr(vis))
+                                          lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, lib.ptr(vis))
 
         # 8. pass 1: last frame's predicted triangles (forward.rs:224-232)
         predicted = self.cam_state.get("predicted_list")
@@ -370,7 +370,7 @@ class OracleRenderer:
         # 9. Hi-Z from pass-1 depth (hi_z.rs:161-234)
         nm = lib.r3o_hiz_mip_count(width, height)
         pyr = np.zeros(int(lib.r3o_hiz_mip_offset(width, height, nm)), dtype=f32)
-        lib.r3o_vis_to_depth(lib.ptr(vis), width * height, lib.ptr(pyr))
+        lib.r3o_vis_to_depth(lib.ptr(vis), width * height, samples, lib.ptr(pyr))
         lib.r3o_hiz_build(lib.ptr(pyr), width, height)
         out["depth_pass1"] = pyr[: width * height].reshape(height, width).copy()
         out["hiz"] = pyr
@@ -390,7 +390,7 @@ class OracleRenderer:
         dir_arr = np.frombuffer(dir_buf, dtype=np.uint8)[16:].copy()
         pt_arr = np.frombuffer(point_buf, dtype=np.uint8)[16:].copy()
         clear = np.asarray(clear_color, dtype=f32)
-        lib.r3o_shade(lib.ptr(vis), width, height, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
+        lib.r3o_shade(lib.ptr(vis), width, height, samples, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
                       lib.ptr(self.mesh_words), lib.ptr(baked), lib.ptr(mats), lib.ptr(tri_base), n_dir,
                       lib.ptr(dir_arr) if n_dir else None, n_pt, lib.ptr(pt_arr) if n_pt else None,
                       lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), lib.ptr(hdr16))

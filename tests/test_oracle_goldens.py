@@ -8,7 +8,8 @@ Each test rebuilds the scene of the reference test it cites and renders it throu
 restatement of BaseRenderGraph::add_to_graph.  `Threshold::Mean(0.0)` goldens are compared
 pixel-exactly; the lit ones within the tolerance the reference test itself uses (FLIP is not
 available offline, so a per-channel LSB bound stands in for it and is stated in each test).
-MSAA goldens (msaa/four.png, msaa/sample-coverage-4.png) belong to row N4 (not built) and are not pinned.
+The MSAA goldens (msaa/four.png, msaa/sample-coverage-4.png, both Threshold::Mean(0.0)) pin row N4: sample
+positions, per-sample coverage and the box resolve.
 """
 import math
 import os
@@ -122,6 +123,49 @@ def test_multi_frame_add():
             r.add_object(mesh, mat, hm.mat4_mul(hm.translation((x, y, 0.0)), base))
         out = r.render(64, 64)
         assert np.array_equal(out["rgba8"], load(f"rend3-test/object/multi-frame-add-{x}.png")), x
+
+
+def build_msaa_triangle(r, hm, mk):
+    """rend3-test/tests/msaa.rs:6-39"""
+    mesh = r.add_mesh([(0.5, -0.5, 0.0), (-0.5, -0.5, 0.0), (0.0, 0.5, 0.0)], mesh_handedness=hm.LEFT)
+    r.add_object(mesh, scenes.unlit(r, mk, (0.25, 0.5, 0.75, 1.0)), hm.identity())
+    r.set_camera_data(hm.identity(), ("raw", hm.identity()))
+
+
+def test_msaa_four():
+    """rend3-test/tests/msaa.rs:6-39, SampleCount::Four, Threshold::Mean(0.0): edge pixels hold k/4 of the colour."""
+    r = OracleRenderer(hm.LEFT)
+    build_msaa_triangle(r, hm, mk)
+    out = r.render(64, 64, samples=4)
+    assert np.array_equal(out["rgba8"], load("rend3-test/msaa/four.png"))
+
+
+def build_sample_coverage(r, hm, mk):
+    """rend3-test/tests/msaa.rs:41-82: 64x64 planes, plane (x, y) covers (1 - x/63) x (1 - y/63) of its pixel."""
+    mat = scenes.unlit(r, mk, (1, 1, 1, 1))
+    base = hm.mat4_mul(hm.translation((0.5, 0.5, 0.0)), hm.scale((0.5, 0.5, 1.0)))
+    mesh = scenes.plane_mesh(r)
+    for x in range(64):
+        for y in range(64):
+            sx = f32(1.0) - (f32(x) / f32(63.0))
+            sy = f32(1.0) - (f32(y) / f32(63.0))
+            m = hm.mat4_mul(hm.mat4_mul(hm.translation((x, y, 0.0)), hm.scale((sx, sy, 1.0))), base)
+            r.add_object(mesh, mat, m)
+    r.set_camera_data(hm.identity(), ("raw", hm.orthographic_lh(0.0, 64.0, 64.0, 0.0, 0.0, 1.0)))
+
+
+def test_sample_coverage_4():
+    """rend3-test/tests/msaa.rs:41-82 at 4 spp, Threshold::Mean(0.0): pins the four sample positions (each plane
+    covers the samples inside its shrinking rectangle), the multisample flag of the cull (no sub-pixel
+    rejection, cull.wgsl:292) and the resolve."""
+    r = OracleRenderer(hm.LEFT)
+    build_sample_coverage(r, hm, mk)
+    out = r.render(64, 64, samples=4)
+    gold = load("rend3-test/msaa/sample-coverage-4.png")
+    # the reference compares RGB only (runner.rs:244-246 FlipImageRgb8): RGB exact.  Alpha of a half-covered pixel is
+    # 0.5 -> 127.5: the GPU that made the golden stored 127, `e * 255 + 0.5` gives 128 (a float -> unorm tie)
+    assert np.array_equal(out["rgba8"][..., :3], gold[..., :3])
+    assert np.abs(out["rgba8"][..., 3].astype(int) - gold[..., 3].astype(int)).max() <= 1
 
 
 def test_sample_coverage_1():
