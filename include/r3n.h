@@ -168,7 +168,10 @@ int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t dire
 
 /* ---- frame (node order of BaseRenderGraph::add_to_graph, rend3-routine/src/base.rs:135-185)
  * r3n_frame_begin: create_frame_uniforms (uniforms.rs:73-125) + render-target setup (base.rs:224-264) +
- * clear_shadow_buffers (clear.rs:4-20).  Clears colour to `clear_color`, depth and the shadow atlas to 0.0. */
+ * clear_shadow_buffers (clear.rs:4-20).  Clears colour to `clear_color`, depth and the shadow atlas to 0.0.
+ * `samples` is SampleCount::One (1) or ::Four (4): the colour / depth targets of the viewport then hold 4 samples per pixel
+ * (forward.rs:358, base.rs:236-258), Hi-Z starts from their depth-min resolve (resolve_depth_min.wgsl) and the HDR target
+ * the tonemapper reads is the render pass's box resolve.  Shadow views are always single-sampled (base.rs:230). */
 int r3n_frame_begin(r3n_ctx *ctx, const r3n_frame_uniforms496 *uniforms, uint32_t width, uint32_t height,
                     uint32_t samples, const float clear_color[4], uint32_t shadow_atlas_width,
                     uint32_t shadow_atlas_height);
@@ -231,8 +234,8 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
-int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height */
-int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys */
+int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height*samples, a pixel's samples contiguous */
+int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys (min over samples) */
 int r3n_readback_hiz(r3n_ctx *ctx, float *pyramid, uint64_t count); /* all mips, mip0 first */
 int r3n_readback_shadow_atlas(r3n_ctx *ctx, float *atlas);  /* atlas_w*atlas_h */
 int r3n_readback_hdr(r3n_ctx *ctx, uint16_t *rgba16f);      /* width*height*4 half bits */

@@ -467,17 +467,19 @@ static void setup_triangle(const float *mvp, const float v[3][3], float half_w, 
     (void)h;
 }
 
-/* Evaluate edge functions at pixel centre; returns 1 if covered (top-left rule). */
+/* Evaluate the three edge functions at a point (all of them: the shading of a multisampled pixel needs E at the pixel
+ * centre even when the centre itself is not covered); returns 1 if covered (top-left rule). */
 static inline int edge_eval(const tri_setup *ts, float px, float py, float E[3]) {
+    int in = 1;
     for (int i = 0; i < 3; ++i) {
         float A = ts->e[i][0], B = ts->e[i][1];
         float v = (A * px + B * py) + ts->e[i][2];
         E[i] = v;
         if (v > 0.0f) continue;
         if (v == 0.0f && (A > 0.0f || (A == 0.0f && B > 0.0f))) continue;
-        return 0; /* negative, NaN, or on a non-owned edge */
+        in = 0; /* negative, NaN, or on a non-owned edge */
     }
-    return 1;
+    return in;
 }
 
 /* Conservative integer pixel bounds of a triangle in a (vw x vh) viewport. */

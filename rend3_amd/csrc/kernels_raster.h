@@ -30,7 +30,7 @@ struct RasterArgs {
     uint32_t key;                          // region to draw
     uint32_t vp_x, vp_y, vp_w, vp_h;       // viewport inside the target
     uint32_t target_pitch;                 // elements per row of the target
-    unsigned long long *vis;               // forward target (u64 per pixel) or null
+    unsigned long long *vis;               // forward target (u64 per sample, samples per pixel contiguous) or null
     uint32_t *depth;                       // depth-only target (f32 bits per pixel) or null
     r3n_big_item *big_items;               // R3N_BIGQ sub-queues of big_capacity entries each
     uint32_t *big_count;                   // [R3N_BIGQ]
@@ -106,25 +106,61 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 // PREREAD: plain load + compare before the atomic.  It filters occluded fragments cheaply (the load may be
 // stale, which is only conservative because keys grow monotonically) but puts a dependent load in front of every
 // atomic; without it the atomic is fire-and-forget.
-template <bool DEPTH_ONLY, bool PREREAD>
+// Multisampling (row N4; forward.rs:358 MultisampleState{count}): coverage and depth at the standard 4x sample
+// positions (the D3D / Vulkan standard locations every wgpu backend uses); the fragment -- here only its cutout
+// alpha -- once per pixel at the pixel centre, covered or not (no centroid qualifier in opaque.wgsl).
+__device__ static const float k_sample_pos4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}};
+
+template <bool DEPTH_ONLY, bool PREREAD, int S = 1>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
-    float E[3];
-    if (!edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
-    float z = frag_depth(tw.ts, E);
-    if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
-    if (z == 0.0f) z = 0.0f;                // canonicalise -0
-    if (tw.cutout) {
-        const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
-        const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-        if (cutout_alpha(tw.mat_flags, tw.mat_alpha, al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
-    }
-    const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
-    const uint32_t zb = __float_as_uint(z);
-    if (DEPTH_ONLY) {
-        if (!PREREAD || zb > a.depth[pix]) atomicMax(&a.depth[pix], zb);
+    if (S == 1) {
+        float E[3];
+        if (!edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
+        float z = frag_depth(tw.ts, E);
+        if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
+        if (z == 0.0f) z = 0.0f;                // canonicalise -0
+        if (tw.cutout) {
+            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
+        }
+        const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
+        const uint32_t zb = __float_as_uint(z);
+        if (DEPTH_ONLY) {
+            if (!PREREAD || zb > a.depth[pix]) atomicMax(&a.depth[pix], zb);
+        } else {
+            const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
+            if (!PREREAD || key > a.vis[pix]) atomicMax(&a.vis[pix], key);
+        }
     } else {
-        const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
-        if (!PREREAD || key > a.vis[pix]) atomicMax(&a.vis[pix], key);
+        uint32_t mask = 0u;
+        float zs[S];
+#pragma unroll
+        for (int sm = 0; sm < S; ++sm) {
+            float E[3];
+            zs[sm] = 0.0f;
+            if (!edge_eval(tw.ts, (float)x + k_sample_pos4[sm][0], (float)y + k_sample_pos4[sm][1], E)) continue;
+            float z = frag_depth(tw.ts, E);
+            if (!(z >= 0.0f && z <= 1.0f)) continue;
+            if (z == 0.0f) z = 0.0f;
+            zs[sm] = z;
+            mask |= 1u << sm;
+        }
+        if (!mask) return;
+        if (tw.cutout) {
+            float E[3];
+            (void)edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E);
+            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, al) < tw.mat_cutoff) return;
+        }
+        const size_t pix = ((size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x) * (size_t)S;
+#pragma unroll
+        for (int sm = 0; sm < S; ++sm)
+            if (mask & (1u << sm)) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(zs[sm]) << 32) | (unsigned long long)tw.slot1;
+                atomicMax(&a.vis[pix + (size_t)sm], key);
+            }
     }
 }
 
@@ -142,7 +178,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
-template <bool DEPTH_ONLY>
+template <bool DEPTH_ONLY, int S = 1>
 __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
@@ -161,7 +197,7 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
-                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0>(a, tw, x, y);
+                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S>(a, tw, x, y);
         } else {
             const uint32_t tx = (uint32_t)(bw + (R3N_TILE - 1)) / R3N_TILE, ty = (uint32_t)(bh + (R3N_TILE - 1)) / R3N_TILE;
             const uint32_t cnt = tx * ty;
@@ -189,7 +225,7 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
                 } else {
                     // queue full: never drop work -- scan the region here (slow path)
                     for (int y = ry0; y <= ry1; ++y)
-                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0>(a, tw, x, y);
+                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S>(a, tw, x, y);
                 }
             }
         }
@@ -199,10 +235,12 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
 // Upper bound of edge function i over the pixel centres of an SxS block whose first pixel is (bx,by).  Each
 // f32 operation is monotone, so evaluating the same expression at the extreme corner gives the exact maximum of
 // the per-pixel values: a block with a negative maximum holds no covered pixel.
-template <int S = 8>
+// MS: the evaluation points are the 4x sample positions, which span [0.125, 0.875] of a pixel in x and y.
+template <int S = 8, bool MS = false>
 R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry1) {
-    const float x_lo = (float)bx + 0.5f, x_hi = (float)min(bx + (S - 1), rx1) + 0.5f;
-    const float y_lo = (float)by + 0.5f, y_hi = (float)min(by + (S - 1), ry1) + 0.5f;
+    const float lo = MS ? 0.125f : 0.5f, hi = MS ? 0.875f : 0.5f;
+    const float x_lo = (float)bx + lo, x_hi = (float)min(bx + (S - 1), rx1) + hi;
+    const float y_lo = (float)by + lo, y_hi = (float)min(by + (S - 1), ry1) + hi;
     bool may = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -220,7 +258,7 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 // the next item's record is in flight while the current one is scanned.  Waves walk the concatenation of the
 // R3N_BIGQ producer sub-queues with a stride of the wave count, which spreads neighbouring (similar-cost) items
 // over different waves.
-template <bool DEPTH_ONLY>
+template <bool DEPTH_ONLY, int S = 1>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     // Pin the kernel arguments the scan uses into SGPRs here: hipcc otherwise sinks the wait for their s_load
     // into the scan loop, and an `s_waitcnt lgkmcnt(0)` there would also wait for the record prefetch below.
@@ -304,7 +342,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
             // fine mode (regions up to 32x32 px): lane = 4x4 block for the rejection test; every step then scans
             // FOUR surviving blocks, 16 lanes each -- small triangles fill the wave far better than with 8x8 blocks
             const int cbx = rx0 + lx * 4, cby = ry0 + ly * 4;
-            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<4>(w.ts, cbx, cby, rx1, ry1);
+            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<4, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
             const uint32_t grp = lane >> 4;
             const int px = (int)(lane & 3u), py = (int)((lane >> 2) & 3u);
@@ -317,17 +355,17 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 }
                 const int b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                 const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
-                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0>(a, w, x, y);
+                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S>(a, w, x, y);
             }
         } else {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
-            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<8>(w.ts, cbx, cby, rx1, ry1);
+            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
             while (blocks) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0>(a, w, x, y);
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S>(a, w, x, y);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
@@ -371,8 +409,9 @@ __global__ __launch_bounds__(256) void k_hiz_downsample(const float *__restrict_
 // Fused head of the pyramid: one block reduces a 32x32 depth tile through mip0 .. mip`levels` (levels <= 4) in one
 // pass -- registers for the first 2x2, LDS for the rest.  Only used for levels whose SOURCE dimensions are even (then
 // hi_z.wgsl's window is a plain 2x2 and tiles are independent); the host picks `levels` accordingly.
+// With multisampling mip 0 is the depth resolve of resolve_depth_min.wgsl:19-27 (nearest = 1.0, min over the samples).
 __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__restrict__ vis, float *__restrict__ pyr,
-                                                  r3n_hiz_desc d, uint32_t levels) {
+                                                  r3n_hiz_desc d, uint32_t levels, uint32_t samples) {
     __shared__ float t[16][17];
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t x0 = (blockIdx.x * 16u + tx) * 2u, y0 = (blockIdx.y * 16u + ty) * 2u;
@@ -384,8 +423,15 @@ __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__re
             const uint32_t x = x0 + (uint32_t)dx, y = y0 + (uint32_t)dy;
             float v = 0.0f;
             if (x < d.width && y < d.height) {
-                v = __uint_as_float((uint32_t)(vis[(size_t)y * d.width + x] >> 32));
-                pyr[(size_t)y * d.width + x] = v;
+                const size_t pix = (size_t)y * d.width + x;
+                if (samples == 1u) {
+                    v = __uint_as_float((uint32_t)(vis[pix] >> 32));
+                } else {
+                    v = 1.0f;
+                    for (uint32_t sm = 0; sm < samples; ++sm)
+                        v = fminf(v, __uint_as_float((uint32_t)(vis[pix * samples + sm] >> 32)));
+                }
+                pyr[pix] = v;
             }
             q[dy][dx] = v;
         }
@@ -664,60 +710,9 @@ R3N_DEV ushort4 pack_half4(const float v[4]) {
     return o;
 }
 
-// One thread per pixel, 16x16 pixel tiles; the light list is transformed once per workgroup and staged in LDS.
-__global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
-    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
-    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
-    const uint32_t n_dir = min(*reinterpret_cast<const uint32_t *>(a.dir_buf), (uint32_t)R3N_MAX_DIR_LIGHTS);
-    const uint32_t n_point = min(*reinterpret_cast<const uint32_t *>(a.point_buf), (uint32_t)R3N_MAX_POINT_LIGHTS);
-    const r3n_dir_light128 *dirs = reinterpret_cast<const r3n_dir_light128 *>(a.dir_buf + 16);
-    const r3n_point_light32 *points = reinterpret_cast<const r3n_point_light32 *>(a.point_buf + 16);
-    for (uint32_t i = threadIdx.x; i < n_dir * 4u; i += 256u) {
-        const uint32_t li = i >> 2, c = i & 3u;
-        const float *col = a.fu->inv_view + 4 * c;  // column c of (view_proj * inv_view)
-        float o[4];
-        mul_vec4(dirs[li].view_proj, col[0], col[1], col[2], col[3], o);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_dir[li].m[4 * c + r] = o[r];
-        if (c == 0) {
-            const float nd[3] = {-dirs[li].direction[0], -dirs[li].direction[1], -dirs[li].direction[2]};
-            float l[3];
-            mat3_mul_vec3(a.fu->view, a.fu->view + 4, a.fu->view + 8, nd, l);
-            normalize3(l);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { s_dir[li].l[r] = l[r]; s_dir[li].color[r] = dirs[li].color[r]; }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                s_dir[li].inv_res[r] = dirs[li].inv_resolution[r];
-                s_dir[li].offset[r] = dirs[li].atlas_offset[r];
-                s_dir[li].size[r] = dirs[li].atlas_size[r];
-            }
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < n_point; i += 256u) {
-        float o[4];
-        mul_vec4(a.fu->view, points[i].position[0], points[i].position[1], points[i].position[2], points[i].position[3], o);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { s_point[i].vpos[r] = o[r]; s_point[i].color[r] = points[i].color[r]; }
-        s_point[i].radius = points[i].radius;
-    }
-    __syncthreads();
-
-    // each wavefront shades an 8x8 pixel quad of the 16x16 tile (fewer distinct triangles / atlas texels per wave
-    // than a 16x4 strip; measured 3 % faster)
-    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-    const uint32_t x = blockIdx.x * 16u + (ln & 7u) + 8u * (wv & 1u);
-    const uint32_t y = a.row_begin + blockIdx.y * 16u + (ln >> 3) + 8u * (wv >> 1);
-    if (x >= a.width || y >= a.row_end) return;
-    const size_t pix = (size_t)y * a.width + x;
-    const unsigned long long key = a.vis[pix];
-    const uint32_t id = (uint32_t)(key & 0xFFFFFFFFull);
-    if (id == 0u) {
-        const ushort4 hc = pack_half4(a.clear);
-        a.hdr_out[pix] = hc;
-        a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc);
-        return;
-    }
+// opaque.wgsl VS (:91-135) + FS (:203-551) for triangle slot `id - 1` at the centre of pixel (x, y).
+R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
+                            uint32_t n_point, uint32_t id, uint32_t x, uint32_t y, float out[4]) {
     const uint32_t slot = id - 1u;
     // object = last o with tri_base[o] <= slot; the coarse table narrows the binary search to the objects that
     // start inside one 256-slot bucket (usually zero or one step instead of log2(capacity))
@@ -800,7 +795,6 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) px.albedo[c] *= mat.albedo[c];
 
-    float out[4];
     if (mflags & R3N_FLAGS_UNLIT) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
@@ -877,6 +871,97 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[c] = fmaxf(a.fu->ambient[c] * px.albedo[c], color[c]);
         out[3] = fmaxf(a.fu->ambient[3] * px.albedo[3], px.albedo[3]);
+    }
+}
+
+// One thread per pixel, 16x16 pixel tiles; the light list is transformed once per workgroup and staged in LDS.
+// S = samples per pixel.  S == 4: every sample of the multisampled Rgba16Float target holds the half-rounded colour
+// of its nearest fragment (shaded once per distinct triangle, at the pixel centre) or the clear colour; the render
+// pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
+template <int S>
+__global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
+    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
+    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    const uint32_t n_dir = min(*reinterpret_cast<const uint32_t *>(a.dir_buf), (uint32_t)R3N_MAX_DIR_LIGHTS);
+    const uint32_t n_point = min(*reinterpret_cast<const uint32_t *>(a.point_buf), (uint32_t)R3N_MAX_POINT_LIGHTS);
+    const r3n_dir_light128 *dirs = reinterpret_cast<const r3n_dir_light128 *>(a.dir_buf + 16);
+    const r3n_point_light32 *points = reinterpret_cast<const r3n_point_light32 *>(a.point_buf + 16);
+    for (uint32_t i = threadIdx.x; i < n_dir * 4u; i += 256u) {
+        const uint32_t li = i >> 2, c = i & 3u;
+        const float *col = a.fu->inv_view + 4 * c;  // column c of (view_proj * inv_view)
+        float o[4];
+        mul_vec4(dirs[li].view_proj, col[0], col[1], col[2], col[3], o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_dir[li].m[4 * c + r] = o[r];
+        if (c == 0) {
+            const float nd[3] = {-dirs[li].direction[0], -dirs[li].direction[1], -dirs[li].direction[2]};
+            float l[3];
+            mat3_mul_vec3(a.fu->view, a.fu->view + 4, a.fu->view + 8, nd, l);
+            normalize3(l);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { s_dir[li].l[r] = l[r]; s_dir[li].color[r] = dirs[li].color[r]; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                s_dir[li].inv_res[r] = dirs[li].inv_resolution[r];
+                s_dir[li].offset[r] = dirs[li].atlas_offset[r];
+                s_dir[li].size[r] = dirs[li].atlas_size[r];
+            }
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n_point; i += 256u) {
+        float o[4];
+        mul_vec4(a.fu->view, points[i].position[0], points[i].position[1], points[i].position[2], points[i].position[3], o);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { s_point[i].vpos[r] = o[r]; s_point[i].color[r] = points[i].color[r]; }
+        s_point[i].radius = points[i].radius;
+    }
+    __syncthreads();
+
+    // each wavefront shades an 8x8 pixel quad of the 16x16 tile (fewer distinct triangles / atlas texels per wave
+    // than a 16x4 strip; measured 3 % faster)
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    const uint32_t x = blockIdx.x * 16u + (ln & 7u) + 8u * (wv & 1u);
+    const uint32_t y = a.row_begin + blockIdx.y * 16u + (ln >> 3) + 8u * (wv >> 1);
+    if (x >= a.width || y >= a.row_end) return;
+    const size_t pix = (size_t)y * a.width + x;
+    float out[4];
+    if (S == 1) {
+        const uint32_t id = (uint32_t)(a.vis[pix] & 0xFFFFFFFFull);
+        if (id == 0u) {
+            const ushort4 hc = pack_half4(a.clear);
+            a.hdr_out[pix] = hc;
+            a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc);
+            return;
+        }
+        shade_fragment(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
+    } else {
+        uint32_t ids[S];
+        float col[S][4];
+#pragma unroll
+        for (int sm = 0; sm < S; ++sm) ids[sm] = (uint32_t)(a.vis[pix * (size_t)S + (size_t)sm] & 0xFFFFFFFFull);
+#pragma unroll
+        for (int sm = 0; sm < S; ++sm) {
+            int same = -1;
+#pragma unroll
+            for (int p = 0; p < sm; ++p)
+                if (ids[p] == ids[sm]) same = p;
+            if (same >= 0) {  // same triangle, same pixel centre: same value
+#pragma unroll
+                for (int c = 0; c < 4; ++c) col[sm][c] = col[same][c];
+                continue;
+            }
+            float v[4];
+            if (ids[sm] == 0u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
+            } else {
+                shade_fragment(a, s_dir, s_point, n_dir, n_point, ids[sm], x, y, v);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = ((col[0][c] + col[1][c]) + (col[2][c] + col[3][c])) * 0.25f;
     }
     const ushort4 ho = pack_half4(out);
     a.hdr_out[pix] = ho;

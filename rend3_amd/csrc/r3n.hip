@@ -532,7 +532,7 @@ int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void
 int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint32_t h, uint32_t samples,
                     const float clear_color[4], uint32_t atlas_w, uint32_t atlas_h) {
     if (!c || !u || !clear_color || !w || !h) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: bad args");
-    if (samples != 1) return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: MSAA (SampleCount::Four) is not built yet (row N4)");
+    if (samples != 1 && samples != 4) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: samples must be 1 or 4 (SampleCount::One | Four)");
     if (w > 65535 || h > 65535) return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: target larger than 65535");
     HIP_TRY(c, hipSetDevice(c->device));
     if (w != c->width || h != c->height) {
@@ -544,7 +544,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     const size_t npix = (size_t)w * h;
     TRY(ensure(c, c->fu, sizeof *u, false, -1));
     TRY(upload_small(c, c->fu.p, u, sizeof *u));
-    TRY(ensure(c, c->vis, npix * 8, false, -1));
+    TRY(ensure(c, c->vis, npix * samples * 8, false, -1));
     TRY(ensure(c, c->hdr16, npix * 8, false, -1));
     TRY(ensure(c, c->out8, npix * 4, false, -1));
     build_hiz_desc(c->hizd, w, h);
@@ -554,7 +554,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     {
         Timed t(c, R3N_STAGE_CLEAR);
         // depth clear 0.0 / no triangle (base.rs:259-263) and shadow atlas clear 0.0 (clear.rs:4-20)
-        HIP_TRY(c, hipMemsetAsync(c->vis.p, 0, npix * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->vis.p, 0, npix * samples * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->atlas.p, 0, apix * 4, c->stream));
     }
     TRY(refresh_tri_base(c));
@@ -710,7 +710,7 @@ int r3n_hi_z(r3n_ctx *c) {
            (c->width >> levels) >= 2u && (c->height >> levels) >= 2u)
         ++levels;
     hipLaunchKernelGGL(k_hiz_head, dim3((c->width + 31u) / 32u, (c->height + 31u) / 32u), dim3(256), 0, c->stream,
-                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels);
+                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->samples);
     if (levels + 1u < c->hizd.mips)
         hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, c->stream, c->hiz.as<float>(), c->hizd, levels + 1u);
     return check_launch(c, "hi_z");
@@ -790,15 +790,20 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
-        { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(k_raster_small<false>, dim3(small_grid), dim3(256), 0, stream, a); }
-        { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        if (c->samples == 4) {
+            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL((k_raster_small<false, 4>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false, 4>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        } else {
+            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL((k_raster_small<false, 1>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false, 1>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        }
     } else {
         if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
             return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
         a.depth = c->atlas.as<uint32_t>();
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL(k_raster_small<true>, dim3(small_grid), dim3(256), 0, stream, a); }
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1>), dim3(small_grid), dim3(256), 0, stream, a); }
+        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
     }
     return check_launch(c, "raster");
 }
@@ -834,7 +839,9 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     a.srgb_lut = c->srgb_lut.as<unsigned char>();
     c->resolved_this_frame = true;
     Timed t(c, R3N_STAGE_SHADE);
-    hipLaunchKernelGGL(k_resolve_opaque, dim3((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u), dim3(256), 0, c->stream, a);
+    const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
+    if (c->samples == 4) hipLaunchKernelGGL(k_resolve_opaque<4>, rgrid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_resolve_opaque<1>, rgrid, dim3(256), 0, c->stream, a);
     return check_launch(c, "k_resolve_opaque");
 }
 
@@ -900,7 +907,7 @@ int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atl
     if (!c || !c->vis.p) return fail(c, R3N_ERR_STATE, "exchange_buffers: no frame targets yet");
     TRY(join_lanes(c));  // collectives are ordered on the main stream
     if (vis) *vis = c->vis.p;
-    if (vis_count) *vis_count = (uint64_t)c->width * c->height;
+    if (vis_count) *vis_count = (uint64_t)c->width * c->height * c->samples;
     if (atlas) *atlas = c->atlas.p;
     if (atlas_count) *atlas_count = (uint64_t)c->atlas_w * c->atlas_h;
     return R3N_OK;
@@ -1020,17 +1027,28 @@ int r3n_readback_mesh(r3n_ctx *c, uint64_t byte_offset, void *dst, uint64_t byte
 
 int r3n_readback_visibility(r3n_ctx *c, uint64_t *keys) {
     if (!c || !c->vis.p || !keys) return fail(c, R3N_ERR_STATE, "readback_visibility: no frame");
-    return d2h(c, keys, c->vis.p, (size_t)c->width * c->height * 8);
+    return d2h(c, keys, c->vis.p, (size_t)c->width * c->height * c->samples * 8);
 }
 
 int r3n_readback_depth(r3n_ctx *c, float *depth) {
     if (!c || !c->vis.p || !depth) return fail(c, R3N_ERR_STATE, "readback_depth: no frame");
-    const size_t n = (size_t)c->width * c->height;
-    std::vector<uint64_t> keys(n);
-    TRY(d2h(c, keys.data(), c->vis.p, n * 8));
+    const size_t n = (size_t)c->width * c->height, S = c->samples;
+    std::vector<uint64_t> keys(n * S);
+    TRY(d2h(c, keys.data(), c->vis.p, n * S * 8));
     for (size_t i = 0; i < n; ++i) {
-        const uint32_t zb = (uint32_t)(keys[i] >> 32);
-        std::memcpy(depth + i, &zb, 4);
+        if (S == 1) {
+            const uint32_t zb = (uint32_t)(keys[i] >> 32);
+            std::memcpy(depth + i, &zb, 4);
+        } else {  // resolve_depth_min.wgsl:19-27
+            float nearest = 1.0f;
+            for (size_t sm = 0; sm < S; ++sm) {
+                const uint32_t zb = (uint32_t)(keys[i * S + sm] >> 32);
+                float z;
+                std::memcpy(&z, &zb, 4);
+                nearest = std::fmin(nearest, z);
+            }
+            depth[i] = nearest;
+        }
     }
     return R3N_OK;
 }

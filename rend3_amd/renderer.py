@@ -374,9 +374,9 @@ class Renderer:
         graph.execute(self, eval_output)
         if not readback:
             return None
-        return self.readback_frame(eval_output, width, height)
+        return self.readback_frame(eval_output, width, height, samples)
 
-    def readback_frame(self, eval_output, width, height):
+    def readback_frame(self, eval_output, width, height, samples=1):
         lib, ctx = self.lib, self.ctx
         cap = self.capacity
         out = {"capacity": cap, "shadows": []}
@@ -398,7 +398,7 @@ class Renderer:
             for si in range(len(eval_output.shadows)):
                 out["shadows"].append(cam_sets(si))
             out.update(cam_sets(_ffi.CAMERA_VIEWPORT))
-        vis = np.zeros((height, width), dtype=np.uint64)
+        vis = np.zeros((height, width) if samples == 1 else (height, width, samples), dtype=np.uint64)
         self._check(lib.r3n_readback_visibility(ctx, _ffi.ptr(vis)), "readback_visibility")
         aw, ah = eval_output.shadow_target_size
         atlas = np.zeros((ah, aw), dtype=f32)

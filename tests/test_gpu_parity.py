@@ -454,7 +454,7 @@ def test_abi_error_behaviour(r3):
     assert lib.r3n_hi_z(ctx) == -4
     assert lib.r3n_frame_end(ctx) == -4
     # unsupported rows fail loudly
-    assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 64, 64, 4, _ffi.ptr(clear), 32, 32) == -5 and b"MSAA" in lib.r3n_last_error(ctx)
+    assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 64, 64, 2, _ffi.ptr(clear), 32, 32) == -1 and b"samples" in lib.r3n_last_error(ctx)
     assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 0, 64, 1, _ffi.ptr(clear), 32, 32) == -1
     assert lib.r3n_frame_begin(ctx, _ffi.ptr(fu), 64, 64, 1, _ffi.ptr(clear), 32, 32) == 0
     assert lib.r3n_forward(ctx, _ffi.CAMERA_VIEWPORT, _ffi.PASS_FORWARD, _ffi.SOURCE_RESIDUAL, _ffi.KEY_BLEND) == -5
@@ -480,6 +480,40 @@ def test_abi_error_behaviour(r3):
     assert lib.r3n_objects_write(ctx, _ffi.ptr(slot), _ffi.ptr(rec), 1, r.capacity) == -1
     assert lib.r3n_objects_write(ctx, None, None, 0, 1) == -1
     r.close()
+
+
+def test_msaa_goldens(r3):
+    """rend3-test/tests/msaa.rs (row N4): SampleCount::Four on the reference's two MSAA scenes -- HIP == oracle bit for
+    bit (per-sample keys included) and the HIP image against the goldens (RGB exact; see test_oracle_goldens for alpha)."""
+    for build, name in ((G.build_msaa_triangle, "four"), (G.build_sample_coverage, "sample-coverage-4")):
+        o, p = both(r3, oh.LEFT)
+        build(o, oh, omk)
+        build(p, r3.host, r3.material_record)
+        for f in range(2):
+            fo = o.render(64, 64, samples=4)
+            fp = p.render(64, 64, samples=4)
+            compare_frames(fo, fp, f"msaa {name} frame {f}")
+        gold = G.load(f"rend3-test/msaa/{name}.png")
+        assert np.array_equal(fp["rgba8"][..., :3], gold[..., :3]), name
+
+
+@pytest.mark.parametrize("handedness", [oh.LEFT, oh.RIGHT])
+def test_msaa_random_scene_multi_frame(r3, handedness):
+    """SampleCount::Four on the lit multi-frame scene of test_random_scene_multi_frame: per-sample keys, depth-min
+    Hi-Z, temporal predicted / residual sets (no sub-pixel rejection under the multisample flag), cutout alpha per
+    pixel, shaded samples and their box resolve -- all bit-identical to the oracle."""
+    o, p = both(r3, handedness, f32(320) / f32(192))
+    scenes.build_random_scene(o, oh, omk, 300, 0xC0FFEE, handedness=handedness, lights=2, with_cutout=True)
+    scenes.build_random_scene(p, oh, r3.material_record, 300, 0xC0FFEE, handedness=handedness, lights=2, with_cutout=True)
+    look = oh.look_at_lh if handedness == oh.LEFT else oh.look_at_rh
+    for f in range(3):
+        ang = 0.35 * f
+        eye = (3.0 * math.sin(ang), 1.0 + 0.5 * f, -3.0 * math.cos(ang))
+        for r in (o, p):
+            r.set_camera_data(look(eye, (10 * math.sin(ang + 0.3), 0, 10 * math.cos(ang + 0.3)), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, 192, samples=4, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, samples=4, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"msaa random scene frame {f}")
 
 
 def test_tonemap_every_half_value(r3):
