@@ -501,3 +501,28 @@ def frame_uniforms(cam, ambient, resolution, lib):
     uu[120] = resolution[0]
     uu[121] = resolution[1]
     return u
+
+
+def mip_chain_texels(w, h, mips):
+    return sum(max(1, w >> k) * max(1, h >> k) for k in range(mips))
+
+
+def prepare_texture(lib, rgba8, srgb, mip_count, mip_source):
+    """Texture upload path of rend3/src/managers/texture.rs: validates the mip count (MipmapCount::Maximum =
+    floor(log2(max(w, h))) + 1, Extent3d::max_mips), lays the mips out contiguously and, for
+    MipmapSource::Generated, builds them (util/mipmap.rs, restated in C: r3o_generate_mips).
+    Returns (u32 texels of the whole chain, width, height, mips)."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if mip_source == "generated" or mip_count == 1:
+        assert a.ndim == 3 and a.shape[2] == 4
+        h, w = a.shape[:2]
+    else:
+        raise ValueError("uploaded mip chains: pass (w, h) explicitly via prepare_texture_chain")
+    max_mips = int(max(w, h)).bit_length()
+    mips = max_mips if mip_count == "maximum" else int(mip_count)
+    assert 1 <= mips <= max_mips
+    out = np.zeros(mip_chain_texels(w, h, mips), dtype=np.uint32)
+    out[: w * h] = a.reshape(-1, 4).view(np.uint32).reshape(-1)
+    if mips > 1:
+        lib.r3o_generate_mips(1 if srgb else 0, w, h, mips, lib.ptr(out))
+    return out, w, h, mips

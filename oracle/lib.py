@@ -53,12 +53,14 @@ class OracleLib:
             "r3o_hiz_build": [vp, ctypes.c_uint32, ctypes.c_uint32],
             "r3o_cull_triangles": [vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp],
             "r3o_raster_visibility": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32,
-                                      ctypes.c_uint32, ctypes.c_uint32, vp],
+                                      ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp],
             "r3o_raster_depth": [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint32,
-                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32],
+                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint32, vp],
             "r3o_vis_to_depth": [vp, ctypes.c_uint64, ctypes.c_uint32, vp],
             "r3o_shade": [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp,
-                          ctypes.c_uint32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp],
+                          ctypes.c_uint32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, ctypes.c_uint32, vp, vp],
+            "r3o_generate_mips": [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp],
+            "r3o_srgb8_table": [vp],
             "r3o_tonemap": [vp, ctypes.c_uint64, vp, vp],
             "r3o_skinning": [vp, vp, ctypes.c_uint32, vp],
         }.items():

@@ -133,6 +133,7 @@ typedef struct {
 #define FLAGS_ALBEDO_BLEND 0x0002u
 #define FLAGS_ALBEDO_VERTEX_SRGB 0x0004u
 #define FLAGS_UNLIT 0x2000u
+#define FLAGS_NEAREST 0x4000u
 
 #define PCU_POSITIVE_AREA_VISIBLE 0x1u
 #define PCU_MULTISAMPLED 0x2u
@@ -519,14 +520,216 @@ static void fetch_triangle(const r3o_object *ob, const uint32_t *mesh, uint32_t 
     }
 }
 
-/* alpha for the cutout test (opaque.wgsl:213-235 / depth.wgsl:112-125), untextured */
-static float material_alpha(const r3o_material *m, float vertex_alpha) {
+/* ------------------------------------------------------------------ textures (row N2, first slice: albedo)
+ * The reference binds every texture of the world as one bindless array (rend3/src/managers/texture.rs) and samples
+ * them with textureSampleGrad through one of two samplers (rend3-routine/src/common/samplers.rs:22-56): `linear`
+ * (mag = min = mipmap = Linear) or `nearest` (all Nearest), both AddressMode::Repeat, anisotropy_clamp 1, LOD clamp
+ * [0, 100].  Restated here for RGBA8 textures (Rgba8Unorm / Rgba8UnormSrgb):
+ *   - texel -> float: c / 255, sRGB-decoded per texel before filtering (exact formula) for the sRGB format;
+ *   - bilinear footprint and weights exactly like the comparison sampler above (u * w - 0.5, floor, Repeat wrap);
+ *   - level of detail from the gradients: rho = max(|ddx * size|, |ddy * size|) (Euclidean lengths, f32).  With
+ *     rho = m * 2^e (1 <= m < 2) the LOD is e + (m - 1): the exponent is exact and the fraction is the mantissa
+ *     (a monotone piecewise-linear stand-in for log2, max error 0.086 levels; hardware LOD units are
+ *     fixed-point approximations of the same kind).  No libm call, so CPU and GPU agree bit for bit.
+ *     rho <= 1 (magnification), NaN gradients: level 0.  Linear: mix of the two adjacent levels with the fraction;
+ *     nearest: the level nearest to the LOD (ties up).
+ */
+typedef struct {
+    uint32_t offset;  /* first texel of mip 0 in the pool (u32 RGBA8 texels, mips contiguous) */
+    uint32_t width, height, mips;
+    uint32_t format;  /* 0 = Rgba8Unorm, 1 = Rgba8UnormSrgb */
+    uint32_t _pad[3];
+} r3o_texture_desc;
+
+typedef struct {
+    const r3o_texture_desc *descs;
+    uint32_t n;
+    const uint32_t *texels;
+} r3o_textures;
+
+static float g_srgb8_to_linear[256];
+static int g_srgb8_ready = 0;
+static void init_srgb8(void) {
+    if (g_srgb8_ready) return;
+    for (int i = 0; i < 256; ++i) {
+        float e = (float)i / 255.0f;
+        g_srgb8_to_linear[i] = e > 0.04045f ? powf((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f;
+    }
+    g_srgb8_ready = 1;
+}
+void r3o_srgb8_table(float *out256) {
+    init_srgb8();
+    memcpy(out256, g_srgb8_to_linear, sizeof g_srgb8_to_linear);
+}
+
+static inline uint32_t tex_mip_dim(uint32_t d, uint32_t k) { uint32_t v = d >> k; return v ? v : 1u; }
+static inline uint32_t wrap_texel_i(float f, uint32_t n) { /* f = floor(coordinate); Repeat; NaN / huge -> 0 */
+    long long i = (f == f && fabsf(f) < 1e9f) ? (long long)f : 0ll;
+    long long w = (long long)n;
+    return (uint32_t)(((i % w) + w) % w);
+}
+static void tex_fetch(const r3o_textures *tt, const r3o_texture_desc *d, uint32_t mip, uint32_t x, uint32_t y, float o[4]) {
+    uint64_t off = d->offset;
+    for (uint32_t k = 0; k < mip; ++k) off += (uint64_t)tex_mip_dim(d->width, k) * tex_mip_dim(d->height, k);
+    uint32_t t = tt->texels[off + (uint64_t)y * tex_mip_dim(d->width, mip) + x];
+    for (int c = 0; c < 4; ++c) {
+        uint32_t b = (t >> (8 * c)) & 0xFFu;
+        o[c] = (d->format == 1u && c < 3) ? g_srgb8_to_linear[b] : (float)b / 255.0f;
+    }
+}
+static void tex_bilinear(const r3o_textures *tt, const r3o_texture_desc *d, uint32_t mip, float u, float v, float o[4]) {
+    uint32_t w = tex_mip_dim(d->width, mip), h = tex_mip_dim(d->height, mip);
+    float tx = u * (float)w - 0.5f, ty = v * (float)h - 0.5f;
+    float fx0 = floorf(tx), fy0 = floorf(ty);
+    float fx = tx - fx0, fy = ty - fy0;
+    if (!(fx == fx)) fx = 0.0f;
+    if (!(fy == fy)) fy = 0.0f;
+    uint32_t x0 = wrap_texel_i(fx0, w), x1 = wrap_texel_i(fx0 + 1.0f, w);
+    uint32_t y0 = wrap_texel_i(fy0, h), y1 = wrap_texel_i(fy0 + 1.0f, h);
+    float c00[4], c10[4], c01[4], c11[4];
+    tex_fetch(tt, d, mip, x0, y0, c00); tex_fetch(tt, d, mip, x1, y0, c10);
+    tex_fetch(tt, d, mip, x0, y1, c01); tex_fetch(tt, d, mip, x1, y1, c11);
+    for (int c = 0; c < 4; ++c) {
+        float top = c00[c] * (1.0f - fx) + c10[c] * fx;
+        float bot = c01[c] * (1.0f - fx) + c11[c] * fx;
+        o[c] = top * (1.0f - fy) + bot * fy;
+    }
+}
+static void tex_nearest(const r3o_textures *tt, const r3o_texture_desc *d, uint32_t mip, float u, float v, float o[4]) {
+    uint32_t w = tex_mip_dim(d->width, mip), h = tex_mip_dim(d->height, mip);
+    tex_fetch(tt, d, mip, wrap_texel_i(floorf(u * (float)w), w), wrap_texel_i(floorf(v * (float)h), h), o);
+}
+/* textureSampleGrad(textures[id - 1], nearest ? nearest_sampler : primary_sampler, (u, v), ddx, ddy) */
+static void tex_sample_grad(const r3o_textures *tt, uint32_t id, int nearest, float u, float v, const float ddx[2],
+                            const float ddy[2], float o[4]) {
+    if (id == 0u || id > tt->n) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
+    const r3o_texture_desc *d = &tt->descs[id - 1u];
+    float W = (float)d->width, H = (float)d->height;
+    float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
+    float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+    uint32_t level = 0;
+    float frac = 0.0f;
+    if (rho > 1.0f && rho < INFINITY) {
+        uint32_t bits; memcpy(&bits, &rho, 4);
+        level = (bits >> 23) - 127u;
+        frac = (float)(bits & 0x7FFFFFu) / 8388608.0f;
+    } else if (rho == INFINITY) {
+        level = d->mips;  /* clamped below */
+    }
+    if (level >= d->mips - 1u) { level = d->mips - 1u; frac = 0.0f; }
+    if (nearest) {
+        if (frac >= 0.5f) level += 1u;  /* level + 1 <= mips - 1 here */
+        tex_nearest(tt, d, level, u, v, o);
+        return;
+    }
+    tex_bilinear(tt, d, level, u, v, o);
+    if (frac > 0.0f) {
+        float hi[4];
+        tex_bilinear(tt, d, level + 1u, u, v, hi);
+        for (int c = 0; c < 4; ++c) o[c] = o[c] * (1.0f - frac) + hi[c] * frac;
+    }
+}
+/*
+ * MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + rend3/shaders/mipmap.wgsl): every level is a blit of the
+ * previous one through a Linear / ClampToEdge sampler at the destination texel centres, rendered into the
+ * texture's own format (so an sRGB texture is decoded, filtered and re-encoded per level).  `texels` holds mip 0 on
+ * entry and the whole chain on return.  Float -> unorm8: x * 255 + 0.5, truncated (sRGB: exact OETF first).
+ */
+static float srgb_oetf_tex(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    if (x <= 0.0031308f) return x * 12.92f;
+    return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
+}
+void r3o_generate_mips(uint32_t format, uint32_t width, uint32_t height, uint32_t mips, uint32_t *texels) {
+    init_srgb8();
+    uint64_t src_off = 0;
+    for (uint32_t l = 1; l < mips; ++l) {
+        uint32_t sw = tex_mip_dim(width, l - 1u), sh = tex_mip_dim(height, l - 1u);
+        uint32_t dw = tex_mip_dim(width, l), dh = tex_mip_dim(height, l);
+        uint64_t dst_off = src_off + (uint64_t)sw * sh;
+        for (uint32_t y = 0; y < dh; ++y)
+            for (uint32_t x = 0; x < dw; ++x) {
+                float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+                float tx = u * (float)sw - 0.5f, ty = v * (float)sh - 0.5f;
+                float fx0 = floorf(tx), fy0 = floorf(ty);
+                float fx = tx - fx0, fy = ty - fy0;
+                int ix = (int)fx0, iy = (int)fy0;
+                uint32_t x0 = (uint32_t)(ix < 0 ? 0 : (ix > (int)sw - 1 ? (int)sw - 1 : ix));
+                uint32_t x1 = (uint32_t)(ix + 1 < 0 ? 0 : (ix + 1 > (int)sw - 1 ? (int)sw - 1 : ix + 1));
+                uint32_t y0 = (uint32_t)(iy < 0 ? 0 : (iy > (int)sh - 1 ? (int)sh - 1 : iy));
+                uint32_t y1 = (uint32_t)(iy + 1 < 0 ? 0 : (iy + 1 > (int)sh - 1 ? (int)sh - 1 : iy + 1));
+                uint32_t t[4] = {texels[src_off + (uint64_t)y0 * sw + x0], texels[src_off + (uint64_t)y0 * sw + x1],
+                                 texels[src_off + (uint64_t)y1 * sw + x0], texels[src_off + (uint64_t)y1 * sw + x1]};
+                uint32_t out = 0;
+                for (int c = 0; c < 4; ++c) {
+                    float q[4];
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t b = (t[k] >> (8 * c)) & 0xFFu;
+                        q[k] = (format == 1u && c < 3) ? g_srgb8_to_linear[b] : (float)b / 255.0f;
+                    }
+                    float top = q[0] * (1.0f - fx) + q[1] * fx;
+                    float bot = q[2] * (1.0f - fx) + q[3] * fx;
+                    float r = top * (1.0f - fy) + bot * fy;
+                    float e = (format == 1u && c < 3) ? srgb_oetf_tex(r) : fminf(fmaxf(r, 0.0f), 1.0f);
+                    out |= (uint32_t)(e * 255.0f + 0.5f) << (8 * c);
+                }
+                texels[dst_off + (uint64_t)y * dw + x] = out;
+            }
+        src_off = dst_off;
+    }
+}
+
+/* vertex_attributes.wgsl: vec2<f32> texture coordinates (attribute 3); missing attribute reads (0, 0) */
+static inline void fetch_uv0(const r3o_object *ob, const uint32_t *mesh, uint32_t vtx, float o[2]) {
+    if (ob->attr_off[3] == R3O_INVALID) { o[0] = o[1] = 0.0f; return; }
+    uint32_t w = ob->attr_off[3] / 4u + vtx * 2u;
+    memcpy(&o[0], &mesh[w], 4);
+    memcpy(&o[1], &mesh[w + 1u], 4);
+}
+
+/* alpha for the cutout test (opaque.wgsl:213-235 / depth.wgsl:112-125); tex_alpha = albedo texture alpha or 1 */
+static float material_alpha(const r3o_material *m, float tex_alpha, float vertex_alpha) {
     float alpha = 1.0f;
     if (m->flags & FLAGS_ALBEDO_ACTIVE) {
+        alpha = tex_alpha;
         if (m->flags & FLAGS_ALBEDO_BLEND) alpha *= vertex_alpha;
     }
     alpha *= m->albedo[3];
     return alpha;
+}
+
+/* perspective-correct interpolation of a vec2 attribute at pixel centre (px + 0.5, py + 0.5), covered or not */
+static void interp_vec2(const tri_setup *ts, const float a[3][2], int px, int py, float o[2]) {
+    float E[3];
+    (void)edge_eval(ts, (float)px + 0.5f, (float)py + 0.5f, E);
+    float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+    float l0 = E[0] * rs, l1 = E[1] * rs, l2 = E[2] * rs;
+    for (int c = 0; c < 2; ++c) o[c] = (l0 * a[0][c] + l1 * a[1][c]) + l2 * a[2][c];
+}
+/* (uv_transform * vec3(uv, 1)).xy, mat3x3 stored as three padded vec4 columns */
+static void uv_transform(const float *m, const float uv[2], float o[2]) {
+    for (int c = 0; c < 2; ++c) o[c] = (m[c] * uv[0] + m[4 + c] * uv[1]) + m[8 + c] * 1.0f;
+}
+/*
+ * Fragment-stage texture coordinates of pixel (x, y) and their screen-space derivatives.  dpdx / dpdy are the
+ * differences inside the pixel's 2x2 quad ("fine" derivatives: same row for dpdx, same column for dpdy), each
+ * operand evaluated as its own fragment invocation would (helper invocations extrapolate the plane of the
+ * triangle exactly like interp_vec2).  `m` = uv_transform0 or NULL (depth.wgsl uses the raw coordinates).
+ */
+static void frag_coords(const tri_setup *ts, const float uv[3][2], const float *m, int x, int y, float coords[2],
+                        float ddx[2], float ddy[2]) {
+    int xq = x & ~1, yq = y & ~1;
+    float c[4][2]; /* (xq,y) (xq+1,y) (x,yq) (x,yq+1) */
+    const int pts[4][2] = {{xq, y}, {xq + 1, y}, {x, yq}, {x, yq + 1}};
+    for (int k = 0; k < 4; ++k) {
+        float raw[2];
+        interp_vec2(ts, uv, pts[k][0], pts[k][1], raw);
+        if (m) uv_transform(m, raw, c[k]); else { c[k][0] = raw[0]; c[k][1] = raw[1]; }
+    }
+    const float *self = (x & 1) ? c[1] : c[0];
+    coords[0] = self[0]; coords[1] = self[1];
+    for (int k = 0; k < 2; ++k) { ddx[k] = c[1][k] - c[0][k]; ddy[k] = c[3][k] - c[2][k]; }
 }
 
 static float fetch_color_alpha(const r3o_object *ob, const uint32_t *mesh, uint32_t vtx) {
@@ -554,8 +757,11 @@ static const float SAMPLE_POS_4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.
 void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
                            const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
                            const uint32_t *tri_base, const uint32_t *list_obj, const uint32_t *list_tri,
-                           uint64_t n, uint32_t w, uint32_t h, uint32_t samples, uint64_t *vis) {
+                           uint64_t n, uint32_t w, uint32_t h, uint32_t samples, const r3o_texture_desc *tdescs,
+                           uint32_t ntex, const uint32_t *texels, uint64_t *vis) {
     const float(*spos)[2] = samples == 4u ? SAMPLE_POS_4 : SAMPLE_POS_1;
+    r3o_textures tt = {tdescs, ntex, texels};
+    init_srgb8();
     float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
     int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -573,10 +779,14 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
         if (!ts.valid) continue;
         int x0, y0, x1, y1;
         tri_bounds(baked[o].model_view_proj, v, half_w, half_h, (int)w, (int)h, &x0, &y0, &x1, &y1);
-        float va[3] = {1.0f, 1.0f, 1.0f};
+        float va[3] = {1.0f, 1.0f, 1.0f}, uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
         int need_alpha = key == 1;
+        int alpha_tex = need_alpha && (mat->flags & FLAGS_ALBEDO_ACTIVE) && mat->tex[0] != 0u;
         if (need_alpha)
-            for (int k = 0; k < 3; ++k) va[k] = fetch_color_alpha(ob, mesh, idx[k]);
+            for (int k = 0; k < 3; ++k) {
+                va[k] = fetch_color_alpha(ob, mesh, idx[k]);
+                if (alpha_tex) fetch_uv0(ob, mesh, idx[k], uv[k]);
+            }
         uint32_t slot = tri_base[o] + t;
         for (int y = y0; y <= y1; ++y)
             for (int x = x0; x <= x1; ++x) {
@@ -596,7 +806,14 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
                     (void)edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E);
                     float rs = 1.0f / ((E[0] + E[1]) + E[2]);
                     float a = ((E[0] * rs) * va[0] + (E[1] * rs) * va[1]) + (E[2] * rs) * va[2];
-                    if (material_alpha(mat, a) < mat->alpha_cutout) continue;
+                    float ta = 1.0f;
+                    if (alpha_tex) { /* opaque.wgsl:207-215: transformed coords, sampler by FLAGS_NEAREST */
+                        float coords[2], ddx[2], ddy[2], texel[4];
+                        frag_coords(&ts, uv, mat->uv_transform0, x, y, coords, ddx, ddy);
+                        tex_sample_grad(&tt, mat->tex[0], (mat->flags & FLAGS_NEAREST) != 0, coords[0], coords[1], ddx, ddy, texel);
+                        ta = texel[3];
+                    }
+                    if (material_alpha(mat, ta, a) < mat->alpha_cutout) continue;
                 }
                 for (uint32_t sm = 0; sm < samples; ++sm) {
                     if (!(mask & (1u << sm))) continue;
@@ -616,7 +833,10 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
 void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
                       const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
                       const uint32_t *list_obj, const uint32_t *list_tri, uint64_t n, float *atlas,
-                      uint32_t atlas_w, uint32_t vp_x, uint32_t vp_y, uint32_t vp_size) {
+                      uint32_t atlas_w, uint32_t vp_x, uint32_t vp_y, uint32_t vp_size, const r3o_texture_desc *tdescs,
+                      uint32_t ntex, const uint32_t *texels) {
+    r3o_textures tt = {tdescs, ntex, texels};
+    init_srgb8();
     float half = (float)vp_size / 2.0f;
     int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -634,10 +854,14 @@ void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, c
         if (!ts.valid) continue;
         int x0, y0, x1, y1;
         tri_bounds(baked[o].model_view_proj, v, half, half, (int)vp_size, (int)vp_size, &x0, &y0, &x1, &y1);
-        float va[3] = {1.0f, 1.0f, 1.0f};
+        float va[3] = {1.0f, 1.0f, 1.0f}, uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
         int need_alpha = key == 1;
+        int alpha_tex = need_alpha && (mat->flags & FLAGS_ALBEDO_ACTIVE) && mat->tex[0] != 0u;
         if (need_alpha)
-            for (int k = 0; k < 3; ++k) va[k] = fetch_color_alpha(ob, mesh, idx[k]);
+            for (int k = 0; k < 3; ++k) {
+                va[k] = fetch_color_alpha(ob, mesh, idx[k]);
+                if (alpha_tex) fetch_uv0(ob, mesh, idx[k], uv[k]);
+            }
         for (int y = y0; y <= y1; ++y)
             for (int x = x0; x <= x1; ++x) {
                 float E[3];
@@ -647,7 +871,15 @@ void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, c
                 if (need_alpha) {
                     float rs = 1.0f / ((E[0] + E[1]) + E[2]);
                     float a = ((E[0] * rs) * va[0] + (E[1] * rs) * va[1]) + (E[2] * rs) * va[2];
-                    if (material_alpha(mat, a) < mat->alpha_cutout) continue;
+                    float ta = 1.0f;
+                    if (alpha_tex) { /* depth.wgsl:108-118 quirks reproduced: raw coords0 (no uv_transform), always the
+                                      * primary sampler, and uvdy = dpdx(coords) */
+                        float coords[2], ddx[2], ddy[2], texel[4];
+                        frag_coords(&ts, uv, NULL, x, y, coords, ddx, ddy);
+                        tex_sample_grad(&tt, mat->tex[0], 0, coords[0], coords[1], ddx, ddx, texel);
+                        ta = texel[3];
+                    }
+                    if (material_alpha(mat, ta, a) < mat->alpha_cutout) continue;
                 }
                 float *dst = &atlas[(uint64_t)(vp_y + (uint32_t)y) * atlas_w + vp_x + (uint32_t)x];
                 if (z >= *dst) *dst = z;
@@ -775,6 +1007,7 @@ typedef struct {
     const float *atlas;
     uint32_t atlas_w, atlas_h;
     const float *light_mats, *light_l, *pview;
+    r3o_textures tt;
 } shade_ctx;
 
 /* opaque.wgsl VS (:91-135) + FS (:203-551) for triangle slot `id - 1` at the centre of pixel (x, y) */
@@ -842,6 +1075,12 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
     pixel_data px;
     if (mat->flags & FLAGS_ALBEDO_ACTIVE) {
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
+        if (mat->tex[0] != 0u) { /* opaque.wgsl:207-215 */
+            float uv[3][2], coords[2], ddx[2], ddy[2];
+            for (int k = 0; k < 3; ++k) fetch_uv0(ob, mesh, idx[k], uv[k]);
+            frag_coords(&ts, uv, mat->uv_transform0, (int)x, (int)y, coords, ddx, ddy);
+            tex_sample_grad(&sc->tt, mat->tex[0], (mat->flags & FLAGS_NEAREST) != 0, coords[0], coords[1], ddx, ddy, px.albedo);
+        }
         if (mat->flags & FLAGS_ALBEDO_BLEND) {
             if (mat->flags & FLAGS_ALBEDO_VERTEX_SRGB) {
                 for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
@@ -924,7 +1163,8 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, co
                const r3o_baked *baked, const r3o_material *materials, const uint32_t *tri_base,
                uint32_t n_dir, const r3o_dir_light *dir, uint32_t n_point, const r3o_point_light *point,
                const float *atlas, uint32_t atlas_w, uint32_t atlas_h, const float *clear_color,
-               uint16_t *hdr_out) {
+               const r3o_texture_desc *tdescs, uint32_t ntex, const uint32_t *texels, uint16_t *hdr_out) {
+    init_srgb8();
     float *light_mats = (float *)malloc(sizeof(float) * 16 * (n_dir ? n_dir : 1));
     float *light_l = (float *)malloc(sizeof(float) * 3 * (n_dir ? n_dir : 1));
     float *pview = (float *)malloc(sizeof(float) * 4 * (n_point ? n_point : 1));
@@ -938,7 +1178,7 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, co
         mat4_mul_vec4(fu->view, point[i].position[0], point[i].position[1], point[i].position[2], point[i].position[3],
                       pview + 4 * i);
     shade_ctx sc = {w, h, fu, hdr, objects, mesh, baked, materials, tri_base, n_dir, dir, n_point, point,
-                    atlas, atlas_w, atlas_h, light_mats, light_l, pview};
+                    atlas, atlas_w, atlas_h, light_mats, light_l, pview, {tdescs, ntex, texels}};
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (uint32_t y = 0; y < h; ++y)

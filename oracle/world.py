@@ -27,16 +27,20 @@ FLAGS_AOMR_COMBINED = 0x0040
 FLAGS_AOMR_SPLIT = 0x0100
 FLAGS_CC_GLTF_COMBINED = 0x0400
 FLAGS_UNLIT = 0x2000
+FLAGS_NEAREST = 0x4000
 
 OPAQUE, CUTOUT, BLEND = 0, 1, 2  # TransparencyType as u64 key, pbr/material.rs:383-392,497-499
 
 
 def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, roughness=0.0, metallic=0.0,
                     reflectance=0.5, emissive=(0, 0, 0), ao=1.0, clear_coat=0.0, clear_coat_roughness=0.0,
-                    cutout=None, vertex_srgb=True):
+                    cutout=None, vertex_srgb=True, albedo_texture=None, nearest=False, uv_transform0=None):
     """ShaderMaterial::from_material (pbr/material.rs:548-583) behind the 48-byte texture-id prefix
     (managers/material.rs:25-29).  albedo_mode: "none" | "vertex" | "value" | "value_vertex"
-    (AlbedoComponent, pbr/material.rs:60-140; Default = None -> flags 0, value (0,0,0,1))."""
+    (AlbedoComponent, pbr/material.rs:60-140; Default = None -> flags 0, value (0,0,0,1)), or with
+    `albedo_texture` (a texture handle) "texture" | "texture_vertex" | "texture_value" | "texture_vertex_value".
+    nearest: SampleType::Nearest (FLAGS_NEAREST); uv_transform0: 3x3 row-major nested list (Mat3, column-major on
+    the GPU as three padded vec4 columns)."""
     rec = np.zeros(52, dtype=f32)
     ru = rec.view(np.uint32)
     # uv transforms = identity mat3 as 3 vec4 columns
@@ -54,8 +58,23 @@ def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, rough
     elif albedo_mode == "value_vertex":
         flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
         alb = albedo
+    elif albedo_mode in ("texture", "texture_value"):
+        flags |= FLAGS_ALBEDO_ACTIVE
+        alb = albedo if albedo_mode == "texture_value" else (1.0, 1.0, 1.0, 1.0)
+    elif albedo_mode in ("texture_vertex", "texture_vertex_value"):
+        flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
+        alb = albedo if albedo_mode == "texture_vertex_value" else (1.0, 1.0, 1.0, 1.0)
     else:
         raise ValueError(albedo_mode)
+    if albedo_mode.startswith("texture"):
+        assert albedo_texture is not None
+        ru[0] = int(albedo_texture) + 1  # NonZeroU32 index into the bindless array (managers/material.rs:25-29)
+    if nearest:
+        flags |= FLAGS_NEAREST
+    if uv_transform0 is not None:
+        m = np.asarray(uv_transform0, dtype=f32).reshape(3, 3)
+        for col in range(3):
+            rec[12 + 4 * col: 12 + 4 * col + 3] = m[:, col]
     # NormalTexture::None -> 0 ; AoMRTextures::None -> AOMR_SPLIT ; ClearcoatTextures::None -> CC_GLTF_COMBINED
     flags |= FLAGS_AOMR_SPLIT | FLAGS_CC_GLTF_COMBINED
     if unlit:
@@ -92,6 +111,9 @@ class OracleRenderer:
         self.free_handles = []
         self.pending_free = []
         self.skip_shadow_draw = False
+        self.tex_descs = np.zeros((0, 8), dtype=np.uint32)  # r3o_texture_desc rows
+        self.tex_pool = np.zeros(1, dtype=np.uint32)
+        self.tex_used = 0
         self.deferred_removals = []
         self.next_handle = 0
         self.dir_lights = []
@@ -130,8 +152,30 @@ class OracleRenderer:
         return inputs, (np.ascontiguousarray(np.concatenate(mats)) if mats else np.zeros((0, 16), dtype=f32))
 
     # ------------------------------------------------------------------ world edits
+    def add_texture_2d(self, rgba8, srgb=True, mip_count=1, mip_source="uploaded"):
+        """Renderer::add_texture_2d (rend3/src/renderer/mod.rs) with Texture{data, format, size, mip_count, mip_source}:
+        rgba8 = (H, W, 4) u8 (mip 0, or every mip concatenated row-major when mip_source == "uploaded" and
+        mip_count > 1); format Rgba8UnormSrgb | Rgba8Unorm; mip_count: int or "maximum" (MipmapCount::Maximum);
+        mip_source "uploaded" | "generated" (MipmapSource).  Returns the texture handle (index)."""
+        host_mod = host
+        data, w, h, mips = host_mod.prepare_texture(self.lib, rgba8, srgb, mip_count, mip_source)
+        desc = np.array([[self.tex_used, w, h, mips, 1 if srgb else 0, 0, 0, 0]], dtype=np.uint32)
+        if self.tex_used + len(data) > len(self.tex_pool):
+            grown = np.zeros(max(2 * len(self.tex_pool), self.tex_used + len(data)), dtype=np.uint32)
+            grown[: self.tex_used] = self.tex_pool[: self.tex_used]
+            self.tex_pool = grown
+        self.tex_pool[self.tex_used: self.tex_used + len(data)] = data
+        self.tex_used += len(data)
+        self.tex_descs = np.concatenate([self.tex_descs, desc])
+        return len(self.tex_descs) - 1
+
+    def _tex_args(self):
+        lib = self.lib
+        return (lib.ptr(np.ascontiguousarray(self.tex_descs)) if len(self.tex_descs) else None, len(self.tex_descs),
+                lib.ptr(self.tex_pool))
+
     def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT, tangents=None,
-                 joint_indices=None, joint_weights=None):
+                 joint_indices=None, joint_weights=None, uv0=None):
         positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
         if indices is None:
             indices = np.arange(len(positions), dtype=np.uint32)
@@ -155,6 +199,8 @@ class OracleRenderer:
         m.attr_off[1] = 4 * push(normals.view(np.uint32).reshape(-1))
         if tangents is not None:
             m.attr_off[2] = 4 * push(np.ascontiguousarray(tangents, dtype=f32).reshape(-1).view(np.uint32))
+        if uv0 is not None:  # VERTEX_ATTRIBUTE_TEXTURE_COORDINATES_0: vec2<f32> (rend3-types/src/attribute.rs)
+            m.attr_off[3] = 4 * push(np.ascontiguousarray(uv0, dtype=f32).reshape(-1, 2).reshape(-1).view(np.uint32))
         if colors is not None:
             colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 4)
             m.attr_off[5] = 4 * push(colors.view(np.uint32).reshape(-1))
@@ -341,7 +387,7 @@ class OracleRenderer:
                 lo, lt = lo[:0], lt[:0]
             lib.r3o_raster_depth(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words), lib.ptr(baked),
                                  lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(lo), lib.ptr(lt), len(lo),
-                                 lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"])
+                                 lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"], *self._tex_args())
             out["shadows"].append(dict(header=hdr, visible=visible, tri_base=tri_base, **{"pass": pass_bits}))
         if exchange is not None and shadows:
             exchange("shadow", atlas)
@@ -357,7 +403,7 @@ class OracleRenderer:
             if len(lo):
                 lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
                                           lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
-                                          lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, lib.ptr(vis))
+                                          lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, *self._tex_args(), lib.ptr(vis))
 
         # 8. pass 1: last frame's predicted triangles (forward.rs:224-232)
         predicted = self.cam_state.get("predicted_list")
@@ -393,7 +439,7 @@ class OracleRenderer:
         lib.r3o_shade(lib.ptr(vis), width, height, samples, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
                       lib.ptr(self.mesh_words), lib.ptr(baked), lib.ptr(mats), lib.ptr(tri_base), n_dir,
                       lib.ptr(dir_arr) if n_dir else None, n_pt, lib.ptr(pt_arr) if n_pt else None,
-                      lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), lib.ptr(hdr16))
+                      lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), *self._tex_args(), lib.ptr(hdr16))
         rgba_f = np.zeros((height, width, 4), dtype=f32)
         rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
         lib.r3o_tonemap(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8))

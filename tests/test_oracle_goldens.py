@@ -287,6 +287,32 @@ def test_static_gltf_example():
     assert (diff <= 1).mean() >= 0.998, (diff <= 1).mean()
 
 
+def build_textured_quad(r, hm, mk, resolution=(1280, 720)):
+    """examples/src/textured_quad/mod.rs:11-113: a 300-unit quad with checker.png (300x300, Rgba8UnormSrgb, one mip)
+    as unlit albedo texture, SampleType::Nearest, orthographic camera sized to the resolution: one texel per pixel."""
+    size = 300.0
+    pos = [(-size * 0.5, size * 0.5, 0.0), (size * 0.5, size * 0.5, 0.0), (size * 0.5, -size * 0.5, 0.0), (-size * 0.5, -size * 0.5, 0.0)]
+    uv = [(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)]
+    mesh = r.add_mesh(pos, indices=[0, 1, 2, 2, 3, 0], mesh_handedness=hm.LEFT, uv0=uv)
+    img = np.array(Image.open(os.path.join(GOLD, "textured_quad-checker.png")).convert("RGBA"))
+    tex = r.add_texture_2d(img, srgb=True, mip_count=1, mip_source="uploaded")
+    mat = r.add_material(mk(albedo_mode="texture", albedo_texture=tex, unlit=True, nearest=True))
+    r.add_object(mesh, mat, hm.identity())
+    view = hm.mat4_mul(hm.from_euler_xyz(0.0, 0.0, 0.0), hm.translation((0.0, 0.0, 1.0)))
+    r.set_camera_data(view, ("orthographic", (float(resolution[0]), float(resolution[1]), 10.0)))
+
+
+def test_textured_quad_example():
+    """examples/src/textured_quad/mod.rs:181-192, Threshold::Mean(0.0) at 1280x720: pins the texture path of row N2
+    (uv attribute, perspective-correct interpolation, texel addressing, sRGB decode, nearest sampler)."""
+    w, h = 1280, 720
+    r = OracleRenderer(hm.LEFT, aspect_ratio=f32(w) / f32(h))
+    build_textured_quad(r, hm, mk)
+    out = r.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+    gold = load("textured_quad-screenshot.png")
+    assert np.array_equal(out["rgba8"][..., :3], gold[..., :3])
+
+
 def build_skinning_example(r, hm, mk, t=0.0):
     """examples/src/skinning/mod.rs:28-110 at time t (the screenshot is t = 0): RiggedSimple.glb through the GLB
     reader + scene instancing (rend3_amd/gltf.py, row N1)."""
