@@ -87,6 +87,18 @@ typedef struct r3n_material208 {
     uint32_t flags;
 } r3n_material208;
 
+/* One entry of the bindless texture array (rend3/src/managers/texture.rs; Texture in rend3-types/src/lib.rs:
+ * data, format, size, mip_count).  RGBA8 only in this slice; `offset` = first texel (u32) of mip 0 in the texel
+ * pool, the mips follow contiguously; material records refer to entry i as texture id i + 1 (0 = none). */
+typedef struct r3n_texture_desc32 {
+    uint32_t offset;
+    uint32_t width, height, mips;
+    uint32_t format; /* R3N_TEXTURE_RGBA8_UNORM | R3N_TEXTURE_RGBA8_UNORM_SRGB */
+    uint32_t _pad[3];
+} r3n_texture_desc32;
+#define R3N_TEXTURE_RGBA8_UNORM 0u
+#define R3N_TEXTURE_RGBA8_UNORM_SRGB 1u
+
 /* PerCameraUniform header, 240 B (rend3-routine/src/culling/culler.rs:158-175) */
 typedef struct r3n_camera_header240 {
     float view[16];
@@ -161,6 +173,10 @@ int r3n_objects_write(r3n_ctx *ctx, const uint32_t *slots, const r3n_object128 *
  *      (R3N_KEY_*), which is host-side state in the reference (not part of the 208-byte record). */
 int r3n_materials_write(r3n_ctx *ctx, const uint32_t *slots, const r3n_material208 *records,
                         const uint8_t *keys, uint32_t n);
+/*      TextureManager (rend3/src/managers/texture.rs): replaces the whole bindless 2D texture array.  Material records
+ *      sample entry `id - 1` (opaque.wgsl:151-160).  Formats other than RGBA8 -> R3N_ERR_UNSUPPORTED. */
+int r3n_textures_write(r3n_ctx *ctx, const r3n_texture_desc32 *descs, uint32_t n_textures, const uint32_t *texels,
+                       uint64_t n_texels);
 /*      DirectionalLightManager / PointLightManager buffers, byte-identical:
  *      u32 count @0, array @16 (stride 128 / 32): rend3/src/managers/directional.rs:31-53,135-153, point.rs:14-74 */
 int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t directional_bytes,
@@ -275,6 +291,9 @@ void r3n_host_look_at(const float eye[3], const float center[3], const float up[
 void r3n_host_projection(int kind, const float *params, int rh, float aspect_ratio, float *out);
 /* Frustum::from_matrix, rend3/src/util/frustum.rs:96-145: 5 planes x vec4 */
 void r3n_host_frustum_from_matrix(const float *m, float *planes20);
+/* MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + rend3/shaders/mipmap.wgsl): fills mips 1.. of an
+ * RGBA8 chain whose mip 0 is in place; Linear / ClampToEdge blit per level in the texture's own format. */
+void r3n_host_generate_mips(uint32_t format, uint32_t width, uint32_t height, uint32_t mips, uint32_t *texels);
 int r3n_host_frustum_contains_sphere(const float *planes20, const float center[3], float radius);
 /* BoundingSphere::{from_mesh, apply_transform}, frustum.rs:15-56 */
 void r3n_host_bounding_sphere_from_mesh(const float *positions, uint64_t vertex_count, float out_center[3],

@@ -31,6 +31,7 @@ SIGNATURES = {
     "r3n_mesh_buffer_write": (cint, [vp, u64, vp, u64]),
     "r3n_objects_write": (cint, [vp, vp, vp, u32, u32]),
     "r3n_materials_write": (cint, [vp, vp, vp, vp, u32]),
+    "r3n_textures_write": (cint, [vp, vp, u32, vp, u64]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
     "r3n_skinning": (cint, [vp, vp, u32, vp, u32]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "r3n_host_calculate_normals": (None, [vp, u64, vp, u64, cint, vp]),
     "r3n_host_shadow_camera": (None, [vp, cfloat, u32, vp, cint, vp, vp]),
     "r3n_host_allocate_shadow_atlas": (u32, [vp, vp, u32, u32, vp, vp]),
+    "r3n_host_generate_mips": (None, [u32, u32, u32, u32, vp]),
 }
 
 _LIB = None

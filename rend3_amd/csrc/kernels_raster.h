@@ -14,6 +14,7 @@
 // wavefront each (8x8 pixel blocks per step).
 #pragma once
 #include "device_math.h"
+#include "texture.h"
 
 struct RasterArgs {
     const r3n_camera_header240 *hdr;
@@ -35,12 +36,18 @@ struct RasterArgs {
     r3n_big_item *big_items;               // R3N_BIGQ sub-queues of big_capacity entries each
     uint32_t *big_count;                   // [R3N_BIGQ]
     uint32_t big_capacity;
+    r3n_big_uv *big_uv;                    // same indexing as big_items; textured cutout triangles only
+    TextureArgs tex;
 };
 
 // opaque.wgsl:214-235 / depth.wgsl:98-125 (untextured paths): alpha the cutout test compares with the threshold
-R3N_DEV float cutout_alpha(uint32_t mat_flags, float mat_alpha, float vertex_alpha) {
+// tex_alpha = alpha of the albedo texture sample, or 1 without one
+R3N_DEV float cutout_alpha(uint32_t mat_flags, float mat_alpha, float tex_alpha, float vertex_alpha) {
     float alpha = 1.0f;
-    if ((mat_flags & R3N_FLAGS_ALBEDO_ACTIVE) && (mat_flags & R3N_FLAGS_ALBEDO_BLEND)) alpha *= vertex_alpha;
+    if (mat_flags & R3N_FLAGS_ALBEDO_ACTIVE) {
+        alpha = tex_alpha;
+        if (mat_flags & R3N_FLAGS_ALBEDO_BLEND) alpha *= vertex_alpha;
+    }
     alpha *= mat_alpha;
     return alpha;
 }
@@ -60,11 +67,15 @@ struct TriWork {
     uint32_t mat_flags;                 // cutout key only: material flags, albedo alpha, alpha_cutout
     float mat_alpha, mat_cutoff;
     uint32_t slot1;  // canonical slot + 1 (forward)
+    float uv[3][2];                     // cutout key + albedo texture only
+    bool alpha_tex;                     // the cutout alpha samples the albedo texture
     bool cutout;
     int x0, y0, x1, y1;
 };
 
-template <bool DEPTH_ONLY>
+// TEX: the launch may meet cutout materials whose alpha comes from the albedo texture (row N2).  The lean variant
+// (no texture code, fewer registers) is launched whenever the world has no textures or the key is not cutout.
+template <bool DEPTH_ONLY, bool TEX>
 R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, bool positive_visible, TriWork &tw) {
     const r3n_object128 &ob = a.objects[obj];
     if (ob.enabled == 0u) return false;  // opaque.wgsl:104-112 / depth.wgsl:64-72
@@ -87,11 +98,19 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     tw.material = ob.material_index < a.n_materials ? ob.material_index : 0u;
     tw.va[0] = tw.va[1] = tw.va[2] = 1.0f;
     tw.mat_flags = 0u; tw.mat_alpha = 1.0f; tw.mat_cutoff = 0.0f;
+    tw.alpha_tex = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tw.uv[k][0] = tw.uv[k][1] = 0.0f;
     if (tw.cutout) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) tw.va[k] = fetch_color_alpha(ob, a.mesh, idx[k]);
         const r3n_material208 &m = a.materials[tw.material];
         tw.mat_flags = m.flags; tw.mat_alpha = m.albedo[3]; tw.mat_cutoff = m.alpha_cutout;
+        tw.alpha_tex = TEX && (m.flags & R3N_FLAGS_ALBEDO_ACTIVE) && m.textures[0] != 0u;
+        if (TEX && tw.alpha_tex) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], tw.uv[k]);
+        }
     }
     if (!DEPTH_ONLY) tw.slot1 = a.tri_base[obj] + tri + 1u;
     return true;
@@ -106,12 +125,30 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 // PREREAD: plain load + compare before the atomic.  It filters occluded fragments cheaply (the load may be
 // stale, which is only conservative because keys grow monotonically) but puts a dependent load in front of every
 // atomic; without it the atomic is fire-and-forget.
+// Alpha of the albedo texture at pixel (x, y) for the cutout test.  Forward (opaque.wgsl:207-215): coordinates through
+// uv_transform0, sampler chosen by FLAGS_NEAREST.  Depth-only (depth.wgsl:108-118, quirks reproduced): raw coords0,
+// always the primary sampler, and uvdy = dpdx(coords).
+template <bool DEPTH_ONLY, bool TEX>
+R3N_DEV float cutout_texture_alpha(const RasterArgs &a, const TriWork &tw, int x, int y) {
+    if (!TEX || !tw.alpha_tex) return 1.0f;
+    const r3n_material208 &m = a.materials[tw.material];
+    float coords[2], ddx[2], ddy[2], texel[4];
+    if (DEPTH_ONLY) {
+        frag_coords(tw.ts, tw.uv, nullptr, x, y, coords, ddx, ddy);
+        tex_sample_grad(a.tex, m.textures[0], false, coords[0], coords[1], ddx, ddx, texel);
+    } else {
+        frag_coords(tw.ts, tw.uv, m.uv_transform0, x, y, coords, ddx, ddy);
+        tex_sample_grad(a.tex, m.textures[0], (m.flags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy, texel);
+    }
+    return texel[3];
+}
+
 // Multisampling (row N4; forward.rs:358 MultisampleState{count}): coverage and depth at the standard 4x sample
 // positions (the D3D / Vulkan standard locations every wgpu backend uses); the fragment -- here only its cutout
 // alpha -- once per pixel at the pixel centre, covered or not (no centroid qualifier in opaque.wgsl).
 __device__ static const float k_sample_pos4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}};
 
-template <bool DEPTH_ONLY, bool PREREAD, int S = 1>
+template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (S == 1) {
         float E[3];
@@ -122,7 +159,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         if (tw.cutout) {
             const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
             const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
         }
         const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
         const uint32_t zb = __float_as_uint(z);
@@ -152,7 +189,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             (void)edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E);
             const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
             const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, al) < tw.mat_cutoff) return;
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;
         }
         const size_t pix = ((size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x) * (size_t)S;
 #pragma unroll
@@ -178,7 +215,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
-template <bool DEPTH_ONLY, int S = 1>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
 __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
@@ -193,11 +230,11 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
     for (uint32_t i = (blockIdx.x / R3N_SUBQ) * 256u + threadIdx.x; i < n; i += stride) {
         const r3n_tri_ref ref = list[i];
         TriWork tw;
-        if (!prepare_triangle<DEPTH_ONLY>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
+        if (!prepare_triangle<DEPTH_ONLY, TEX>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
-                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S>(a, tw, x, y);
+                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
         } else {
             const uint32_t tx = (uint32_t)(bw + (R3N_TILE - 1)) / R3N_TILE, ty = (uint32_t)(bh + (R3N_TILE - 1)) / R3N_TILE;
             const uint32_t cnt = tx * ty;
@@ -222,10 +259,17 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
                     it.xy0 = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
                     it.xy1 = (uint32_t)rx1 | ((uint32_t)ry1 << 16);
                     big[start + t] = it;
+                    if (TEX && tw.alpha_tex) {
+                        r3n_big_uv bu;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { bu.uv[k][0] = tw.uv[k][0]; bu.uv[k][1] = tw.uv[k][1]; }
+                        bu._pad[0] = bu._pad[1] = 0u;
+                        a.big_uv[(size_t)bq * a.big_capacity + start + t] = bu;
+                    }
                 } else {
                     // queue full: never drop work -- scan the region here (slow path)
                     for (int y = ry0; y <= ry1; ++y)
-                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S>(a, tw, x, y);
+                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
                 }
             }
         }
@@ -258,7 +302,7 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 // the next item's record is in flight while the current one is scanned.  Waves walk the concatenation of the
 // R3N_BIGQ producer sub-queues with a stride of the wave count, which spreads neighbouring (similar-cost) items
 // over different waves.
-template <bool DEPTH_ONLY, int S = 1>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     // Pin the kernel arguments the scan uses into SGPRs here: hipcc otherwise sinks the wait for their s_load
     // into the scan loop, and an `s_waitcnt lgkmcnt(0)` there would also wait for the record prefetch below.
@@ -329,11 +373,21 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
         w.cutout = a.key == R3N_KEY_CUTOUT;  // launch-uniform
         w.material = bu(17);
         w.mat_flags = 0u; w.mat_alpha = 1.0f; w.mat_cutoff = 0.0f;
+        w.alpha_tex = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w.uv[k][0] = w.uv[k][1] = 0.0f;
         if (w.cutout) {
             sptr_t mp = (sptr_t)(unsigned long long)(a.materials + w.material);
             w.mat_alpha = __uint_as_float(mp[offsetof(r3n_material208, albedo) / 4 + 3]);
             w.mat_cutoff = __uint_as_float(mp[offsetof(r3n_material208, alpha_cutout) / 4]);
             w.mat_flags = mp[offsetof(r3n_material208, flags) / 4];
+            w.alpha_tex = TEX && (w.mat_flags & R3N_FLAGS_ALBEDO_ACTIVE) && mp[0] != 0u;
+            if (TEX && w.alpha_tex) {  // rec - big_items = item index; the uv record has the same index
+                const size_t item = (size_t)(reinterpret_cast<const r3n_big_item *>(rec) - a.big_items);
+                sptr_t up = (sptr_t)(unsigned long long)(a.big_uv + item);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { w.uv[k][0] = __uint_as_float(up[2 * k]); w.uv[k][1] = __uint_as_float(up[2 * k + 1]); }
+            }
         }
         const uint32_t kxy0 = bu(18), kxy1 = bu(19);
         const int rx0 = (int)(kxy0 & 0xFFFFu), ry0 = (int)(kxy0 >> 16);
@@ -355,7 +409,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 }
                 const int b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                 const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
-                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S>(a, w, x, y);
+                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX>(a, w, x, y);
             }
         } else {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
@@ -365,7 +419,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S>(a, w, x, y);
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX>(a, w, x, y);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
@@ -525,6 +579,7 @@ struct ShadeArgs {
     ushort4 *hdr_out;          // Rgba16Float
     uchar4 *ldr_out;           // Rgba8UnormSrgb: the tonemap blit fused into the resolve (one HDR round trip less)
     const unsigned char *srgb_lut;
+    TextureArgs tex;
 };
 
 struct LdsDirLight {
@@ -711,6 +766,7 @@ R3N_DEV ushort4 pack_half4(const float v[4]) {
 }
 
 // opaque.wgsl VS (:91-135) + FS (:203-551) for triangle slot `id - 1` at the centre of pixel (x, y).
+template <bool TEX>
 R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
                             uint32_t n_point, uint32_t id, uint32_t x, uint32_t y, float out[4]) {
     const uint32_t slot = id - 1u;
@@ -778,6 +834,13 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
+        if (TEX && mat.textures[0] != 0u) {  // opaque.wgsl:207-215
+            float uv[3][2], coords[2], ddx[2], ddy[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], uv[k]);
+            frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy);
+            tex_sample_grad(a.tex, mat.textures[0], (mflags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy, px.albedo);
+        }
         if (mflags & R3N_FLAGS_ALBEDO_BLEND) {
             if (mflags & R3N_FLAGS_ALBEDO_VERTEX_SRGB) {
 #pragma unroll
@@ -878,7 +941,7 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 // S = samples per pixel.  S == 4: every sample of the multisampled Rgba16Float target holds the half-rounded colour
 // of its nearest fragment (shaded once per distinct triangle, at the pixel centre) or the clear colour; the render
 // pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
-template <int S>
+template <int S, bool TEX>
 __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
@@ -933,7 +996,7 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
             a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc);
             return;
         }
-        shade_fragment(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
+        shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
     } else {
         uint32_t ids[S];
         float col[S][4];
@@ -955,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
             } else {
-                shade_fragment(a, s_dir, s_point, n_dir, n_point, ids[sm], x, y, v);
+                shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, ids[sm], x, y, v);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];

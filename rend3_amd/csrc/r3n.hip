@@ -78,6 +78,9 @@ struct r3n_ctx {
     bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
+    DevBuf tex_descs, tex_texels, srgb8_decode;  // bindless texture array (row N2) + sRGB8 -> linear table
+    uint32_t n_textures = 0;
+    DevBuf big_uv[1 + R3N_AUX_STREAMS];
     DevBuf srgb_lut;  // Rgba8UnormSrgb code of every half in [0, 1): kernels_raster.h k_build_srgb_lut
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
     uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {0, 0, 0, 0, 0};
@@ -381,15 +384,26 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
             return nullptr;
         }
     // empty light buffers: count = 0
-    bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
+    bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->srgb8_decode, 256 * 4, false, -1) == R3N_OK &&
+              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
               ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
     for (int lane = 0; ok && lane < 1 + R3N_AUX_STREAMS; ++lane)
         ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
-             ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK;
+             ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK &&
+             ensure(c, c->big_uv[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_uv), false, -1) == R3N_OK;
     if (ok) {
         hipLaunchKernelGGL(k_build_srgb_lut, dim3((R3N_SRGB_LUT_SIZE + 255u) / 256u), dim3(256), 0, c->stream,
                            c->srgb_lut.as<unsigned char>());
-        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        // sRGB8 -> linear decode table for texture fetches: built on the HOST (libm powf, like the oracle's), because
+        // every entry feeds f32 filtering arithmetic directly -- a last-ulp difference between libm and the device
+        // math library in any of the 256 entries would show up as 1-ulp HDR differences
+        float decode[256];
+        for (int i = 0; i < 256; ++i) {
+            const float e = (float)i / 255.0f;
+            decode[i] = e > 0.04045f ? std::pow((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f;
+        }
+        ok = hipMemcpyAsync(c->srgb8_decode.p, decode, sizeof decode, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
         if (!ok) c->err = "k_build_srgb_lut failed";
     }
     if (!ok) {
@@ -407,11 +421,11 @@ void r3n_destroy(r3n_ctx *c) {
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
         if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
     for (int lane = 0; lane < 1 + R3N_AUX_STREAMS; ++lane)
-        for (DevBuf *b : {&c->big_items[lane], &c->big_count[lane]})
+        for (DevBuf *b : {&c->big_items[lane], &c->big_uv[lane], &c->big_count[lane]})
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut};
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -505,6 +519,41 @@ int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208
         HIP_TRY(c, hipMemcpyAsync(c->material_keys.as<uint8_t>() + slots[i], keys + i, 1, hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return R3N_OK;
+}
+
+static TextureArgs texture_args(r3n_ctx *c) {
+    TextureArgs t;
+    t.descs = c->tex_descs.as<r3n_texture_desc32>();
+    t.count = c->n_textures;
+    t.texels = c->tex_texels.as<uint32_t>();
+    t.srgb8_to_linear = c->srgb8_decode.as<float>();
+    return t;
+}
+
+int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, const uint32_t *texels, uint64_t n_texels) {
+    if (!c || (n && (!descs || !texels))) return fail(c, R3N_ERR_INVALID_ARG, "textures write: null");
+    for (uint32_t i = 0; i < n; ++i) {
+        const r3n_texture_desc32 &d = descs[i];
+        if (d.format > R3N_TEXTURE_RGBA8_UNORM_SRGB) return fail(c, R3N_ERR_UNSUPPORTED, "textures write: only RGBA8 formats are built (row N2)");
+        if (!d.width || !d.height || !d.mips || d.width > 65535u || d.height > 65535u) return fail(c, R3N_ERR_INVALID_ARG, "textures write: bad extent");
+        uint32_t max_mips = 0;
+        for (uint32_t m = std::max(d.width, d.height); m; m >>= 1) ++max_mips;
+        if (d.mips > max_mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write: more mips than the extent has");
+        uint64_t need = d.offset;
+        for (uint32_t k = 0; k < d.mips; ++k) need += (uint64_t)std::max(1u, d.width >> k) * std::max(1u, d.height >> k);
+        if (need > n_texels) return fail(c, R3N_ERR_INVALID_ARG, "textures write: mip chain outside the texel pool");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));  // no frame may still sample the old array
+    TRY(ensure(c, c->tex_descs, std::max<size_t>(n, 1) * sizeof(r3n_texture_desc32), false, -1));
+    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4, false, -1));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->tex_descs.p, descs, (size_t)n * sizeof(r3n_texture_desc32), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->tex_texels.p, texels, n_texels * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the sources only for the duration of the call
+    }
+    c->n_textures = n;
     return R3N_OK;
 }
 
@@ -781,6 +830,8 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     const uint32_t fwd = std::min(c->forward_index_lane[lane]++, 63u);
     a.big_count = c->big_count[lane].as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
     a.big_capacity = c->big_capacity;
+    a.big_uv = c->big_uv[lane].as<r3n_big_uv>();
+    a.tex = texture_args(c);
 #ifndef R3N_BIG_GRID
 #define R3N_BIG_GRID 2048  // 8 waves per SIMD: the scan kernel needs 27 VGPRs
 #endif
@@ -790,20 +841,32 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
+        // textured variant only where it can matter: cutout key and a non-empty texture array
+        const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
+        auto launch = [&](auto small, auto big) {
+            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        };
         if (c->samples == 4) {
-            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL((k_raster_small<false, 4>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false, 4>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+            if (tex) launch(k_raster_small<false, 4, true>, k_raster_big<false, 4, true>);
+            else launch(k_raster_small<false, 4, false>, k_raster_big<false, 4, false>);
         } else {
-            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL((k_raster_small<false, 1>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<false, 1>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+            if (tex) launch(k_raster_small<false, 1, true>, k_raster_big<false, 1, true>);
+            else launch(k_raster_small<false, 1, false>, k_raster_big<false, 1, false>);
         }
     } else {
         if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
             return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
         a.depth = c->atlas.as<uint32_t>();
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1>), dim3(small_grid), dim3(256), 0, stream, a); }
-        { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
+        if (tex) {
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        } else {
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+        }
     }
     return check_launch(c, "raster");
 }
@@ -837,11 +900,18 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     a.hdr_out = c->hdr16.as<ushort4>();
     a.ldr_out = c->out8.as<uchar4>();
     a.srgb_lut = c->srgb_lut.as<unsigned char>();
+    a.tex = texture_args(c);
     c->resolved_this_frame = true;
     Timed t(c, R3N_STAGE_SHADE);
     const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
-    if (c->samples == 4) hipLaunchKernelGGL(k_resolve_opaque<4>, rgrid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_resolve_opaque<1>, rgrid, dim3(256), 0, c->stream, a);
+    const bool tex = c->n_textures > 0;
+    if (c->samples == 4) {
+        if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true>), rgrid, dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<4, false>), rgrid, dim3(256), 0, c->stream, a);
+    } else {
+        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true>), rgrid, dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, false>), rgrid, dim3(256), 0, c->stream, a);
+    }
     return check_launch(c, "k_resolve_opaque");
 }
 

@@ -34,13 +34,17 @@ FLAGS_ALBEDO_VERTEX_SRGB = 0x0004
 FLAGS_AOMR_SPLIT = 0x0100
 FLAGS_CC_GLTF_COMBINED = 0x0400
 FLAGS_UNLIT = 0x2000
+FLAGS_NEAREST = 0x4000
 
 
 def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, roughness=0.0, metallic=0.0,
                     reflectance=0.5, emissive=(0, 0, 0), ao=1.0, clear_coat=0.0, clear_coat_roughness=0.0,
-                    cutout=None, vertex_srgb=True):
-    """ShaderMaterial::from_material (rend3-routine/src/pbr/material.rs:548-583) for untextured PbrMaterials,
-    behind the 48-byte texture-id prefix (rend3/src/managers/material.rs:25-29).  208 bytes as f32[52]."""
+                    cutout=None, vertex_srgb=True, albedo_texture=None, nearest=False, uv_transform0=None):
+    """ShaderMaterial::from_material (rend3-routine/src/pbr/material.rs:548-583) behind the 48-byte texture-id prefix
+    (rend3/src/managers/material.rs:25-29).  208 bytes as f32[52].  albedo_mode (AlbedoComponent, material.rs:60-140):
+    "none" | "vertex" | "value" | "value_vertex", or with `albedo_texture` (texture handle) "texture" |
+    "texture_vertex" | "texture_value" | "texture_vertex_value".  nearest = SampleType::Nearest; uv_transform0 = Mat3
+    (row-major nested list)."""
     rec = np.zeros(52, dtype=f32)
     ru = rec.view(np.uint32)
     for base in (12, 24):  # uv_transform0/1 = identity mat3 (3 x vec4 columns)
@@ -57,8 +61,24 @@ def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, rough
     elif albedo_mode == "value_vertex":
         flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
         alb = albedo
+    elif albedo_mode in ("texture", "texture_value"):
+        flags |= FLAGS_ALBEDO_ACTIVE
+        alb = albedo if albedo_mode == "texture_value" else (1.0, 1.0, 1.0, 1.0)
+    elif albedo_mode in ("texture_vertex", "texture_vertex_value"):
+        flags |= FLAGS_ALBEDO_ACTIVE | FLAGS_ALBEDO_BLEND | (FLAGS_ALBEDO_VERTEX_SRGB if vertex_srgb else 0)
+        alb = albedo if albedo_mode == "texture_vertex_value" else (1.0, 1.0, 1.0, 1.0)
     else:
         raise ValueError(albedo_mode)
+    if albedo_mode.startswith("texture"):
+        if albedo_texture is None:
+            raise ValueError("texture albedo modes need albedo_texture")
+        ru[0] = int(albedo_texture) + 1  # NonZeroU32 index into the bindless array
+    if nearest:
+        flags |= FLAGS_NEAREST
+    if uv_transform0 is not None:
+        m = np.asarray(uv_transform0, dtype=f32).reshape(3, 3)
+        for col in range(3):
+            rec[12 + 4 * col: 12 + 4 * col + 3] = m[:, col]
     if unlit:
         flags |= FLAGS_UNLIT
     rec[36:40] = alb
@@ -105,6 +125,9 @@ class Renderer:
         self.mesh_cursor = 0  # in u32 words
         self.meshes = []
         self.materials = []
+        self.tex_descs = np.zeros((0, 8), dtype=np.uint32)  # r3n_texture_desc32 rows
+        self.tex_pool = np.zeros(1, dtype=np.uint32)
+        self.tex_used = 0
         self.capacity = 16  # FreelistDerivedBuffer::STARTING_SIZE
         self.object_meta = {}
         self.free_handles, self.pending_free, self.deferred_removals = [], [], []
@@ -132,7 +155,7 @@ class Renderer:
 
     # ------------------------------------------------------------------ world edits
     def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT, tangents=None,
-                 joint_indices=None, joint_weights=None):
+                 joint_indices=None, joint_weights=None, uv0=None):
         positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
         if indices is None:
             indices = np.arange(len(positions), dtype=np.uint32)
@@ -156,6 +179,8 @@ class Renderer:
         m.attr_off[1] = 4 * push(normals.view(np.uint32).reshape(-1))
         if tangents is not None:
             m.attr_off[2] = 4 * push(np.ascontiguousarray(tangents, dtype=f32).reshape(-1).view(np.uint32))
+        if uv0 is not None:  # VERTEX_ATTRIBUTE_TEXTURE_COORDINATES_0: vec2<f32>
+            m.attr_off[3] = 4 * push(np.ascontiguousarray(uv0, dtype=f32).reshape(-1, 2).reshape(-1).view(np.uint32))
         if colors is not None:
             colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 4)
             m.attr_off[5] = 4 * push(colors.view(np.uint32).reshape(-1))
@@ -228,6 +253,23 @@ class Renderer:
             self._skin_inputs = inputs
         mats = np.ascontiguousarray(np.concatenate([sk["matrices"] for sk in self.skeletons]))
         return self._skin_inputs, mats
+
+    def add_texture_2d(self, rgba8, srgb=True, mip_count=1, mip_source="uploaded"):
+        """Renderer::add_texture_2d with Texture{data, format, size, mip_count, mip_source}: rgba8 = (H, W, 4) u8;
+        format Rgba8UnormSrgb | Rgba8Unorm; mip_count int or "maximum"; mip_source "uploaded" | "generated".
+        The whole bindless array is re-sent (r3n_textures_write).  Returns the texture handle (index)."""
+        data, w, h, mips = host.prepare_texture(rgba8, srgb, mip_count, mip_source)
+        desc = np.array([[self.tex_used, w, h, mips, 1 if srgb else 0, 0, 0, 0]], dtype=np.uint32)
+        if self.tex_used + len(data) > len(self.tex_pool):
+            grown = np.zeros(max(2 * len(self.tex_pool), self.tex_used + len(data)), dtype=np.uint32)
+            grown[: self.tex_used] = self.tex_pool[: self.tex_used]
+            self.tex_pool = grown
+        self.tex_pool[self.tex_used: self.tex_used + len(data)] = data
+        self.tex_used += len(data)
+        self.tex_descs = np.ascontiguousarray(np.concatenate([self.tex_descs, desc]))
+        self._check(self.lib.r3n_textures_write(self.ctx, _ffi.ptr(self.tex_descs), len(self.tex_descs),
+                                                _ffi.ptr(self.tex_pool), self.tex_used), "r3n_textures_write")
+        return len(self.tex_descs) - 1
 
     def add_material(self, record, key=OPAQUE):
         idx = len(self.materials)

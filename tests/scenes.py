@@ -94,3 +94,69 @@ def build_random_scene(r, hm, mk, n_objects, seed, extent=(30.0, 8.0, 30.0), n_m
                                 direction=(math.cos(ang) - 0.3, -2.0, math.sin(ang) + 0.2),
                                 distance=shadow_distance, resolution=shadow_res)
     return handles
+
+
+def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), handedness=LEFT, lights=1,
+                         shadow_res=256, shadow_distance=50.0):
+    """Row N2 scene: the instanced meshes of build_random_scene with texture coordinates, four RGBA8 textures
+    (sRGB and linear formats, square / odd / 1x1 extents, full generated mip chains and a single-mip one) and ten
+    materials covering the albedo-texture variants: linear and nearest samplers, value / vertex multipliers, a
+    uv transform, unlit, and cutout materials whose alpha comes from the texture (forward and shadow passes)."""
+    rng = Pcg32(seed)
+    nrng = np.random.default_rng(seed)
+    meshes = []
+    for sub in (0, 1, 2):
+        p, i, n = icosphere(sub)
+        if handedness == LEFT:
+            i = i.reshape(-1, 3)[:, ::-1].reshape(-1)
+        uv = (p[:, :2] * np.float32(1.5 + sub) + np.float32(0.5)).astype(np.float32)
+        meshes.append(r.add_mesh(p, i, normals=n, uv0=uv))
+    p, i, n = box()
+    if handedness == RIGHT:
+        i = i.reshape(-1, 3)[:, ::-1].reshape(-1)
+    uv = (p[:, [0, 2]] * np.float32(0.75) + p[:, [1, 1]] * np.float32(0.25)).astype(np.float32)
+    meshes.append(r.add_mesh(p, i, normals=n, uv0=uv))
+
+    noise = nrng.integers(0, 256, (64, 64, 4), dtype=np.uint8)
+    noise[..., 3] = np.where(nrng.random((64, 64)) < 0.45, 40, 230).astype(np.uint8)
+    yy, xx = np.mgrid[0:32, 0:128]
+    checker = np.zeros((32, 128, 4), dtype=np.uint8)
+    checker[..., 0] = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 230, 30)
+    checker[..., 1] = (xx * 2).astype(np.uint8)
+    checker[..., 2] = (yy * 8).astype(np.uint8)
+    checker[..., 3] = np.where(((xx // 4) % 3) == 0, 60, 255)
+    odd = nrng.integers(0, 256, (19, 37, 4), dtype=np.uint8)
+    one = np.array([[[200, 120, 40, 255]]], dtype=np.uint8)
+    t_noise = r.add_texture_2d(noise, srgb=True, mip_count="maximum", mip_source="generated")
+    t_check = r.add_texture_2d(checker, srgb=False, mip_count="maximum", mip_source="generated")
+    t_odd = r.add_texture_2d(odd, srgb=True, mip_count="maximum", mip_source="generated")
+    t_one = r.add_texture_2d(one, srgb=True, mip_count=1, mip_source="uploaded")
+    t_flat = r.add_texture_2d(noise, srgb=False, mip_count=1, mip_source="uploaded")
+
+    c30, s30 = math.cos(0.5), math.sin(0.5)
+    mats = [
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_noise, roughness=0.5)),
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_check, roughness=0.3, nearest=True)),
+        r.add_material(mk(albedo_mode="texture_value", albedo_texture=t_odd, albedo=(0.9, 0.7, 0.5, 1.0), roughness=0.7, metallic=1.0)),
+        r.add_material(mk(albedo_mode="texture_vertex", albedo_texture=t_check, roughness=0.6)),
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_one, roughness=0.4)),
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_flat, unlit=True)),
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_noise, roughness=0.5,
+                          uv_transform0=[[2.0 * c30, -2.0 * s30, 0.25], [2.0 * s30, 2.0 * c30, -0.5], [0.0, 0.0, 1.0]])),
+        r.add_material(mk(albedo=(0.4, 0.8, 0.3, 1.0), albedo_mode="value", roughness=0.5)),
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_noise, roughness=0.5, cutout=0.5), CUTOUT),
+        r.add_material(mk(albedo_mode="texture_value", albedo_texture=t_check, albedo=(1.0, 1.0, 1.0, 0.9), roughness=0.5,
+                          cutout=0.5, nearest=True), CUTOUT),
+    ]
+    handles = []
+    for _ in range(n_objects):
+        pos = (rng.uniform(-extent[0], extent[0]), rng.uniform(-extent[1], extent[1]), rng.uniform(-extent[2], extent[2]))
+        s = math.exp(rng.uniform(math.log(0.3), math.log(2.5)))
+        xf = hm.mat4_mul(hm.mat4_mul(hm.translation(pos), random_rotation(rng, hm)), hm.scale((s, s, s)))
+        handles.append(r.add_object(meshes[rng.randint(len(meshes))], mats[rng.randint(len(mats))], xf))
+    for k in range(lights):
+        ang = 2 * math.pi * k / max(lights, 1)
+        r.add_directional_light(color=(1, 1, 1), intensity=3.0,
+                                direction=(math.cos(ang) - 0.3, -2.0, math.sin(ang) + 0.2),
+                                distance=shadow_distance, resolution=shadow_res)
+    return handles

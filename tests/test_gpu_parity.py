@@ -516,6 +516,39 @@ def test_msaa_random_scene_multi_frame(r3, handedness):
         compare_frames(fo, fp, f"msaa random scene frame {f}")
 
 
+def test_golden_textured_quad_example(r3):
+    """examples/src/textured_quad/mod.rs at 1280x720 (row N2): albedo texture, nearest sampler, sRGB decode -- HIP ==
+    oracle bit for bit, and the HIP image against the reference's screenshot (Threshold::Mean(0.0): RGB exact)."""
+    w, h = 1280, 720
+    o, p = both(r3, oh.LEFT, f32(w) / f32(h))
+    G.build_textured_quad(o, oh, omk)
+    G.build_textured_quad(p, r3.host, r3.material_record)
+    for f in range(2):
+        fo = o.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+        fp = p.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+        compare_frames(fo, fp, f"textured_quad frame {f}")
+    assert np.array_equal(fp["rgba8"][..., :3], G.load("textured_quad-screenshot.png")[..., :3])
+
+
+@pytest.mark.parametrize("handedness,samples", [(oh.LEFT, 1), (oh.RIGHT, 1), (oh.LEFT, 4)])
+def test_textured_scene_multi_frame(r3, handedness, samples):
+    """Row N2 on a lit multi-frame scene: five textures (sRGB / linear, odd extents, 1x1, generated mip chains), linear
+    and nearest samplers over magnified and heavily minified surfaces, uv transform, texture x value / vertex, unlit,
+    and cutout materials whose alpha is the texture's (forward pass and shadow views, each with its own derivative
+    rules): visible sets, keys, atlas and HDR bit-identical to the oracle, also under MSAA x4."""
+    o, p = both(r3, handedness, f32(320) / f32(192))
+    scenes.build_textured_scene(o, oh, omk, 200, 0xBEEF, handedness=handedness, lights=2)
+    scenes.build_textured_scene(p, oh, r3.material_record, 200, 0xBEEF, handedness=handedness, lights=2)
+    look = oh.look_at_lh if handedness == oh.LEFT else oh.look_at_rh
+    for f in range(3):
+        eye = (-14.0 + 3.0 * f, 3.0 + f, -14.0 + 2.0 * f)
+        for r in (o, p):
+            r.set_camera_data(look(eye, (0.0, 0.0, 0.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, 192, samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"textured scene frame {f}")
+
+
 def test_tonemap_every_half_value(r3):
     """blit.wgsl + the Rgba8UnormSrgb store over EVERY Rgba16Float bit pattern (all 65536 halves in every channel,
     NaN / inf / negative / denormal included): the device's sRGB table and the stand-alone blit kernel against the
