@@ -132,6 +132,16 @@ typedef struct {
 #define FLAGS_ALBEDO_ACTIVE 0x0001u
 #define FLAGS_ALBEDO_BLEND 0x0002u
 #define FLAGS_ALBEDO_VERTEX_SRGB 0x0004u
+#define FLAGS_BICOMPONENT_NORMAL 0x0008u
+#define FLAGS_SWIZZLED_NORMAL 0x0010u
+#define FLAGS_YDOWN_NORMAL 0x0020u
+#define FLAGS_AOMR_COMBINED 0x0040u
+#define FLAGS_AOMR_SWIZZLED_SPLIT 0x0080u
+#define FLAGS_AOMR_SPLIT 0x0100u
+#define FLAGS_AOMR_BW_SPLIT 0x0200u
+#define FLAGS_CC_GLTF_COMBINED 0x0400u
+#define FLAGS_CC_GLTF_SPLIT 0x0800u
+#define FLAGS_CC_BW_SPLIT 0x1000u
 #define FLAGS_UNLIT 0x2000u
 #define FLAGS_NEAREST 0x4000u
 
@@ -1053,7 +1063,7 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
     const float *mv = baked[o].model_view;
     float inv_s2[3] = {1.0f / dot3(mv + 0, mv + 0), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
     float vpos[4] = {0, 0, 0, 0}, nrm[3] = {0, 0, 0}, col[4] = {0, 0, 0, 0};
-    float vp[3][4], vn[3][3], vc[3][4];
+    float vp[3][4], vn[3][3], vc[3][4], vt[3][3], tng[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) {
         mat4_mul_vec4(mv, v[k][0], v[k][1], v[k][2], 1.0f, vp[k]);
         float nm[3] = {0, 0, 0};
@@ -1061,6 +1071,13 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
         float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
         mat3_mul_vec3(mv + 0, mv + 4, mv + 8, sn, vn[k]);
         normalize3(vn[k]);
+        { /* vs_out.tangent = normalize(mv_mat3 * (inv_scale_sq * vs_in.tangent)), opaque.wgsl:129 */
+            float tg[3] = {0, 0, 0};
+            if (ob->attr_off[2] != R3O_INVALID) fetch_vec3(mesh, ob->attr_off[2], idx[k], tg);
+            float st[3] = {inv_s2[0] * tg[0], inv_s2[1] * tg[1], inv_s2[2] * tg[2]};
+            mat3_mul_vec3(mv + 0, mv + 4, mv + 8, st, vt[k]);
+            normalize3(vt[k]);
+        }
         if (ob->attr_off[5] != R3O_INVALID) {
             uint32_t cw = mesh[ob->attr_off[5] / 4u + idx[k]];
             for (int c = 0; c < 4; ++c) vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
@@ -1069,18 +1086,25 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
     }
     for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
     for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
+    for (int c = 0; c < 3; ++c) tng[c] = (lam[0] * vt[0][c] + lam[1] * vt[1][c]) + lam[2] * vt[2][c];
     for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
 
-    /* fragment stage, opaque.wgsl:203-424 (untextured paths) */
+    /* fragment stage, opaque.wgsl:203-424.  Texture slots (managers/material.rs:25-29 order): 0 albedo, 1 normal,
+     * 2 roughness, 3 metallic, 4 reflectance, 5 clear coat, 6 clear coat roughness, 7 emissive, 8 anisotropy, 9 AO */
     pixel_data px;
+    int any_tex = 0;
+    for (int k = 0; k < 10; ++k) any_tex |= mat->tex[k] != 0u;
+    float coords[2] = {0, 0}, ddx[2] = {0, 0}, ddy[2] = {0, 0};
+    const int nearest = (mat->flags & FLAGS_NEAREST) != 0;
+    if (any_tex) { /* opaque.wgsl:207-209 */
+        float uv[3][2];
+        for (int k = 0; k < 3; ++k) fetch_uv0(ob, mesh, idx[k], uv[k]);
+        frag_coords(&ts, uv, mat->uv_transform0, (int)x, (int)y, coords, ddx, ddy);
+    }
+#define TEX(slot, dst) tex_sample_grad(&sc->tt, mat->tex[slot], nearest, coords[0], coords[1], ddx, ddy, dst)
     if (mat->flags & FLAGS_ALBEDO_ACTIVE) {
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
-        if (mat->tex[0] != 0u) { /* opaque.wgsl:207-215 */
-            float uv[3][2], coords[2], ddx[2], ddy[2];
-            for (int k = 0; k < 3; ++k) fetch_uv0(ob, mesh, idx[k], uv[k]);
-            frag_coords(&ts, uv, mat->uv_transform0, (int)x, (int)y, coords, ddx, ddy);
-            tex_sample_grad(&sc->tt, mat->tex[0], (mat->flags & FLAGS_NEAREST) != 0, coords[0], coords[1], ddx, ddy, px.albedo);
-        }
+        if (mat->tex[0] != 0u) TEX(0, px.albedo);
         if (mat->flags & FLAGS_ALBEDO_BLEND) {
             if (mat->flags & FLAGS_ALBEDO_VERTEX_SRGB) {
                 for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
@@ -1097,13 +1121,86 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
     if (mat->flags & FLAGS_UNLIT) {
         for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
     } else {
-        for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
+        /* --- normal (opaque.wgsl:246-273) */
+        if (mat->tex[1] != 0u) {
+            float t[4], n[3];
+            TEX(1, t);
+            if (mat->flags & FLAGS_BICOMPONENT_NORMAL) {
+                const int sw = (mat->flags & FLAGS_SWIZZLED_NORMAL) != 0;
+                float b0 = sw ? t[3] : t[0], b1 = t[1]; /* texture_read.ag : texture_read.rg */
+                b0 = b0 * 2.0f - 1.0f;
+                b1 = b1 * 2.0f - 1.0f;
+                n[0] = b0; n[1] = b1;
+                n[2] = sqrtf((1.0f - b0 * b0) - b1 * b1);
+            } else {
+                for (int c = 0; c < 3; ++c) n[c] = t[c] * 2.0f - 1.0f;
+                normalize3(n);
+            }
+            if (mat->flags & FLAGS_YDOWN_NORMAL) n[1] = -n[1];
+            float nn[3] = {nrm[0], nrm[1], nrm[2]}, tn[3] = {tng[0], tng[1], tng[2]};
+            normalize3(nn);
+            normalize3(tn);
+            float bt[3] = {nn[1] * tn[2] - tn[1] * nn[2], nn[2] * tn[0] - tn[2] * nn[0], nn[0] * tn[1] - tn[0] * nn[1]};
+            mat3_mul_vec3(tn, bt, nn, n, px.normal); /* tbn * normal */
+        } else {
+            for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
+        }
         normalize3(px.normal);
+        /* --- AO, metallic, roughness (opaque.wgsl:277-351) */
         float ao = mat->ambient_occlusion, pr = mat->roughness, metallic = mat->metallic;
+        if (mat->flags & FLAGS_AOMR_COMBINED) {
+            if (mat->tex[2] != 0u) {
+                float t[4];
+                TEX(2, t);
+                ao = mat->ambient_occlusion * t[0];
+                pr = mat->roughness * t[1];
+                metallic = mat->metallic * t[2];
+            }
+        } else if (mat->flags & FLAGS_AOMR_BW_SPLIT) {
+            float t[4];
+            if (mat->tex[2] != 0u) { TEX(2, t); pr = mat->roughness * t[0]; }
+            if (mat->tex[3] != 0u) { TEX(3, t); metallic = mat->metallic * t[0]; }
+            if (mat->tex[9] != 0u) { TEX(9, t); ao = mat->ambient_occlusion * t[0]; }
+        } else {
+            float t[4];
+            if (mat->tex[2] != 0u) {
+                TEX(2, t);
+                int sw = (mat->flags & FLAGS_AOMR_SWIZZLED_SPLIT) != 0;
+                pr = mat->roughness * (sw ? t[1] : t[0]);
+                metallic = mat->metallic * (sw ? t[2] : t[1]);
+            }
+            if (mat->tex[9] != 0u) { TEX(9, t); ao = mat->ambient_occlusion * t[0]; }
+        }
+        /* --- reflectance (opaque.wgsl:355-359) */
+        float reflectance = mat->reflectance;
+        if (mat->tex[4] != 0u) { float t[4]; TEX(4, t); reflectance = mat->reflectance * t[0]; }
+        /* --- clear coat (opaque.wgsl:363-391) */
         float cc = mat->clear_coat, ccpr = mat->clear_coat_roughness;
+        if (mat->flags & FLAGS_CC_GLTF_COMBINED) {
+            if (mat->tex[5] != 0u) {
+                float t[4];
+                TEX(5, t);
+                cc = mat->clear_coat * t[0];
+                ccpr = mat->clear_coat_roughness * t[1];
+            }
+        } else {
+            float t[4];
+            if (mat->tex[5] != 0u) { TEX(5, t); cc = mat->clear_coat * t[0]; }
+            if (mat->tex[6] != 0u) {
+                TEX(6, t);
+                ccpr = mat->clear_coat_roughness * ((mat->flags & FLAGS_CC_GLTF_SPLIT) ? t[1] : t[0]);
+            }
+        }
+        /* --- emissive (opaque.wgsl:395-399); the anisotropy texture (:403-407) feeds nothing downstream */
         for (int c = 0; c < 3; ++c) px.emissive[c] = mat->emissive[c];
+        if (mat->tex[7] != 0u) {
+            float t[4];
+            TEX(7, t);
+            for (int c = 0; c < 3; ++c) px.emissive[c] = mat->emissive[c] * t[c];
+        }
+#undef TEX
         for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
-        float refl = (0.16f * mat->reflectance) * mat->reflectance;
+        float refl = (0.16f * reflectance) * reflectance;
         for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
         if (cc != 0.0f) {
             float base_pr = fmaxf(pr, ccpr);

@@ -786,7 +786,7 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 
     // vertex stage for the 3 vertices (opaque.wgsl:114-134)
     uint32_t idx[3];
-    float p[3][4], vp[3][4], vn[3][3], vc[3][4];
+    float p[3][4], vp[3][4], vn[3][3], vc[3][4], vt[3][3];
     const float inv_s2[3] = {1.0f / dot3(mv, mv), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
     const uint32_t first = ob.first_index + tri * 3u;
     const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
@@ -804,6 +804,16 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         const float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
         mat3_mul_vec3(mv, mv + 4, mv + 8, sn, vn[k]);
         normalize3(vn[k]);
+        if (TEX && mat.textures[1] != 0u) {  // vs_out.tangent (opaque.wgsl:129); only the normal map reads it
+            float tg[3] = {0.0f, 0.0f, 0.0f};
+            const uint32_t tan_off = ob.vertex_attribute_start_offsets[2];
+            if (tan_off != R3N_INVALID) fetch_vec3(a.mesh, tan_off, idx[k], tg);
+            const float st[3] = {inv_s2[0] * tg[0], inv_s2[1] * tg[1], inv_s2[2] * tg[2]};
+            mat3_mul_vec3(mv, mv + 4, mv + 8, st, vt[k]);
+            normalize3(vt[k]);
+        } else {
+            vt[k][0] = vt[k][1] = vt[k][2] = 0.0f;
+        }
         if (col_off != R3N_INVALID) {
             const uint32_t cw = a.mesh[col_off / 4u + idx[k]];
 #pragma unroll
@@ -828,19 +838,29 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 #pragma unroll
     for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
 
-    // fragment stage (opaque.wgsl:203-424, untextured paths)
+    // fragment stage (opaque.wgsl:203-424).  Texture slots (managers/material.rs:25-29 order): 0 albedo, 1 normal,
+    // 2 roughness, 3 metallic, 4 reflectance, 5 clear coat, 6 clear coat roughness, 7 emissive, 8 anisotropy, 9 AO
     PixelData px;
     const uint32_t mflags = mat.flags;
+    bool any_tex = false;
+    if (TEX) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) any_tex = any_tex || mat.textures[k] != 0u;
+    }
+    float coords[2] = {0.0f, 0.0f}, ddx[2] = {0.0f, 0.0f}, ddy[2] = {0.0f, 0.0f};
+    const bool nearest = (mflags & R3N_FLAGS_NEAREST) != 0u;
+    if (TEX && any_tex) {  // opaque.wgsl:207-209
+        float uv[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], uv[k]);
+        frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy);
+    }
+    auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    auto has = [&](int slot) { return TEX && mat.textures[slot] != 0u; };
     if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
-        if (TEX && mat.textures[0] != 0u) {  // opaque.wgsl:207-215
-            float uv[3][2], coords[2], ddx[2], ddy[2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], uv[k]);
-            frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy);
-            tex_sample_grad(a.tex, mat.textures[0], (mflags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy, px.albedo);
-        }
+        if (has(0)) tex(0, px.albedo);
         if (mflags & R3N_FLAGS_ALBEDO_BLEND) {
             if (mflags & R3N_FLAGS_ALBEDO_VERTEX_SRGB) {
 #pragma unroll
@@ -862,17 +882,92 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
     } else {
+        // --- normal (opaque.wgsl:246-273)
+        if (has(1)) {
+            float t[4], n[3];
+            tex(1, t);
+            if (mflags & R3N_FLAGS_BICOMPONENT_NORMAL) {
+                float b0 = (mflags & R3N_FLAGS_SWIZZLED_NORMAL) ? t[3] : t[0], b1 = t[1];  // texture_read.ag : .rg
+                b0 = b0 * 2.0f - 1.0f;
+                b1 = b1 * 2.0f - 1.0f;
+                n[0] = b0; n[1] = b1;
+                n[2] = sqrtf((1.0f - b0 * b0) - b1 * b1);
+            } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
-        normalize3(px.normal);
-        float pr = mat.roughness;
-        const float metallic = mat.metallic, cc = mat.clear_coat, ccpr = mat.clear_coat_roughness;
+                for (int c = 0; c < 3; ++c) n[c] = t[c] * 2.0f - 1.0f;
+                normalize3(n);
+            }
+            if (mflags & R3N_FLAGS_YDOWN_NORMAL) n[1] = -n[1];
+            float tng[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            px.emissive[c] = mat.emissive[c];
-            px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
+            for (int c = 0; c < 3; ++c) tng[c] = (lam[0] * vt[0][c] + lam[1] * vt[1][c]) + lam[2] * vt[2][c];
+            float nn[3] = {nrm[0], nrm[1], nrm[2]};
+            normalize3(nn);
+            normalize3(tng);
+            const float bt[3] = {nn[1] * tng[2] - tng[1] * nn[2], nn[2] * tng[0] - tng[2] * nn[0], nn[0] * tng[1] - tng[0] * nn[1]};
+            mat3_mul_vec3(tng, bt, nn, n, px.normal);  // tbn * normal
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
         }
-        const float refl = (0.16f * mat.reflectance) * mat.reflectance;
+        normalize3(px.normal);
+        // --- AO, metallic, roughness (opaque.wgsl:277-351)
+        float ao = mat.ambient_occlusion, pr = mat.roughness, metallic = mat.metallic;
+        if (mflags & R3N_FLAGS_AOMR_COMBINED) {
+            if (has(2)) {
+                float t[4];
+                tex(2, t);
+                ao = mat.ambient_occlusion * t[0];
+                pr = mat.roughness * t[1];
+                metallic = mat.metallic * t[2];
+            }
+        } else if (mflags & R3N_FLAGS_AOMR_BW_SPLIT) {
+            float t[4];
+            if (has(2)) { tex(2, t); pr = mat.roughness * t[0]; }
+            if (has(3)) { tex(3, t); metallic = mat.metallic * t[0]; }
+            if (has(9)) { tex(9, t); ao = mat.ambient_occlusion * t[0]; }
+        } else {
+            float t[4];
+            if (has(2)) {
+                tex(2, t);
+                const bool sw = (mflags & R3N_FLAGS_AOMR_SWIZZLED_SPLIT) != 0u;
+                pr = mat.roughness * (sw ? t[1] : t[0]);
+                metallic = mat.metallic * (sw ? t[2] : t[1]);
+            }
+            if (has(9)) { tex(9, t); ao = mat.ambient_occlusion * t[0]; }
+        }
+        // --- reflectance (opaque.wgsl:355-359)
+        float reflectance = mat.reflectance;
+        if (has(4)) { float t[4]; tex(4, t); reflectance = mat.reflectance * t[0]; }
+        // --- clear coat (opaque.wgsl:363-391)
+        float cc = mat.clear_coat, ccpr = mat.clear_coat_roughness;
+        if (mflags & R3N_FLAGS_CC_GLTF_COMBINED) {
+            if (has(5)) {
+                float t[4];
+                tex(5, t);
+                cc = mat.clear_coat * t[0];
+                ccpr = mat.clear_coat_roughness * t[1];
+            }
+        } else {
+            float t[4];
+            if (has(5)) { tex(5, t); cc = mat.clear_coat * t[0]; }
+            if (has(6)) {
+                tex(6, t);
+                ccpr = mat.clear_coat_roughness * ((mflags & R3N_FLAGS_CC_GLTF_SPLIT) ? t[1] : t[0]);
+            }
+        }
+        // --- emissive (opaque.wgsl:395-399); the anisotropy texture (:403-407) feeds nothing downstream
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px.emissive[c] = mat.emissive[c];
+        if (has(7)) {
+            float t[4];
+            tex(7, t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px.emissive[c] = mat.emissive[c] * t[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
+        const float refl = (0.16f * reflectance) * reflectance;
 #pragma unroll
         for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
         if (cc != 0.0f) {
@@ -880,7 +975,7 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             pr = pr * (1.0f - cc) + base_pr * cc;
         }
         px.roughness = pr * pr;
-        px.ao = mat.ambient_occlusion;
+        px.ao = ao;
 
         float vv[3] = {vpos[0], vpos[1], vpos[2]};
         normalize3(vv);
@@ -892,7 +987,8 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
             // (D <= 1/(pi a^2), V <= 0.5/(nov a), nov >= 1e-5), so the light adds exactly +0: skip the shadow lookup
             // and the BRDF.  `+= 0.0f` keeps the -0 -> +0 behaviour of the full expression.
-            if (px.roughness > 0.0f && sat(dot3(px.normal, L.l)) == 0.0f) {
+            const float nl_raw = dot3(px.normal, L.l);
+            if (px.roughness > 0.0f && nl_raw == nl_raw && sat(nl_raw) == 0.0f) {  // (a NaN normal must stay NaN)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) color[c] += 0.0f;
                 continue;
@@ -941,8 +1037,10 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 // S = samples per pixel.  S == 4: every sample of the multisampled Rgba16Float target holds the half-rounded colour
 // of its nearest fragment (shaded once per distinct triangle, at the pixel centre) or the clear colour; the render
 // pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
+// Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
+// (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
 template <int S, bool TEX>
-__global__ __launch_bounds__(256) void k_resolve_opaque(ShadeArgs a) {
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     const uint32_t n_dir = min(*reinterpret_cast<const uint32_t *>(a.dir_buf), (uint32_t)R3N_MAX_DIR_LIGHTS);

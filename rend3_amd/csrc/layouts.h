@@ -29,6 +29,16 @@ static_assert(sizeof(r3n_indirect_call) == 20, "IndirectCall must be 20 B");
 #define R3N_FLAGS_ALBEDO_ACTIVE 0x0001u
 #define R3N_FLAGS_ALBEDO_BLEND 0x0002u
 #define R3N_FLAGS_ALBEDO_VERTEX_SRGB 0x0004u
+#define R3N_FLAGS_BICOMPONENT_NORMAL 0x0008u
+#define R3N_FLAGS_SWIZZLED_NORMAL 0x0010u
+#define R3N_FLAGS_YDOWN_NORMAL 0x0020u
+#define R3N_FLAGS_AOMR_COMBINED 0x0040u
+#define R3N_FLAGS_AOMR_SWIZZLED_SPLIT 0x0080u
+#define R3N_FLAGS_AOMR_SPLIT 0x0100u
+#define R3N_FLAGS_AOMR_BW_SPLIT 0x0200u
+#define R3N_FLAGS_CC_GLTF_COMBINED 0x0400u
+#define R3N_FLAGS_CC_GLTF_SPLIT 0x0800u
+#define R3N_FLAGS_CC_BW_SPLIT 0x1000u
 #define R3N_FLAGS_UNLIT 0x2000u
 #define R3N_FLAGS_NEAREST 0x4000u
 // structures.wgsl:64-72

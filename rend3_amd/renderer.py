@@ -31,15 +31,74 @@ OPAQUE, CUTOUT, BLEND = 0, 1, 2
 FLAGS_ALBEDO_ACTIVE = 0x0001
 FLAGS_ALBEDO_BLEND = 0x0002
 FLAGS_ALBEDO_VERTEX_SRGB = 0x0004
+FLAGS_AOMR_COMBINED = 0x0040
 FLAGS_AOMR_SPLIT = 0x0100
 FLAGS_CC_GLTF_COMBINED = 0x0400
+FLAGS_BICOMPONENT_NORMAL = 0x0008
+FLAGS_SWIZZLED_NORMAL = 0x0010
+FLAGS_YDOWN_NORMAL = 0x0020
+FLAGS_AOMR_SWIZZLED_SPLIT = 0x0080
+FLAGS_AOMR_BW_SPLIT = 0x0200
+FLAGS_CC_GLTF_SPLIT = 0x0800
+FLAGS_CC_BW_SPLIT = 0x1000
 FLAGS_UNLIT = 0x2000
 FLAGS_NEAREST = 0x4000
 
 
+
+def material_texture_slots(ru, normal_texture, normal_mode, normal_y_down, aomr, reflectance_texture,
+                           clearcoat_textures, emissive_texture, anisotropy_texture):
+    """Texture ids (handle + 1) of slots 1..9 of the 208-byte record and the flags of NormalTexture / AoMRTextures /
+    ClearcoatTextures::to_flags (pbr/material.rs:201-222, 305-317, 354-364).  aomr: None | ("combined", tex) |
+    ("swizzled_split", ao, mr) | ("split", ao, mr) | ("bw_split", ao, m, r); clearcoat_textures: None |
+    ("gltf_combined", tex) | ("gltf_split", cc, ccr) | ("bw_split", cc, ccr); any texture may be None."""
+    def put(slot, tex):
+        if tex is not None:
+            ru[slot] = int(tex) + 1
+    flags = 0
+    if normal_texture is not None:
+        put(1, normal_texture)
+        flags |= {"tricomponent": 0, "bicomponent": FLAGS_BICOMPONENT_NORMAL,
+                  "bicomponent_swizzled": FLAGS_BICOMPONENT_NORMAL | FLAGS_SWIZZLED_NORMAL}[normal_mode]
+        if normal_y_down:
+            flags |= FLAGS_YDOWN_NORMAL
+    if aomr is None:
+        flags |= FLAGS_AOMR_COMBINED  # "so shader only checks roughness texture, then bails"
+    elif aomr[0] == "combined":
+        flags |= FLAGS_AOMR_COMBINED
+        put(2, aomr[1])
+    elif aomr[0] in ("swizzled_split", "split"):
+        flags |= FLAGS_AOMR_SWIZZLED_SPLIT if aomr[0] == "swizzled_split" else FLAGS_AOMR_SPLIT
+        put(9, aomr[1])
+        put(2, aomr[2])
+    elif aomr[0] == "bw_split":
+        flags |= FLAGS_AOMR_BW_SPLIT
+        put(9, aomr[1])
+        put(3, aomr[2])
+        put(2, aomr[3])
+    else:
+        raise ValueError(aomr)
+    put(4, reflectance_texture)
+    if clearcoat_textures is None or clearcoat_textures[0] == "gltf_combined":
+        flags |= FLAGS_CC_GLTF_COMBINED
+        if clearcoat_textures is not None:
+            put(5, clearcoat_textures[1])
+    elif clearcoat_textures[0] in ("gltf_split", "bw_split"):
+        flags |= FLAGS_CC_GLTF_SPLIT if clearcoat_textures[0] == "gltf_split" else FLAGS_CC_BW_SPLIT
+        put(5, clearcoat_textures[1])
+        put(6, clearcoat_textures[2])
+    else:
+        raise ValueError(clearcoat_textures)
+    put(7, emissive_texture)
+    put(8, anisotropy_texture)
+    return flags
+
+
 def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, roughness=0.0, metallic=0.0,
                     reflectance=0.5, emissive=(0, 0, 0), ao=1.0, clear_coat=0.0, clear_coat_roughness=0.0,
-                    cutout=None, vertex_srgb=True, albedo_texture=None, nearest=False, uv_transform0=None):
+                    cutout=None, vertex_srgb=True, albedo_texture=None, nearest=False, uv_transform0=None,
+                    normal_texture=None, normal_mode="tricomponent", normal_y_down=False, aomr=None,
+                    reflectance_texture=None, clearcoat_textures=None, emissive_texture=None, anisotropy_texture=None):
     """ShaderMaterial::from_material (rend3-routine/src/pbr/material.rs:548-583) behind the 48-byte texture-id prefix
     (rend3/src/managers/material.rs:25-29).  208 bytes as f32[52].  albedo_mode (AlbedoComponent, material.rs:60-140):
     "none" | "vertex" | "value" | "value_vertex", or with `albedo_texture` (texture handle) "texture" |
@@ -49,7 +108,8 @@ def material_record(albedo=(0, 0, 0, 1), albedo_mode="value", unlit=False, rough
     ru = rec.view(np.uint32)
     for base in (12, 24):  # uv_transform0/1 = identity mat3 (3 x vec4 columns)
         rec[base + 0] = rec[base + 5] = rec[base + 10] = 1.0
-    flags = FLAGS_AOMR_SPLIT | FLAGS_CC_GLTF_COMBINED
+    flags = material_texture_slots(ru, normal_texture, normal_mode, normal_y_down, aomr, reflectance_texture,
+                                   clearcoat_textures, emissive_texture, anisotropy_texture)
     if albedo_mode == "none":
         alb = (0.0, 0.0, 0.0, 1.0)
     elif albedo_mode == "vertex":

@@ -96,6 +96,15 @@ def build_random_scene(r, hm, mk, n_objects, seed, extent=(30.0, 8.0, 30.0), n_m
     return handles
 
 
+def _tangents(normals):
+    """Some unit tangent per vertex, perpendicular to the normal (any deterministic choice will do for parity)."""
+    n = np.asarray(normals, dtype=np.float32)
+    ref = np.where(np.abs(n[:, 1:2]) < 0.9, np.array([[0.0, 1.0, 0.0]], dtype=np.float32), np.array([[1.0, 0.0, 0.0]], dtype=np.float32))
+    t = np.cross(ref, n).astype(np.float32)
+    t /= np.maximum(np.linalg.norm(t, axis=1, keepdims=True), np.float32(1e-20))
+    return t.astype(np.float32)
+
+
 def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), handedness=LEFT, lights=1,
                          shadow_res=256, shadow_distance=50.0):
     """Row N2 scene: the instanced meshes of build_random_scene with texture coordinates, four RGBA8 textures
@@ -110,12 +119,12 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
         if handedness == LEFT:
             i = i.reshape(-1, 3)[:, ::-1].reshape(-1)
         uv = (p[:, :2] * np.float32(1.5 + sub) + np.float32(0.5)).astype(np.float32)
-        meshes.append(r.add_mesh(p, i, normals=n, uv0=uv))
+        meshes.append(r.add_mesh(p, i, normals=n, uv0=uv, tangents=_tangents(n)))
     p, i, n = box()
     if handedness == RIGHT:
         i = i.reshape(-1, 3)[:, ::-1].reshape(-1)
     uv = (p[:, [0, 2]] * np.float32(0.75) + p[:, [1, 1]] * np.float32(0.25)).astype(np.float32)
-    meshes.append(r.add_mesh(p, i, normals=n, uv0=uv))
+    meshes.append(r.add_mesh(p, i, normals=n, uv0=uv, tangents=_tangents(n)))
 
     noise = nrng.integers(0, 256, (64, 64, 4), dtype=np.uint8)
     noise[..., 3] = np.where(nrng.random((64, 64)) < 0.45, 40, 230).astype(np.uint8)
@@ -147,6 +156,35 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
         r.add_material(mk(albedo_mode="texture", albedo_texture=t_noise, roughness=0.5, cutout=0.5), CUTOUT),
         r.add_material(mk(albedo_mode="texture_value", albedo_texture=t_check, albedo=(1.0, 1.0, 1.0, 0.9), roughness=0.5,
                           cutout=0.5, nearest=True), CUTOUT),
+    ]
+    # normal map (tangent-space bumps), packed AO/roughness/metallic, emissive stripes -- linear formats, full mip chains
+    yy, xx = np.mgrid[0:64, 0:64]
+    nx = 0.35 * np.sin(xx * (2 * math.pi / 16.0)) + 0.5
+    ny = 0.35 * np.cos(yy * (2 * math.pi / 8.0)) + 0.5
+    nmap = np.stack([nx * 255, ny * 255, np.full_like(nx, 235.0), ny * 255], axis=2).astype(np.uint8)
+    aomr_tex = nrng.integers(40, 256, (32, 32, 4), dtype=np.uint8)
+    emis = np.zeros((16, 16, 4), dtype=np.uint8)
+    emis[::4, :, 0] = 255
+    emis[:, ::4, 2] = 200
+    emis[..., 3] = 255
+    t_nmap = r.add_texture_2d(nmap, srgb=False, mip_count="maximum", mip_source="generated")
+    t_aomr = r.add_texture_2d(aomr_tex, srgb=False, mip_count="maximum", mip_source="generated")
+    t_emis = r.add_texture_2d(emis, srgb=True, mip_count="maximum", mip_source="generated")
+    mats += [
+        r.add_material(mk(albedo=(0.8, 0.8, 0.8, 1.0), albedo_mode="value", roughness=0.6, normal_texture=t_nmap)),
+        r.add_material(mk(albedo_mode="texture", albedo_texture=t_noise, roughness=0.8, metallic=1.0, normal_texture=t_nmap,
+                          normal_mode="bicomponent", normal_y_down=True, aomr=("combined", t_aomr))),
+        r.add_material(mk(albedo=(0.7, 0.6, 0.5, 1.0), albedo_mode="value", roughness=0.9, metallic=0.8, normal_texture=t_nmap,
+                          normal_mode="bicomponent_swizzled", aomr=("swizzled_split", t_aomr, t_aomr))),
+        r.add_material(mk(albedo=(0.5, 0.6, 0.9, 1.0), albedo_mode="value", roughness=0.7, metallic=0.5,
+                          aomr=("split", None, t_aomr), emissive=(0.5, 0.4, 0.3), emissive_texture=t_emis)),
+        r.add_material(mk(albedo=(0.9, 0.9, 0.2, 1.0), albedo_mode="value", roughness=0.9, metallic=1.0,
+                          aomr=("bw_split", t_aomr, t_check, t_noise), reflectance_texture=t_aomr,
+                          clear_coat=0.8, clear_coat_roughness=0.6, clearcoat_textures=("gltf_combined", t_aomr))),
+        r.add_material(mk(albedo=(0.3, 0.9, 0.8, 1.0), albedo_mode="value", roughness=0.5, clear_coat=0.9,
+                          clear_coat_roughness=0.7, clearcoat_textures=("gltf_split", t_aomr, t_check), nearest=True)),
+        r.add_material(mk(albedo=(0.9, 0.3, 0.8, 1.0), albedo_mode="value", roughness=0.5, clear_coat=0.9,
+                          clear_coat_roughness=0.7, clearcoat_textures=("bw_split", None, t_aomr), anisotropy_texture=t_aomr)),
     ]
     handles = []
     for _ in range(n_objects):
