@@ -114,22 +114,100 @@ def _node_local_matrix(node, hm):
     return hm.mat4_mul(hm.mat4_mul(hm.translation(t), r), hm.scale(s))
 
 
-def material_from_gltf(g, index, mk):
-    """load_materials_and_textures (rend3-gltf/src/lib.rs:806-943) for materials WITHOUT textures: albedo =
-    ValueVertex{base_color_factor, srgb: false}, metallic / roughness factors (glTF defaults 1.0), emissive factor,
-    alpha mode -> transparency.  load_default_material (:777-800) when the primitive has no material.
+def _image_bytes(g, image):
+    """gltf::image::Source: a buffer view, a data URI or a file next to the document (filesystem_io_func)."""
+    if "bufferView" in image:
+        bv = g.json["bufferViews"][image["bufferView"]]
+        off = bv.get("byteOffset", 0)
+        return bytes(g.buffers[bv["buffer"]][off: off + bv["byteLength"]])
+    uri = image["uri"]
+    if uri.startswith("data:"):
+        import base64
+        return base64.b64decode(uri.split(",", 1)[1])
+    from urllib.parse import unquote
+    return open(os.path.join(os.path.dirname(g.path), unquote(uri)), "rb").read()
+
+
+def load_image(g, r, cache, image_index, srgb):
+    """load_image_cached + load_image + util::convert_dynamic_image (rend3-gltf/src/lib.rs:951-1128, 1163-1181) for the
+    formats the `image` crate decodes (PNG / JPEG ...): 8-bit luma (with or without alpha) becomes R8Unorm (one
+    component; stored here as RGBA8 (L, 0, 0, 255), which samples identically), RGB / RGBA become Rgba8Unorm[Srgb];
+    MipmapCount::Maximum + MipmapSource::Generated.  KTX2 / DDS containers are not read.
+    Returns (texture handle, components)."""
+    key = (image_index, bool(srgb))
+    if key not in cache:
+        import io
+        from PIL import Image
+        im = Image.open(io.BytesIO(_image_bytes(g, g.json["images"][image_index])))
+        if im.mode in ("L", "LA"):
+            lum = np.array(im.convert("L"), dtype=np.uint8)
+            rgba = np.zeros(lum.shape + (4,), dtype=np.uint8)
+            rgba[..., 0] = lum
+            rgba[..., 3] = 255
+            cache[key] = (r.add_texture_2d(rgba, srgb=False, mip_count="maximum", mip_source="generated"), 1)
+        else:
+            rgba = np.array(im.convert("RGBA"), dtype=np.uint8)
+            cache[key] = (r.add_texture_2d(rgba, srgb=bool(srgb), mip_count="maximum", mip_source="generated"), 4)
+    return cache[key]
+
+
+def material_from_gltf(g, index, mk, r=None, image_cache=None):
+    """load_materials_and_textures (rend3-gltf/src/lib.rs:806-943): albedo = TextureVertexValue / ValueVertex
+    {base_color_factor, srgb: false}; sampler from the base colour texture's magFilter; KHR_texture_transform of the
+    base colour texture as uv_transform0; normal texture Tricomponent (>= 3 components) with
+    GltfLoadSettings::default().normal_direction = Up; AO / metallic-roughness packing Combined (same image) |
+    Split (AO with < 3 components) | SwizzledSplit; emissive TextureValue; alpha mode -> transparency;
+    KHR_materials_unlit.  load_default_material (:777-800) when the primitive has no material.
+    `r` (a renderer with add_texture_2d) is only needed when the material has textures.
     Returns (record, material key)."""
     if index is None:
         return mk(albedo=(1.0, 1.0, 1.0, 1.0), albedo_mode="value", roughness=1.0, metallic=1.0, ao=1.0, clear_coat=1.0,
                   clear_coat_roughness=1.0), 0
     m = g.json["materials"][index]
     pbr = m.get("pbrMetallicRoughness", {})
-    for key in ("baseColorTexture", "metallicRoughnessTexture"):
-        if key in pbr:
-            raise NotImplementedError("textured glTF materials are row N2 (not built)")
+    cache = image_cache if image_cache is not None else {}
+
+    def tex(info, srgb):
+        if info is None:
+            return None
+        if r is None:
+            raise ValueError("textured glTF material: pass the renderer")
+        t = g.json["textures"][info["index"]]
+        return load_image(g, r, cache, t["source"], srgb)
+
+    albedo_info = pbr.get("baseColorTexture")
+    albedo = tex(albedo_info, True)
+    occlusion = tex(m.get("occlusionTexture"), False)
+    emissive = tex(m.get("emissiveTexture"), True)
+    normals = tex(m.get("normalTexture"), False)
+    mr = tex(pbr.get("metallicRoughnessTexture"), False)
+
+    nearest = False
+    uv_transform = None
+    if albedo_info is not None:
+        t = g.json["textures"][albedo_info["index"]]
+        if "sampler" in t:
+            nearest = g.json["samplers"][t["sampler"]].get("magFilter") == 9728  # NEAREST
+        tt = albedo_info.get("extensions", {}).get("KHR_texture_transform")
+        if tt is not None:  # Mat3::from_scale_angle_translation(scale, rotation, offset)
+            sx, sy = tt.get("scale", [1.0, 1.0])
+            ox, oy = tt.get("offset", [0.0, 0.0])
+            a = np.float32(tt.get("rotation", 0.0))
+            c, sn = np.float32(np.cos(a)), np.float32(np.sin(a))
+            uv_transform = [[np.float32(sx) * c, -np.float32(sy) * sn, ox], [np.float32(sx) * sn, np.float32(sy) * c, oy], [0.0, 0.0, 1.0]]
+    if mr is not None and occlusion is not None and mr[0] == occlusion[0]:
+        aomr = ("combined", mr[0])
+    elif occlusion is not None and occlusion[1] < 3:
+        aomr = ("split", occlusion[0], None if mr is None else mr[0])
+    else:
+        aomr = ("swizzled_split", None if occlusion is None else occlusion[0], None if mr is None else mr[0])
     mode = m.get("alphaMode", "OPAQUE")
     key = {"OPAQUE": 0, "MASK": 1, "BLEND": 2}[mode]
-    rec = mk(albedo=tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])), albedo_mode="value_vertex", vertex_srgb=False,
+    rec = mk(albedo=tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])),
+             albedo_mode="value_vertex" if albedo is None else "texture_vertex_value", vertex_srgb=False,
+             albedo_texture=None if albedo is None else albedo[0], nearest=nearest, uv_transform0=uv_transform,
+             normal_texture=normals[0] if normals is not None and normals[1] >= 3 else None,
+             aomr=aomr, emissive_texture=None if emissive is None else emissive[0],
              roughness=pbr.get("roughnessFactor", 1.0), metallic=pbr.get("metallicFactor", 1.0),
              emissive=tuple(m.get("emissiveFactor", [0.0, 0.0, 0.0])),
              cutout=(m.get("alphaCutoff", 0.5) if mode == "MASK" else None),
@@ -158,6 +236,7 @@ def instance_scene(g, r, hm, mk, scale=1.0):
     root = hm.scale((s, s, -s if lh else s))
     meshes = {}
     materials = {}
+    image_cache = {}
     xf = [None] * len(nodes)
     out = dict(objects=[], skeletons=[], inverse_bind_matrices=[], node_transforms=xf)
     for sk in g.json.get("skins", []):
@@ -177,10 +256,10 @@ def instance_scene(g, r, hm, mk, scale=1.0):
                 idx = p["indices"].reshape(-1, 3)[:, ::-1].reshape(-1) if lh else p["indices"]
                 meshes[(mi, pi)] = (r.add_mesh(p["positions"], idx, normals=p.get("normals"), tangents=p.get("tangents"),
                                                joint_indices=p.get("joints"), joint_weights=p.get("weights"),
-                                               mesh_handedness=r.handedness), p["material"])
+                                               uv0=p.get("uv0"), mesh_handedness=r.handedness), p["material"])
             mesh, mat_index = meshes[(mi, pi)]
             if mat_index not in materials:
-                rec, key = material_from_gltf(g, mat_index, mk)
+                rec, key = material_from_gltf(g, mat_index, mk, r, image_cache)
                 materials[mat_index] = r.add_material(rec, key)
             if "skin" in node:
                 nj = len(out["inverse_bind_matrices"][node["skin"]])

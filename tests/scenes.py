@@ -198,3 +198,80 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
                                 direction=(math.cos(ang) - 0.3, -2.0, math.sin(ang) + 0.2),
                                 distance=shadow_distance, resolution=shadow_res)
     return handles
+
+
+def write_textured_gltf(path):
+    """A small self-contained .gltf (buffers and PNG images as data URIs) exercising the texture side of the glTF
+    loader: base colour texture with a NEAREST sampler and KHR_texture_transform, normal map, one image used for both
+    occlusion and metallic-roughness (-> Combined packing), emissive texture, a MASK material whose alpha comes from
+    the texture, and a luminance-only occlusion image (-> Split packing)."""
+    import base64
+    import io
+    import json
+
+    from PIL import Image
+
+    rng = np.random.default_rng(77)
+
+    def png(arr, mode):
+        b = io.BytesIO()
+        Image.fromarray(arr, mode).save(b, format="PNG")
+        return "data:image/png;base64," + base64.b64encode(b.getvalue()).decode()
+
+    base = rng.integers(0, 256, (32, 32, 4), dtype=np.uint8)
+    base[..., 3] = np.where(rng.random((32, 32)) < 0.5, 30, 240).astype(np.uint8)
+    yy, xx = np.mgrid[0:16, 0:16]
+    nrm = np.stack([128 + 60 * np.sin(xx), 128 + 60 * np.cos(yy), np.full_like(xx, 230)], axis=2).astype(np.uint8)
+    orm = rng.integers(60, 256, (16, 16, 3), dtype=np.uint8)
+    emi = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    lum = rng.integers(100, 256, (8, 8), dtype=np.uint8)
+    images = [png(base, "RGBA"), png(nrm, "RGB"), png(orm, "RGB"), png(emi, "RGB"), png(lum, "L")]
+
+    # one quad (two triangles) with normals, tangents, uvs
+    pos = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
+    nor = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (4, 1))
+    tan = np.tile(np.array([[1, 0, 0, 1]], dtype=np.float32), (4, 1))
+    uv = np.array([[0, 1], [1, 1], [1, 0], [0, 0]], dtype=np.float32) * np.float32(1.7)
+    idx = np.array([0, 1, 2, 2, 3, 0], dtype=np.uint16)
+    blobs = [pos.tobytes(), nor.tobytes(), tan.tobytes(), uv.tobytes(), idx.tobytes()]
+    offs, cur = [], 0
+    for b in blobs:
+        offs.append(cur)
+        cur += (len(b) + 3) // 4 * 4
+    buf = bytearray(cur)
+    for o, b in zip(offs, blobs):
+        buf[o: o + len(b)] = b
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"byteLength": len(buf), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(buf)).decode()}],
+        "bufferViews": [{"buffer": 0, "byteOffset": o, "byteLength": len(b)} for o, b in zip(offs, blobs)],
+        "accessors": [
+            {"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3", "min": [-1, -1, 0], "max": [1, 1, 0]},
+            {"bufferView": 1, "componentType": 5126, "count": 4, "type": "VEC3"},
+            {"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC4"},
+            {"bufferView": 3, "componentType": 5126, "count": 4, "type": "VEC2"},
+            {"bufferView": 4, "componentType": 5123, "count": 6, "type": "SCALAR"},
+        ],
+        "images": [{"uri": u} for u in images],
+        "samplers": [{"magFilter": 9728}, {"magFilter": 9729}],
+        "textures": [{"source": 0, "sampler": 0}, {"source": 1, "sampler": 1}, {"source": 2, "sampler": 1},
+                     {"source": 3}, {"source": 4, "sampler": 1}, {"source": 0, "sampler": 1}],
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorFactor": [1.0, 0.9, 0.8, 1.0], "baseColorTexture": {"index": 0, "extensions": {
+                "KHR_texture_transform": {"offset": [0.1, 0.2], "rotation": 0.3, "scale": [1.5, 0.75]}}},
+                "metallicRoughnessTexture": {"index": 2}, "roughnessFactor": 0.9, "metallicFactor": 0.7},
+             "normalTexture": {"index": 1}, "occlusionTexture": {"index": 2}, "emissiveTexture": {"index": 3},
+             "emissiveFactor": [0.3, 0.2, 0.1]},
+            {"pbrMetallicRoughness": {"baseColorTexture": {"index": 5}, "roughnessFactor": 0.5, "metallicFactor": 0.0},
+             "alphaMode": "MASK", "alphaCutoff": 0.4, "occlusionTexture": {"index": 4}},
+        ],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TANGENT": 2, "TEXCOORD_0": 3}, "indices": 4, "material": 0}]},
+                   {"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TANGENT": 2, "TEXCOORD_0": 3}, "indices": 4, "material": 1}]}],
+        "nodes": [{"mesh": 0, "translation": [-1.2, 0.0, 0.0], "rotation": [0.0, 0.3826834, 0.0, 0.9238795]},
+                  {"mesh": 1, "translation": [1.2, 0.0, 0.5], "scale": [1.0, 1.3, 1.0]}],
+        "scenes": [{"nodes": [0, 1]}],
+        "scene": 0,
+    }
+    with open(path, "w") as fh:
+        json.dump(doc, fh)
+    return path
