@@ -58,7 +58,8 @@ class OracleLib:
                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint32, vp],
             "r3o_vis_to_depth": [vp, ctypes.c_uint64, ctypes.c_uint32, vp],
             "r3o_shade": [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, vp,
-                          ctypes.c_uint32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, ctypes.c_uint32, vp, vp],
+                          ctypes.c_uint32, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, ctypes.c_uint32, vp,
+                          vp, vp, ctypes.c_uint64, vp],
             "r3o_generate_mips": [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp],
             "r3o_srgb8_table": [vp],
             "r3o_tonemap": [vp, ctypes.c_uint64, vp, vp],

@@ -1254,13 +1254,22 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
  * `samples` keys per pixel (pixel-major).  Every sample of the multisampled Rgba16Float target holds the
  * half-rounded colour of its nearest fragment (or the clear colour); the render pass resolve
  * (base.rs:245-258) is their box average, evaluated here as ((s0 + s1) + (s2 + s3)) * 0.25 in f32.
+ *
+ * Transparent pass (row N3; base.rs:451-465, pbr/routine.rs:113-118): the triangles of the blend-key objects in
+ * DRAW ORDER (blend_obj / blend_tri: objects back to front, batching.rs:146-176, triangles in index order --
+ * the non-atomic residual list of cull.wgsl:372-378) are rasterised after the opaque passes with depth test
+ * GreaterEqual against the final opaque depth, no depth write, and BlendState::ALPHA_BLENDING
+ * (rgb = src * a + dst * (1 - a), alpha = src.a + dst.a * (1 - a)) into the Rgba16Float samples: f32
+ * arithmetic on the half-rounded destination, result rounded to half.  The fragment is evaluated once per
+ * pixel and triangle (pixel centre) and blended into every covered sample that passes the depth test.
  */
 void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, const r3o_frame_uniforms *fu,
                const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
                const r3o_baked *baked, const r3o_material *materials, const uint32_t *tri_base,
                uint32_t n_dir, const r3o_dir_light *dir, uint32_t n_point, const r3o_point_light *point,
                const float *atlas, uint32_t atlas_w, uint32_t atlas_h, const float *clear_color,
-               const r3o_texture_desc *tdescs, uint32_t ntex, const uint32_t *texels, uint16_t *hdr_out) {
+               const r3o_texture_desc *tdescs, uint32_t ntex, const uint32_t *texels,
+               const uint32_t *blend_obj, const uint32_t *blend_tri, uint64_t n_blend, uint16_t *hdr_out) {
     init_srgb8();
     float *light_mats = (float *)malloc(sizeof(float) * 16 * (n_dir ? n_dir : 1));
     float *light_l = (float *)malloc(sizeof(float) * 3 * (n_dir ? n_dir : 1));
@@ -1276,19 +1285,20 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, co
                       pview + 4 * i);
     shade_ctx sc = {w, h, fu, hdr, objects, mesh, baked, materials, tri_base, n_dir, dir, n_point, point,
                     atlas, atlas_w, atlas_h, light_mats, light_l, pview, {tdescs, ntex, texels}};
+    /* the Rgba16Float sample values, as floats */
+    float *smp = (float *)malloc(sizeof(float) * 4 * (size_t)w * h * samples);
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (uint32_t y = 0; y < h; ++y)
         for (uint32_t x = 0; x < w; ++x) {
             const uint64_t pix = (uint64_t)y * w + x;
-            uint16_t *o16 = hdr_out + 4 * pix;
-            float half_s[4][4];
+            float *half_s = smp + 4 * pix * samples;
             uint32_t last_id = 0xFFFFFFFFu;
             uint32_t last_s = 0;
             for (uint32_t sm = 0; sm < samples; ++sm) {
                 uint32_t id = (uint32_t)(vis[pix * samples + sm] & 0xFFFFFFFFu);
                 if (id == last_id) {  /* same triangle, same pixel centre: same value */
-                    for (int c = 0; c < 4; ++c) half_s[sm][c] = half_s[last_s][c];
+                    for (int c = 0; c < 4; ++c) half_s[4 * sm + c] = half_s[4 * last_s + c];
                     continue;
                 }
                 float out[4];
@@ -1296,17 +1306,73 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, co
                     for (int c = 0; c < 4; ++c) out[c] = clear_color[c];
                 else
                     shade_fragment(&sc, id, x, y, out);
-                for (int c = 0; c < 4; ++c) half_s[sm][c] = f16_to_f32(f32_to_f16(out[c]));
+                for (int c = 0; c < 4; ++c) half_s[4 * sm + c] = f16_to_f32(f32_to_f16(out[c]));
                 last_id = id;
                 last_s = sm;
             }
-            if (samples == 1u) {
-                for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(half_s[0][c]);
-            } else {
-                for (int c = 0; c < 4; ++c)
-                    o16[c] = f32_to_f16(((half_s[0][c] + half_s[1][c]) + (half_s[2][c] + half_s[3][c])) * 0.25f);
-            }
         }
+
+    /* transparent pass, strictly in draw order */
+    {
+        const float(*spos)[2] = samples == 4u ? SAMPLE_POS_4 : SAMPLE_POS_1;
+        float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
+        int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+        for (uint64_t i = 0; i < n_blend; ++i) {
+            uint32_t o = blend_obj[i], t = blend_tri[i];
+            const r3o_object *ob = &objects[o];
+            if (ob->enabled == 0u) continue;
+            uint32_t idx[3];
+            float v[3][3];
+            fetch_triangle(ob, mesh, t, idx, v);
+            tri_setup ts;
+            setup_triangle(baked[o].model_view_proj, v, half_w, half_h, positive_visible, &ts);
+            if (!ts.valid) continue;
+            int x0, y0, x1, y1;
+            tri_bounds(baked[o].model_view_proj, v, half_w, half_h, (int)w, (int)h, &x0, &y0, &x1, &y1);
+            uint32_t id = tri_base[o] + t + 1u;
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) {
+                    const uint64_t pix = (uint64_t)y * w + (uint64_t)x;
+                    uint32_t mask = 0;
+                    for (uint32_t sm = 0; sm < samples; ++sm) {
+                        float E[3];
+                        if (!edge_eval(&ts, (float)x + spos[sm][0], (float)y + spos[sm][1], E)) continue;
+                        float z = frag_depth(&ts, E);
+                        if (!(z >= 0.0f && z <= 1.0f)) continue;
+                        uint32_t db = (uint32_t)(vis[pix * samples + sm] >> 32);
+                        float dz; memcpy(&dz, &db, 4);
+                        if (!(z >= dz)) continue; /* CompareFunction::GreaterEqual, depth write off */
+                        mask |= 1u << sm;
+                    }
+                    if (!mask) continue;
+                    float src[4];
+                    shade_fragment(&sc, id, (uint32_t)x, (uint32_t)y, src);
+                    float a = src[3];
+                    for (uint32_t sm = 0; sm < samples; ++sm) {
+                        if (!(mask & (1u << sm))) continue;
+                        float *d = smp + 4 * (pix * samples + sm);
+                        float r[4];
+                        for (int c = 0; c < 3; ++c) r[c] = src[c] * a + d[c] * (1.0f - a);
+                        r[3] = src[3] * 1.0f + d[3] * (1.0f - a);
+                        for (int c = 0; c < 4; ++c) d[c] = f16_to_f32(f32_to_f16(r[c]));
+                    }
+                }
+        }
+    }
+
+#pragma omp parallel for schedule(static)
+    for (uint64_t pix = 0; pix < (uint64_t)w * h; ++pix) {
+        const float *half_s = smp + 4 * pix * samples;
+        uint16_t *o16 = hdr_out + 4 * pix;
+        if (samples == 1u) {
+            for (int c = 0; c < 4; ++c) o16[c] = f32_to_f16(half_s[c]);
+        } else {
+            for (int c = 0; c < 4; ++c)
+                o16[c] = f32_to_f16(((half_s[c] + half_s[4 + c]) + (half_s[8 + c] + half_s[12 + c])) * 0.25f);
+        }
+    }
+    free(smp);
     free(light_mats);
     free(light_l);
     free(pview);

@@ -326,6 +326,8 @@ class OracleRenderer:
         self.object_meta[h] = dict(mesh=mesh, material=material, transform=np.asarray(transform, dtype=f32).copy(),
                                    enabled=True, skeleton=skeleton)
         self._write_object(h)
+        # object.rs:273: a new object's sorting location is its transformed bounding-sphere centre
+        self.object_meta[h]["location"] = self.objects[h].view(f32)[16:19].copy()
         return h
 
     def add_objects_bulk(self, mesh_ids, material_ids, transforms):
@@ -335,6 +337,8 @@ class OracleRenderer:
     def set_object_transform(self, h, transform):
         self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
         self._write_object(h)
+        # object.rs:313: ... and after a transform update it is the translation (transform_point3a(ZERO))
+        self.object_meta[h]["location"] = self.object_meta[h]["transform"][12:15].copy()
 
     def remove_object(self, h):
         # object.rs:330-342: only disabled now, really removed at the next evaluate
@@ -379,8 +383,13 @@ class OracleRenderer:
         lib.r3o_frustum_cull(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(visible))
         if self.object_range is not None:  # multi-rank sharding: this rank owns object slots [begin, end)
             b, e = self.object_range
-            visible[:b] = 0
-            visible[e:] = 0
+            # ... of the opaque / cutout objects; blend objects are culled and drawn by every rank (ordered blending
+            # cannot be merged by a MAX reduce)
+            _mats, mat_keys = self.material_buffers()
+            is_blend = mat_keys[np.minimum(self.objects[:, 22], len(mat_keys) - 1)] == BLEND
+            outside = np.ones(cap, dtype=bool)
+            outside[b:e] = False
+            visible[outside & ~is_blend] = 0
         tri_base, total = self.tri_base()
         pass_bits = np.zeros(max(total, 1), dtype=np.uint8)
         residual = np.zeros(max(total, 1), dtype=np.uint8)
@@ -495,10 +504,25 @@ class OracleRenderer:
         dir_arr = np.frombuffer(dir_buf, dtype=np.uint8)[16:].copy()
         pt_arr = np.frombuffer(point_buf, dtype=np.uint8)[16:].copy()
         clear = np.asarray(clear_color, dtype=f32)
+        # transparent pass input (base.rs:181): this frame's passing triangles of the blend objects, back to front
+        blend_objs = [h for h, m in sorted(self.object_meta.items())
+                      if m["enabled"] and self.materials[m["material"]][1] == BLEND and visible[h]]
+        order = host.blend_draw_order(cam.location, blend_objs, [self.object_meta[h]["location"] for h in blend_objs])
+        bo, bt = [], []
+        for h in order:
+            nt = int(self.meshes[self.object_meta[h]["mesh"]].index_count // 3)
+            tris = np.flatnonzero(pass_bits[int(tri_base[h]): int(tri_base[h]) + nt]).astype(np.uint32)
+            bo.append(np.full(len(tris), h, dtype=np.uint32))
+            bt.append(tris)
+        blend_obj = np.ascontiguousarray(np.concatenate(bo)) if bo else np.zeros(0, dtype=np.uint32)
+        blend_tri = np.ascontiguousarray(np.concatenate(bt)) if bt else np.zeros(0, dtype=np.uint32)
+        out["blend_list"] = (blend_obj, blend_tri)
         lib.r3o_shade(lib.ptr(vis), width, height, samples, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
                       lib.ptr(self.mesh_words), lib.ptr(baked), lib.ptr(mats), lib.ptr(tri_base), n_dir,
                       lib.ptr(dir_arr) if n_dir else None, n_pt, lib.ptr(pt_arr) if n_pt else None,
-                      lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), *self._tex_args(), lib.ptr(hdr16))
+                      lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), *self._tex_args(),
+                      lib.ptr(blend_obj) if len(blend_obj) else None, lib.ptr(blend_tri) if len(blend_tri) else None,
+                      len(blend_obj), lib.ptr(hdr16))
         rgba_f = np.zeros((height, width, 4), dtype=f32)
         rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
         lib.r3o_tonemap(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8))
