@@ -34,6 +34,7 @@ extern "C" {
 #define R3N_ERR_NO_DEVICE (-3)
 #define R3N_ERR_STATE (-4)
 #define R3N_ERR_UNSUPPORTED (-5)
+#define R3N_ERR_CAPACITY (-6) /* a fixed-size internal buffer (raster work queue, blend fragment list) overflowed */
 
 /* CameraSpecifier (rend3-routine/src/common/camera.rs:3-35): shadow index, or R3N_CAMERA_VIEWPORT
  * (== CameraSpecifier::Viewport.to_shader_index() == u32::MAX). */
@@ -177,6 +178,10 @@ int r3n_materials_write(r3n_ctx *ctx, const uint32_t *slots, const r3n_material2
  *      sample entry `id - 1` (opaque.wgsl:151-160).  Formats other than RGBA8 -> R3N_ERR_UNSUPPORTED. */
 int r3n_textures_write(r3n_ctx *ctx, const r3n_texture_desc32 *descs, uint32_t n_textures, const uint32_t *texels,
                        uint64_t n_texels);
+/*      Draw order of the blend-key objects for the transparent pass: object slots back to front, as the CPU batcher
+ *      sorts them every frame (rend3-routine/src/culling/batching.rs:146-176, Sorting::BLENDING: -distance^2 from the
+ *      camera location to the object location).  Call once per frame before r3n_resolve_opaque (n may be 0). */
+int r3n_blend_order_write(r3n_ctx *ctx, const uint32_t *objects_back_to_front, uint32_t n);
 /*      DirectionalLightManager / PointLightManager buffers, byte-identical:
  *      u32 count @0, array @16 (stride 128 / 32): rend3/src/managers/directional.rs:31-53,135-153, point.rs:14-74 */
 int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t directional_bytes,
@@ -212,7 +217,11 @@ int r3n_shadow_viewport(r3n_ctx *ctx, r3n_camera shadow_camera, uint32_t x, uint
  * FORWARD colour is resolved per pixel by r3n_resolve_opaque (each pixel shaded once, for its nearest fragment). */
 int r3n_forward(r3n_ctx *ctx, r3n_camera camera, uint32_t pass, uint32_t source, uint32_t material_key);
 /* Evaluates opaque.wgsl (VS :91-135 + FS :203-551) for the nearest fragment of every pixel -> Rgba16Float HDR.
- * Must follow the last FORWARD r3n_forward of the frame (base.rs:172) and precede r3n_tonemap. */
+ * Must follow the last opaque / cutout FORWARD r3n_forward of the frame (base.rs:172) and precede r3n_tonemap.
+ * The transparent pass -- r3n_forward(R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_BLEND),
+ * base.rs:181 -- comes after it: this frame's passing triangles of the blend-key objects, in the order given to
+ * r3n_blend_order_write, depth-tested against the opaque depth (no depth write) and alpha-blended into the HDR target
+ * (pbr/routine.rs:113-118). */
 int r3n_resolve_opaque(r3n_ctx *ctx);
 /* TonemappingRoutine::add_to_graph (tonemapping.rs:108-147) + blit.wgsl into an Rgba8UnormSrgb target.
  * If `host_rgba8` is non-NULL the image is also copied out (synchronises), `pitch_bytes` per row. */

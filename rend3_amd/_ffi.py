@@ -32,6 +32,7 @@ SIGNATURES = {
     "r3n_objects_write": (cint, [vp, vp, vp, u32, u32]),
     "r3n_materials_write": (cint, [vp, vp, vp, vp, u32]),
     "r3n_textures_write": (cint, [vp, vp, u32, vp, u64]),
+    "r3n_blend_order_write": (cint, [vp, vp, u32]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
     "r3n_skinning": (cint, [vp, vp, u32, vp, u32]),

@@ -58,7 +58,12 @@ __global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240
         const uint32_t enabled = o->enabled;
         const uint32_t ntri = enabled ? o->index_count / 3u : 0u;
         ntri_all = ntri;
-        if (ntri > 0u && i >= range_begin && i < range_end) {
+        const uint32_t mi0 = o->material_index;
+        uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
+        if (key0 > 2u) key0 = 2u;
+        // multi-rank sharding: a rank owns the opaque / cutout objects of its slot range; blend-key objects are culled and
+        // drawn by every rank (ordered blending cannot be merged by the MAX reduce of the depth keys)
+        if (ntri > 0u && ((i >= range_begin && i < range_end) || key0 == 2u)) {
             const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
             const float c[3] = {sph.x, sph.y, sph.z};
             const float neg_radius = -sph.w;

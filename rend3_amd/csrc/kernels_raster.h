@@ -38,6 +38,12 @@ struct RasterArgs {
     uint32_t big_capacity;
     r3n_big_uv *big_uv;                    // same indexing as big_items; textured cutout triangles only
     TextureArgs tex;
+    // transparent pass (row N3): fragments that pass the depth test are appended here instead of written as keys
+    unsigned long long *frag_keys;         // (pixel * samples + sample) << 32 | draw order of the triangle
+    uint32_t *frag_vals;                   // canonical slot + 1
+    uint32_t *frag_count;
+    uint32_t frag_capacity;
+    uint32_t row_begin, row_end;           // rows this rank resolves
 };
 
 // opaque.wgsl:214-235 / depth.wgsl:98-125 (untextured paths): alpha the cutout test compares with the threshold
@@ -148,8 +154,31 @@ R3N_DEV float cutout_texture_alpha(const RasterArgs &a, const TriWork &tw, int x
 // alpha -- once per pixel at the pixel centre, covered or not (no centroid qualifier in opaque.wgsl).
 __device__ static const float k_sample_pos4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}};
 
-template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false>
+template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
+    if (BLEND) {
+        // Transparent pass: depth test GreaterEqual against the final opaque depth, depth write off (pbr/routine.rs:
+        // 113-118); what passes is recorded for the ordered blend (k_blend_apply).  tw.material = draw order.
+        if ((uint32_t)y < a.row_begin || (uint32_t)y >= a.row_end) return;
+        const size_t pix = (size_t)y * a.target_pitch + (size_t)x;
+#pragma unroll
+        for (int sm = 0; sm < S; ++sm) {
+            float E[3];
+            const float sx = S == 1 ? 0.5f : k_sample_pos4[sm][0], sy = S == 1 ? 0.5f : k_sample_pos4[sm][1];
+            if (!edge_eval(tw.ts, (float)x + sx, (float)y + sy, E)) continue;
+            const float z = frag_depth(tw.ts, E);
+            if (!(z >= 0.0f && z <= 1.0f)) continue;
+            const size_t ps = pix * (size_t)S + (size_t)sm;
+            const float dz = __uint_as_float((uint32_t)(a.vis[ps] >> 32));
+            if (!(z >= dz)) continue;
+            const uint32_t at = atomicAdd(a.frag_count, 1u);
+            if (at < a.frag_capacity) {
+                a.frag_keys[at] = ((unsigned long long)ps << 32) | (unsigned long long)tw.material;
+                a.frag_vals[at] = tw.slot1;
+            }
+        }
+        return;
+    }
     if (S == 1) {
         float E[3];
         if (!edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
@@ -276,6 +305,65 @@ __global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
     }
 }
 
+// Transparent pass, stage 1 (row N3): one thread per triangle of the blend-key objects, in DRAW ORDER -- objects back
+// to front (blend_order, sorted on the host like batching.rs:146-176), triangles in index order; g is therefore
+// the triangle's draw order.  Triangles that passed this frame's cull (cull.wgsl:372-378 writes exactly those into
+// the non-atomic residual list) are set up and split into <= R3N_TILE^2 px work items; stage 2 is k_raster_big in
+// BLEND mode.
+struct BlendSetupArgs {
+    const uint32_t *order;             // blend objects, back to front
+    const uint32_t *rank_base;         // n + 1: exclusive scan of their triangle counts
+    uint32_t n_objects;
+    const unsigned long long *mask;    // this frame's cull result bits (viewport)
+    const uint32_t *slot_base;         // first bit of each object in `mask`, or INVALID when it was not batched
+};
+__global__ __launch_bounds__(256) void k_blend_setup(RasterArgs a, BlendSetupArgs b) {
+    const uint32_t total = b.rank_base[b.n_objects];
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= total) return;
+    uint32_t lo = 0, hi = b.n_objects;  // last k with rank_base[k] <= g
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (b.rank_base[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint32_t obj = b.order[lo], tri = g - b.rank_base[lo];
+    const uint32_t sb = b.slot_base[obj];
+    if (sb == R3N_INVALID) return;
+    const uint32_t bit = sb + tri;
+    if (!((b.mask[bit >> 6] >> (bit & 63u)) & 1ull)) return;
+    const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
+    TriWork tw;
+    if (!prepare_triangle<false, false>(a, obj, tri, positive_visible, tw)) return;
+    const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
+    const uint32_t tx = (uint32_t)(bw + (R3N_TILE - 1)) / R3N_TILE, ty = (uint32_t)(bh + (R3N_TILE - 1)) / R3N_TILE;
+    const uint32_t cnt = tx * ty;
+    const uint32_t bq = (blockIdx.x * 4u + (threadIdx.x >> 6)) % R3N_BIGQ;
+    const uint32_t start = atomicAdd(&a.big_count[bq], cnt);
+    r3n_big_item *big = a.big_items + (size_t)bq * a.big_capacity;
+    for (uint32_t t = 0; t < cnt; ++t) {
+        const uint32_t ix = t % tx, iy = t / tx;
+        const int rx0 = tw.x0 + (int)ix * R3N_TILE, ry0 = tw.y0 + (int)iy * R3N_TILE;
+        const int rx1 = min(rx0 + (R3N_TILE - 1), tw.x1), ry1 = min(ry0 + (R3N_TILE - 1), tw.y1);
+        if (start + t >= a.big_capacity) {  // the caller sees big_count > capacity and fails the frame
+            continue;
+        }
+        r3n_big_item it;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) it.e[i][c] = tw.ts.e[i][c];
+            it.z[i] = tw.ts.z[i];
+            it.va[i] = 1.0f;
+        }
+        it.det = tw.ts.det;
+        it.slot1 = tw.slot1;
+        it.material = g;  // draw order
+        it.xy0 = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
+        it.xy1 = (uint32_t)rx1 | ((uint32_t)ry1 << 16);
+        big[start + t] = it;
+    }
+}
+
 // Upper bound of edge function i over the pixel centres of an SxS block whose first pixel is (bx,by).  Each
 // f32 operation is monotone, so evaluating the same expression at the extreme corner gives the exact maximum of
 // the per-pixel values: a block with a negative maximum holds no covered pixel.
@@ -302,7 +390,7 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 // the next item's record is in flight while the current one is scanned.  Waves walk the concatenation of the
 // R3N_BIGQ producer sub-queues with a stride of the wave count, which spreads neighbouring (similar-cost) items
 // over different waves.
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     // Pin the kernel arguments the scan uses into SGPRs here: hipcc otherwise sinks the wait for their s_load
     // into the scan loop, and an `s_waitcnt lgkmcnt(0)` there would also wait for the record prefetch below.
@@ -370,7 +458,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
         w.ts.det = bf(12);
         w.ts.valid = true;
         w.slot1 = bu(16);
-        w.cutout = a.key == R3N_KEY_CUTOUT;  // launch-uniform
+        w.cutout = !BLEND && a.key == R3N_KEY_CUTOUT;  // launch-uniform
         w.material = bu(17);
         w.mat_flags = 0u; w.mat_alpha = 1.0f; w.mat_cutoff = 0.0f;
         w.alpha_tex = false;
@@ -409,7 +497,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 }
                 const int b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                 const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
-                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX>(a, w, x, y);
+                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX, BLEND>(a, w, x, y);
             }
         } else {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
@@ -419,7 +507,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX>(a, w, x, y);
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX, BLEND>(a, w, x, y);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
@@ -580,6 +668,7 @@ struct ShadeArgs {
     uchar4 *ldr_out;           // Rgba8UnormSrgb: the tonemap blit fused into the resolve (one HDR round trip less)
     const unsigned char *srgb_lut;
     TextureArgs tex;
+    ushort4 *samples_out;      // S == 4 and a transparent pass follows: the per-sample colours (else null)
 };
 
 struct LdsDirLight {
@@ -1033,18 +1122,12 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     }
 }
 
-// One thread per pixel, 16x16 pixel tiles; the light list is transformed once per workgroup and staged in LDS.
-// S = samples per pixel.  S == 4: every sample of the multisampled Rgba16Float target holds the half-rounded colour
-// of its nearest fragment (shaded once per distinct triangle, at the pixel centre) or the clear colour; the render
-// pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
-// Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
-// (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
-template <int S, bool TEX>
-__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaque(ShadeArgs a) {
-    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
-    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
-    const uint32_t n_dir = min(*reinterpret_cast<const uint32_t *>(a.dir_buf), (uint32_t)R3N_MAX_DIR_LIGHTS);
-    const uint32_t n_point = min(*reinterpret_cast<const uint32_t *>(a.point_buf), (uint32_t)R3N_MAX_POINT_LIGHTS);
+// The light list in view space, once per workgroup (LDS): matrices light.view_proj * uniforms.inv_view, directions,
+// point-light positions.  Ends with a barrier.
+R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight *s_point, uint32_t &n_dir, uint32_t &n_point) {
+    n_dir = min(*reinterpret_cast<const uint32_t *>(a.dir_buf), (uint32_t)R3N_MAX_DIR_LIGHTS);
+    n_point = min(*reinterpret_cast<const uint32_t *>(a.point_buf), (uint32_t)R3N_MAX_POINT_LIGHTS);
+
     const r3n_dir_light128 *dirs = reinterpret_cast<const r3n_dir_light128 *>(a.dir_buf + 16);
     const r3n_point_light32 *points = reinterpret_cast<const r3n_point_light32 *>(a.point_buf + 16);
     for (uint32_t i = threadIdx.x; i < n_dir * 4u; i += 256u) {
@@ -1077,6 +1160,20 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaqu
         s_point[i].radius = points[i].radius;
     }
     __syncthreads();
+}
+
+// One thread per pixel, 16x16 pixel tiles; the light list is transformed once per workgroup and staged in LDS.
+// S = samples per pixel.  S == 4: every sample of the multisampled Rgba16Float target holds the half-rounded colour
+// of its nearest fragment (shaded once per distinct triangle, at the pixel centre) or the clear colour; the render
+// pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
+// Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
+// (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
+template <int S, bool TEX>
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaque(ShadeArgs a) {
+    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
+    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    uint32_t n_dir, n_point;
+    stage_lights(a, s_dir, s_point, n_dir, n_point);
 
     // each wavefront shades an 8x8 pixel quad of the 16x16 tile (fewer distinct triangles / atlas texels per wave
     // than a 16x4 strip; measured 3 % faster)
@@ -1121,12 +1218,75 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaqu
 #pragma unroll
             for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];
         }
+        if (a.samples_out != nullptr) {
+#pragma unroll
+            for (int sm = 0; sm < S; ++sm) a.samples_out[pix * (size_t)S + (size_t)sm] = pack_half4(col[sm]);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = ((col[0][c] + col[1][c]) + (col[2][c] + col[3][c])) * 0.25f;
     }
     const ushort4 ho = pack_half4(out);
     a.hdr_out[pix] = ho;
     a.ldr_out[pix] = tonemap_half4(a.srgb_lut, ho);
+}
+
+// ------------------------------------------------------------------------------------------------ transparent pass
+// Stage 3 (row N3): the collected fragments, sorted by (pixel sample, draw order).  The thread that owns the first
+// fragment of a sample walks that sample's run in order: evaluate the fragment (once per triangle and pixel centre,
+// like the forward pass), BlendState::ALPHA_BLENDING on the half-rounded destination -- rgb = src * a + dst * (1 - a),
+// alpha = src.a + dst.a * (1 - a) in f32, result rounded to half -- exactly the oracle's sequence.
+struct BlendApplyArgs {
+    const unsigned long long *keys;
+    const uint32_t *vals;
+    uint32_t n;
+    ushort4 *samples;  // S == 1: the HDR target itself; S == 4: the per-sample colours
+};
+template <int S, bool TEX>
+__global__ __launch_bounds__(256) void k_blend_apply(ShadeArgs a, BlendApplyArgs b) {
+    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
+    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    uint32_t n_dir, n_point;
+    stage_lights(a, s_dir, s_point, n_dir, n_point);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= b.n) return;
+    const uint32_t ps = (uint32_t)(b.keys[i] >> 32);
+    if (i > 0u && (uint32_t)(b.keys[i - 1u] >> 32) == ps) return;  // not the head of its run
+    const uint32_t pix = ps / (uint32_t)S;
+    const uint32_t x = pix % a.width, y = pix / a.width;
+    const ushort4 d16 = b.samples[ps];
+    float d[4] = {(float)__builtin_bit_cast(_Float16, d16.x), (float)__builtin_bit_cast(_Float16, d16.y),
+                  (float)__builtin_bit_cast(_Float16, d16.z), (float)__builtin_bit_cast(_Float16, d16.w)};
+    for (uint32_t j = i; j < b.n && (uint32_t)(b.keys[j] >> 32) == ps; ++j) {
+        float src[4];
+        shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, b.vals[j], x, y, src);
+        const float al = src[3];
+        float r[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = src[c] * al + d[c] * (1.0f - al);
+        r[3] = src[3] * 1.0f + d[3] * (1.0f - al);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[c] = (float)(_Float16)r[c];
+    }
+    b.samples[ps] = pack_half4(d);
+}
+
+// Render-pass resolve of the blended samples (S == 4): box average, same expression as in k_resolve_opaque.
+__global__ __launch_bounds__(256) void k_resolve_samples(const ushort4 *__restrict__ samples, ushort4 *__restrict__ hdr_out,
+                                                         size_t first_pixel, size_t n_pixels) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pixels) return;
+    const size_t pix = first_pixel + i;
+    float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float col[4][4];
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) {
+        const ushort4 h = samples[pix * 4u + (size_t)sm];
+        col[sm][0] = (float)__builtin_bit_cast(_Float16, h.x); col[sm][1] = (float)__builtin_bit_cast(_Float16, h.y);
+        col[sm][2] = (float)__builtin_bit_cast(_Float16, h.z); col[sm][3] = (float)__builtin_bit_cast(_Float16, h.w);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = ((col[0][c] + col[1][c]) + (col[2][c] + col[3][c])) * 0.25f;
+    hdr_out[pix] = pack_half4(out);
 }
 
 // ------------------------------------------------------------------------------------------------ K7 tonemap

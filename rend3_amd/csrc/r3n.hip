@@ -75,9 +75,15 @@ struct r3n_ctx {
     uint32_t width = 0, height = 0, samples = 1, atlas_w = 0, atlas_h = 0;
     float clear[4] = {0, 0, 0, 0};
     bool in_frame = false;
+    bool blended_this_frame = false;
     bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
+    // transparent pass (row N3)
+    DevBuf blend_order, blend_rank_base, frag_keys[2], frag_vals[2], frag_count, sort_temp, samples16;
+    std::vector<uint32_t> h_blend_order;
+    uint32_t n_blend = 0, blend_tris = 0;
+    uint32_t frag_capacity = 32u << 20;  // fragments (24 B each incl. the sort's double buffers), allocated on first use
     DevBuf tex_descs, tex_texels, srgb8_decode;  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
     DevBuf big_uv[1 + R3N_AUX_STREAMS];
@@ -425,7 +431,9 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode};
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
+                      &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
+                      &c->frag_count, &c->sort_temp, &c->samples16};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -610,6 +618,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     c->in_frame = true;
     for (auto &f : c->forward_index_lane) f = 0;
     c->resolved_this_frame = false;
+    c->blended_this_frame = false;
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
@@ -773,11 +782,12 @@ int r3n_shadow_viewport(r3n_ctx *c, r3n_camera cam, uint32_t x, uint32_t y, uint
     return R3N_OK;
 }
 
+static int forward_blend(r3n_ctx *c);
+
 int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint32_t key) {
     if (!c || pass > R3N_PASS_FORWARD || source > R3N_SOURCE_RESIDUAL || key > R3N_KEY_BLEND)
         return fail(c, R3N_ERR_INVALID_ARG, "forward: bad args");
     if (!c->in_frame) return fail(c, R3N_ERR_STATE, "forward: outside a frame");
-    if (key == R3N_KEY_BLEND) return fail(c, R3N_ERR_UNSUPPORTED, "forward: blend routine is not built yet (row N3)");
     CamState *s = find_cam(c, cam, false);
     if (!s || !s->has_hdr || c->capacity == 0) return R3N_OK;  // nothing baked / culled yet: forward.rs:214-242
     if (c->key_census_dirty) {
@@ -794,6 +804,12 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     if (c->key_objects[key] == 0) return R3N_OK;
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     if ((pass == R3N_PASS_FORWARD) != viewport) return fail(c, R3N_ERR_UNSUPPORTED, "forward: FORWARD needs the viewport, DEPTH a shadow camera");
+    if (key == R3N_KEY_BLEND) {
+        // shadow views have no blend routine (base.rs:366-396 draws opaque_depth and cutout_depth only)
+        if (!viewport || source != R3N_SOURCE_RESIDUAL) return fail(c, R3N_ERR_INVALID_ARG, "forward: the blend routine draws the viewport's residual source (base.rs:451-465)");
+        HIP_TRY(c, hipSetDevice(c->device));
+        return forward_blend(c);
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     int idx;
     const r3n_tri_ref *list;
@@ -871,14 +887,8 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     return check_launch(c, "raster");
 }
 
-int r3n_resolve_opaque(r3n_ctx *c) {
-    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "resolve_opaque: outside a frame");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t r0 = std::min(c->row_begin, c->height), r1 = std::min(c->row_end, c->height);
-    if (r1 <= r0) return R3N_OK;
+static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     CamState &s = c->viewport;
-    if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
-    TRY(join_lanes(c));  // the shadow atlas must be complete
     ShadeArgs a{};
     a.vis = c->vis.as<unsigned long long>();
     a.width = c->width; a.height = c->height; a.row_begin = r0; a.row_end = r1;
@@ -901,6 +911,23 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     a.ldr_out = c->out8.as<uchar4>();
     a.srgb_lut = c->srgb_lut.as<unsigned char>();
     a.tex = texture_args(c);
+    a.samples_out = nullptr;
+    return a;
+}
+
+int r3n_resolve_opaque(r3n_ctx *c) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "resolve_opaque: outside a frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t r0 = std::min(c->row_begin, c->height), r1 = std::min(c->row_end, c->height);
+    if (r1 <= r0) return R3N_OK;
+    CamState &s = c->viewport;
+    if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
+    TRY(join_lanes(c));  // the shadow atlas must be complete
+    ShadeArgs a = make_shade_args(c, r0, r1);
+    if (c->samples == 4 && c->blend_tris > 0) {  // a transparent pass will blend into the individual samples
+        TRY(ensure(c, c->samples16, (size_t)c->width * c->height * 4 * 8, false, -1));
+        a.samples_out = c->samples16.as<ushort4>();
+    }
     c->resolved_this_frame = true;
     Timed t(c, R3N_STAGE_SHADE);
     const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
@@ -913,6 +940,132 @@ int r3n_resolve_opaque(r3n_ctx *c) {
         else hipLaunchKernelGGL((k_resolve_opaque<1, false>), rgrid, dim3(256), 0, c->stream, a);
     }
     return check_launch(c, "k_resolve_opaque");
+}
+
+extern "C" int r3n_internal_sort_pairs(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
+                                       unsigned long long *keys_out, const unsigned int *vals_in, unsigned int *vals_out,
+                                       unsigned int n, int end_bit, hipStream_t stream);
+
+int r3n_blend_order_write(r3n_ctx *c, const uint32_t *objects, uint32_t n) {
+    if (!c || (n && !objects)) return fail(c, R3N_ERR_INVALID_ARG, "blend order: null");
+    std::vector<uint32_t> rank(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (objects[i] >= c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "blend order: object slot >= capacity");
+        rank[i + 1] = rank[i] + c->h_ntri[objects[i]];
+    }
+    c->n_blend = n;
+    c->blend_tris = rank[n];
+    if (n == 0) return R3N_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure(c, c->blend_order, (size_t)n * 4, false, -1));
+    TRY(ensure(c, c->blend_rank_base, (size_t)(n + 1) * 4, false, -1));
+    c->h_blend_order.assign(objects, objects + n);
+    HIP_TRY(c, hipMemcpyAsync(c->blend_order.p, objects, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->blend_rank_base.p, rank.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // both sources are caller / stack memory
+    return R3N_OK;
+}
+
+// Transparent pass (base.rs:181,451-465): collect -> sort -> ordered blend.  See kernels_raster.h.
+static int forward_blend(r3n_ctx *c) {
+    CamState &s = c->viewport;
+    if (!s.culled || c->blend_tris == 0) return R3N_OK;  // nothing culled this frame / no blend triangles
+    if (!c->resolved_this_frame) return fail(c, R3N_ERR_STATE, "forward: the transparent pass must follow r3n_resolve_opaque");
+    const uint32_t r0 = std::min(c->row_begin, c->height), r1 = std::min(c->row_end, c->height);
+    if (r1 <= r0) return R3N_OK;
+    const uint32_t S = c->samples;
+    for (int k = 0; k < 2; ++k) {
+        TRY(ensure(c, c->frag_keys[k], (size_t)c->frag_capacity * 8, false, -1));
+        TRY(ensure(c, c->frag_vals[k], (size_t)c->frag_capacity * 4, false, -1));
+    }
+    TRY(ensure(c, c->frag_count, 16, false, 0));
+    const int idx = s.cur;
+    RasterArgs a{};
+    a.hdr = s.d_hdr.as<r3n_camera_header240>();
+    a.objects = c->objects.as<r3n_object128>();
+    a.mesh = c->mesh.as<uint32_t>();
+    a.baked = s.baked.as<r3n_baked128>();
+    a.materials = c->materials.as<r3n_material208>();
+    a.material_keys = c->material_keys.as<uint8_t>();
+    a.n_materials = c->n_materials;
+    a.tri_base = c->tri_base.as<uint32_t>();
+    a.key = R3N_KEY_BLEND;
+    a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
+    a.vis = c->vis.as<unsigned long long>();
+    a.big_items = c->big_items[0].as<r3n_big_item>();
+    const uint32_t fwd = std::min(c->forward_index_lane[0]++, 63u);
+    a.big_count = c->big_count[0].as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
+    a.big_capacity = c->big_capacity;
+    a.big_uv = c->big_uv[0].as<r3n_big_uv>();
+    a.tex = texture_args(c);
+    a.frag_keys = c->frag_keys[0].as<unsigned long long>();
+    a.frag_vals = c->frag_vals[0].as<uint32_t>();
+    a.frag_count = c->frag_count.as<uint32_t>();
+    a.frag_capacity = c->frag_capacity;
+    a.row_begin = r0; a.row_end = r1;
+    BlendSetupArgs b{};
+    b.order = c->blend_order.as<uint32_t>();
+    b.rank_base = c->blend_rank_base.as<uint32_t>();
+    b.n_objects = c->n_blend;
+    b.mask = s.mask[idx].as<unsigned long long>();
+    b.slot_base = s.slot_base[idx].as<uint32_t>();
+    hipStream_t stream = c->stream;
+    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(a.frag_count, 0, 4, stream));
+    {
+        Timed t(c, R3N_STAGE_RASTER, stream);
+        hipLaunchKernelGGL(k_blend_setup, dim3((c->blend_tris + 255u) / 256u), dim3(256), 0, stream, a, b);
+    }
+    {
+        Timed t(c, R3N_STAGE_RASTER_BIG, stream);
+        if (S == 4) hipLaunchKernelGGL((k_raster_big<false, 4, false, true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_raster_big<false, 1, false, true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a);
+    }
+    TRY(check_launch(c, "blend collect"));
+    // the sort needs the fragment count on the host (only frames with blend objects pay for this round trip)
+    uint32_t n_frag = 0, items[R3N_BIGQ];
+    HIP_TRY(c, hipMemcpyAsync(&n_frag, a.frag_count, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(items, a.big_count, sizeof items, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    for (uint32_t q = 0; q < R3N_BIGQ; ++q)
+        if (items[q] > c->big_capacity) return fail(c, R3N_ERR_CAPACITY, "forward: transparent pass overflowed the raster work queue (r3n_config.max_big_items)");
+    if (n_frag > c->frag_capacity) return fail(c, R3N_ERR_CAPACITY, "forward: transparent pass produced more fragments than the fragment buffer holds");
+    if (n_frag == 0) return R3N_OK;
+    int end_bit = 32;
+    for (uint64_t m = (uint64_t)c->width * c->height * S; m; m >>= 1) ++end_bit;
+    size_t temp_bytes = 0;
+    if (r3n_internal_sort_pairs(nullptr, &temp_bytes, nullptr, nullptr, nullptr, nullptr, n_frag, end_bit, stream) != 0)
+        return fail(c, R3N_ERR_HIP, "forward: radix sort sizing failed");
+    TRY(ensure(c, c->sort_temp, std::max<size_t>(temp_bytes, 16), false, -1));
+    if (r3n_internal_sort_pairs(c->sort_temp.p, &temp_bytes, c->frag_keys[0].as<unsigned long long>(),
+                                c->frag_keys[1].as<unsigned long long>(), c->frag_vals[0].as<uint32_t>(),
+                                c->frag_vals[1].as<uint32_t>(), n_frag, end_bit, stream) != 0)
+        return fail(c, R3N_ERR_HIP, "forward: radix sort failed");
+    ShadeArgs sa = make_shade_args(c, r0, r1);
+    BlendApplyArgs ba{};
+    ba.keys = c->frag_keys[1].as<unsigned long long>();
+    ba.vals = c->frag_vals[1].as<uint32_t>();
+    ba.n = n_frag;
+    ba.samples = S == 4 ? c->samples16.as<ushort4>() : c->hdr16.as<ushort4>();
+    if (S == 4 && !c->samples16.p) return fail(c, R3N_ERR_STATE, "forward: r3n_blend_order_write must precede r3n_resolve_opaque");
+    {
+        Timed t(c, R3N_STAGE_SHADE, stream);
+        const dim3 g((n_frag + 255u) / 256u);
+        const bool tex = c->n_textures > 0;
+        if (S == 4) {
+            if (tex) hipLaunchKernelGGL((k_blend_apply<4, true>), g, dim3(256), 0, stream, sa, ba);
+            else hipLaunchKernelGGL((k_blend_apply<4, false>), g, dim3(256), 0, stream, sa, ba);
+            const size_t first = (size_t)r0 * c->width, npx = (size_t)(r1 - r0) * c->width;
+            hipLaunchKernelGGL(k_resolve_samples, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream,
+                               c->samples16.as<ushort4>(), c->hdr16.as<ushort4>(), first, npx);
+        } else {
+            if (tex) hipLaunchKernelGGL((k_blend_apply<1, true>), g, dim3(256), 0, stream, sa, ba);
+            else hipLaunchKernelGGL((k_blend_apply<1, false>), g, dim3(256), 0, stream, sa, ba);
+        }
+    }
+    c->resolved_this_frame = false;  // the fused blit shows the HDR target before blending: r3n_tonemap re-runs it
+    c->blended_this_frame = true;
+    return check_launch(c, "blend apply");
 }
 
 static int launch_tonemap(r3n_ctx *c, float4 *f32_out) {

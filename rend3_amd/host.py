@@ -290,3 +290,17 @@ def prepare_texture(rgba8, srgb, mip_count, mip_source):
     if mips > 1:
         _ffi.lib().r3n_host_generate_mips(1 if srgb else 0, w, h, mips, _ffi.ptr(out))
     return out, w, h, mips
+
+
+def blend_draw_order(camera_location, object_indices, locations):
+    """Back-to-front order of the blend-key objects (rend3-routine/src/culling/batching.rs:146-176 with
+    Sorting::BLENDING: key = -distance^2 from the camera location to the object location, ascending; ties -- which the
+    reference's unstable sort leaves open -- by object index).  distance_squared as glam: (dx*dx + dy*dy) + dz*dz in f32."""
+    cam = np.asarray(camera_location, dtype=f32)
+    keyed = []
+    for idx, loc in zip(object_indices, locations):
+        d = cam - np.asarray(loc, dtype=f32)
+        dist = f32(f32(d[0] * d[0]) + f32(d[1] * d[1])) + f32(d[2] * d[2])
+        keyed.append((-float(f32(dist)), int(idx)))
+    keyed.sort()
+    return [i for _k, i in keyed]

@@ -185,6 +185,7 @@ class Renderer:
         self.mesh_cursor = 0  # in u32 words
         self.meshes = []
         self.materials = []
+        self._had_blend = False
         self.tex_descs = np.zeros((0, 8), dtype=np.uint32)  # r3n_texture_desc32 rows
         self.tex_pool = np.zeros(1, dtype=np.uint32)
         self.tex_used = 0
@@ -393,7 +394,10 @@ class Renderer:
             mesh = self.skeletons[skeleton]["mesh"]
         self.object_meta[h] = dict(mesh=mesh, material=material, transform=np.asarray(transform, dtype=f32).copy(),
                                    enabled=True, skeleton=skeleton)
-        self._mark(h, self._object_record(h))
+        rec = self._object_record(h)
+        self._mark(h, rec)
+        # object.rs:273: a new object's sorting location is its transformed bounding-sphere centre
+        self.object_meta[h]["location"] = rec.view(f32)[16:19].copy()
         return h
 
     def add_objects_bulk(self, mesh_ids, material_ids, transforms):
@@ -413,7 +417,8 @@ class Renderer:
         handles = []
         for i in range(n):
             h = self._alloc_handle()
-            self.object_meta[h] = dict(mesh=int(mesh_ids[i]), material=int(material_ids[i]), transform=transforms[i], enabled=True)
+            self.object_meta[h] = dict(mesh=int(mesh_ids[i]), material=int(material_ids[i]), transform=transforms[i], enabled=True,
+                                       location=recs[i].view(f32)[16:19].copy())
             self._mark(h, recs[i])
             handles.append(h)
         return handles
@@ -421,6 +426,8 @@ class Renderer:
     def set_object_transform(self, h, transform):
         self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
         self._mark(h, self._object_record(h))
+        # object.rs:313: after a transform update the sorting location is the translation
+        self.object_meta[h]["location"] = self.object_meta[h]["transform"][12:15].copy()
 
     def remove_object(self, h):
         self.object_meta[h]["enabled"] = False  # object.rs:330-342: disabled now, removed next frame
@@ -461,6 +468,13 @@ class Renderer:
         self._check(self.lib.r3n_lights_write(self.ctx, _ffi.ptr(dir_buf), dir_buf.nbytes, _ffi.ptr(point_buf),
                                               point_buf.nbytes), "r3n_lights_write")
         self._dir_buf, self._point_buf = dir_buf, point_buf
+        # the CPU batcher's back-to-front order of the blend-key objects (batching.rs:146-176), every frame
+        blend = [h for h, m in sorted(self.object_meta.items()) if m["enabled"] and self.materials[m["material"]][1] == BLEND]
+        order = host.blend_draw_order(self.camera.location, blend, [self.object_meta[h]["location"] for h in blend]) if blend else []
+        if order or self._had_blend:
+            arr = np.asarray(order, dtype=np.uint32)
+            self._check(self.lib.r3n_blend_order_write(self.ctx, _ffi.ptr(arr) if len(arr) else None, len(arr)), "r3n_blend_order_write")
+        self._had_blend = bool(order)
         return EvalOutput(shadows, size)
 
     # ------------------------------------------------------------------ convenience: one whole frame
@@ -634,7 +648,6 @@ class TonemappingRoutine:
 
     def add_to_graph(self, graph):
         def body(r, ev):
-            r._check(r.lib.r3n_resolve_opaque(r.ctx), "r3n_resolve_opaque")
             r._check(r.lib.r3n_tonemap(r.ctx, None, 0), "r3n_tonemap")
 
         graph.add_node("Tonemapping", body)
@@ -725,7 +738,10 @@ class BaseRenderGraph:
             routine.add_forward_to_graph(graph, "PBR Forward Pass 2", VP, _ffi.SOURCE_RESIDUAL)
         if exchange is not None:
             graph.add_node("exchange pass-2 keys", lambda r, _ev: exchange("pass2", r))
-        # skybox (base.rs:175): out of scope.  pbr_forward_rendering_transparent (base.rs:181): row N3, not built
+        # the deferred evaluation of the opaque passes' fragments (this design's stand-in for their fragment shaders)
+        graph.add_node("Resolve Opaque", lambda r, _ev: r._check(r.lib.r3n_resolve_opaque(r.ctx), "r3n_resolve_opaque"))
+        # skybox (base.rs:175): out of scope.  pbr_forward_rendering_transparent (base.rs:181)
+        pbr.blend_routine.add_forward_to_graph(graph, "PBR Forward Transparent", VP, _ffi.SOURCE_RESIDUAL)
         # tonemapping (base.rs:184)
         inputs.routines.tonemapping.add_to_graph(graph)
         graph.add_node("Frame End", lambda r, _ev: r._check(r.lib.r3n_frame_end(r.ctx), "r3n_frame_end"))

@@ -275,3 +275,34 @@ def write_textured_gltf(path):
     with open(path, "w") as fh:
         json.dump(doc, fh)
     return path
+
+
+def add_blend_objects(r, hm, mk, seed, n=12, textured=False):
+    """Translucent boxes and spheres (TransparencyType::Blend) scattered in front of the camera of the random scenes:
+    overlapping each other and the opaque geometry, different alphas, one unlit, optionally a textured one."""
+    rng = Pcg32(seed)
+    p, i, nrm = box()
+    if getattr(r, "handedness", LEFT) == RIGHT:
+        i = i.reshape(-1, 3)[:, ::-1].reshape(-1)
+    uv = (p[:, [0, 2]] * np.float32(0.75) + p[:, [1, 1]] * np.float32(0.25)).astype(np.float32)
+    mbox = r.add_mesh(p, i, normals=nrm, uv0=uv)
+    ps, is_, ns = icosphere(2)
+    if getattr(r, "handedness", LEFT) == LEFT:
+        is_ = is_.reshape(-1, 3)[:, ::-1].reshape(-1)
+    msph = r.add_mesh(ps, is_, normals=ns, uv0=(ps[:, :2] * np.float32(2.0)).astype(np.float32))
+    mats = []
+    for k in range(5):
+        col = (rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.25, 0.8))
+        mats.append(r.add_material(mk(albedo=col, albedo_mode="value", roughness=rng.uniform(0.2, 0.8), unlit=(k == 3)), BLEND))
+    if textured:
+        nrng = np.random.default_rng(seed)
+        img = nrng.integers(0, 256, (32, 32, 4), dtype=np.uint8)
+        t = r.add_texture_2d(img, srgb=True, mip_count="maximum", mip_source="generated")
+        mats.append(r.add_material(mk(albedo_mode="texture_value", albedo_texture=t, albedo=(1.0, 1.0, 1.0, 0.7), roughness=0.5), BLEND))
+    handles = []
+    for k in range(n):
+        pos = (rng.uniform(-6.0, 6.0), rng.uniform(-1.0, 3.0), rng.uniform(3.0, 14.0))
+        sc = (rng.uniform(0.5, 3.0), rng.uniform(0.5, 3.0), rng.uniform(0.05, 1.0))
+        xf = hm.mat4_mul(hm.mat4_mul(hm.translation(pos), random_rotation(rng, hm)), hm.scale(sc))
+        handles.append(r.add_object(mbox if k % 3 else msph, mats[rng.randint(len(mats))], xf))
+    return handles
