@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--objects", type=int, default=3000)
     ap.add_argument("--tris", type=int, default=2_800_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--untextured", action="store_true",
+                    help="factor-only materials (the round-1 workload before textures were built); default: every material "
+                         "has base colour + normal + AO/roughness/metallic maps")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange path (RCCL all-reduce / all-gather) even with one rank: plumbing check")
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
@@ -79,7 +82,8 @@ def main():
 
     # ---------------------------------------------------------------- scene: replicated on every rank
     r = r3.Renderer(r3.host.RIGHT, np.float32(WIDTH) / np.float32(HEIGHT), device=local_rank)
-    info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=args.objects, target_tris=args.tris)
+    info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=args.objects, target_tris=args.tris,
+                                 textured=not args.untextured)
     view0 = info["camera"][0]
     exchange = None
     if distributed:
@@ -193,7 +197,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2] stand-in: bistro_like (seed 0xB157), 3840x2160, "
-                                   "full PBR opaque + 4 directional shadow views (2048^2), camera dolly",
+                                   "full PBR opaque + 4 directional shadow views (2048^2), camera dolly, "
+                                   + ("factor-only materials" if args.untextured else
+                                      "130 materials with base colour + normal + AO/roughness/metallic maps (RGBA8, mips, trilinear)"),
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
                        "parallelism": "single GPU" if world == 1 else f"object-range sharding x{world}, RCCL max all-reduce of depth keys"},
             "fps": round(args.steps / elapsed, 2),
@@ -226,7 +232,7 @@ def cpu_baseline(args, info):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     o = OracleRenderer(oh.RIGHT, np.float32(WIDTH) / np.float32(HEIGHT))
-    info_o = r3.scenes.bistro_like(o, oh, omk, n_objects=args.objects, target_tris=args.tris)
+    info_o = r3.scenes.bistro_like(o, oh, omk, n_objects=args.objects, target_tris=args.tris, textured=not args.untextured)
     view0 = info_o["camera"][0]
     o.set_camera_data(camera_path(oh, view0, 0), info_o["camera"][1])
     o.render(WIDTH, HEIGHT, ambient=AMBIENT, clear_color=CLEAR)  # history frame (untimed)

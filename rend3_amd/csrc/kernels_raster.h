@@ -942,9 +942,13 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         float uv[3][2];
 #pragma unroll
         for (int k = 0; k < 3; ++k) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], uv[k]);
-        frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy);
+        const float self_raw[2] = {(lam[0] * uv[0][0] + lam[1] * uv[1][0]) + lam[2] * uv[2][0],
+                                   (lam[0] * uv[0][1] + lam[1] * uv[1][1]) + lam[2] * uv[2][1]};
+        frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
     }
-    auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    TexFootprint fp_cache;
+    fp_cache.width = 0u; fp_cache.height = 0u; fp_cache.mips = 0u; fp_cache.nearest = false;  // matches no texture
+    auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst, &fp_cache); };
     auto has = [&](int slot) { return TEX && mat.textures[slot] != 0u; };
     if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
 #pragma unroll

@@ -18,9 +18,23 @@
 struct TextureArgs {
     const r3n_texture_desc32 *descs;
     uint32_t count;
-    const uint32_t *texels;       // RGBA8, every texture's mips contiguous
-    const float *srgb8_to_linear; // 256 entries
+    const float4 *texels;         // DECODED texels (c / 255, sRGB channels through the exact sRGB8 -> linear table), every
+                                  // texture's mips contiguous.  16 B per texel instead of 4: the resolve is VALU-bound
+                                  // (profiles/), HBM capacity is not the constraint on a 288 GB part, and a fetch is one
+                                  // dwordx4 load instead of a load + 4 extracts + 4 table reads.  Same values, same
+                                  // filtering arithmetic as decoding per fetch.
 };
+
+// Expands one texture's RGBA8 chain into the decoded pool (r3n_textures_write).  decode: 512 floats, [0, 256) = c / 255,
+// [256, 512) = sRGB8 -> linear, both built on the host (libm) like the oracle's.
+__global__ __launch_bounds__(256) void k_decode_texels(const uint32_t *__restrict__ rgba8, float4 *__restrict__ out, size_t n,
+                                                       const float *__restrict__ decode, uint32_t srgb) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = rgba8[i];
+    const float *rgb = decode + (srgb ? 256 : 0);
+    out[i] = make_float4(rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu], rgb[(v >> 16) & 0xFFu], decode[v >> 24]);
+}
 
 R3N_DEV uint32_t tex_mip_dim(uint32_t d, uint32_t k) {
     const uint32_t v = d >> k;
@@ -29,21 +43,28 @@ R3N_DEV uint32_t tex_mip_dim(uint32_t d, uint32_t k) {
 R3N_DEV uint32_t tex_wrap(float f, uint32_t n) {  // f = floor(coordinate); Repeat; NaN / huge -> texel 0
     const int i = (f == f && fabsf(f) < 1e9f) ? (int)f : 0;
     if ((uint32_t)i < n) return (uint32_t)i;
-    const long long w = (long long)n;
-    return (uint32_t)((((long long)i % w) + w) % w);
+    // tiled coordinates leave [0, n) all the time: keep this path cheap.  Power-of-two extents (the common case) wrap
+    // with a mask -- two's complement makes that the floor-modulo for negative indices too; other extents (<= 65535) use
+    // a 32-bit remainder.
+    if ((n & (n - 1u)) == 0u) return (uint32_t)i & (n - 1u);
+    const int m = i % (int)n;
+    return (uint32_t)(m < 0 ? m + (int)n : m);
 }
-R3N_DEV void tex_fetch(const TextureArgs &t, const r3n_texture_desc32 &d, uint32_t mip, uint32_t x, uint32_t y, float o[4]) {
-    size_t off = d.offset;
-    for (uint32_t k = 0; k < mip; ++k) off += (size_t)tex_mip_dim(d.width, k) * tex_mip_dim(d.height, k);
-    const uint32_t v = t.texels[off + (size_t)y * tex_mip_dim(d.width, mip) + x];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t b = (v >> (8 * c)) & 0xFFu;
-        o[c] = (d.format == 1u && c < 3) ? t.srgb8_to_linear[b] : (float)b / 255.0f;
-    }
-}
-R3N_DEV void tex_bilinear(const TextureArgs &t, const r3n_texture_desc32 &d, uint32_t mip, float u, float v, float o[4]) {
-    const uint32_t w = tex_mip_dim(d.width, mip), h = tex_mip_dim(d.height, mip);
+// Everything about one sample that depends only on the texture's extent / mip count, the coordinates and the gradients
+// -- not on its texels: the level(s), the blend fraction and the bilinear footprints.  The maps of one material usually
+// share their extent, so the resolve computes this once and applies it to each of them (tex_apply).
+struct TexFootprint {
+    uint32_t width, height, mips;  // key
+    bool nearest;
+    uint32_t level;                // first (or only) level
+    float frac;                    // weight of level + 1 (0: single level)
+    uint32_t level_off;            // first texel of `level`, relative to the texture's offset
+    struct Lvl {
+        uint32_t w, i00, i10, i01, i11;  // texel indices inside the level (row-major)
+        float fx, fy;
+    } l[2];
+};
+R3N_DEV void tex_level_footprint(uint32_t w, uint32_t h, float u, float v, TexFootprint::Lvl &l) {
     const float tx = u * (float)w - 0.5f, ty = v * (float)h - 0.5f;
     const float fx0 = floorf(tx), fy0 = floorf(ty);
     float fx = tx - fx0, fy = ty - fy0;
@@ -51,28 +72,17 @@ R3N_DEV void tex_bilinear(const TextureArgs &t, const r3n_texture_desc32 &d, uin
     if (!(fy == fy)) fy = 0.0f;
     const uint32_t x0 = tex_wrap(fx0, w), x1 = tex_wrap(fx0 + 1.0f, w);
     const uint32_t y0 = tex_wrap(fy0, h), y1 = tex_wrap(fy0 + 1.0f, h);
-    float c00[4], c10[4], c01[4], c11[4];
-    tex_fetch(t, d, mip, x0, y0, c00); tex_fetch(t, d, mip, x1, y0, c10);
-    tex_fetch(t, d, mip, x0, y1, c01); tex_fetch(t, d, mip, x1, y1, c11);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float top = c00[c] * (1.0f - fx) + c10[c] * fx;
-        const float bot = c01[c] * (1.0f - fx) + c11[c] * fx;
-        o[c] = top * (1.0f - fy) + bot * fy;
-    }
+    l.w = w;
+    l.i00 = y0 * w + x0; l.i10 = y0 * w + x1; l.i01 = y1 * w + x0; l.i11 = y1 * w + x1;
+    l.fx = fx; l.fy = fy;
 }
-R3N_DEV void tex_nearest(const TextureArgs &t, const r3n_texture_desc32 &d, uint32_t mip, float u, float v, float o[4]) {
-    const uint32_t w = tex_mip_dim(d.width, mip), h = tex_mip_dim(d.height, mip);
-    tex_fetch(t, d, mip, tex_wrap(floorf(u * (float)w), w), tex_wrap(floorf(v * (float)h), h), o);
-}
-// textureSampleGrad(textures[id - 1], nearest ? nearest_sampler : primary_sampler, (u, v), ddx, ddy)
-R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, float u, float v, const float ddx[2],
-                             const float ddy[2], float o[4]) {
-    if (id == 0u || id > t.count) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
-    const r3n_texture_desc32 d = t.descs[id - 1u];
+R3N_DEV void tex_footprint(const r3n_texture_desc32 &d, bool nearest, float u, float v, const float ddx[2], const float ddy[2],
+                           TexFootprint &f) {
+    f.width = d.width; f.height = d.height; f.mips = d.mips; f.nearest = nearest;
     const float W = (float)d.width, H = (float)d.height;
     const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
-    const float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+    // max(sqrt(a), sqrt(b)) == sqrt(max(a, b)): correctly rounded sqrt is monotone
+    const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
     uint32_t level = 0;
     float frac = 0.0f;
     if (rho > 1.0f && rho < INFINITY) {
@@ -85,16 +95,64 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
     if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
     if (nearest) {
         if (frac >= 0.5f) level += 1u;  // level + 1 <= mips - 1 here
-        tex_nearest(t, d, level, u, v, o);
+        frac = 0.0f;
+    }
+    uint32_t off = 0;  // the chain is contiguous (a whole chain is < 2^32 texels: extents <= 65535)
+    for (uint32_t k = 0; k < level; ++k) off += tex_mip_dim(d.width, k) * tex_mip_dim(d.height, k);
+    f.level = level; f.frac = frac; f.level_off = off;
+    const uint32_t w = tex_mip_dim(d.width, level), h = tex_mip_dim(d.height, level);
+    if (nearest) {
+        f.l[0].w = w;
+        f.l[0].i00 = tex_wrap(floorf(v * (float)h), h) * w + tex_wrap(floorf(u * (float)w), w);
         return;
     }
-    tex_bilinear(t, d, level, u, v, o);
-    if (frac > 0.0f) {
-        float hi[4];
-        tex_bilinear(t, d, level + 1u, u, v, hi);
+    tex_level_footprint(w, h, u, v, f.l[0]);
+    if (frac > 0.0f) tex_level_footprint(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), u, v, f.l[1]);
+}
+R3N_DEV void tex_texel(const float4 *__restrict__ lvl, uint32_t i, float o[4]) {
+    const float4 v = lvl[i];
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+R3N_DEV void tex_bilinear(const float4 *__restrict__ lvl, const TexFootprint::Lvl &l, float o[4]) {
+    float c00[4], c10[4], c01[4], c11[4];
+    tex_texel(lvl, l.i00, c00); tex_texel(lvl, l.i10, c10);
+    tex_texel(lvl, l.i01, c01); tex_texel(lvl, l.i11, c11);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = o[c] * (1.0f - frac) + hi[c] * frac;
+    for (int c = 0; c < 4; ++c) {
+        const float top = c00[c] * (1.0f - l.fx) + c10[c] * l.fx;
+        const float bot = c01[c] * (1.0f - l.fx) + c11[c] * l.fx;
+        o[c] = top * (1.0f - l.fy) + bot * l.fy;
     }
+}
+R3N_DEV void tex_apply(const TextureArgs &t, const r3n_texture_desc32 &d, const TexFootprint &f, float o[4]) {
+    const float4 *lvl = t.texels + (size_t)d.offset + f.level_off;
+    if (f.nearest) {
+        tex_texel(lvl, f.l[0].i00, o);
+        return;
+    }
+    tex_bilinear(lvl, f.l[0], o);
+    if (f.frac > 0.0f) {
+        float hi[4];
+        tex_bilinear(lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level), f.l[1], hi);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = o[c] * (1.0f - f.frac) + hi[c] * f.frac;
+    }
+}
+// textureSampleGrad(textures[id - 1], nearest ? nearest_sampler : primary_sampler, (u, v), ddx, ddy).
+// `cache` (optional): the footprint of the previous sample of this fragment; reused when the extent matches.
+R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, float u, float v, const float ddx[2],
+                             const float ddy[2], float o[4], TexFootprint *cache = nullptr) {
+    if (id == 0u || id > t.count) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
+    const r3n_texture_desc32 d = t.descs[id - 1u];
+    if (cache != nullptr) {
+        if (!(cache->width == d.width && cache->height == d.height && cache->mips == d.mips && cache->nearest == nearest))
+            tex_footprint(d, nearest, u, v, ddx, ddy, *cache);
+        tex_apply(t, d, *cache, o);
+        return;
+    }
+    TexFootprint f;
+    tex_footprint(d, nearest, u, v, ddx, ddy, f);
+    tex_apply(t, d, f, o);
 }
 
 // vertex_attributes.wgsl: vec2<f32> texture coordinates (attribute 3); a missing attribute reads (0, 0)
@@ -120,20 +178,22 @@ R3N_DEV void uv_transform(const float *m, const float uv[2], float o[2]) {
 }
 // Fragment-stage texture coordinates of pixel (x, y) and their derivatives: differences inside the pixel's 2x2 quad
 // ("fine": same row for dpdx, same column for dpdy), every operand evaluated like its own (helper) invocation.
-// m = uv_transform0 or nullptr (depth.wgsl uses the raw coordinates).
+// m = uv_transform0 or nullptr (depth.wgsl uses the raw coordinates).  Only the two quad neighbours are evaluated
+// here; the pixel's own value comes from `self_raw` (its interpolated coordinates) when the caller already has them.
 R3N_DEV void frag_coords(const TriSetup &ts, const float uv[3][2], const float *m, int x, int y, float coords[2],
-                         float ddx[2], float ddy[2]) {
-    const int xq = x & ~1, yq = y & ~1;
-    float c[4][2];
-    const int pts[4][2] = {{xq, y}, {xq + 1, y}, {x, yq}, {x, yq + 1}};
+                         float ddx[2], float ddy[2], const float *self_raw = nullptr) {
+    float raw[2], self[2], nx[2], ny[2];
+    if (self_raw) { raw[0] = self_raw[0]; raw[1] = self_raw[1]; } else interp_vec2(ts, uv, x, y, raw);
+    if (m) uv_transform(m, raw, self); else { self[0] = raw[0]; self[1] = raw[1]; }
+    interp_vec2(ts, uv, x ^ 1, y, raw);
+    if (m) uv_transform(m, raw, nx); else { nx[0] = raw[0]; nx[1] = raw[1]; }
+    interp_vec2(ts, uv, x, y ^ 1, raw);
+    if (m) uv_transform(m, raw, ny); else { ny[0] = raw[0]; ny[1] = raw[1]; }
+    coords[0] = self[0]; coords[1] = self[1];
+    // value at the odd pixel of the pair minus value at the even one
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float raw[2];
-        interp_vec2(ts, uv, pts[k][0], pts[k][1], raw);
-        if (m) uv_transform(m, raw, c[k]); else { c[k][0] = raw[0]; c[k][1] = raw[1]; }
+    for (int k = 0; k < 2; ++k) {
+        ddx[k] = (x & 1) ? self[k] - nx[k] : nx[k] - self[k];
+        ddy[k] = (y & 1) ? self[k] - ny[k] : ny[k] - self[k];
     }
-    const int self = (x & 1) ? 1 : 0;
-    coords[0] = c[self][0]; coords[1] = c[self][1];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { ddx[k] = c[1][k] - c[0][k]; ddy[k] = c[3][k] - c[2][k]; }
 }

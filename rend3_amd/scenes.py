@@ -130,12 +130,82 @@ def _flip(idx):
     return np.ascontiguousarray(idx.reshape(-1, 3)[:, ::-1].reshape(-1))
 
 
+def planar_uv_tangent(positions, normals, tiles):
+    """Box-projected texture coordinates (the two axes other than the dominant normal axis, `tiles` repeats per unit)
+    and a unit tangent along the first of those axes, re-orthogonalised against the normal."""
+    p = np.asarray(positions, dtype=f32)
+    n = np.asarray(normals, dtype=f32)
+    dom = np.argmax(np.abs(n), axis=1)
+    ua = np.where(dom == 0, 2, 0)
+    va = np.where(dom == 1, 2, 1)
+    rows = np.arange(len(p))
+    uv = np.stack([p[rows, ua], p[rows, va]], axis=1).astype(f32) * f32(tiles)
+    t = np.zeros_like(p)
+    t[rows, ua] = 1.0
+    t = t - n * (t * n).sum(axis=1, keepdims=True)
+    t /= np.maximum(np.linalg.norm(t, axis=1, keepdims=True), f32(1e-20))
+    return uv.astype(f32), t.astype(f32)
+
+
+def procedural_textures(n_albedo=16, n_normal=8, n_orm=8, size=1024, seed=0x7E57):
+    """RGBA8 stand-ins for a scanned material set: tinted brick / plaster albedo (sRGB), tangent-space bump maps and
+    packed AO / roughness / metallic maps (linear).  Deterministic (numpy Generator)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    out = {"albedo": [], "normal": [], "orm": []}
+
+    def smooth_noise(cells):
+        g = rng.random((cells + 1, cells + 1)).astype(np.float32)
+        fx, fy = xx * cells / size, yy * cells / size
+        ix, iy = fx.astype(int), fy.astype(int)
+        tx, ty = fx - ix, fy - iy
+        a = g[iy, ix] * (1 - tx) + g[iy, ix + 1] * tx
+        b = g[iy + 1, ix] * (1 - tx) + g[iy + 1, ix + 1] * tx
+        return a * (1 - ty) + b * ty
+
+    for k in range(n_albedo):
+        base = rng.uniform(0.35, 0.95, 3)
+        bricks_x, bricks_y = 4 << (k % 3), 8 << (k % 3)
+        row = (yy * bricks_y / size).astype(int)
+        mortar = (((xx * bricks_x / size + 0.5 * (row % 2)) % 1.0) < 0.06) | (((yy * bricks_y / size) % 1.0) < 0.1)
+        tone = 0.75 + 0.25 * smooth_noise(16) + 0.1 * rng.random((size, size)).astype(np.float32)
+        img = np.empty((size, size, 4), dtype=np.uint8)
+        for c in range(3):
+            img[..., c] = np.clip(np.where(mortar, 0.55, base[c]) * tone * 255.0, 0, 255).astype(np.uint8)
+        img[..., 3] = 255
+        out["albedo"].append(img)
+    for k in range(n_normal):
+        hgt = smooth_noise(32 << (k % 2)) + 0.3 * smooth_noise(128)
+        dx = np.roll(hgt, -1, axis=1) - np.roll(hgt, 1, axis=1)
+        dy = np.roll(hgt, -1, axis=0) - np.roll(hgt, 1, axis=0)
+        nx, ny, nz = -dx * 6.0, -dy * 6.0, np.ones_like(dx)
+        ln = np.sqrt(nx * nx + ny * ny + nz * nz)
+        img = np.empty((size, size, 4), dtype=np.uint8)
+        img[..., 0] = ((nx / ln) * 0.5 + 0.5) * 255.0
+        img[..., 1] = ((ny / ln) * 0.5 + 0.5) * 255.0
+        img[..., 2] = ((nz / ln) * 0.5 + 0.5) * 255.0
+        img[..., 3] = 255
+        out["normal"].append(img)
+    for k in range(n_orm):
+        img = np.empty((size // 2, size // 2, 4), dtype=np.uint8)
+        sub = (slice(None, None, 2), slice(None, None, 2))
+        img[..., 0] = (0.7 + 0.3 * smooth_noise(8)[sub]) * 255.0
+        img[..., 1] = np.clip(0.35 + 0.6 * smooth_noise(24)[sub], 0, 1) * 255.0
+        img[..., 2] = np.where(smooth_noise(6)[sub] > 0.8, 255, 0) if k % 4 == 0 else 0
+        img[..., 3] = 255
+        out["orm"].append(img)
+    return out
+
+
 def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=130, seed=0xB157, shadow_res=2048,
-                n_lights=4):
+                n_lights=4, textured=False):
     """BASELINE.json configs[2] stand-in (SURVEY.md section 8d cfg 3): street canyon with real occlusion, ~3 000 objects,
-    ~2.8 M triangles (log-normal per object), 130 untextured PBR materials (roughness U[0.2,0.9], metallic in {0,1}
-    p=0.2), 4 directional lights with 2048^2 shadow views, distance 100, ambient 0.1 (applied by the caller),
+    ~2.8 M triangles (log-normal per object), 130 PBR materials (roughness U[0.2,0.9], metallic in {0,1} p=0.2),
+    4 directional lights with 2048^2 shadow views, distance 100, ambient 0.1 (applied by the caller),
     Bistro test camera of examples/src/scene_viewer/mod.rs:727-751.  Right-handed like scene_viewer (:435).
+    textured: every material gets a base colour, a normal and a packed AO / roughness / metallic map (1024^2 / 512^2
+    RGBA8 with full mip chains, trilinear) from a pool of 32 procedural textures, like the scanned material set of the
+    real asset; meshes then carry box-projected texture coordinates and tangents.
     Returns dict(objects, triangles, camera=(view, projection))."""
     rng = Pcg32(seed)
     rh = r.handedness == RIGHT
@@ -143,20 +213,39 @@ def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=13
 
     # ---- mesh library: triangle counts from 12 to 20 480
     lib = []
+
+    def add(p, i, nr):
+        if not textured:
+            return r.add_mesh(p, fix(i), normals=nr)
+        uv, tan = planar_uv_tangent(p, nr, 2.0)
+        return r.add_mesh(p, fix(i), normals=nr, uv0=uv, tangents=tan)
+
     for n in (1, 2, 4, 8, 16, 32):
         p, i, nr = subdivided_box(n)
-        lib.append(("box", 12 * n * n, r.add_mesh(p, fix(i), normals=nr)))
+        lib.append(("box", 12 * n * n, add(p, i, nr)))
     for sub in (1, 2, 3, 4, 5):
         p, i, nr = icosphere(sub)
-        lib.append(("sphere", 20 * 4 ** sub, r.add_mesh(p, fix(i), normals=nr)))
+        lib.append(("sphere", 20 * 4 ** sub, add(p, i, nr)))
     boxes = [m for m in lib if m[0] == "box"]
     spheres = [m for m in lib if m[0] == "sphere"]
 
+    tex = None
+    if textured:
+        imgs = procedural_textures()
+        tex = {"albedo": [r.add_texture_2d(im, srgb=True, mip_count="maximum", mip_source="generated") for im in imgs["albedo"]],
+               "normal": [r.add_texture_2d(im, srgb=False, mip_count="maximum", mip_source="generated") for im in imgs["normal"]],
+               "orm": [r.add_texture_2d(im, srgb=False, mip_count="maximum", mip_source="generated") for im in imgs["orm"]]}
     mats = []
-    for _ in range(n_materials):
+    for k in range(n_materials):
         col = (rng.uniform(0.15, 0.95), rng.uniform(0.15, 0.95), rng.uniform(0.15, 0.95), 1.0)
-        mats.append(r.add_material(mk(albedo=col, albedo_mode="value", roughness=rng.uniform(0.2, 0.9),
-                                      metallic=1.0 if rng.uniform() < 0.2 else 0.0), OPAQUE))
+        rough, metal = rng.uniform(0.2, 0.9), 1.0 if rng.uniform() < 0.2 else 0.0
+        if textured:
+            rec = mk(albedo=col, albedo_mode="texture_value", albedo_texture=tex["albedo"][k % len(tex["albedo"])],
+                     roughness=rough, metallic=metal, normal_texture=tex["normal"][k % len(tex["normal"])],
+                     aomr=("combined", tex["orm"][k % len(tex["orm"])]))
+        else:
+            rec = mk(albedo=col, albedo_mode="value", roughness=rough, metallic=metal)
+        mats.append(r.add_material(rec, OPAQUE))
 
     # ---- camera (scene_viewer/mod.rs:739-741, view = euler XYZ(-pitch,-yaw,0) * T(-loc), :640-641)
     loc = (-17.174278, 3.715882, -4.631997)
