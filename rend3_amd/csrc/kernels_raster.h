@@ -946,9 +946,7 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
                                    (lam[0] * uv[0][1] + lam[1] * uv[1][1]) + lam[2] * uv[2][1]};
         frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
     }
-    TexFootprint fp_cache;
-    fp_cache.width = 0u; fp_cache.height = 0u; fp_cache.mips = 0u; fp_cache.nearest = false;  // matches no texture
-    auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst, &fp_cache); };
+    auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
     auto has = [&](int slot) { return TEX && mat.textures[slot] != 0u; };
     if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
 #pragma unroll
@@ -1176,6 +1174,12 @@ template <int S, bool TEX>
 __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    __shared__ float s_decode[512];
+    if (TEX) {  // texel decode tables into LDS (texture.h)
+        s_decode[threadIdx.x] = a.tex.decode[threadIdx.x];
+        s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
+        a.tex.decode = s_decode;
+    }
     uint32_t n_dir, n_point;
     stage_lights(a, s_dir, s_point, n_dir, n_point);
 
@@ -1249,6 +1253,12 @@ template <int S, bool TEX>
 __global__ __launch_bounds__(256) void k_blend_apply(ShadeArgs a, BlendApplyArgs b) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    __shared__ float s_decode[512];
+    if (TEX) {
+        s_decode[threadIdx.x] = a.tex.decode[threadIdx.x];
+        s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
+        a.tex.decode = s_decode;
+    }
     uint32_t n_dir, n_point;
     stage_lights(a, s_dir, s_point, n_dir, n_point);
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;

@@ -84,7 +84,7 @@ struct r3n_ctx {
     std::vector<uint32_t> h_blend_order;
     uint32_t n_blend = 0, blend_tris = 0;
     uint32_t frag_capacity = 32u << 20;  // fragments (24 B each incl. the sort's double buffers), allocated on first use
-    DevBuf tex_descs, tex_texels, tex_rgba8, srgb8_decode;  // decoded pool (float4), upload staging (RGBA8), decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
+    DevBuf tex_descs, tex_texels, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
     DevBuf big_uv[1 + R3N_AUX_STREAMS];
     DevBuf srgb_lut;  // Rgba8UnormSrgb code of every half in [0, 1): kernels_raster.h k_build_srgb_lut
@@ -391,7 +391,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         }
     // empty light buffers: count = 0
     bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->srgb8_decode, 512 * 4, false, -1) == R3N_OK &&
-              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 16, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
+              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
               ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
     for (int lane = 0; ok && lane < 1 + R3N_AUX_STREAMS; ++lane)
         ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
@@ -432,7 +432,7 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->tex_rgba8, &c->srgb8_decode,
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
                       &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16};
     for (DevBuf *b : bufs)
@@ -535,7 +535,8 @@ static TextureArgs texture_args(r3n_ctx *c) {
     TextureArgs t;
     t.descs = c->tex_descs.as<r3n_texture_desc32>();
     t.count = c->n_textures;
-    t.texels = c->tex_texels.as<float4>();
+    t.texels = c->tex_texels.as<uint32_t>();
+    t.decode = c->srgb8_decode.as<float>();
     return t;
 }
 
@@ -555,19 +556,10 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(sync_all(c));  // no frame may still sample the old array
     TRY(ensure(c, c->tex_descs, std::max<size_t>(n, 1) * sizeof(r3n_texture_desc32), false, -1));
-    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 16, false, -1));
-    TRY(ensure(c, c->tex_rgba8, std::max<uint64_t>(n_texels, 1) * 4, false, -1));
+    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4, false, -1));
     if (n) {
         HIP_TRY(c, hipMemcpyAsync(c->tex_descs.p, descs, (size_t)n * sizeof(r3n_texture_desc32), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->tex_rgba8.p, texels, n_texels * 4, hipMemcpyHostToDevice, c->stream));
-        for (uint32_t i = 0; i < n; ++i) {  // decode every chain into the float4 pool (texture.h)
-            uint64_t chain = 0;
-            for (uint32_t k = 0; k < descs[i].mips; ++k) chain += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k);
-            hipLaunchKernelGGL(k_decode_texels, dim3((unsigned)((chain + 255) / 256)), dim3(256), 0, c->stream,
-                               c->tex_rgba8.as<uint32_t>() + descs[i].offset, c->tex_texels.as<float4>() + descs[i].offset, (size_t)chain,
-                               c->srgb8_decode.as<float>(), descs[i].format == R3N_TEXTURE_RGBA8_UNORM_SRGB ? 1u : 0u);
-        }
-        TRY(check_launch(c, "k_decode_texels"));
+        HIP_TRY(c, hipMemcpyAsync(c->tex_texels.p, texels, n_texels * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the sources only for the duration of the call
     }
     c->n_textures = n;

@@ -18,23 +18,13 @@
 struct TextureArgs {
     const r3n_texture_desc32 *descs;
     uint32_t count;
-    const float4 *texels;         // DECODED texels (c / 255, sRGB channels through the exact sRGB8 -> linear table), every
-                                  // texture's mips contiguous.  16 B per texel instead of 4: the resolve is VALU-bound
-                                  // (profiles/), HBM capacity is not the constraint on a 288 GB part, and a fetch is one
-                                  // dwordx4 load instead of a load + 4 extracts + 4 table reads.  Same values, same
-                                  // filtering arithmetic as decoding per fetch.
+    const uint32_t *texels;       // RGBA8, every texture's mips contiguous
+    const float *decode;          // 512 entries: [0, 256) = c / 255 (unorm), [256, 512) = sRGB8 -> linear, built on the
+                                  // host with libm like the oracle's.  Both hold exactly what the per-texel expressions
+                                  // give.  The resolve stages them in LDS: a texel decode is then 4 LDS reads instead of
+                                  // 4 IEEE divisions.  (Measured alternative: a pre-decoded float4 pool, 4x the memory,
+                                  // same speed -- the kernel is bound by VALU work, not by the decode.)
 };
-
-// Expands one texture's RGBA8 chain into the decoded pool (r3n_textures_write).  decode: 512 floats, [0, 256) = c / 255,
-// [256, 512) = sRGB8 -> linear, both built on the host (libm) like the oracle's.
-__global__ __launch_bounds__(256) void k_decode_texels(const uint32_t *__restrict__ rgba8, float4 *__restrict__ out, size_t n,
-                                                       const float *__restrict__ decode, uint32_t srgb) {
-    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = rgba8[i];
-    const float *rgb = decode + (srgb ? 256 : 0);
-    out[i] = make_float4(rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu], rgb[(v >> 16) & 0xFFu], decode[v >> 24]);
-}
 
 R3N_DEV uint32_t tex_mip_dim(uint32_t d, uint32_t k) {
     const uint32_t v = d >> k;
@@ -51,8 +41,7 @@ R3N_DEV uint32_t tex_wrap(float f, uint32_t n) {  // f = floor(coordinate); Repe
     return (uint32_t)(m < 0 ? m + (int)n : m);
 }
 // Everything about one sample that depends only on the texture's extent / mip count, the coordinates and the gradients
-// -- not on its texels: the level(s), the blend fraction and the bilinear footprints.  The maps of one material usually
-// share their extent, so the resolve computes this once and applies it to each of them (tex_apply).
+// -- not on its texels: the level(s), the blend fraction and the bilinear footprints.
 struct TexFootprint {
     uint32_t width, height, mips;  // key
     bool nearest;
@@ -109,14 +98,16 @@ R3N_DEV void tex_footprint(const r3n_texture_desc32 &d, bool nearest, float u, f
     tex_level_footprint(w, h, u, v, f.l[0]);
     if (frac > 0.0f) tex_level_footprint(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), u, v, f.l[1]);
 }
-R3N_DEV void tex_texel(const float4 *__restrict__ lvl, uint32_t i, float o[4]) {
-    const float4 v = lvl[i];
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+R3N_DEV void tex_texel(const TextureArgs &t, bool srgb, const uint32_t *__restrict__ lvl, uint32_t i, float o[4]) {
+    const uint32_t v = lvl[i];
+    const float *rgb = t.decode + (srgb ? 256 : 0);
+    o[0] = rgb[v & 0xFFu]; o[1] = rgb[(v >> 8) & 0xFFu]; o[2] = rgb[(v >> 16) & 0xFFu]; o[3] = t.decode[v >> 24];
 }
-R3N_DEV void tex_bilinear(const float4 *__restrict__ lvl, const TexFootprint::Lvl &l, float o[4]) {
+R3N_DEV void tex_bilinear(const TextureArgs &t, bool srgb, size_t lvl_off, const TexFootprint::Lvl &l, float o[4]) {
     float c00[4], c10[4], c01[4], c11[4];
-    tex_texel(lvl, l.i00, c00); tex_texel(lvl, l.i10, c10);
-    tex_texel(lvl, l.i01, c01); tex_texel(lvl, l.i11, c11);
+    const uint32_t *lvl = t.texels + lvl_off;
+    tex_texel(t, srgb, lvl, l.i00, c00); tex_texel(t, srgb, lvl, l.i10, c10);
+    tex_texel(t, srgb, lvl, l.i01, c01); tex_texel(t, srgb, lvl, l.i11, c11);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float top = c00[c] * (1.0f - l.fx) + c10[c] * l.fx;
@@ -125,31 +116,27 @@ R3N_DEV void tex_bilinear(const float4 *__restrict__ lvl, const TexFootprint::Lv
     }
 }
 R3N_DEV void tex_apply(const TextureArgs &t, const r3n_texture_desc32 &d, const TexFootprint &f, float o[4]) {
-    const float4 *lvl = t.texels + (size_t)d.offset + f.level_off;
+    const size_t lvl = (size_t)d.offset + f.level_off;
+    const bool srgb = d.format == 1u;
     if (f.nearest) {
-        tex_texel(lvl, f.l[0].i00, o);
+        tex_texel(t, srgb, t.texels + lvl, f.l[0].i00, o);
         return;
     }
-    tex_bilinear(lvl, f.l[0], o);
+    tex_bilinear(t, srgb, lvl, f.l[0], o);
     if (f.frac > 0.0f) {
         float hi[4];
-        tex_bilinear(lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level), f.l[1], hi);
+        tex_bilinear(t, srgb, lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level), f.l[1], hi);
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = o[c] * (1.0f - f.frac) + hi[c] * f.frac;
     }
 }
 // textureSampleGrad(textures[id - 1], nearest ? nearest_sampler : primary_sampler, (u, v), ddx, ddy).
-// `cache` (optional): the footprint of the previous sample of this fragment; reused when the extent matches.
+// (Sharing one footprint between the maps of a material that have the same extent was measured: slower -- the cached
+// footprint stays live across the whole fragment stage and costs an occupancy step.)
 R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, float u, float v, const float ddx[2],
-                             const float ddy[2], float o[4], TexFootprint *cache = nullptr) {
+                             const float ddy[2], float o[4]) {
     if (id == 0u || id > t.count) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const r3n_texture_desc32 d = t.descs[id - 1u];
-    if (cache != nullptr) {
-        if (!(cache->width == d.width && cache->height == d.height && cache->mips == d.mips && cache->nearest == nearest))
-            tex_footprint(d, nearest, u, v, ddx, ddy, *cache);
-        tex_apply(t, d, *cache, o);
-        return;
-    }
     TexFootprint f;
     tex_footprint(d, nearest, u, v, ddx, ddy, f);
     tex_apply(t, d, f, o);
