@@ -190,7 +190,9 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get("k_resolve_opaque") if world == 1 else None,
                 "bytes_per_launch": int(shade_bytes),
                 "ms_per_launch": round(shade_ms, 5),
-                "note": "dominant kernel by time; VALU-bound (about 1500 vector instructions per pixel: vertex stage, 4 lights x (5-tap PCF + GGX), all IEEE div/sqrt), see DESIGN.md"}
+                "note": "dominant kernel by time; VALU-bound, vector ALUs busy > 90 % of the launch (SQ counters, profiles/r01_summary.md): about "
+                        + ("1500" if args.untextured else "3260") + " vector instructions per pixel (vertex stage, 4 lights x (5-tap PCF + GGX)"
+                        + ("" if args.untextured else ", 3 trilinear maps, tangent frame") + ", all IEEE div/sqrt); bytes = key + HDR + sRGB per pixel, texels excluded"}
         result = {
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
