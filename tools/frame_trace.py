@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # frame marker: the resolve (one launch per frame; the blit is fused into it)
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_resolve_opaque')]
+idx = [i for i, r in enumerate(rows) if 'k_resolve_opaque' in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 a, b = idx[k], idx[k + 1]
 tot = 0
