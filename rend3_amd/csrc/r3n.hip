@@ -50,6 +50,23 @@ struct r3n_ctx {
     // chains overlap and the launch gaps of one hide behind the work of the others.
     hipStream_t aux[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    // Frames in flight.  The resolve is VALU-bound and everything before it (culls, rasterisers, Hi-Z) is latency- and
+    // atomic-bound, so frame N's resolve runs on its own stream while the main stream and the lanes already work on frame
+    // N + 1.  Everything the resolve reads that the next frame rewrites exists twice; the two sets swap at frame_begin:
+    //   vis, atlas, fu, dir_buf, point_buf, viewport.baked, viewport.d_hdr  <->  alt_*
+    // shade_done[slot] (recorded on the shade stream after the resolve of the frame that used `slot`) is what the main
+    // stream waits for before it clears that slot's targets two frames later.  R3N_PIPELINE=0 disables the overlap.
+    hipStream_t shade = nullptr;
+    hipEvent_t vp_ev = nullptr, shade_done[2] = {nullptr, nullptr};
+    bool shade_pending[2] = {false, false};
+    bool shade_unjoined = false;      // the main stream has not yet been ordered after the latest resolve
+    int shade_last = 0;               // the slot of that resolve
+    int slot = 0;
+    uint64_t frame_no = 0;
+    bool overlap = true;
+    DevBuf alt_vis, alt_atlas, alt_fu, alt_dir, alt_point, alt_vp_baked, alt_vp_hdr;
+    std::vector<uint8_t> h_dir, h_point;   // the light buffers as last written (uploaded into the frame's slot at frame_begin)
+    uint64_t lights_version = 1, slot_lights_version[2] = {0, 0};
     hipEvent_t join_ev[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
     bool aux_used[R3N_AUX_STREAMS] = {false, false, false, false};
     bool multi_stream = true;
@@ -126,6 +143,7 @@ int fail(r3n_ctx *c, int code, const std::string &msg) {
     } while (0)
 
 int sync_all(r3n_ctx *c);
+int join_shade(r3n_ctx *c);
 
 // Grow-only device buffer.  preserve: keep old contents; fill: byte value for the newly allocated tail.
 int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
@@ -232,10 +250,21 @@ int join_lanes(r3n_ctx *c) {
         }
     return R3N_OK;
 }
+// Order the main stream after the latest resolve (shade stream).
+int join_shade(r3n_ctx *c) {
+    if (c->shade_unjoined) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->shade_done[c->shade_last], 0));
+        c->shade_unjoined = false;
+    }
+    return R3N_OK;
+}
 int sync_all(r3n_ctx *c) {
     int r = join_lanes(c);
     if (r != R3N_OK) return r;
+    r = join_shade(c);
+    if (r != R3N_OK) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->shade) HIP_TRY(c, hipStreamSynchronize(c->shade));
     return R3N_OK;
 }
 
@@ -381,6 +410,15 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         return nullptr;
     }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
+    if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
+    if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->shade_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->shade_done[1], hipEventDisableTiming) != hipSuccess) {
+        g_create_error = "shade stream creation failed";
+        r3n_destroy(c);
+        return nullptr;
+    }
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
         if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->fork_ev[k], hipEventDisableTiming) != hipSuccess ||
@@ -425,6 +463,7 @@ void r3n_destroy(r3n_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->shade) (void)hipStreamSynchronize(c->shade);
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
         if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
     for (int lane = 0; lane < 1 + R3N_AUX_STREAMS; ++lane)
@@ -432,7 +471,7 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
                       &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16};
     for (DevBuf *b : bufs)
@@ -440,6 +479,10 @@ void r3n_destroy(r3n_ctx *c) {
     free_cam(c->canon);
     free_cam(c->viewport);
     for (auto &kv : c->shadows) free_cam(kv.second);
+    if (c->vp_ev) (void)hipEventDestroy(c->vp_ev);
+    for (auto e : c->shade_done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->shade) (void)hipStreamDestroy(c->shade);
     for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < R3N_AUX_STREAMS; ++k) {
@@ -568,21 +611,21 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
 
 int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void *point, uint64_t point_bytes) {
     if (!c) return R3N_ERR_INVALID_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    auto upload = [&](DevBuf &b, const void *src, uint64_t bytes, uint32_t stride, uint32_t cap) -> int {
-        if (!src || bytes < 16) {
-            HIP_TRY(c, hipMemsetAsync(b.p, 0, 16, c->stream));
-            return R3N_OK;
-        }
+    // kept on the host; r3n_frame_begin uploads them into the frame's own copy (frames in flight: the previous frame's
+    // resolve may still be reading its lights)
+    auto take = [&](std::vector<uint8_t> &h, const void *src, uint64_t bytes, uint32_t stride, uint32_t cap) -> int {
+        if (!src || bytes < 16) { h.assign(16, 0); return R3N_OK; }
         uint32_t count;
         std::memcpy(&count, src, 4);
         if ((uint64_t)count * stride + 16 > bytes) return fail(c, R3N_ERR_INVALID_ARG, "lights write: count exceeds buffer");
         if (count > cap) return fail(c, R3N_ERR_UNSUPPORTED, "lights write: more lights than the LDS light list holds");
-        TRY(ensure(c, b, bytes, false, -1));
-        return upload_small(c, b.p, src, bytes);
+        h.assign(static_cast<const uint8_t *>(src), static_cast<const uint8_t *>(src) + bytes);
+        return R3N_OK;
     };
-    TRY(upload(c->dir_buf, dir, dir_bytes, 128, R3N_MAX_DIR_LIGHTS));
-    TRY(upload(c->point_buf, point, point_bytes, 32, R3N_MAX_POINT_LIGHTS));
+    const std::vector<uint8_t> old_dir = c->h_dir, old_point = c->h_point;
+    TRY(take(c->h_dir, dir, dir_bytes, 128, R3N_MAX_DIR_LIGHTS));
+    TRY(take(c->h_point, point, point_bytes, 32, R3N_MAX_POINT_LIGHTS));
+    if (old_dir != c->h_dir || old_point != c->h_point) ++c->lights_version;  // unchanged lights: nothing to upload
     return R3N_OK;
 }
 
@@ -599,6 +642,28 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     }
     c->width = w; c->height = h; c->samples = samples; c->atlas_w = atlas_w; c->atlas_h = atlas_h;
     std::memcpy(c->clear, clear_color, 16);
+    // frames in flight: this frame renders into the other set of targets / per-frame inputs
+    c->slot = (int)(c->frame_no++ & 1u);
+    std::swap(c->vis, c->alt_vis);
+    std::swap(c->atlas, c->alt_atlas);
+    std::swap(c->fu, c->alt_fu);
+    std::swap(c->dir_buf, c->alt_dir);
+    std::swap(c->point_buf, c->alt_point);
+    std::swap(c->viewport.baked, c->alt_vp_baked);
+    std::swap(c->viewport.d_hdr, c->alt_vp_hdr);
+    if (c->shade_pending[c->slot]) {  // the resolve that last read this set (two frames ago)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->shade_done[c->slot], 0));
+        c->shade_pending[c->slot] = false;
+    }
+    if (c->slot_lights_version[c->slot] != c->lights_version) {
+        if (c->h_dir.size() < 16) c->h_dir.assign(16, 0);
+        if (c->h_point.size() < 16) c->h_point.assign(16, 0);
+        TRY(ensure(c, c->dir_buf, c->h_dir.size(), false, -1));
+        TRY(ensure(c, c->point_buf, c->h_point.size(), false, -1));
+        TRY(upload_small(c, c->dir_buf.p, c->h_dir.data(), c->h_dir.size()));
+        TRY(upload_small(c, c->point_buf.p, c->h_point.data(), c->h_point.size()));
+        c->slot_lights_version[c->slot] = c->lights_version;
+    }
     const size_t npix = (size_t)w * h;
     TRY(ensure(c, c->fu, sizeof *u, false, -1));
     TRY(upload_small(c, c->fu.p, u, sizeof *u));
@@ -923,24 +988,50 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     if (r1 <= r0) return R3N_OK;
     CamState &s = c->viewport;
     if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
-    TRY(join_lanes(c));  // the shadow atlas must be complete
+    // frames in flight: the resolve goes to the shade stream, ordered after this frame's viewport chain (main stream up
+    // to here) and shadow views (lanes); the main stream is free to start the next frame.  Not when a transparent pass
+    // follows (it continues on the main stream with the HDR target) or while stage timing is on.
+    const bool on_shade = c->overlap && c->multi_stream && !c->timing && c->blend_tris == 0;
+    hipStream_t stream = on_shade ? c->shade : c->stream;
+    if (on_shade) {
+        HIP_TRY(c, hipEventRecord(c->vp_ev, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->shade, c->vp_ev, 0));
+        for (int k = 0; k < R3N_AUX_STREAMS; ++k)
+            if (c->aux_used[k]) {  // the shadow atlas must be complete
+                HIP_TRY(c, hipEventRecord(c->join_ev[k], c->aux[k]));
+                HIP_TRY(c, hipStreamWaitEvent(c->shade, c->join_ev[k], 0));
+                c->aux_used[k] = false;
+            }
+    } else {
+        TRY(join_lanes(c));  // the shadow atlas must be complete
+        TRY(join_shade(c));  // an earlier frame's resolve may still be writing the HDR / output targets
+    }
     ShadeArgs a = make_shade_args(c, r0, r1);
     if (c->samples == 4 && c->blend_tris > 0) {  // a transparent pass will blend into the individual samples
         TRY(ensure(c, c->samples16, (size_t)c->width * c->height * 4 * 8, false, -1));
         a.samples_out = c->samples16.as<ushort4>();
     }
     c->resolved_this_frame = true;
-    Timed t(c, R3N_STAGE_SHADE);
-    const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
-    const bool tex = c->n_textures > 0;
-    if (c->samples == 4) {
-        if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true>), rgrid, dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<4, false>), rgrid, dim3(256), 0, c->stream, a);
-    } else {
-        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true>), rgrid, dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, false>), rgrid, dim3(256), 0, c->stream, a);
+    {
+        Timed t(c, R3N_STAGE_SHADE, stream);
+        const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
+        const bool tex = c->n_textures > 0;
+        if (c->samples == 4) {
+            if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true>), rgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_resolve_opaque<4, false>), rgrid, dim3(256), 0, stream, a);
+        } else {
+            if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true>), rgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_resolve_opaque<1, false>), rgrid, dim3(256), 0, stream, a);
+        }
     }
-    return check_launch(c, "k_resolve_opaque");
+    TRY(check_launch(c, "k_resolve_opaque"));
+    if (on_shade) {
+        HIP_TRY(c, hipEventRecord(c->shade_done[c->slot], c->shade));
+        c->shade_pending[c->slot] = true;
+        c->shade_unjoined = true;
+        c->shade_last = c->slot;
+    }
+    return R3N_OK;
 }
 
 extern "C" int r3n_internal_sort_pairs(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
@@ -1085,6 +1176,7 @@ int r3n_hdr_write(r3n_ctx *c, const uint16_t *rgba16f, uint64_t first_pixel, uin
     const uint64_t total = (uint64_t)c->width * c->height;
     if (!rgba16f || first_pixel > total || n_pixels > total - first_pixel) return fail(c, R3N_ERR_INVALID_ARG, "hdr_write: range outside the target");
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(join_shade(c));
     if (n_pixels) {
         HIP_TRY(c, hipMemcpyAsync(c->hdr16.as<uint16_t>() + first_pixel * 4u, rgba16f, n_pixels * 8u, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the source only for the duration of the call
@@ -1098,8 +1190,12 @@ int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
     HIP_TRY(c, hipSetDevice(c->device));
     // the blit is fused into r3n_resolve_opaque (same arithmetic on the Rgba16Float-rounded value); the separate
     // kernel only runs when the HDR buffer was produced some other way
-    if (!c->resolved_this_frame) TRY(launch_tonemap(c, nullptr));
+    if (!c->resolved_this_frame) {
+        TRY(join_shade(c));
+        TRY(launch_tonemap(c, nullptr));
+    }
     if (host_rgba8) {
+        TRY(join_shade(c));
         if (pitch < (uint64_t)c->width * 4) return fail(c, R3N_ERR_INVALID_ARG, "tonemap: pitch too small");
         HIP_TRY(c, hipMemcpy2DAsync(host_rgba8, pitch, c->out8.p, (size_t)c->width * 4, (size_t)c->width * 4, c->height,
                                     hipMemcpyDeviceToHost, c->stream));
@@ -1143,6 +1239,7 @@ int r3n_set_row_range(r3n_ctx *c, uint32_t b, uint32_t e) {
 }
 int r3n_output_buffer(r3n_ctx *c, void **rgba8, uint64_t *bytes) {
     if (!c || !c->out8.p) return fail(c, R3N_ERR_STATE, "output_buffer: no frame targets yet");
+    TRY(join_shade(c));  // whoever reads the buffer orders itself on the main stream (r3n_stream)
     if (rgba8) *rgba8 = c->out8.p;
     if (bytes) *bytes = (uint64_t)c->width * c->height * 4;
     return R3N_OK;
@@ -1152,6 +1249,7 @@ int r3n_output_buffer(r3n_ctx *c, void **rgba8, uint64_t *bytes) {
 static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(join_lanes(c));
+    TRY(join_shade(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return R3N_OK;
@@ -1298,6 +1396,7 @@ int r3n_readback_output(r3n_ctx *c, uint8_t *rgba8, float *rgba_f32) {
     const size_t n = (size_t)c->width * c->height;
     if (rgba_f32) {
         HIP_TRY(c, hipSetDevice(c->device));
+        TRY(join_shade(c));
         TRY(ensure(c, c->out_f32, n * 16, false, -1));
         TRY(launch_tonemap(c, c->out_f32.as<float4>()));
         TRY(d2h(c, rgba_f32, c->out_f32.p, n * 16));
