@@ -646,6 +646,7 @@ __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_
 }
 
 // ------------------------------------------------------------------------------------------------ K6 resolve
+struct TriRecord;
 struct ShadeArgs {
     const unsigned long long *vis;
     uint32_t width, height, row_begin, row_end;
@@ -669,6 +670,9 @@ struct ShadeArgs {
     const unsigned char *srgb_lut;
     TextureArgs tex;
     ushort4 *samples_out;      // S == 4 and a transparent pass follows: the per-sample colours (else null)
+    TriRecord *tri_rec;        // S == 1: per-triangle vertex-stage records by canonical slot (else null)
+    unsigned char *seen;       // ... and which slots own a pixel this frame
+    uint32_t total_tris;
 };
 
 struct LdsDirLight {
@@ -855,9 +859,24 @@ R3N_DEV ushort4 pack_half4(const float v[4]) {
 }
 
 // opaque.wgsl VS (:91-135) + FS (:203-551) for triangle slot `id - 1` at the centre of pixel (x, y).
+// What the vertex stage (opaque.wgsl:91-135) and the triangle setup produce for one triangle: everything the fragment
+// stage needs that does not depend on the pixel.  64 floats = 256 B.  With one sample per pixel the resolve does not
+// recompute this per pixel: k_mark_visible flags the triangles that own a pixel, k_vertex_stage evaluates the record once
+// per flagged triangle, the per-pixel kernel loads it (neighbouring pixels share it).  Same arithmetic either way.
+struct TriRecord {
+    float e[3][3];      // oriented edge functions of the triangle setup
+    float vp[3][4];     // view-space positions
+    float vn[3][3];     // view-space normals (normalised per vertex)
+    float vt[3][3];     // view-space tangents (only when the material has a normal map, else 0)
+    float vc[3][4];     // vertex colours
+    float uv[3][2];     // texture coordinates 0
+    uint32_t object, material;
+    uint32_t _pad[5];
+};
+static_assert(sizeof(TriRecord) == 256, "triangle record is 64 dwords");
+
 template <bool TEX>
-R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
-                            uint32_t n_point, uint32_t id, uint32_t x, uint32_t y, float out[4]) {
+R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
     const uint32_t slot = id - 1u;
     // object = last o with tri_base[o] <= slot; the coarse table narrows the binary search to the objects that
     // start inside one 256-slot bucket (usually zero or one step instead of log2(capacity))
@@ -870,62 +889,91 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     }
     const uint32_t obj = lo, tri = slot - a.tri_base[obj];
     const r3n_object128 &ob = a.objects[obj];
-    const r3n_material208 &mat = a.materials[ob.material_index < a.n_materials ? ob.material_index : 0u];
+    const uint32_t mat_index = ob.material_index < a.n_materials ? ob.material_index : 0u;
+    const r3n_material208 &mat = a.materials[mat_index];
     const float *mv = a.baked[obj].model_view;
+    r.object = obj;
+    r.material = mat_index;
 
     // vertex stage for the 3 vertices (opaque.wgsl:114-134)
     uint32_t idx[3];
-    float p[3][4], vp[3][4], vn[3][3], vc[3][4], vt[3][3];
+    float p[3][4];
     const float inv_s2[3] = {1.0f / dot3(mv, mv), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
     const uint32_t first = ob.first_index + tri * 3u;
     const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
     const uint32_t nrm_off = ob.vertex_attribute_start_offsets[1];
     const uint32_t col_off = ob.vertex_attribute_start_offsets[5];
+    bool any_tex = false;
+    if (TEX) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) any_tex = any_tex || mat.textures[k] != 0u;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         idx[k] = a.mesh[first + (uint32_t)k];
         float v[3];
         fetch_vec3(a.mesh, pos_off, idx[k], v);
         mul_point(a.baked[obj].model_view_proj, v, p[k]);
-        mul_point(mv, v, vp[k]);
+        mul_point(mv, v, r.vp[k]);
         float nm[3] = {0.0f, 0.0f, 0.0f};
         if (nrm_off != R3N_INVALID) fetch_vec3(a.mesh, nrm_off, idx[k], nm);
         const float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
-        mat3_mul_vec3(mv, mv + 4, mv + 8, sn, vn[k]);
-        normalize3(vn[k]);
+        mat3_mul_vec3(mv, mv + 4, mv + 8, sn, r.vn[k]);
+        normalize3(r.vn[k]);
         if (TEX && mat.textures[1] != 0u) {  // vs_out.tangent (opaque.wgsl:129); only the normal map reads it
             float tg[3] = {0.0f, 0.0f, 0.0f};
             const uint32_t tan_off = ob.vertex_attribute_start_offsets[2];
             if (tan_off != R3N_INVALID) fetch_vec3(a.mesh, tan_off, idx[k], tg);
             const float st[3] = {inv_s2[0] * tg[0], inv_s2[1] * tg[1], inv_s2[2] * tg[2]};
-            mat3_mul_vec3(mv, mv + 4, mv + 8, st, vt[k]);
-            normalize3(vt[k]);
+            mat3_mul_vec3(mv, mv + 4, mv + 8, st, r.vt[k]);
+            normalize3(r.vt[k]);
         } else {
-            vt[k][0] = vt[k][1] = vt[k][2] = 0.0f;
+            r.vt[k][0] = r.vt[k][1] = r.vt[k][2] = 0.0f;
         }
         if (col_off != R3N_INVALID) {
             const uint32_t cw = a.mesh[col_off / 4u + idx[k]];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
+            for (int c = 0; c < 4; ++c) r.vc[k][c] = (float)((cw >> (8 * c)) & 0xFFu) / 255.0f;
         } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) vc[k][c] = 1.0f;
+            for (int c = 0; c < 4; ++c) r.vc[k][c] = 1.0f;
         }
+        if (TEX && any_tex) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], r.uv[k]);
+        else r.uv[k][0] = r.uv[k][1] = 0.0f;
     }
     TriSetup ts;
     setup_triangle(p, (float)a.width / 2.0f, (float)a.height / 2.0f,
                    (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u, ts);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r.e[i][c] = ts.e[i][c];
+}
+
+// opaque.wgsl FS (:203-551) for the triangle record `r` at the centre of pixel (x, y).
+template <bool TEX>
+R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
+                            uint32_t n_point, const TriRecord &r, uint32_t x, uint32_t y, float out[4]) {
+    const r3n_material208 &mat = a.materials[r.material];
+    TriSetup ts;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ts.e[i][c] = r.e[i][c];
+    ts.z[0] = ts.z[1] = ts.z[2] = 0.0f; ts.det = 1.0f; ts.valid = true;  // not used by the fragment stage
     float E[3];
     (void)edge_eval(ts, (float)x + 0.5f, (float)y + 0.5f, E);
     const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
     const float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
-    float vpos[4], nrm[3], col[4];
+    float vpos[4], nrm[3], col[4] = {1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
+    for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * r.vp[0][c] + lam[1] * r.vp[1][c]) + lam[2] * r.vp[2][c];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
+    for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * r.vn[0][c] + lam[1] * r.vn[1][c]) + lam[2] * r.vn[2][c];
+    if ((mat.flags & R3N_FLAGS_ALBEDO_ACTIVE) && (mat.flags & R3N_FLAGS_ALBEDO_BLEND)) {  // the only reader of vs_out.color
 #pragma unroll
-    for (int c = 0; c < 4; ++c) col[c] = (lam[0] * vc[0][c] + lam[1] * vc[1][c]) + lam[2] * vc[2][c];
+        for (int c = 0; c < 4; ++c) col[c] = (lam[0] * r.vc[0][c] + lam[1] * r.vc[1][c]) + lam[2] * r.vc[2][c];
+    }
 
     // fragment stage (opaque.wgsl:203-424).  Texture slots (managers/material.rs:25-29 order): 0 albedo, 1 normal,
     // 2 roughness, 3 metallic, 4 reflectance, 5 clear coat, 6 clear coat roughness, 7 emissive, 8 anisotropy, 9 AO
@@ -939,12 +987,9 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     float coords[2] = {0.0f, 0.0f}, ddx[2] = {0.0f, 0.0f}, ddy[2] = {0.0f, 0.0f};
     const bool nearest = (mflags & R3N_FLAGS_NEAREST) != 0u;
     if (TEX && any_tex) {  // opaque.wgsl:207-209
-        float uv[3][2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], uv[k]);
-        const float self_raw[2] = {(lam[0] * uv[0][0] + lam[1] * uv[1][0]) + lam[2] * uv[2][0],
-                                   (lam[0] * uv[0][1] + lam[1] * uv[1][1]) + lam[2] * uv[2][1]};
-        frag_coords(ts, uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
+        const float self_raw[2] = {(lam[0] * r.uv[0][0] + lam[1] * r.uv[1][0]) + lam[2] * r.uv[2][0],
+                                   (lam[0] * r.uv[0][1] + lam[1] * r.uv[1][1]) + lam[2] * r.uv[2][1]};
+        frag_coords(ts, r.uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
     }
     auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
     auto has = [&](int slot) { return TEX && mat.textures[slot] != 0u; };
@@ -991,7 +1036,7 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             if (mflags & R3N_FLAGS_YDOWN_NORMAL) n[1] = -n[1];
             float tng[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) tng[c] = (lam[0] * vt[0][c] + lam[1] * vt[1][c]) + lam[2] * vt[2][c];
+            for (int c = 0; c < 3; ++c) tng[c] = (lam[0] * r.vt[0][c] + lam[1] * r.vt[1][c]) + lam[2] * r.vt[2][c];
             float nn[3] = {nrm[0], nrm[1], nrm[2]};
             normalize3(nn);
             normalize3(tng);
@@ -1124,6 +1169,33 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     }
 }
 
+template <bool TEX>
+R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
+                            uint32_t n_point, uint32_t id, uint32_t x, uint32_t y, float out[4]) {
+    TriRecord r;
+    vertex_stage<TEX>(a, id, r);
+    fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, r, x, y, out);
+}
+
+// Flags the triangles that own at least one pixel (plain byte stores: every writer writes 1).
+__global__ __launch_bounds__(256) void k_mark_visible(const unsigned long long *__restrict__ vis, unsigned char *__restrict__ seen,
+                                                      size_t first_pixel, size_t n_pixels) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pixels) return;
+    const uint32_t id = (uint32_t)(vis[first_pixel + i] & 0xFFFFFFFFull);
+    if (id != 0u) seen[id - 1u] = 1;
+}
+// One thread per canonical triangle slot: the vertex stage + setup of the flagged ones, once per frame.
+template <bool TEX>
+__global__ __launch_bounds__(256) void k_vertex_stage(ShadeArgs a) {
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= a.total_tris || !a.seen[slot]) return;
+    TriRecord r;
+    vertex_stage<TEX>(a, slot + 1u, r);
+    r._pad[0] = r._pad[1] = r._pad[2] = r._pad[3] = r._pad[4] = 0u;
+    a.tri_rec[slot] = r;
+}
+
 // The light list in view space, once per workgroup (LDS): matrices light.view_proj * uniforms.inv_view, directions,
 // point-light positions.  Ends with a barrier.
 R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight *s_point, uint32_t &n_dir, uint32_t &n_point) {
@@ -1170,7 +1242,8 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
 // pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
 // Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
 // (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
-template <int S, bool TEX>
+// REC: the per-triangle records exist (S == 1 only): no vertex-stage code in the kernel at all.
+template <int S, bool TEX, bool REC = false>
 __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
@@ -1199,7 +1272,8 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaqu
             a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc);
             return;
         }
-        shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
+        if (REC) fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
+        else shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
     } else {
         uint32_t ids[S];
         float col[S][4];

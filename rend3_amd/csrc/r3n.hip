@@ -97,6 +97,7 @@ struct r3n_ctx {
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
     // transparent pass (row N3)
+    DevBuf tri_rec, tri_seen;  // per-triangle vertex-stage records of the resolve (kernels_raster.h TriRecord)
     DevBuf blend_order, blend_rank_base, frag_keys[2], frag_vals[2], frag_count, sort_temp, samples16;
     std::vector<uint32_t> h_blend_order;
     uint32_t n_blend = 0, blend_tris = 0;
@@ -472,7 +473,7 @@ void r3n_destroy(r3n_ctx *c) {
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
                       &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
-                      &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
+                      &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -978,6 +979,9 @@ static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     a.srgb_lut = c->srgb_lut.as<unsigned char>();
     a.tex = texture_args(c);
     a.samples_out = nullptr;
+    a.tri_rec = nullptr;
+    a.seen = nullptr;
+    a.total_tris = (uint32_t)c->total_tris;
     return a;
 }
 
@@ -1012,16 +1016,34 @@ int r3n_resolve_opaque(r3n_ctx *c) {
         a.samples_out = c->samples16.as<ushort4>();
     }
     c->resolved_this_frame = true;
+    const bool tex = c->n_textures > 0;
+    // one sample per pixel: the vertex stage runs once per visible triangle instead of once per pixel (256 B per
+    // triangle slot; skipped for worlds whose record array would pass 8 GiB)
+    if (c->samples == 1 && c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30)) {
+        TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
+        TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, -1));
+        a.tri_rec = c->tri_rec.as<TriRecord>();
+        a.seen = c->tri_seen.as<unsigned char>();
+        Timed t(c, R3N_STAGE_SHADE, stream);
+        HIP_TRY(c, hipMemsetAsync(a.seen, 0, (size_t)c->total_tris, stream));
+        const size_t first = (size_t)r0 * c->width, npx = (size_t)(r1 - r0) * c->width;
+        hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, a.vis, a.seen, first, npx);
+        const dim3 vgrid((unsigned)(((size_t)c->total_tris + 255) / 256));
+        if (tex) hipLaunchKernelGGL(k_vertex_stage<true>, vgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(k_vertex_stage<false>, vgrid, dim3(256), 0, stream, a);
+    }
     {
         Timed t(c, R3N_STAGE_SHADE, stream);
         const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
-        const bool tex = c->n_textures > 0;
         if (c->samples == 4) {
             if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true>), rgrid, dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((k_resolve_opaque<4, false>), rgrid, dim3(256), 0, stream, a);
+        } else if (a.tri_rec != nullptr) {
+            if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_resolve_opaque<1, false, true>), rgrid, dim3(256), 0, stream, a);
         } else {
-            if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true>), rgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_resolve_opaque<1, false>), rgrid, dim3(256), 0, stream, a);
+            if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, false>), rgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_resolve_opaque<1, false, false>), rgrid, dim3(256), 0, stream, a);
         }
     }
     TRY(check_launch(c, "k_resolve_opaque"));

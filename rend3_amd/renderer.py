@@ -186,6 +186,7 @@ class Renderer:
         self.meshes = []
         self.materials = []
         self._had_blend = False
+        self._blend_cache = None
         self.tex_descs = np.zeros((0, 8), dtype=np.uint32)  # r3n_texture_desc32 rows
         self.tex_pool = np.zeros(1, dtype=np.uint32)
         self.tex_used = 0
@@ -376,6 +377,7 @@ class Renderer:
         return rec
 
     def _mark(self, h, rec):
+        self._blend_cache = None
         self._use_index(h)
         self.dirty_objects[h] = rec
 
@@ -469,7 +471,10 @@ class Renderer:
                                               point_buf.nbytes), "r3n_lights_write")
         self._dir_buf, self._point_buf = dir_buf, point_buf
         # the CPU batcher's back-to-front order of the blend-key objects (batching.rs:146-176), every frame
-        blend = [h for h, m in sorted(self.object_meta.items()) if m["enabled"] and self.materials[m["material"]][1] == BLEND]
+        if self._blend_cache is None:  # rebuilt only after objects / materials changed
+            self._blend_cache = [h for h, m in sorted(self.object_meta.items())
+                                 if m["enabled"] and self.materials[m["material"]][1] == BLEND]
+        blend = self._blend_cache
         order = host.blend_draw_order(self.camera.location, blend, [self.object_meta[h]["location"] for h in blend]) if blend else []
         if order or self._had_blend:
             arr = np.asarray(order, dtype=np.uint32)
