@@ -280,7 +280,8 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_SHADOW_RASTER 9   /* shadow views: per-triangle pass */
 #define R3N_STAGE_SHADOW_RASTER_BIG 10
 #define R3N_STAGE_SKINNING 11
-#define R3N_STAGE_COUNT 12
+#define R3N_STAGE_VERTEX 12         /* resolve pre-pass: flag the visible triangles + one vertex stage per flagged triangle */
+#define R3N_STAGE_COUNT 13
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
 /* Shadow views normally run on auxiliary streams concurrently with the viewport chain; per-kernel durations measured
  * while kernels of other streams are resident are inflated, so timing passes can serialise everything on the main

@@ -18,7 +18,7 @@ PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
-          "shadow_raster", "shadow_raster_big", "skinning"]
+          "shadow_raster", "shadow_raster_big", "skinning", "vertex"]
 
 # every symbol include/r3n.h declares: (restype, argtypes)
 SIGNATURES = {

@@ -1024,7 +1024,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
         TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, -1));
         a.tri_rec = c->tri_rec.as<TriRecord>();
         a.seen = c->tri_seen.as<unsigned char>();
-        Timed t(c, R3N_STAGE_SHADE, stream);
+        Timed t(c, R3N_STAGE_VERTEX, stream);
         HIP_TRY(c, hipMemsetAsync(a.seen, 0, (size_t)c->total_tris, stream));
         const size_t first = (size_t)r0 * c->width, npx = (size_t)(r1 - r0) * c->width;
         hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, a.vis, a.seen, first, npx);
