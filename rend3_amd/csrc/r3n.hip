@@ -323,6 +323,7 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
 int refresh_tri_base(r3n_ctx *c) {
     if (!c->tri_base_dirty) return R3N_OK;
     if (c->capacity == 0) { c->tri_base_dirty = false; return R3N_OK; }
+    TRY(join_shade(c));  // frames in flight: the previous frame's resolve reads tri_base / slot_table
     TRY(ensure(c, c->tri_base, (size_t)c->capacity * 4u, false, 0));
     r3n_camera_header240 h{};
     h.object_count = c->capacity;
@@ -511,6 +512,7 @@ void *r3n_stream(r3n_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int r3n_mesh_buffer_write(r3n_ctx *c, uint64_t byte_offset, const void *data, uint64_t bytes) {
     if (!c || (!data && bytes) || (byte_offset & 3u) || (bytes & 3u)) return fail(c, R3N_ERR_INVALID_ARG, "mesh write: bad args");
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(join_shade(c));  // frames in flight: world buffers are read by the previous frame's resolve
     TRY(ensure(c, c->mesh, byte_offset + bytes, true, 0));
     if (bytes) {
         HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(c->mesh.p) + byte_offset, data, bytes, hipMemcpyHostToDevice, c->stream));
@@ -526,6 +528,7 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
         if (slots[i] >= capacity) return fail(c, R3N_ERR_INVALID_ARG, "objects write: slot >= capacity");
     if (n == 0 && capacity == c->capacity) return R3N_OK;  // nothing dirty: no upload, no synchronisation
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(join_shade(c));
     TRY(ensure(c, c->objects, (size_t)capacity * sizeof(r3n_object128), true, 0));
     if (capacity != c->capacity) {
         c->capacity = capacity;
@@ -555,6 +558,7 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
 int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208 *records, const uint8_t *keys, uint32_t n) {
     if (!c || (n && (!slots || !records || !keys))) return fail(c, R3N_ERR_INVALID_ARG, "materials write: null");
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(join_shade(c));
     uint32_t need = c->n_materials;
     for (uint32_t i = 0; i < n; ++i) {
         if (keys[i] > R3N_KEY_BLEND) return fail(c, R3N_ERR_INVALID_ARG, "materials write: bad key");
@@ -696,6 +700,7 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
     if (n == 0) return R3N_OK;  // skinning.rs:216-218: nothing to do without skeletons
     if (!inputs || !joint_matrices || n_joints == 0) return fail(c, R3N_ERR_INVALID_ARG, "skinning: null inputs");
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(join_shade(c));  // frames in flight: the previous frame's resolve reads the skinned attribute runs this rewrites
     const size_t mesh_words = c->mesh.bytes / 4;
     for (uint32_t i = 0; i < n; ++i) {
         const r3n_skinning_input40 &in = inputs[i];
