@@ -113,8 +113,11 @@ R3N_DEV bool edge_eval(const TriSetup &ts, float px, float py, float E[3]) {
         const float A = ts.e[i][0], B = ts.e[i][1];
         const float v = (A * px + B * py) + ts.e[i][2];
         E[i] = v;
-        const bool ok = (v > 0.0f) || (v == 0.0f && (A > 0.0f || (A == 0.0f && B > 0.0f)));
-        in = in && ok;
+        // top-left rule: v > 0, or v == 0 on a top / left edge.  As ONE comparison against a per-edge threshold:
+        // 0 for a top / left edge (accepts +-0), the smallest subnormal otherwise (accepts exactly v > 0; f32
+        // subnormals are kept, float_denorm_mode_32 = 3).  NaN fails both forms.
+        const float thr = (A > 0.0f || (A == 0.0f && B > 0.0f)) ? 0.0f : 1.401298464324817e-45f;
+        in = in && (v >= thr);
     }
     return in;
 }

@@ -154,6 +154,18 @@ R3N_DEV float cutout_texture_alpha(const RasterArgs &a, const TriWork &tw, int x
 // alpha -- once per pixel at the pixel centre, covered or not (no centroid qualifier in opaque.wgsl).
 __device__ static const float k_sample_pos4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}};
 
+// Depth / visibility atomics, explicitly in the GLOBAL address space.  k_raster_big pins its kernel arguments through
+// an asm statement, after which the compiler no longer knows the targets are global and would emit FLAT atomics, which
+// also count on lgkmcnt -- the counter the next record's scalar prefetch is waited on.
+R3N_DEV void global_max_u32(uint32_t *p, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint32_t *gp_t;
+    (void)__hip_atomic_fetch_max((gp_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+R3N_DEV void global_max_u64(unsigned long long *p, unsigned long long v) {
+    typedef __attribute__((address_space(1))) unsigned long long *gp_t;
+    (void)__hip_atomic_fetch_max((gp_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (BLEND) {
@@ -192,11 +204,15 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         }
         const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
         const uint32_t zb = __float_as_uint(z);
+#if R3N_ABLATE == 2
+        asm volatile("" : : "v"(zb), "v"(pix));
+        return;
+#endif
         if (DEPTH_ONLY) {
-            if (!PREREAD || zb > a.depth[pix]) atomicMax(&a.depth[pix], zb);
+            if (!PREREAD || zb > a.depth[pix]) global_max_u32(&a.depth[pix], zb);
         } else {
             const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
-            if (!PREREAD || key > a.vis[pix]) atomicMax(&a.vis[pix], key);
+            if (!PREREAD || key > a.vis[pix]) global_max_u64(&a.vis[pix], key);
         }
     } else {
         uint32_t mask = 0u;
@@ -225,7 +241,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         for (int sm = 0; sm < S; ++sm)
             if (mask & (1u << sm)) {
                 const unsigned long long key = ((unsigned long long)__float_as_uint(zs[sm]) << 32) | (unsigned long long)tw.slot1;
-                atomicMax(&a.vis[pix + (size_t)sm], key);
+                global_max_u64(&a.vis[pix + (size_t)sm], key);
             }
     }
 }
@@ -237,6 +253,9 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 // big): tile 64 coarse-only 478 / 218, tile 32 coarse-only 475 / 204, tile 32 + fine 423 / 185, tile 16 + fine 482 / 191.
 #ifndef R3N_TILE
 #define R3N_TILE 32
+#endif
+#ifndef R3N_ABLATE
+#define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
 #endif
 #ifndef R3N_FINE
 #define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block
@@ -390,8 +409,17 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 // the next item's record is in flight while the current one is scanned.  Waves walk the concatenation of the
 // R3N_BIGQ producer sub-queues with a stride of the wave count, which spreads neighbouring (similar-cost) items
 // over different waves.
+#ifdef R3N_WAVE_TRACE
+// diagnostics build only (tools/wave_trace.py): per wave of the shadow-view launches {start, end (s_memrealtime, 100 MHz
+// ticks, low 32 bits), items, scan steps}, indexed by the cascade's atlas quadrant
+__device__ uint32_t g_wave_trace[4][32768][4];
+#endif
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
+#ifdef R3N_WAVE_TRACE
+    const uint32_t trace_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t trace_items = 0, trace_steps = 0;
+#endif
     // Pin the kernel arguments the scan uses into SGPRs here: hipcc otherwise sinks the wait for their s_load
     // into the scan loop, and an `s_waitcnt lgkmcnt(0)` there would also wait for the record prefetch below.
     asm volatile("" : "+s"(a.target_pitch), "+s"(a.vp_x), "+s"(a.vp_y), "+s"(a.depth), "+s"(a.vis), "+s"(a.key),
@@ -401,20 +429,25 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     const uint32_t nwaves = gridDim.x * 4u;
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t cap = a.big_capacity;
-    // scalar cursor over the sub-queues: [qbase, qbase + qcnt) are the flat indices of sub-queue q
-    typedef __attribute__((address_space(4))) const uint32_t *sptr_t;
-    sptr_t counts = (sptr_t)(unsigned long long)a.big_count;
-    uint32_t q = 0, qbase = 0;
-    uint32_t qcnt = min(counts[0], cap);
-    auto locate = [&](uint32_t flat) -> const uint32_t * {  // nullptr past the end; flat only grows
-        while (q < R3N_BIGQ && flat >= qbase + qcnt) {
-            qbase += qcnt;
-            ++q;
-            qcnt = q < R3N_BIGQ ? min(counts[q], cap) : 0u;
-        }
-        if (q >= R3N_BIGQ) return nullptr;
-        return reinterpret_cast<const uint32_t *>(a.big_items + (size_t)q * cap + (flat - qbase));
+    // Sub-queue bounds live in registers: lane q < R3N_BIGQ holds [excl, incl), the flat indices of sub-queue q in the
+    // concatenation (one vector load + a wave scan at kernel start, before any atomic is in flight).  Locating an item
+    // is then a ballot + readlane, with no memory access in the item loop.
+    const uint32_t qcnt_l = lane < R3N_BIGQ ? min(a.big_count[lane], cap) : 0u;
+    uint32_t incl = qcnt_l;
+#pragma unroll
+    for (uint32_t d = 1; d < R3N_BIGQ; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const uint32_t excl = incl - qcnt_l;
+    auto locate = [&](uint32_t flat) -> const uint32_t * {  // nullptr past the end
+        const unsigned long long m = __ballot(flat >= excl && flat < incl);  // lanes >= R3N_BIGQ hold an empty range
+        if (!m) return nullptr;
+        const uint32_t q = (uint32_t)__builtin_ctzll(m);
+        const uint32_t qb = __builtin_amdgcn_readlane(excl, q);
+        return reinterpret_cast<const uint32_t *>(a.big_items + (size_t)q * cap + (flat - qb));
     };
+    typedef __attribute__((address_space(4))) const uint32_t *sptr_t;
     // The record is read with SCALAR loads (constant address space + wave-uniform address => s_load into SGPRs).
     // A vector load would share the vmcnt counter with the scan's fire-and-forget atomics, and waiting for the
     // record would then wait for every outstanding atomic of the previous item (measured: 2.4 us per item).
@@ -480,15 +513,27 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
         const uint32_t kxy0 = bu(18), kxy1 = bu(19);
         const int rx0 = (int)(kxy0 & 0xFFFFu), ry0 = (int)(kxy0 >> 16);
         const int rx1 = (int)(kxy1 & 0xFFFFu), ry1 = (int)(kxy1 >> 16);
+#if R3N_ABLATE == 3
+        asm volatile("" : : "s"(rx0), "s"(ry0), "s"(rx1), "s"(ry1), "s"(w.ts.e[0][0]), "s"(w.ts.z[2]));
+        if (false) {
+#else
         if (R3N_FINE && rx1 - rx0 < 32 && ry1 - ry0 < 32) {
+#endif
             // fine mode (regions up to 32x32 px): lane = 4x4 block for the rejection test; every step then scans
             // FOUR surviving blocks, 16 lanes each -- small triangles fill the wave far better than with 8x8 blocks
             const int cbx = rx0 + lx * 4, cby = ry0 + ly * 4;
             const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<4, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
+#if R3N_ABLATE == 1
+            asm volatile("" : : "s"(blocks));
+            blocks = 0ull;
+#endif
             const uint32_t grp = lane >> 4;
             const int px = (int)(lane & 3u), py = (int)((lane >> 2) & 3u);
             while (blocks) {
+#ifdef R3N_WAVE_TRACE
+                ++trace_steps;
+#endif
                 int bsel[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -499,22 +544,35 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
                 if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX, BLEND>(a, w, x, y);
             }
-        } else {
+        } else if (R3N_ABLATE != 3) {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
             const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
             while (blocks) {
+#ifdef R3N_WAVE_TRACE
+                ++trace_steps;
+#endif
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
                 if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX, BLEND>(a, w, x, y);
             }
         }
+#ifdef R3N_WAVE_TRACE
+        ++trace_items;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
         rec = nrec;
         da = na;
         db = nb;
     }
+#ifdef R3N_WAVE_TRACE
+    if (DEPTH_ONLY && lane == 0u && wave_global < 32768u) {
+        const uint32_t quad = (a.vp_x ? 1u : 0u) + (a.vp_y ? 2u : 0u);
+        uint32_t *t = g_wave_trace[quad][wave_global];
+        t[0] = trace_t0; t[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); t[2] = trace_items; t[3] = trace_steps;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ clears

@@ -549,6 +549,46 @@ def test_textured_scene_multi_frame(r3, handedness, samples):
         compare_frames(fo, fp, f"textured scene frame {f}")
 
 
+def test_frames_in_flight_world_mutation(r3):
+    """Frames in flight: six frames submitted back to back with no read-back and no host
+    synchronisation between them, so the resolve of frame N runs on the shade stream while frame N + 1 is culled and
+    rasterised -- and the world changes before EVERY frame: object transforms, a removal, a new object (which moves
+    the per-object triangle bases the resolve reads), a material rewrite.  Each world write has to order itself after
+    the resolve still in flight.  The last frame must be bit-identical to the oracle that rendered the same sequence
+    (the oracle needs every frame for the temporal state: previous-frame masks, predicted / residual sets)."""
+    W, H = 960, 540
+    o, p = both(r3, oh.LEFT, f32(W) / f32(H))
+    ho = scenes.build_textured_scene(o, oh, omk, 200, 0xF1F0, handedness=oh.LEFT, lights=2)
+    hp = scenes.build_textured_scene(p, oh, r3.material_record, 200, 0xF1F0, handedness=oh.LEFT, lights=2)
+    extra = {}
+    for r, mk in ((o, omk), (p, r3.material_record)):
+        pos, idx, nrm = scenes.box()
+        extra[id(r)] = (r.add_mesh(pos, idx, normals=nrm), r.add_material(mk(albedo=(0.9, 0.2, 0.1, 1.0), roughness=0.4)))
+    frames = 6
+    fo = fp = None
+    for f in range(frames):
+        eye = (-14.0 + 2.0 * f, 3.0 + 0.5 * f, -14.0 + 1.5 * f)
+        for r, hs in ((o, ho), (p, hp)):
+            r.set_camera_data(oh.look_at_lh(eye, (0.0, 0.0, 0.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+            for k in range(0, 40, 3):  # moving objects, every frame
+                r.set_object_transform(hs[k], oh.mat4_mul(oh.translation((0.4 * f - 6.0 + 0.3 * k, 0.5 + 0.1 * k, 0.25 * f * (k % 5) - 2.0)),
+                                                          oh.scale((1.0 + 0.05 * f,) * 3)))
+            if f == 2:
+                r.remove_object(hs[50])
+                r.remove_object(hs[51])
+            if f == 3:
+                mesh, mat = extra[id(r)]
+                r.add_object(mesh, mat, oh.mat4_mul(oh.translation((0.0, 1.0, 0.0)), oh.scale((3.0, 0.5, 3.0))))
+            if f == 4:
+                mesh, mat = extra[id(r)]
+                r.add_object(mesh, mat, oh.translation((-3.0, 2.0, 1.0)))
+        last = f == frames - 1
+        fo = o.render(W, H, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(W, H, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0), readback=last)
+    compare_frames(fo, fp, "frames in flight, last frame")
+    assert fo["visible"].sum() > 0 and fo["pass"].sum() > 0
+
+
 @pytest.mark.parametrize("handedness,samples,textured", [(oh.LEFT, 1, False), (oh.RIGHT, 1, True), (oh.LEFT, 4, True)])
 def test_transparent_pass_multi_frame(r3, handedness, samples, textured):
     """Row N3: translucent (TransparencyType::Blend) objects over the lit random scene, four frames with the camera

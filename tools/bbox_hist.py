@@ -53,6 +53,18 @@ def stats(name, cam, bits, res):
         print(f"   ({a:>4},{b:>7}]  tris {s.sum():>8}  bbox texels {int(area[s].sum()):>11}  mean area {area[s].mean() if s.any() else 0:8.1f}")
     s = ok & (m == 0)
     print(f"   empty bbox: {s.sum()}")
+    big = ok & (m > 8)
+    if big.any():
+        cnt = (np.ceil(bw[big] / 32) * np.ceil(bh[big] / 32))
+        grp = np.add.reduceat(big.astype(np.int64), np.arange(0, len(big), 64))
+        # per list-order group of 64 triangles (what one wave of k_raster_small holds): emit-loop trip count = max cnt
+        cnt_full = np.where(big, np.ceil(bw / 32) * np.ceil(bh / 32), 0)
+        gmax = np.maximum.reduceat(cnt_full, np.arange(0, len(big), 64))
+        a_full = np.where(ok & (m <= 8), area, 0)
+        amax = np.maximum.reduceat(a_full, np.arange(0, len(big), 64))
+        print(f"   big (>8): {big.sum()} triangles, items {int(cnt.sum())}, items/triangle mean {cnt.mean():.2f} p90 {np.percentile(cnt, 90):.0f} p99 {np.percentile(cnt, 99):.0f} max {cnt.max():.0f};"
+              f" per-64 group: big lanes mean {grp.mean():.1f}, emit trips (max cnt) mean {gmax.mean():.1f} p90 {np.percentile(gmax, 90):.0f} max {gmax.max():.0f};"
+              f" scan trips (max small area) mean {amax.mean():.1f}; sum of small areas / 64 = {a_full.sum() / len(amax) / 64:.1f}")
     small = ok & (m <= 8) & (m > 0)
     if small.any():
         a = area[small]
