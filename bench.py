@@ -141,10 +141,12 @@ def main():
     last = frame(args.warmup + args.steps + n_inst, readback=(world == 1))
 
     result = None
-    traffic = {}
+    traffic, valu_busy = {}, {}
     try:  # HBM bytes per launch from the committed PMC passes (collected separately, see profiles/r01_summary.md)
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            traffic = json.load(fh).get("bytes_per_launch", {})
+            committed = json.load(fh)
+            traffic = committed.get("bytes_per_launch", {})
+            valu_busy = committed.get("valu_busy", {})
     except OSError:
         pass
     if rank == 0:
@@ -190,8 +192,10 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get("k_resolve_opaque") if world == 1 else None,
                 "bytes_per_launch": int(shade_bytes),
                 "ms_per_launch": round(shade_ms, 5),
-                "note": "dominant kernel by time; VALU-bound, vector ALUs busy > 90 % of the launch (SQ counters, profiles/r01_summary.md): about "
-                        + ("1500" if args.untextured else "3260") + " vector instructions per pixel (vertex stage, 4 lights x (5-tap PCF + GGX)"
+                "valu_busy": valu_busy.get("k_resolve_opaque" if not args.untextured else "k_resolve_opaque_untextured") if world == 1 else None,
+                "note": "dominant kernel by time; VALU-bound, not HBM-bound: valu_busy = SQ_ACTIVE_INST_VALU / SIMD issue cycles of the "
+                        "launch (SQ counter pass, profiles/r01_summary.md section 2); about "
+                        + ("1500" if args.untextured else "2400") + " vector instructions per pixel (4 lights x (5-tap PCF + GGX)"
                         + ("" if args.untextured else ", 3 trilinear maps, tangent frame") + ", all IEEE div/sqrt); bytes = key + HDR + sRGB per pixel, texels excluded"}
         result = {
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",

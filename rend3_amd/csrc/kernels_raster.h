@@ -254,6 +254,15 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 #ifndef R3N_TILE
 #define R3N_TILE 32
 #endif
+#ifndef R3N_SMALL_OCC
+#define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
+#endif
+#ifndef R3N_TEX_OCC
+#define R3N_TEX_OCC 5  // min waves per SIMD asked of the textured record-based resolve (launch bound)
+#endif
+#ifndef R3N_SKIP_OCCLUDED
+#define R3N_SKIP_OCCLUDED 1
+#endif
 #ifndef R3N_ABLATE
 #define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
 #endif
@@ -264,7 +273,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
-__global__ __launch_bounds__(256) void k_raster_small(RasterArgs a) {
+__global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs a) {
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
     const uint32_t n = a.sub_counts[a.key * R3N_SUBQ + q];
@@ -738,6 +747,7 @@ struct LdsDirLight {
     float l[3];       // normalize(view_mat3 * -direction)   (opaque.wgsl:519)
     float color[3];
     float inv_res[2], offset[2], size[2];
+    float sane;       // 1: |colour| <= 1e6 (lets the fragment stage skip fully occluded lights), else 0
 };
 struct LdsPointLight {
     float vpos[3];    // (uniforms.view * position).xyz (opaque.wgsl:528)
@@ -1176,6 +1186,16 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
         float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
+#if R3N_SKIP_OCCLUDED
+        // A fully occluded light (shadow * ao == 0) adds (finite) * 0 = +-0 when every factor of surface_shading is
+        // finite: skip its BRDF.  Finite is guaranteed by: all pixel inputs finite (the sum of magnitudes is finite;
+        // NaN fails the comparison), roughness^2 >= 1e-9 (D <= 1/(pi a^2) <= 3.2e17 without underflow of f^2,
+        // V <= 0.5/(1e-5 a) <= 5e13, Fresnel <= 2) and |light colour| <= 1e6 (checked when the lights are staged).
+        const float mag = (((fabsf(px.normal[0]) + fabsf(px.normal[1])) + (fabsf(px.normal[2]) + fabsf(vv[0]))) +
+                           ((fabsf(vv[1]) + fabsf(vv[2])) + (fabsf(px.f0[0]) + fabsf(px.f0[1])))) +
+                          (((fabsf(px.f0[2]) + fabsf(px.diffuse[0])) + (fabsf(px.diffuse[1]) + fabsf(px.diffuse[2]))) + fabsf(px.ao));
+        const bool skip_ok = px.roughness >= 1e-9f && px.roughness <= 1e9f && mag < 1e30f;
+#endif
         for (uint32_t i = 0; i < n_dir; ++i) {
             const LdsDirLight &L = s_dir[i];
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
@@ -1202,6 +1222,13 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             // opaque.wgsl:509-514 (quirk: `any`, un-atlased coords vs atlas-space bounds -- reproduced)
             if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f)
                 shadow = shadow_pcf5(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], sn[2]);
+#if R3N_SKIP_OCCLUDED
+            if (skip_ok && L.sane != 0.0f && shadow * px.ao == 0.0f) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) color[c] += 0.0f;
+                continue;
+            }
+#endif
             float res[3];
             surface_shading(L.l, L.color, px, vv, shadow * px.ao, res);
 #pragma unroll
@@ -1276,6 +1303,8 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
             normalize3(l);
 #pragma unroll
             for (int r = 0; r < 3; ++r) { s_dir[li].l[r] = l[r]; s_dir[li].color[r] = dirs[li].color[r]; }
+            s_dir[li].sane = (fabsf(dirs[li].color[0]) <= 1e6f && fabsf(dirs[li].color[1]) <= 1e6f && fabsf(dirs[li].color[2]) <= 1e6f &&
+                              fabsf(l[0]) <= 2.0f && fabsf(l[1]) <= 2.0f && fabsf(l[2]) <= 2.0f) ? 1.0f : 0.0f;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 s_dir[li].inv_res[r] = dirs[li].inv_resolution[r];
@@ -1302,7 +1331,7 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
 // (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
 // REC: the per-triangle records exist (S == 1 only): no vertex-stage code in the kernel at all.
 template <int S, bool TEX, bool REC = false>
-__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : 1) void k_resolve_opaque(ShadeArgs a) {
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : ((S == 1 && REC) ? R3N_TEX_OCC : 1)) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
