@@ -94,11 +94,29 @@ typedef struct r3n_material208 {
 typedef struct r3n_texture_desc32 {
     uint32_t offset;
     uint32_t width, height, mips;
-    uint32_t format; /* R3N_TEXTURE_RGBA8_UNORM | R3N_TEXTURE_RGBA8_UNORM_SRGB */
+    uint32_t format; /* R3N_TEXTURE_* */
     uint32_t _pad[3];
 } r3n_texture_desc32;
 #define R3N_TEXTURE_RGBA8_UNORM 0u
 #define R3N_TEXTURE_RGBA8_UNORM_SRGB 1u
+/* formats accepted by r3n_textures_write_encoded only (rend3-types TextureFormat names; what rend3-gltf's
+ * util::map_ktx2_format / map_dxgi_format / map_d3d_format / convert_dynamic_image produce for 8-bit colour data,
+ * rend3-gltf/src/lib.rs:1157-1175,1176-1410).  R / RG read (r, 0, 0, 1) / (r, g, 0, 1) like a sampled texture. */
+#define R3N_TEXTURE_R8_UNORM 2u
+#define R3N_TEXTURE_RG8_UNORM 3u
+#define R3N_TEXTURE_BGRA8_UNORM 4u
+#define R3N_TEXTURE_BGRA8_UNORM_SRGB 5u
+#define R3N_TEXTURE_BC1_RGBA_UNORM 6u
+#define R3N_TEXTURE_BC1_RGBA_UNORM_SRGB 7u
+#define R3N_TEXTURE_BC2_RGBA_UNORM 8u
+#define R3N_TEXTURE_BC2_RGBA_UNORM_SRGB 9u
+#define R3N_TEXTURE_BC3_RGBA_UNORM 10u
+#define R3N_TEXTURE_BC3_RGBA_UNORM_SRGB 11u
+#define R3N_TEXTURE_BC4_R_UNORM 12u
+#define R3N_TEXTURE_BC5_RG_UNORM 13u
+#define R3N_TEXTURE_BC7_RGBA_UNORM 14u
+#define R3N_TEXTURE_BC7_RGBA_UNORM_SRGB 15u
+#define R3N_TEXTURE_FORMAT_COUNT 16u
 
 /* PerCameraUniform header, 240 B (rend3-routine/src/culling/culler.rs:158-175) */
 typedef struct r3n_camera_header240 {
@@ -178,6 +196,13 @@ int r3n_materials_write(r3n_ctx *ctx, const uint32_t *slots, const r3n_material2
  *      sample entry `id - 1` (opaque.wgsl:151-160).  Formats other than RGBA8 -> R3N_ERR_UNSUPPORTED. */
 int r3n_textures_write(r3n_ctx *ctx, const r3n_texture_desc32 *descs, uint32_t n_textures, const uint32_t *texels,
                        uint64_t n_texels);
+/*      Same, for textures in the formats the loader produces (above): `payload` holds every texture's levels back to
+ *      back in ITS OWN format (block-compressed levels: ceil(w/4) x ceil(h/4) blocks, 8 or 16 B each), desc.offset =
+ *      BYTE offset of level 0 in `payload`.  The library expands / decodes everything on the GPU into its RGBA8 texel
+ *      pool (the texture unit's job in the reference: formats go straight to wgpu, rend3/src/managers/texture.rs:59-
+ *      150).  Snorm / float / 16-bit / ETC2 / ASTC / BC6H formats -> R3N_ERR_UNSUPPORTED. */
+int r3n_textures_write_encoded(r3n_ctx *ctx, const r3n_texture_desc32 *descs, uint32_t n_textures, const void *payload,
+                               uint64_t payload_bytes);
 /*      Draw order of the blend-key objects for the transparent pass: object slots back to front, as the CPU batcher
  *      sorts them every frame (rend3-routine/src/culling/batching.rs:146-176, Sorting::BLENDING: -distance^2 from the
  *      camera location to the object location).  Call once per frame before r3n_resolve_opaque (n may be 0). */
@@ -259,6 +284,8 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
+int r3n_readback_texels(r3n_ctx *ctx, uint64_t first_texel, uint32_t *rgba8, uint64_t n_texels); /* the decoded RGBA8 texel pool: texture i's
+                                                                                         levels back to back, textures in array order */
 int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height*samples, a pixel's samples contiguous */
 int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys (min over samples) */
 int r3n_readback_hiz(r3n_ctx *ctx, float *pyramid, uint64_t count); /* all mips, mip0 first */

@@ -13,6 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libr3o.so")
 _SRC = os.path.join(_HERE, "r3o.c")
+_SRCS = [_SRC, os.path.join(_HERE, "bcn.c")]
+_DEPS = _SRCS + [os.path.join(_HERE, "bc7_tables.h")]
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 vp = ctypes.c_void_p
@@ -20,11 +22,11 @@ vp = ctypes.c_void_p
 
 def build(force=False):
     """gcc -O2 -ffp-contract=off: no FMA contraction so every f32 op rounds once."""
-    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(_SRC):
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in _DEPS):
         return _SO
     cmd = [
         "gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
-        "-Wall", "-Wextra", "-o", _SO, _SRC, "-lm",
+        "-Wall", "-Wextra", "-o", _SO, *_SRCS, "-lm",
     ]
     subprocess.run(cmd, check=True)
     return _SO
@@ -41,6 +43,10 @@ class OracleLib:
         c.r3o_hiz_mip_offset.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         c.r3o_frustum_contains_sphere.restype = ctypes.c_int
         c.r3o_frustum_contains_sphere.argtypes = [vp, vp, ctypes.c_float]
+        c.r3o_texture_level_bytes.restype = ctypes.c_uint64
+        c.r3o_texture_level_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        c.r3o_texture_decode_level.restype = ctypes.c_int
+        c.r3o_texture_decode_level.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         c.r3o_f32_to_f16.restype = ctypes.c_uint16
         c.r3o_f32_to_f16.argtypes = [ctypes.c_float]
         c.r3o_f16_to_f32.restype = ctypes.c_float

@@ -218,6 +218,9 @@ class OracleRenderer:
         mip_source "uploaded" | "generated" (MipmapSource).  Returns the texture handle (index)."""
         host_mod = host
         data, w, h, mips = host_mod.prepare_texture(self.lib, rgba8, srgb, mip_count, mip_source)
+        return self._append_texels(data, w, h, mips, srgb)
+
+    def _append_texels(self, data, w, h, mips, srgb):
         desc = np.array([[self.tex_used, w, h, mips, 1 if srgb else 0, 0, 0, 0]], dtype=np.uint32)
         if self.tex_used + len(data) > len(self.tex_pool):
             grown = np.zeros(max(2 * len(self.tex_pool), self.tex_used + len(data)), dtype=np.uint32)
@@ -227,6 +230,25 @@ class OracleRenderer:
         self.tex_used += len(data)
         self.tex_descs = np.concatenate([self.tex_descs, desc])
         return len(self.tex_descs) - 1
+
+    def add_texture_2d_encoded(self, fmt, width, height, levels, generate_mips=False):
+        """Mirror of the product's add_texture_2d_encoded: every level is decoded to RGBA8 by the oracle's decoders
+        (oracle/bcn.c); generate_mips expands level 0 and runs the RGBA8 blit chain."""
+        c = self.lib.c
+        decoded = []
+        for k, lv in enumerate(levels):
+            w, h = max(1, width >> k), max(1, height >> k)
+            src = np.frombuffer(lv, dtype=np.uint8)
+            assert len(src) == c.r3o_texture_level_bytes(fmt, w, h), "level byte count"
+            out = np.zeros((h, w, 4), dtype=np.uint8)
+            assert c.r3o_texture_decode_level(fmt, w, h, src.ctypes.data, out.ctypes.data) == 0
+            decoded.append(out)
+        srgb = fmt in (1, 5, 7, 9, 11, 15)
+        if generate_mips:
+            assert len(levels) == 1 and fmt < 6
+            return self.add_texture_2d(decoded[0], srgb=srgb, mip_count="maximum", mip_source="generated")
+        data = np.concatenate([d.reshape(-1, 4).view(np.uint32).reshape(-1) for d in decoded])
+        return self._append_texels(data, width, height, len(levels), srgb)
 
     def _tex_args(self):
         lib = self.lib

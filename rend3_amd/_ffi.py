@@ -32,6 +32,7 @@ SIGNATURES = {
     "r3n_objects_write": (cint, [vp, vp, vp, u32, u32]),
     "r3n_materials_write": (cint, [vp, vp, vp, vp, u32]),
     "r3n_textures_write": (cint, [vp, vp, u32, vp, u64]),
+    "r3n_textures_write_encoded": (cint, [vp, vp, u32, vp, u64]),
     "r3n_blend_order_write": (cint, [vp, vp, u32]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "r3n_readback_raster_stats": (cint, [vp, vp]),
     "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
     "r3n_readback_mesh": (cint, [vp, u64, vp, u64]),
+    "r3n_readback_texels": (cint, [vp, u64, vp, u64]),
     "r3n_readback_visibility": (cint, [vp, vp]),
     "r3n_readback_depth": (cint, [vp, vp]),
     "r3n_readback_hiz": (cint, [vp, vp, u64]),

@@ -614,6 +614,66 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
     return R3N_OK;
 }
 
+extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h);
+extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h, const void *src, uint32_t *dst, hipStream_t stream);
+
+int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, const void *payload, uint64_t payload_bytes) {
+    if (!c || (n && (!descs || !payload))) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): null");
+    std::vector<r3n_texture_desc32> internal(n);
+    uint64_t n_texels = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const r3n_texture_desc32 &d = descs[i];
+        if (d.format >= R3N_TEXTURE_FORMAT_COUNT) return fail(c, R3N_ERR_UNSUPPORTED, "textures write (encoded): format not built (8-bit colour, BC1-5, BC7 only)");
+        if (!d.width || !d.height || !d.mips || d.width > 65535u || d.height > 65535u) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): bad extent");
+        uint32_t max_mips = 0;
+        for (uint32_t m = std::max(d.width, d.height); m; m >>= 1) ++max_mips;
+        if (d.mips > max_mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): more mips than the extent has");
+        uint64_t end = d.offset, texels = 0;
+        for (uint32_t k = 0; k < d.mips; ++k) {
+            const uint32_t w = std::max(1u, d.width >> k), h = std::max(1u, d.height >> k);
+            end += r3n_internal_level_bytes(d.format, w, h);
+            texels += (uint64_t)w * h;
+        }
+        if (end > payload_bytes) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): levels outside the payload");
+        if ((d.offset & 3u) != 0u) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): level 0 must start on a 4-byte boundary");
+        if (n_texels + texels > 0xFFFFFFFFull) return fail(c, R3N_ERR_CAPACITY, "textures write (encoded): texel pool exceeds 2^32 texels");
+        const bool srgb = d.format == R3N_TEXTURE_RGBA8_UNORM_SRGB || d.format == R3N_TEXTURE_BGRA8_UNORM_SRGB ||
+                          d.format == R3N_TEXTURE_BC1_RGBA_UNORM_SRGB || d.format == R3N_TEXTURE_BC2_RGBA_UNORM_SRGB ||
+                          d.format == R3N_TEXTURE_BC3_RGBA_UNORM_SRGB || d.format == R3N_TEXTURE_BC7_RGBA_UNORM_SRGB;
+        internal[i] = d;
+        internal[i].offset = (uint32_t)n_texels;
+        internal[i].format = srgb ? R3N_TEXTURE_RGBA8_UNORM_SRGB : R3N_TEXTURE_RGBA8_UNORM;
+        n_texels += texels;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));  // no frame may still sample the old array
+    TRY(ensure(c, c->tex_descs, std::max<size_t>(n, 1) * sizeof(r3n_texture_desc32), false, -1));
+    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4, false, -1));
+    if (n) {
+        void *staged = nullptr;
+        HIP_TRY(c, hipMalloc(&staged, std::max<uint64_t>(payload_bytes, 4)));
+        hipError_t e = hipMemcpyAsync(staged, payload, payload_bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->tex_descs.p, internal.data(), (size_t)n * sizeof(r3n_texture_desc32), hipMemcpyHostToDevice, c->stream);
+        for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
+            uint64_t src = descs[i].offset, dst = internal[i].offset;
+            for (uint32_t k = 0; k < descs[i].mips && e == hipSuccess; ++k) {
+                const uint32_t w = std::max(1u, descs[i].width >> k), h = std::max(1u, descs[i].height >> k);
+                // block-compressed and 32-bit sources are read as dwords: every level of those formats is a multiple of 4 B
+                e = (hipError_t)r3n_internal_decode_level(descs[i].format, w, h, static_cast<const char *>(staged) + src,
+                                                          c->tex_texels.as<uint32_t>() + dst, c->stream);
+                src += r3n_internal_level_bytes(descs[i].format, w, h);
+                dst += (uint64_t)w * h;
+            }
+        }
+        const hipError_t e2 = hipStreamSynchronize(c->stream);  // the caller owns the sources only for the duration of the call
+        (void)hipFree(staged);
+        if (e != hipSuccess) return fail(c, R3N_ERR_HIP, std::string("textures write (encoded): ") + hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(c, R3N_ERR_HIP, std::string("textures write (encoded): ") + hipGetErrorString(e2));
+    }
+    c->n_textures = n;
+    return R3N_OK;
+}
+
 int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void *point, uint64_t point_bytes) {
     if (!c) return R3N_ERR_INVALID_ARG;
     // kept on the host; r3n_frame_begin uploads them into the frame's own copy (frames in flight: the previous frame's
@@ -1374,6 +1434,11 @@ int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity
 int r3n_readback_mesh(r3n_ctx *c, uint64_t byte_offset, void *dst, uint64_t bytes) {
     if (!c || !dst || byte_offset + bytes > c->mesh.bytes) return fail(c, R3N_ERR_INVALID_ARG, "readback_mesh: range outside the mesh buffer");
     return d2h(c, dst, static_cast<char *>(c->mesh.p) + byte_offset, bytes);
+}
+
+int r3n_readback_texels(r3n_ctx *c, uint64_t first_texel, uint32_t *rgba8, uint64_t n_texels) {
+    if (!c || !rgba8 || (first_texel + n_texels) * 4 > c->tex_texels.bytes) return fail(c, R3N_ERR_INVALID_ARG, "readback_texels: range outside the texel pool");
+    return d2h(c, rgba8, c->tex_texels.as<uint32_t>() + first_texel, n_texels * 4);
 }
 
 int r3n_readback_visibility(r3n_ctx *c, uint64_t *keys) {

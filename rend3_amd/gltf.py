@@ -129,25 +129,34 @@ def _image_bytes(g, image):
 
 
 def load_image(g, r, cache, image_index, srgb):
-    """load_image_cached + load_image + util::convert_dynamic_image (rend3-gltf/src/lib.rs:951-1128, 1163-1181) for the
-    formats the `image` crate decodes (PNG / JPEG ...): 8-bit luma (with or without alpha) becomes R8Unorm (one
-    component; stored here as RGBA8 (L, 0, 0, 255), which samples identically), RGB / RGBA become Rgba8Unorm[Srgb];
-    MipmapCount::Maximum + MipmapSource::Generated.  KTX2 / DDS containers are not read.
+    """load_image_cached + load_image (rend3-gltf/src/lib.rs:951-1128): KTX2 first, then DDS (containers.py: the
+    `ktx2` / `ddsfile` readers and the loader's format maps; stored levels are uploaded as they are, a single-level file
+    gets a generated chain only when its format can be rendered to, i.e. is not block-compressed), else the `image`
+    crate's decoders + util::convert_dynamic_image (:1157-1175): 8-bit luma (with or without alpha) becomes R8Unorm,
+    RGB / RGBA become Rgba8Unorm[Srgb], MipmapCount::Maximum + MipmapSource::Generated.
     Returns (texture handle, components)."""
     key = (image_index, bool(srgb))
     if key not in cache:
-        import io
-        from PIL import Image
-        im = Image.open(io.BytesIO(_image_bytes(g, g.json["images"][image_index])))
-        if im.mode in ("L", "LA"):
-            lum = np.array(im.convert("L"), dtype=np.uint8)
-            rgba = np.zeros(lum.shape + (4,), dtype=np.uint8)
-            rgba[..., 0] = lum
-            rgba[..., 3] = 255
-            cache[key] = (r.add_texture_2d(rgba, srgb=False, mip_count="maximum", mip_source="generated"), 1)
+        from . import containers
+        data = _image_bytes(g, g.json["images"][image_index])
+        parsed = containers.parse_ktx2(data, bool(srgb)) or containers.parse_dds(data, bool(srgb))
+        if parsed is not None:
+            fmt = parsed["format"]
+            generate = len(parsed["levels"]) == 1 and containers.generate_mips_allowed(fmt)
+            handle = r.add_texture_2d_encoded(fmt, parsed["width"], parsed["height"], parsed["levels"], generate_mips=generate)
+            comps = {containers.R8: 1, containers.BC4: 1, containers.RG8: 2, containers.BC5: 2}.get(fmt, 4)
+            cache[key] = (handle, comps)
         else:
-            rgba = np.array(im.convert("RGBA"), dtype=np.uint8)
-            cache[key] = (r.add_texture_2d(rgba, srgb=bool(srgb), mip_count="maximum", mip_source="generated"), 4)
+            import io
+            from PIL import Image
+            im = Image.open(io.BytesIO(data))
+            if im.mode in ("L", "LA"):
+                lum = np.ascontiguousarray(np.array(im.convert("L"), dtype=np.uint8))
+                cache[key] = (r.add_texture_2d_encoded(containers.R8, lum.shape[1], lum.shape[0], [lum.tobytes()],
+                                                       generate_mips=True), 1)
+            else:
+                rgba = np.array(im.convert("RGBA"), dtype=np.uint8)
+                cache[key] = (r.add_texture_2d(rgba, srgb=bool(srgb), mip_count="maximum", mip_source="generated"), 4)
     return cache[key]
 
 

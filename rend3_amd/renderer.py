@@ -188,7 +188,7 @@ class Renderer:
         self._had_blend = False
         self._blend_cache = None
         self.tex_descs = np.zeros((0, 8), dtype=np.uint32)  # r3n_texture_desc32 rows
-        self.tex_pool = np.zeros(1, dtype=np.uint32)
+        self.tex_pool = np.zeros(4, dtype=np.uint8)   # every texture's levels in ITS format (bytes)
         self.tex_used = 0
         self.capacity = 16  # FreelistDerivedBuffer::STARTING_SIZE
         self.object_meta = {}
@@ -319,18 +319,51 @@ class Renderer:
     def add_texture_2d(self, rgba8, srgb=True, mip_count=1, mip_source="uploaded"):
         """Renderer::add_texture_2d with Texture{data, format, size, mip_count, mip_source}: rgba8 = (H, W, 4) u8;
         format Rgba8UnormSrgb | Rgba8Unorm; mip_count int or "maximum"; mip_source "uploaded" | "generated".
-        The whole bindless array is re-sent (r3n_textures_write).  Returns the texture handle (index)."""
+        The whole bindless array is re-sent (r3n_textures_write_encoded).  Returns the texture handle (index)."""
         data, w, h, mips = host.prepare_texture(rgba8, srgb, mip_count, mip_source)
-        desc = np.array([[self.tex_used, w, h, mips, 1 if srgb else 0, 0, 0, 0]], dtype=np.uint32)
-        if self.tex_used + len(data) > len(self.tex_pool):
-            grown = np.zeros(max(2 * len(self.tex_pool), self.tex_used + len(data)), dtype=np.uint32)
+        return self._append_texture(data.view(np.uint8), w, h, mips, 1 if srgb else 0)
+
+    def add_texture_2d_encoded(self, fmt, width, height, levels, generate_mips=False):
+        """Renderer::add_texture_2d for the other formats rend3-gltf's loader produces (containers.py ids = R3N_TEXTURE_*):
+        `levels` = the stored levels' bytes, largest first.  generate_mips: MipmapCount::Maximum + MipmapSource::Generated
+        (single-level uncompressed files, rend3-gltf/src/lib.rs:1031-1036); the chain is then built from the expanded
+        RGBA8 level, which gives every channel the values the format's own blit chain would.  Block-compressed data
+        goes to the GPU as stored and is decoded there."""
+        from . import containers
+        if generate_mips:
+            if containers.is_block_format(fmt) or len(levels) != 1:
+                raise ValueError("mips are generated for single-level uncompressed textures only")
+            a = np.frombuffer(levels[0], dtype=np.uint8)
+            rgba = np.zeros((height, width, 4), dtype=np.uint8)
+            rgba[..., 3] = 255
+            if fmt == containers.R8:
+                rgba[..., 0] = a.reshape(height, width)
+            elif fmt == containers.RG8:
+                rgba[..., :2] = a.reshape(height, width, 2)
+            elif fmt in (containers.BGRA8, containers.BGRA8_SRGB):
+                rgba[...] = a.reshape(height, width, 4)[..., [2, 1, 0, 3]]
+            else:
+                rgba[...] = a.reshape(height, width, 4)
+            srgb = fmt in (containers.RGBA8_SRGB, containers.BGRA8_SRGB)
+            return self.add_texture_2d(rgba, srgb=srgb, mip_count="maximum", mip_source="generated")
+        for k, lv in enumerate(levels):
+            if len(lv) != containers.level_bytes(fmt, max(1, width >> k), max(1, height >> k)):
+                raise ValueError(f"level {k}: wrong byte count for its extent")
+        return self._append_texture(np.frombuffer(b"".join(levels), dtype=np.uint8), width, height, len(levels), fmt)
+
+    def _append_texture(self, data_u8, w, h, mips, fmt):
+        start = (self.tex_used + 3) & ~3  # level 0 of every texture starts on a 4-byte boundary
+        end = start + len(data_u8)
+        if end > len(self.tex_pool):
+            grown = np.zeros(max(2 * len(self.tex_pool), end), dtype=np.uint8)
             grown[: self.tex_used] = self.tex_pool[: self.tex_used]
             self.tex_pool = grown
-        self.tex_pool[self.tex_used: self.tex_used + len(data)] = data
-        self.tex_used += len(data)
+        self.tex_pool[start:end] = data_u8
+        self.tex_used = end
+        desc = np.array([[start, w, h, mips, fmt, 0, 0, 0]], dtype=np.uint32)
         self.tex_descs = np.ascontiguousarray(np.concatenate([self.tex_descs, desc]))
-        self._check(self.lib.r3n_textures_write(self.ctx, _ffi.ptr(self.tex_descs), len(self.tex_descs),
-                                                _ffi.ptr(self.tex_pool), self.tex_used), "r3n_textures_write")
+        self._check(self.lib.r3n_textures_write_encoded(self.ctx, _ffi.ptr(self.tex_descs), len(self.tex_descs),
+                                                        _ffi.ptr(self.tex_pool), self.tex_used), "r3n_textures_write_encoded")
         return len(self.tex_descs) - 1
 
     def add_material(self, record, key=OPAQUE):
@@ -536,6 +569,14 @@ class Renderer:
         out = np.zeros(n_words, dtype=np.uint32)
         self._check(self.lib.r3n_readback_mesh(self.ctx, byte_offset, _ffi.ptr(out), out.nbytes), "r3n_readback_mesh")
         return out
+
+    def readback_texels(self):
+        """The decoded RGBA8 texel pool (every texture's levels back to back, array order) as (n, 4) u8."""
+        n = sum(sum(max(1, int(d[1]) >> k) * max(1, int(d[2]) >> k) for k in range(int(d[3]))) for d in self.tex_descs)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        if n:
+            self._check(self.lib.r3n_readback_texels(self.ctx, 0, _ffi.ptr(out), n), "r3n_readback_texels")
+        return out[:n].view(np.uint8).reshape(-1, 4)
 
     def readback_hiz(self, width, height):
         n = 0

@@ -106,11 +106,14 @@ def _tangents(normals):
 
 
 def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), handedness=LEFT, lights=1,
-                         shadow_res=256, shadow_distance=50.0):
+                         shadow_res=256, shadow_distance=50.0, encoded=False):
     """Row N2 scene: the instanced meshes of build_random_scene with texture coordinates, four RGBA8 textures
     (sRGB and linear formats, square / odd / 1x1 extents, full generated mip chains and a single-mip one) and ten
     materials covering the albedo-texture variants: linear and nearest samplers, value / vertex multipliers, a
-    uv transform, unlit, and cutout materials whose alpha comes from the texture (forward and shadow passes)."""
+    uv transform, unlit, and cutout materials whose alpha comes from the texture (forward and shadow passes).
+    encoded: the same materials over textures in the loader's other formats -- BC7 / BC1 / BC3 / BC5 blocks with stored
+    mip chains (random block data: every BC7 mode, punch-through BC1 blocks, both BC3 / BC5 endpoint orders), BGRA8,
+    and RG8 / R8 with generated chains (add_texture_2d_encoded)."""
     rng = Pcg32(seed)
     nrng = np.random.default_rng(seed)
     meshes = []
@@ -136,11 +139,24 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
     checker[..., 3] = np.where(((xx // 4) % 3) == 0, 60, 255)
     odd = nrng.integers(0, 256, (19, 37, 4), dtype=np.uint8)
     one = np.array([[[200, 120, 40, 255]]], dtype=np.uint8)
-    t_noise = r.add_texture_2d(noise, srgb=True, mip_count="maximum", mip_source="generated")
-    t_check = r.add_texture_2d(checker, srgb=False, mip_count="maximum", mip_source="generated")
-    t_odd = r.add_texture_2d(odd, srgb=True, mip_count="maximum", mip_source="generated")
-    t_one = r.add_texture_2d(one, srgb=True, mip_count=1, mip_source="uploaded")
-    t_flat = r.add_texture_2d(noise, srgb=False, mip_count=1, mip_source="uploaded")
+    def blocks(fmt_id, block_bytes, w, h, levels, k):
+        g = np.random.default_rng(seed * 16 + k)
+        lv = [g.integers(0, 256, ((max(1, w >> i) + 3) // 4) * ((max(1, h >> i) + 3) // 4) * block_bytes, dtype=np.uint8).tobytes()
+              for i in range(levels)]
+        return r.add_texture_2d_encoded(fmt_id, w, h, lv)
+
+    if encoded:
+        t_noise = blocks(15, 16, 64, 64, 4, 0)       # Bc7RgbaUnormSrgb, 4 stored levels
+        t_check = blocks(6, 8, 128, 32, 1, 1)        # Bc1RgbaUnorm, single level
+        t_odd = blocks(11, 16, 37, 19, 3, 2)         # Bc3RgbaUnormSrgb, extent not a multiple of the block
+        t_one = r.add_texture_2d(one, srgb=True, mip_count=1, mip_source="uploaded")
+        t_flat = r.add_texture_2d_encoded(4, 64, 64, [noise[..., [2, 1, 0, 3]].tobytes()])  # Bgra8Unorm
+    else:
+        t_noise = r.add_texture_2d(noise, srgb=True, mip_count="maximum", mip_source="generated")
+        t_check = r.add_texture_2d(checker, srgb=False, mip_count="maximum", mip_source="generated")
+        t_odd = r.add_texture_2d(odd, srgb=True, mip_count="maximum", mip_source="generated")
+        t_one = r.add_texture_2d(one, srgb=True, mip_count=1, mip_source="uploaded")
+        t_flat = r.add_texture_2d(noise, srgb=False, mip_count=1, mip_source="uploaded")
 
     c30, s30 = math.cos(0.5), math.sin(0.5)
     mats = [
@@ -167,9 +183,14 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
     emis[::4, :, 0] = 255
     emis[:, ::4, 2] = 200
     emis[..., 3] = 255
-    t_nmap = r.add_texture_2d(nmap, srgb=False, mip_count="maximum", mip_source="generated")
-    t_aomr = r.add_texture_2d(aomr_tex, srgb=False, mip_count="maximum", mip_source="generated")
-    t_emis = r.add_texture_2d(emis, srgb=True, mip_count="maximum", mip_source="generated")
+    if encoded:
+        t_nmap = blocks(13, 16, 64, 64, 7, 3)        # Bc5RgUnorm, full stored chain
+        t_aomr = r.add_texture_2d_encoded(3, 32, 32, [np.ascontiguousarray(aomr_tex[..., :2]).tobytes()], generate_mips=True)  # Rg8Unorm
+        t_emis = r.add_texture_2d_encoded(2, 16, 16, [np.ascontiguousarray(emis[..., 0]).tobytes()], generate_mips=True)       # R8Unorm
+    else:
+        t_nmap = r.add_texture_2d(nmap, srgb=False, mip_count="maximum", mip_source="generated")
+        t_aomr = r.add_texture_2d(aomr_tex, srgb=False, mip_count="maximum", mip_source="generated")
+        t_emis = r.add_texture_2d(emis, srgb=True, mip_count="maximum", mip_source="generated")
     mats += [
         r.add_material(mk(albedo=(0.8, 0.8, 0.8, 1.0), albedo_mode="value", roughness=0.6, normal_texture=t_nmap)),
         r.add_material(mk(albedo_mode="texture", albedo_texture=t_noise, roughness=0.8, metallic=1.0, normal_texture=t_nmap,

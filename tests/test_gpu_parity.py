@@ -549,6 +549,54 @@ def test_textured_scene_multi_frame(r3, handedness, samples):
         compare_frames(fo, fp, f"textured scene frame {f}")
 
 
+def test_texture_decode_matches_oracle(r3):
+    """Row N2, formats: every source format r3n_textures_write_encoded accepts, decoded / expanded on the GPU
+    (csrc/texture_decode.hip) against the oracle's decoders (oracle/bcn.c, pinned on an independent decoder's output):
+    the committed block vectors (every BC7 mode x partition, punch-through BC1, both endpoint orders), random blocks with
+    extents that are not multiples of the block and stored mip chains down to 1 x 1, and the uncompressed expansions.
+    Byte work: bit-exact."""
+    import test_texture_formats as T
+    o, p = both(r3)
+    rng = np.random.default_rng(0xDEC0DE)
+    expect = []
+    for case in T.CASES:
+        fmt, w, h = (int(v) for v in T.GOLD[case + "_meta"])
+        data = T.GOLD[case + "_data"].tobytes()
+        p.add_texture_2d_encoded(fmt, w, h, [data])
+        expect.append(T.oracle_decode(fmt, w, h, data).reshape(-1, 4))
+    for fmt in range(2, 16):
+        w, h = (37, 21) if fmt >= 6 else (13, 7)
+        levels = []
+        for k in range(int(max(w, h)).bit_length()):
+            lw, lh = max(1, w >> k), max(1, h >> k)
+            data = rng.integers(0, 256, T.C.level_bytes(fmt, lw, lh), dtype=np.uint8).tobytes()
+            levels.append(data)
+            expect.append(T.oracle_decode(fmt, lw, lh, data).reshape(-1, 4))
+        p.add_texture_2d_encoded(fmt, w, h, levels)
+    got = p.readback_texels()
+    want = np.concatenate(expect)
+    assert got.shape == want.shape
+    bad = (got != want).any(axis=1)
+    assert not bad.any(), f"{bad.sum()} of {len(bad)} texels differ, first at {np.nonzero(bad)[0][:4]}"
+    del o
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_encoded_textures_in_a_scene(r3, samples):
+    """The textured multi-frame scene over block-compressed / BGRA / RG / R textures (stored and generated chains):
+    what the sampler reads is the decoded pool, so visible sets, keys, atlas and HDR stay bit-identical to the oracle."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    scenes.build_textured_scene(o, oh, omk, 200, 0xBC7, lights=2, encoded=True)
+    scenes.build_textured_scene(p, oh, r3.material_record, 200, 0xBC7, lights=2, encoded=True)
+    for f in range(2):
+        eye = (-14.0 + 4.0 * f, 3.0 + f, -14.0 + 3.0 * f)
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh(eye, (0.0, 0.0, 0.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, 192, samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"encoded textures frame {f}")
+
+
 def test_frames_in_flight_world_mutation(r3):
     """Frames in flight: six frames submitted back to back with no read-back and no host
     synchronisation between them, so the resolve of frame N runs on the shade stream while frame N + 1 is culled and
