@@ -284,8 +284,9 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
-int r3n_readback_texels(r3n_ctx *ctx, uint64_t first_texel, uint32_t *rgba8, uint64_t n_texels); /* the decoded RGBA8 texel pool: texture i's
-                                                                                         levels back to back, textures in array order */
+int r3n_readback_texels(r3n_ctx *ctx, uint64_t first_texel, uint32_t *rgba8, uint64_t n_texels); /* the decoded RGBA8 texel pool (after
+                                                                                         r3n_textures_write_encoded: texture i's levels back to back, textures
+                                                                                         in array order, each starting on a 4-texel boundary) */
 int r3n_readback_visibility(r3n_ctx *ctx, uint64_t *keys);  /* width*height*samples, a pixel's samples contiguous */
 int r3n_readback_depth(r3n_ctx *ctx, float *depth);         /* width*height, from the visibility keys (min over samples) */
 int r3n_readback_hiz(r3n_ctx *ctx, float *pyramid, uint64_t count); /* all mips, mip0 first */

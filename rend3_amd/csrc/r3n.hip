@@ -640,6 +640,7 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         const bool srgb = d.format == R3N_TEXTURE_RGBA8_UNORM_SRGB || d.format == R3N_TEXTURE_BGRA8_UNORM_SRGB ||
                           d.format == R3N_TEXTURE_BC1_RGBA_UNORM_SRGB || d.format == R3N_TEXTURE_BC2_RGBA_UNORM_SRGB ||
                           d.format == R3N_TEXTURE_BC3_RGBA_UNORM_SRGB || d.format == R3N_TEXTURE_BC7_RGBA_UNORM_SRGB;
+        n_texels = (n_texels + 3u) & ~3ull;  // 16-byte-aligned texture starts: the block decoder stores whole rows
         internal[i] = d;
         internal[i].offset = (uint32_t)n_texels;
         internal[i].format = srgb ? R3N_TEXTURE_RGBA8_UNORM_SRGB : R3N_TEXTURE_RGBA8_UNORM;

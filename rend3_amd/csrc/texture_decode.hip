@@ -228,14 +228,20 @@ __global__ __launch_bounds__(256) void k_decode_blocks(uint32_t format, uint32_t
         decode_bc7_block((uint64_t)d0 | ((uint64_t)d1 << 32), (uint64_t)d2 | ((uint64_t)d3 << 32), px);
         break;
     }
+    // rows of a block are 16 B; whole, 16-byte-aligned rows (level width a multiple of 4 and an aligned level start,
+    // which r3n_textures_write_encoded arranges for every texture) go out as one dwordx4 store per row
+    const bool vec = (w & 3u) == 0u && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u;
 #pragma unroll
     for (uint32_t y = 0; y < 4u; ++y) {
         const uint32_t ty = by * 4u + y;
         if (ty >= h) break;
+        uint32_t *row = dst + (size_t)ty * w + bx * 4u;
+        if (vec) {
+            *reinterpret_cast<uint4 *>(row) = make_uint4(px[y * 4u], px[y * 4u + 1u], px[y * 4u + 2u], px[y * 4u + 3u]);
+        } else {
 #pragma unroll
-        for (uint32_t x = 0; x < 4u; ++x) {
-            const uint32_t tx = bx * 4u + x;
-            if (tx < w) dst[(size_t)ty * w + tx] = px[y * 4u + x];
+            for (uint32_t x = 0; x < 4u; ++x)
+                if (bx * 4u + x < w) row[x] = px[y * 4u + x];
         }
     }
 }

@@ -163,7 +163,7 @@ def load_image(g, r, cache, image_index, srgb):
 def material_from_gltf(g, index, mk, r=None, image_cache=None):
     """load_materials_and_textures (rend3-gltf/src/lib.rs:806-943): albedo = TextureVertexValue / ValueVertex
     {base_color_factor, srgb: false}; sampler from the base colour texture's magFilter; KHR_texture_transform of the
-    base colour texture as uv_transform0; normal texture Tricomponent (>= 3 components) with
+    base colour texture as uv_transform0; normal texture Bicomponent (2 components, e.g. BC5) / Tricomponent (>= 3) with
     GltfLoadSettings::default().normal_direction = Up; AO / metallic-roughness packing Combined (same image) |
     Split (AO with < 3 components) | SwizzledSplit; emissive TextureValue; alpha mode -> transparency;
     KHR_materials_unlit.  load_default_material (:777-800) when the primitive has no material.
@@ -215,7 +215,8 @@ def material_from_gltf(g, index, mk, r=None, image_cache=None):
     rec = mk(albedo=tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])),
              albedo_mode="value_vertex" if albedo is None else "texture_vertex_value", vertex_srgb=False,
              albedo_texture=None if albedo is None else albedo[0], nearest=nearest, uv_transform0=uv_transform,
-             normal_texture=normals[0] if normals is not None and normals[1] >= 3 else None,
+             normal_texture=normals[0] if normals is not None and normals[1] >= 2 else None,
+             normal_mode="bicomponent" if normals is not None and normals[1] == 2 else "tricomponent",
              aomr=aomr, emissive_texture=None if emissive is None else emissive[0],
              roughness=pbr.get("roughnessFactor", 1.0), metallic=pbr.get("metallicFactor", 1.0),
              emissive=tuple(m.get("emissiveFactor", [0.0, 0.0, 0.0])),

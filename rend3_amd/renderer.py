@@ -571,12 +571,19 @@ class Renderer:
         return out
 
     def readback_texels(self):
-        """The decoded RGBA8 texel pool (every texture's levels back to back, array order) as (n, 4) u8."""
-        n = sum(sum(max(1, int(d[1]) >> k) * max(1, int(d[2]) >> k) for k in range(int(d[3]))) for d in self.tex_descs)
-        out = np.zeros(max(n, 1), dtype=np.uint32)
-        if n:
-            self._check(self.lib.r3n_readback_texels(self.ctx, 0, _ffi.ptr(out), n), "r3n_readback_texels")
-        return out[:n].view(np.uint8).reshape(-1, 4)
+        """The decoded RGBA8 texels of every texture (levels back to back, array order) as (n, 4) u8.  In the library's
+        pool every texture starts on a 4-texel boundary (r3n_textures_write_encoded); the gaps are dropped here."""
+        sizes = [sum(max(1, int(d[1]) >> k) * max(1, int(d[2]) >> k) for k in range(int(d[3]))) for d in self.tex_descs]
+        starts, cur = [], 0
+        for n in sizes:
+            cur = (cur + 3) & ~3
+            starts.append(cur)
+            cur += n
+        pool = np.zeros(max(cur, 1), dtype=np.uint32)
+        if cur:
+            self._check(self.lib.r3n_readback_texels(self.ctx, 0, _ffi.ptr(pool), cur), "r3n_readback_texels")
+        parts = [pool[s0:s0 + n] for s0, n in zip(starts, sizes)]
+        return (np.concatenate(parts) if parts else pool[:0]).view(np.uint8).reshape(-1, 4)
 
     def readback_hiz(self, width, height):
         n = 0

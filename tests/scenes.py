@@ -221,8 +221,12 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
     return handles
 
 
-def write_textured_gltf(path):
-    """A small self-contained .gltf (buffers and PNG images as data URIs) exercising the texture side of the glTF
+def write_textured_gltf(path, containers=False):
+    """containers: the base colour image is a DDS file (DX10 header, BC7, 3 stored levels), the normal map a KTX2 file
+    (BC5: two components -> the loader's bicomponent normal mode), the occlusion / metallic-roughness image a legacy
+    DXT1 DDS and the luminance occlusion image a single-level R8 KTX2 (-> generated chain).
+
+    A small self-contained .gltf (buffers and PNG images as data URIs) exercising the texture side of the glTF
     loader: base colour texture with a NEAREST sampler and KHR_texture_transform, normal map, one image used for both
     occlusion and metallic-roughness (-> Combined packing), emissive texture, a MASK material whose alpha comes from
     the texture, and a luminance-only occlusion image (-> Split packing)."""
@@ -247,6 +251,19 @@ def write_textured_gltf(path):
     emi = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
     lum = rng.integers(100, 256, (8, 8), dtype=np.uint8)
     images = [png(base, "RGBA"), png(nrm, "RGB"), png(orm, "RGB"), png(emi, "RGB"), png(lum, "L")]
+    if containers:
+        import test_texture_formats as T
+
+        def uri(blob):
+            return "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+
+        def blocks(bb, w, h, n):
+            return [rng.integers(0, 256, ((max(1, w >> k) + 3) // 4) * ((max(1, h >> k) + 3) // 4) * bb, dtype=np.uint8).tobytes() for k in range(n)]
+
+        images[0] = uri(T.write_dds(32, 32, blocks(16, 32, 32, 3), dxgi=98))
+        images[1] = uri(T.write_ktx2(141, 16, 16, blocks(16, 16, 16, 5)))
+        images[2] = uri(T.write_dds(16, 16, blocks(8, 16, 16, 1), fourcc=b"DXT1"))
+        images[4] = uri(T.write_ktx2(9, 8, 8, [lum.tobytes()]))
 
     # one quad (two triangles) with normals, tangents, uvs
     pos = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
