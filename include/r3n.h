@@ -163,6 +163,40 @@ typedef struct r3n_skinning_input40 {
     uint32_t joint_matrix_base_offset, vertex_count;
 } r3n_skinning_input40;
 
+/* ---- rend3-anim (rend3-anim/src/lib.rs) tables, row N4.  A RIG is one skin: its joints in the skin's order, each with
+ * its parent joint and its depth in the joint hierarchy (AnimationData::from_gltf_scene, :77-145, flattened); a CLIP is
+ * one animation applied to one rig: a track per joint with the key ranges of its translation / rotation / scale
+ * channels and the bind components used where a channel is absent (pose_animation_frame, :226-236). */
+typedef struct r3n_anim_rig16 {
+    uint32_t first_joint, n_joints; /* into the joints array; n_joints <= 512 */
+    uint32_t max_depth, _pad;
+} r3n_anim_rig16;
+typedef struct r3n_anim_joint80 {
+    int32_t parent;  /* joint index inside the rig; -1: the node has no parent (global = local); -2: its parent node is
+                        not a joint of this skin (global = IDENTITY * local), rend3-anim/src/lib.rs:246-256 */
+    uint32_t depth;  /* 0 for parent < 0, else depth(parent) + 1 */
+    uint32_t _pad[2];
+    float inverse_bind[16];
+} r3n_anim_joint80;
+typedef struct r3n_anim_clip16 {
+    uint32_t rig, first_track; /* tracks [first_track, first_track + rig.n_joints) */
+    float duration;            /* Animation::duration: the time is clamped to [0, duration] (:189) */
+    uint32_t _pad;
+} r3n_anim_clip16;
+typedef struct r3n_anim_track80 {
+    uint32_t animated;        /* 0: the clip has no channel for this joint's node -> local matrix IDENTITY (:220) */
+    uint32_t key_first[3];    /* translation, rotation, scale: first key time (index into `times`) */
+    uint32_t key_count[3];    /* 0: channel absent -> bind component */
+    uint32_t value_first[3];  /* first value (index into `values`: 3 floats per vec3 key, 4 per quaternion key, xyzw) */
+    float bind_t[3], bind_r[4], bind_s[3]; /* Mat4::to_scale_rotation_translation of the node's local transform */
+} r3n_anim_track80;
+typedef struct r3n_pose_request16 {
+    uint32_t clip;
+    float time;
+    uint32_t matrix_base; /* first joint matrix of the skeleton (GpuSkinningInput.joint_matrix_base_offset) */
+    uint32_t _pad;
+} r3n_pose_request16;
+
 typedef struct r3n_config {
     uint32_t struct_size;      /* sizeof(r3n_config) */
     uint32_t max_big_items;    /* raster work-queue capacity (0 = default 4 Mi items) */
@@ -227,6 +261,14 @@ int r3n_frame_begin(r3n_ctx *ctx, const r3n_frame_uniforms496 *uniforms, uint32_
  * one dispatch + one dynamic-offset bind per skeleton).  Must precede the frame's bakes (base.rs:145). */
 int r3n_skinning(r3n_ctx *ctx, const r3n_skinning_input40 *inputs, uint32_t n_skeletons, const float *joint_matrices,
                  uint32_t n_joint_matrices);
+/* rend3-anim on the GPU.  r3n_animation_write replaces the rig / clip tables.  r3n_pose_skeletons queues
+ * pose_animation_frame's per-skin work (rend3-anim/src/lib.rs:213-262) for `n` skeleton instances: the NEXT r3n_skinning
+ * evaluates them on the GPU -- after copying its host `joint_matrices` (which may be NULL when every skeleton is posed
+ * this way) -- and writes each skeleton's joint matrices (global * inverse bind) at its matrix_base. */
+int r3n_animation_write(r3n_ctx *ctx, const r3n_anim_rig16 *rigs, uint32_t n_rigs, const r3n_anim_joint80 *joints,
+                        uint32_t n_joints, const r3n_anim_clip16 *clips, uint32_t n_clips, const r3n_anim_track80 *tracks,
+                        uint32_t n_tracks, const float *times, uint32_t n_times, const float *values, uint32_t n_values);
+int r3n_pose_skeletons(r3n_ctx *ctx, const r3n_pose_request16 *requests, uint32_t n);
 /* GpuCuller::object_uniform_upload (culler.rs:427-529) + uniform_prep.wgsl */
 int r3n_uniform_bake(r3n_ctx *ctx, r3n_camera camera, const r3n_camera_header240 *header);
 /* GpuCuller::add_culling_to_graph (culler.rs:682-713) = batch_objects (batching.rs:120-250, frustum cull +
@@ -284,6 +326,7 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
+int r3n_readback_joint_matrices(r3n_ctx *ctx, uint32_t first_matrix, float *dst, uint32_t n_matrices); /* what the last r3n_skinning read */
 int r3n_readback_texels(r3n_ctx *ctx, uint64_t first_texel, uint32_t *rgba8, uint64_t n_texels); /* the decoded RGBA8 texel pool (after
                                                                                          r3n_textures_write_encoded: texture i's levels back to back, textures
                                                                                          in array order, each starting on a 4-texel boundary) */
@@ -309,7 +352,8 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_SHADOW_RASTER_BIG 10
 #define R3N_STAGE_SKINNING 11
 #define R3N_STAGE_VERTEX 12         /* resolve pre-pass: flag the visible triangles + one vertex stage per flagged triangle */
-#define R3N_STAGE_COUNT 13
+#define R3N_STAGE_POSE 13           /* animation poses evaluated in front of the skinning kernel */
+#define R3N_STAGE_COUNT 14
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
 /* Shadow views normally run on auxiliary streams concurrently with the viewport chain; per-kernel durations measured
  * while kernels of other streams are resident are inflated, so timing passes can serialise everything on the main

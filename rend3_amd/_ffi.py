@@ -18,7 +18,7 @@ PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
-          "shadow_raster", "shadow_raster_big", "skinning", "vertex"]
+          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose"]
 
 # every symbol include/r3n.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -33,6 +33,8 @@ SIGNATURES = {
     "r3n_materials_write": (cint, [vp, vp, vp, vp, u32]),
     "r3n_textures_write": (cint, [vp, vp, u32, vp, u64]),
     "r3n_textures_write_encoded": (cint, [vp, vp, u32, vp, u64]),
+    "r3n_animation_write": (cint, [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32]),
+    "r3n_pose_skeletons": (cint, [vp, vp, u32]),
     "r3n_blend_order_write": (cint, [vp, vp, u32]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
@@ -57,6 +59,7 @@ SIGNATURES = {
     "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
     "r3n_readback_mesh": (cint, [vp, u64, vp, u64]),
     "r3n_readback_texels": (cint, [vp, u64, vp, u64]),
+    "r3n_readback_joint_matrices": (cint, [vp, u32, vp, u32]),
     "r3n_readback_visibility": (cint, [vp, vp]),
     "r3n_readback_depth": (cint, [vp, vp]),
     "r3n_readback_hiz": (cint, [vp, vp, u64]),

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "librend3_amd.so")
-SOURCES = ["r3n.hip", "blend_sort.hip", "texture_decode.hip", "host.cpp"]
+SOURCES = ["r3n.hip", "blend_sort.hip", "texture_decode.hip", "anim.hip", "host.cpp"]
 DEPS = SOURCES + ["layouts.h", "device_math.h", "texture.h", "kernels_cull.h", "kernels_raster.h", "bc7_tables.h", "../../include/r3n.h"]
 
 

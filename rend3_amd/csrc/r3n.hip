@@ -104,6 +104,11 @@ struct r3n_ctx {
     uint32_t frag_capacity = 32u << 20;  // fragments (24 B each incl. the sort's double buffers), allocated on first use
     DevBuf tex_descs, tex_texels, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
+    // rend3-anim tables (row N4) and the pose requests queued for the next r3n_skinning
+    DevBuf anim_rigs, anim_joints, anim_clips, anim_tracks, anim_times, anim_values, pose_requests;
+    std::vector<r3n_anim_rig16> h_anim_rigs;
+    std::vector<r3n_anim_clip16> h_anim_clips;
+    uint32_t n_pose_requests = 0, pose_matrix_end = 0;
     DevBuf big_uv[1 + R3N_AUX_STREAMS];
     DevBuf srgb_lut;  // Rgba8UnormSrgb code of every half in [0, 1): kernels_raster.h k_build_srgb_lut
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
@@ -475,7 +480,8 @@ void r3n_destroy(r3n_ctx *c) {
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
                       &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
-                      &c->frag_count, &c->sort_temp, &c->samples16};
+                      &c->frag_count, &c->sort_temp, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
+                      &c->anim_times, &c->anim_values, &c->pose_requests};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -614,6 +620,8 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
     return R3N_OK;
 }
 
+extern "C" int r3n_internal_pose_skeletons(const void *requests, uint32_t n, const void *rigs, const void *joints, const void *clips,
+                                           const void *tracks, const float *times, const float *values, float *out, hipStream_t stream);
 extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h);
 extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h, const void *src, uint32_t *dst, hipStream_t stream);
 
@@ -759,7 +767,9 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
 int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, const float *joint_matrices, uint32_t n_joints) {
     if (!c) return R3N_ERR_INVALID_ARG;
     if (n == 0) return R3N_OK;  // skinning.rs:216-218: nothing to do without skeletons
-    if (!inputs || !joint_matrices || n_joints == 0) return fail(c, R3N_ERR_INVALID_ARG, "skinning: null inputs");
+    if (!inputs || n_joints == 0) return fail(c, R3N_ERR_INVALID_ARG, "skinning: null inputs");
+    if (!joint_matrices && c->n_pose_requests == 0) return fail(c, R3N_ERR_INVALID_ARG, "skinning: no joint matrices and no queued poses");
+    if (c->pose_matrix_end > n_joints) return fail(c, R3N_ERR_INVALID_ARG, "skinning: a queued pose writes past the joint matrices");
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(join_shade(c));  // frames in flight: the previous frame's resolve reads the skinned attribute runs this rewrites
     const size_t mesh_words = c->mesh.bytes / 4;
@@ -793,15 +803,99 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         if (w) HIP_TRY(c, hipMemcpyAsync(c->skin_wave_skeleton.p, wave_skel.data(), (size_t)w * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors above are temporaries
     }
-    TRY(ensure(c, c->skin_matrices, (size_t)n_joints * 64, false, -1));
-    HIP_TRY(c, hipMemcpyAsync(c->skin_matrices.p, joint_matrices, (size_t)n_joints * 64, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns `joint_matrices` only for the duration of the call
+    TRY(ensure(c, c->skin_matrices, (size_t)n_joints * 64, true, -1));
+    if (joint_matrices) {
+        HIP_TRY(c, hipMemcpyAsync(c->skin_matrices.p, joint_matrices, (size_t)n_joints * 64, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns `joint_matrices` only for the duration of the call
+    }
+    if (c->n_pose_requests) {  // rend3-anim: poses queued by r3n_pose_skeletons overwrite their skeletons' matrices
+        Timed t(c, R3N_STAGE_POSE);
+        const int e = r3n_internal_pose_skeletons(c->pose_requests.p, c->n_pose_requests, c->anim_rigs.p, c->anim_joints.p, c->anim_clips.p,
+                                                  c->anim_tracks.p, c->anim_times.as<float>(), c->anim_values.as<float>(),
+                                                  c->skin_matrices.as<float>(), c->stream);
+        c->n_pose_requests = 0;
+        c->pose_matrix_end = 0;
+        if (e != 0) return fail(c, R3N_ERR_HIP, std::string("k_pose_skeletons: ") + hipGetErrorString((hipError_t)e));
+    }
     if (c->skin_total_waves == 0) return R3N_OK;
     Timed t(c, R3N_STAGE_SKINNING);
     hipLaunchKernelGGL(k_skinning, dim3((c->skin_total_waves + 3u) / 4u), dim3(256), 0, c->stream, c->mesh.as<uint32_t>(),
                        c->skin_inputs.as<r3n_skinning_input40>(), c->skin_matrices.as<float>(),
                        c->skin_wave_skeleton.as<uint32_t>(), c->skin_wave_first.as<uint32_t>(), c->skin_total_waves);
     return check_launch(c, "k_skinning");
+}
+
+int r3n_animation_write(r3n_ctx *c, const r3n_anim_rig16 *rigs, uint32_t n_rigs, const r3n_anim_joint80 *joints, uint32_t n_joints,
+                        const r3n_anim_clip16 *clips, uint32_t n_clips, const r3n_anim_track80 *tracks, uint32_t n_tracks,
+                        const float *times, uint32_t n_times, const float *values, uint32_t n_values) {
+    if (!c || (n_rigs && (!rigs || !joints)) || (n_clips && (!clips || !tracks)) || (n_times && !times) || (n_values && !values))
+        return fail(c, R3N_ERR_INVALID_ARG, "animation write: null");
+    for (uint32_t i = 0; i < n_rigs; ++i) {
+        const r3n_anim_rig16 &r = rigs[i];
+        if (r.n_joints == 0 || r.n_joints > 512u) return fail(c, R3N_ERR_CAPACITY, "animation write: a rig has 0 or more than 512 joints");
+        if ((uint64_t)r.first_joint + r.n_joints > n_joints) return fail(c, R3N_ERR_INVALID_ARG, "animation write: rig joints out of range");
+        uint32_t max_depth = 0;
+        for (uint32_t j = 0; j < r.n_joints; ++j) {
+            const r3n_anim_joint80 &jt = joints[r.first_joint + j];
+            if (jt.parent < -2 || jt.parent >= (int32_t)r.n_joints) return fail(c, R3N_ERR_INVALID_ARG, "animation write: parent joint out of range");
+            const uint32_t want = jt.parent < 0 ? 0u : joints[r.first_joint + jt.parent].depth + 1u;
+            if (jt.depth != want) return fail(c, R3N_ERR_INVALID_ARG, "animation write: joint depth does not match its parent's");
+            max_depth = std::max(max_depth, jt.depth);
+        }
+        if (max_depth != r.max_depth) return fail(c, R3N_ERR_INVALID_ARG, "animation write: rig max_depth does not match its joints");
+    }
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        const r3n_anim_clip16 &cl = clips[i];
+        if (cl.rig >= n_rigs) return fail(c, R3N_ERR_INVALID_ARG, "animation write: clip rig out of range");
+        if ((uint64_t)cl.first_track + rigs[cl.rig].n_joints > n_tracks) return fail(c, R3N_ERR_INVALID_ARG, "animation write: clip tracks out of range");
+        for (uint32_t j = 0; j < rigs[cl.rig].n_joints; ++j) {
+            const r3n_anim_track80 &t = tracks[cl.first_track + j];
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t width = k == 1 ? 4u : 3u;
+                if ((uint64_t)t.key_first[k] + t.key_count[k] > n_times || (uint64_t)t.value_first[k] + (uint64_t)t.key_count[k] * width > n_values)
+                    return fail(c, R3N_ERR_INVALID_ARG, "animation write: channel keys out of range");
+            }
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));
+    auto put = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        TRY(ensure(c, b, std::max<size_t>(bytes, 16), false, -1));
+        if (bytes) HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return R3N_OK;
+    };
+    TRY(put(c->anim_rigs, rigs, (size_t)n_rigs * sizeof *rigs));
+    TRY(put(c->anim_joints, joints, (size_t)n_joints * sizeof *joints));
+    TRY(put(c->anim_clips, clips, (size_t)n_clips * sizeof *clips));
+    TRY(put(c->anim_tracks, tracks, (size_t)n_tracks * sizeof *tracks));
+    TRY(put(c->anim_times, times, (size_t)n_times * 4));
+    TRY(put(c->anim_values, values, (size_t)n_values * 4));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller owns the sources only for the duration of the call
+    c->h_anim_rigs.assign(rigs, rigs + n_rigs);
+    c->h_anim_clips.assign(clips, clips + n_clips);
+    c->n_pose_requests = 0;
+    c->pose_matrix_end = 0;
+    return R3N_OK;
+}
+
+int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t n) {
+    if (!c || (n && !requests)) return fail(c, R3N_ERR_INVALID_ARG, "pose skeletons: null");
+    uint32_t end = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (requests[i].clip >= c->h_anim_clips.size()) return fail(c, R3N_ERR_INVALID_ARG, "pose skeletons: clip out of range");
+        const uint64_t e = (uint64_t)requests[i].matrix_base + c->h_anim_rigs[c->h_anim_clips[requests[i].clip].rig].n_joints;
+        if (e > 0xFFFFFFFFull) return fail(c, R3N_ERR_INVALID_ARG, "pose skeletons: matrix base out of range");
+        end = std::max(end, (uint32_t)e);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure(c, c->pose_requests, std::max<size_t>(n, 1) * sizeof *requests, false, -1));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->pose_requests.p, requests, (size_t)n * sizeof *requests, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->n_pose_requests = n;
+    c->pose_matrix_end = end;
+    return R3N_OK;
 }
 
 int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr) {
@@ -1435,6 +1529,11 @@ int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity
 int r3n_readback_mesh(r3n_ctx *c, uint64_t byte_offset, void *dst, uint64_t bytes) {
     if (!c || !dst || byte_offset + bytes > c->mesh.bytes) return fail(c, R3N_ERR_INVALID_ARG, "readback_mesh: range outside the mesh buffer");
     return d2h(c, dst, static_cast<char *>(c->mesh.p) + byte_offset, bytes);
+}
+
+int r3n_readback_joint_matrices(r3n_ctx *c, uint32_t first, float *dst, uint32_t n) {
+    if (!c || !dst || ((uint64_t)first + n) * 64 > c->skin_matrices.bytes) return fail(c, R3N_ERR_INVALID_ARG, "readback_joint_matrices: range outside the matrix buffer");
+    return d2h(c, dst, c->skin_matrices.as<float>() + (size_t)first * 16, (size_t)n * 64);
 }
 
 int r3n_readback_texels(r3n_ctx *c, uint64_t first_texel, uint32_t *rgba8, uint64_t n_texels) {

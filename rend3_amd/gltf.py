@@ -248,7 +248,9 @@ def instance_scene(g, r, hm, mk, scale=1.0):
     materials = {}
     image_cache = {}
     xf = [None] * len(nodes)
-    out = dict(objects=[], skeletons=[], inverse_bind_matrices=[], node_transforms=xf)
+    out = dict(objects=[], skeletons=[], inverse_bind_matrices=[], node_transforms=xf, topological_order=order,
+               nodes=[dict(parent=parent_of.get(i), local_transform=None, objects=[], skin=None, skeletons=[]) for i in range(len(nodes))],
+               skins=[dict(joints=list(sk["joints"])) for sk in g.json.get("skins", [])])
     for sk in g.json.get("skins", []):
         nj = len(sk["joints"])
         ibm = g.accessor(sk["inverseBindMatrices"]).astype(np.float32) if "inverseBindMatrices" in sk else np.tile(hm.identity(), (nj, 1))
@@ -256,7 +258,8 @@ def instance_scene(g, r, hm, mk, scale=1.0):
     for ni in order:
         node = nodes[ni]
         parent = xf[parent_of[ni]] if ni in parent_of else root
-        xf[ni] = hm.mat4_mul(parent, _node_local_matrix(node, hm))
+        out["nodes"][ni]["local_transform"] = _node_local_matrix(node, hm)
+        xf[ni] = hm.mat4_mul(parent, out["nodes"][ni]["local_transform"])
         if "mesh" not in node:
             continue
         mi = node["mesh"]
@@ -275,7 +278,36 @@ def instance_scene(g, r, hm, mk, scale=1.0):
                 nj = len(out["inverse_bind_matrices"][node["skin"]])
                 sk = r.add_skeleton(mesh, np.tile(hm.identity(), (nj, 1)))
                 out["skeletons"].append(sk)
+                out["nodes"][ni]["skin"] = node["skin"]
+                out["nodes"][ni]["skeletons"].append(sk)
                 out["objects"].append(r.add_object(None, materials[mat_index], xf[ni], skeleton=sk))
             else:
                 out["objects"].append(r.add_object(mesh, materials[mat_index], xf[ni]))
+            out["nodes"][ni]["objects"].append(out["objects"][-1])
+    for k, sk in enumerate(out["skins"]):
+        sk["inverse_bind_matrices"] = out["inverse_bind_matrices"][k]
+    return out
+
+
+def load_animations(g):
+    """load_animations (rend3-gltf/src/lib.rs:724-773): per animation {"channels": {node: {"translation" | "rotation" |
+    "scale": (times, values)}}, "duration"}.  Keyframe values are taken as stored -- the reference ignores the
+    sampler's interpolation mode and always blends linearly (rend3-anim/src/lib.rs:163-175); rotations are read as f32
+    (normalised integer encodings converted like the gltf crate's into_f32).  Morph-target weights are skipped (:765).
+    duration = the latest key time of any channel (compute_animation_duration :706-722)."""
+    out = []
+    for anim in g.json.get("animations", []):
+        channels = {}
+        duration = 0.0
+        for ch in anim["channels"]:
+            target = ch["target"]
+            if "node" not in target or target["path"] == "weights":
+                continue
+            smp = anim["samplers"][ch["sampler"]]
+            times = g.accessor(smp["input"]).astype(np.float32).reshape(-1)
+            values = g.accessor(smp["output"]).astype(np.float32)
+            channels.setdefault(target["node"], {})[target["path"]] = (times, values)
+            if len(times):
+                duration = max(duration, float(times.max()))
+        out.append(dict(channels=channels, duration=np.float32(duration), name=anim.get("name")))
     return out

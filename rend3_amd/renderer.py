@@ -300,7 +300,33 @@ class Renderer:
         return list(range(first, first + n))
 
     def set_skeleton_joint_matrices(self, sk, joint_matrices):
+        getattr(self, "_pose_state", {}).pop(sk, None)
         self.skeletons[sk]["matrices"] = np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)
+
+    def animation_write(self, rigs, joints, clips, tracks, times, values):
+        """r3n_animation_write: the rend3-anim tables (anim.AnimationData builds them; record layouts in include/r3n.h)."""
+        arrs = [np.ascontiguousarray(a) for a in (rigs, joints, clips, tracks, times, values)]
+        args = []
+        for a, rec in zip(arrs, (16, 80, 16, 80, 4, 4)):
+            args += [_ffi.ptr(a) if a.size else None, a.nbytes // rec]
+        self._check(self.lib.r3n_animation_write(self.ctx, *args), "r3n_animation_write")
+
+    def pose_skeletons(self, requests):
+        """rend3-anim poses: requests = [(clip, time, skeleton handle)].  The joint matrices are evaluated on the GPU
+        (csrc/anim.hip) in front of every skinning pass, straight into the buffer the skinning kernel reads, until the
+        skeleton gets another pose or explicit matrices (Renderer::set_skeleton_joint_matrices semantics: the last
+        value set stays)."""
+        if not hasattr(self, "_pose_state"):
+            self._pose_state = {}
+        for clip, time, sk in requests:
+            self._pose_state[sk] = (int(clip), np.float32(time))
+
+    def _pose_requests(self):
+        state = getattr(self, "_pose_state", {})
+        rq = np.zeros(len(state), dtype=[("clip", np.uint32), ("time", np.float32), ("base", np.uint32), ("pad", np.uint32)])
+        for i, (sk, (clip, time)) in enumerate(sorted(state.items())):
+            rq[i] = (clip, time, int(self._skin_inputs[sk][8]), 0)
+        return rq
 
     def skinning_buffers(self):
         """build_gpu_skinning_input_buffers (rend3-routine/src/skinning.rs:54-139)"""
@@ -570,6 +596,14 @@ class Renderer:
         self._check(self.lib.r3n_readback_mesh(self.ctx, byte_offset, _ffi.ptr(out), out.nbytes), "r3n_readback_mesh")
         return out
 
+    def readback_joint_matrices(self):
+        """The joint matrices the last skinning pass read (host-provided and GPU-posed), (n, 16) f32."""
+        n = sum(len(sk["matrices"]) for sk in self.skeletons)
+        out = np.zeros((max(n, 1), 16), dtype=f32)
+        if n:
+            self._check(self.lib.r3n_readback_joint_matrices(self.ctx, 0, _ffi.ptr(out), n), "r3n_readback_joint_matrices")
+        return out[:n]
+
     def readback_texels(self):
         """The decoded RGBA8 texels of every texture (levels back to back, array order) as (n, 4) u8.  In the library's
         pool every texture starts on a 4-texel boundary (r3n_textures_write_encoded); the gaps are dropped here."""
@@ -748,6 +782,9 @@ class BaseRenderGraph:
         def skin(r, _ev):
             if r.skeletons:
                 sk_in, sk_m = r.skinning_buffers()
+                poses = r._pose_requests()
+                if len(poses):
+                    r._check(r.lib.r3n_pose_skeletons(r.ctx, _ffi.ptr(np.ascontiguousarray(poses)), len(poses)), "r3n_pose_skeletons")
                 r._check(r.lib.r3n_skinning(r.ctx, _ffi.ptr(sk_in), len(sk_in), _ffi.ptr(sk_m), len(sk_m)), "r3n_skinning")
 
         graph.add_node("Skinning", skin)

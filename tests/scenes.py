@@ -344,3 +344,104 @@ def add_blend_objects(r, hm, mk, seed, n=12, textured=False):
         xf = hm.mat4_mul(hm.mat4_mul(hm.translation(pos), random_rotation(rng, hm)), hm.scale(sc))
         handles.append(r.add_object(mbox if k % 3 else msph, mats[rng.randint(len(mats))], xf))
     return handles
+
+
+def write_animated_gltf(path):
+    """A skinned, animated .gltf for row N4 (rend3-anim): a 4 x 1 x 1 bar of 5 vertex rings skinned to a 4-joint chain
+    (joint 0 = root, parented to a plain node; one extra joint hangs off joint 1), one clip with rotation channels on
+    three joints, a translation channel on one, a scale channel on one, an unanimated joint, keys that start after t = 0
+    on one channel, plus an animated plain node carrying a cube
+    (node-transform half of pose_animation_frame)."""
+    import base64
+    import json
+
+    rings = 9
+    pos, nor, jnt, wgt, idx = [], [], [], [], []
+    for i in range(rings):
+        x = 4.0 * i / (rings - 1)
+        for (y, z) in ((-0.3, -0.3), (0.3, -0.3), (0.3, 0.3), (-0.3, 0.3)):
+            pos.append([x, y, z])
+            n = np.array([0.0, y, z]) / np.hypot(y, z)
+            nor.append(n.tolist())
+            f = x  # joints sit at x = 0, 1, 2, 3
+            j0 = min(int(f), 3)
+            j1 = min(j0 + 1, 3)
+            w1 = f - int(f) if j0 < 3 else 0.0
+            jnt.append([j0, j1, 4 if i == rings - 1 else 0, 0])
+            wgt.append([1.0 - w1 if i != rings - 1 else 0.75 * (1.0 - w1), w1 if i != rings - 1 else 0.75 * w1, 0.25 if i == rings - 1 else 0.0, 0.0])
+    for i in range(rings - 1):
+        for k in range(4):
+            a, b = 4 * i + k, 4 * i + (k + 1) % 4
+            idx += [a, b, a + 4, b, b + 4, a + 4]
+    pos, nor = np.array(pos, np.float32), np.array(nor, np.float32)
+    jnt, wgt, idx = np.array(jnt, np.uint16), np.array(wgt, np.float32), np.array(idx, np.uint16)
+    ibm = np.stack([np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, -x, 0, 0, 1], np.float32) for x in (0.0, 1.0, 2.0, 3.0, 1.0)])
+    cube_p = np.array([[x, y, z] for x in (-.4, .4) for y in (-.4, .4) for z in (-.4, .4)], np.float32)
+    cube_i = np.array([0, 1, 3, 0, 3, 2, 4, 6, 7, 4, 7, 5, 0, 4, 5, 0, 5, 1, 2, 3, 7, 2, 7, 6, 0, 2, 6, 0, 6, 4, 1, 5, 7, 1, 7, 3], np.uint16)
+
+    def quat_z(a):
+        return [0.0, 0.0, float(np.sin(a / 2)), float(np.cos(a / 2))]
+
+    t_a = np.array([0.0, 0.5, 1.0, 2.0], np.float32)
+    t_b = np.array([0.25, 1.5], np.float32)          # starts after t = 0
+    rot1 = np.array([quat_z(0.0), quat_z(0.6), quat_z(-0.4), quat_z(0.9)], np.float32)
+    rot2 = np.array([quat_z(0.3), [0.0, 0.0, -float(np.sin(0.5)), -float(np.cos(0.5))]], np.float32)  # second key on the far hemisphere
+    rot3 = np.array([[float(np.sin(0.2)), 0.0, 0.0, float(np.cos(0.2))], quat_z(0.0), quat_z(0.0), [0.0, float(np.sin(0.4)), 0.0, float(np.cos(0.4))]], np.float32)
+    tra0 = np.array([[0, 0, 0], [0, 0.5, 0], [0.2, 0.5, 0.1], [0, 0, 0]], np.float32)
+    sca2 = np.array([[1, 1, 1], [1.5, 0.8, 1.2], [1, 1, 1], [0.7, 1.3, 1.0]], np.float32)
+    cube_t = np.array([[0, 2, 0], [1, 2.5, 0], [2, 2, 1], [0, 2, 0]], np.float32)
+    blobs = [pos, nor, jnt, wgt, idx, ibm, cube_p, cube_i, t_a, t_b, rot1, rot2, rot3, tra0, sca2, cube_t]
+    raw = [np.ascontiguousarray(b).tobytes() for b in blobs]
+    offs, cur = [], 0
+    for b in raw:
+        offs.append(cur)
+        cur += (len(b) + 3) // 4 * 4
+    buf = bytearray(cur)
+    for o, b in zip(offs, raw):
+        buf[o:o + len(b)] = b
+
+    def acc(i, ctype, count, typ, **kw):
+        return dict(bufferView=i, componentType=ctype, count=count, type=typ, **kw)
+
+    doc = {
+        "asset": {"version": "2.0"},
+        "buffers": [{"byteLength": len(buf), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(buf)).decode()}],
+        "bufferViews": [{"buffer": 0, "byteOffset": o, "byteLength": len(b)} for o, b in zip(offs, raw)],
+        "accessors": [
+            acc(0, 5126, len(pos), "VEC3", min=pos.min(0).tolist(), max=pos.max(0).tolist()), acc(1, 5126, len(nor), "VEC3"),
+            acc(2, 5123, len(jnt), "VEC4"), acc(3, 5126, len(wgt), "VEC4"), acc(4, 5123, len(idx), "SCALAR"), acc(5, 5126, 5, "MAT4"),
+            acc(6, 5126, 8, "VEC3", min=[-.4] * 3, max=[.4] * 3), acc(7, 5123, 36, "SCALAR"),
+            acc(8, 5126, 4, "SCALAR", min=[0.0], max=[2.0]), acc(9, 5126, 2, "SCALAR", min=[0.25], max=[1.5]),
+            acc(10, 5126, 4, "VEC4"), acc(11, 5126, 2, "VEC4"), acc(12, 5126, 4, "VEC4"), acc(13, 5126, 4, "VEC3"), acc(14, 5126, 4, "VEC3"),
+            acc(15, 5126, 4, "VEC3"),
+        ],
+        "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.5, 0.3, 1.0], "roughnessFactor": 0.6, "metallicFactor": 0.1}},
+                      {"pbrMetallicRoughness": {"baseColorFactor": [0.3, 0.6, 0.9, 1.0], "roughnessFactor": 0.4, "metallicFactor": 0.0}}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "JOINTS_0": 2, "WEIGHTS_0": 3}, "indices": 4, "material": 0}]},
+                   {"primitives": [{"attributes": {"POSITION": 6}, "indices": 7, "material": 1}]}],
+        # 0: armature root (plain node), 1-4: joint chain, 5: side joint under joint 2 (node), 6: skinned mesh node, 7: cube
+        "nodes": [
+            {"children": [1], "translation": [-2.0, 0.0, 0.0]},
+            {"children": [2], "rotation": quat_z(0.1)},
+            {"children": [3, 5], "translation": [1.0, 0.0, 0.0]},
+            {"children": [4], "translation": [1.0, 0.0, 0.0], "scale": [1.0, 1.0, 1.0]},
+            {"translation": [1.0, 0.0, 0.0]},
+            {"translation": [0.0, 0.5, 0.0]},
+            {"mesh": 0, "skin": 0},
+            {"mesh": 1, "translation": [0.0, 2.0, 0.0]},
+        ],
+        "skins": [{"joints": [1, 2, 3, 4, 5], "inverseBindMatrices": 5, "skeleton": 1}],
+        "animations": [{
+            "name": "bend",
+            "samplers": [{"input": 8, "output": 10}, {"input": 9, "output": 11}, {"input": 8, "output": 12}, {"input": 8, "output": 13},
+                         {"input": 8, "output": 14}, {"input": 8, "output": 15}],
+            "channels": [{"sampler": 0, "target": {"node": 2, "path": "rotation"}}, {"sampler": 1, "target": {"node": 3, "path": "rotation"}},
+                         {"sampler": 2, "target": {"node": 4, "path": "rotation"}}, {"sampler": 3, "target": {"node": 1, "path": "translation"}},
+                         {"sampler": 4, "target": {"node": 3, "path": "scale"}}, {"sampler": 5, "target": {"node": 7, "path": "translation"}}],
+        }],
+        "scenes": [{"nodes": [0, 6, 7]}],
+        "scene": 0,
+    }
+    with open(path, "w") as fh:
+        json.dump(doc, fh)
+    return path
