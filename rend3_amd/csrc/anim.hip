@@ -16,7 +16,7 @@
 
 namespace {
 
-#define R3N_ANIM_MAX_JOINTS 512u  // per rig: 32 KB of LDS for the matrices
+#define R3N_ANIM_MAX_JOINTS 512u  // per rig (r3n_animation_write checks it): at most 32 KB of LDS for the matrices
 
 __device__ inline float dot4(const float a[4], const float b[4]) { return ((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]) + a[3] * b[3]; }
 __device__ inline void normalize4(float q[4]) {
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64) void k_pose_skeletons(const r3n_pose_request16 
                                                        const r3n_anim_clip16 *__restrict__ clips, const r3n_anim_track80 *__restrict__ tracks,
                                                        const float *__restrict__ times, const float *__restrict__ values,
                                                        float *__restrict__ out) {
-    __shared__ float s_m[R3N_ANIM_MAX_JOINTS][16];
+    extern __shared__ float s_dyn[];  // 64 B per joint of the largest rig (a fixed 512-joint array would cap a CU at 5 waves)
+    float (*s_m)[16] = reinterpret_cast<float (*)[16]>(s_dyn);
     const uint32_t req = blockIdx.x;
     if (req >= n_requests) return;
     const r3n_pose_request16 rq = requests[req];
@@ -145,8 +146,9 @@ __global__ __launch_bounds__(64) void k_pose_skeletons(const r3n_pose_request16 
 }  // namespace
 
 extern "C" int r3n_internal_pose_skeletons(const void *requests, uint32_t n, const void *rigs, const void *joints, const void *clips,
-                                           const void *tracks, const float *times, const float *values, float *out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_pose_skeletons, dim3(n), dim3(64), 0, stream, static_cast<const r3n_pose_request16 *>(requests), n,
+                                           const void *tracks, const float *times, const float *values, float *out, uint32_t max_joints,
+                                           hipStream_t stream) {
+    hipLaunchKernelGGL(k_pose_skeletons, dim3(n), dim3(64), (size_t)max_joints * 64u, stream, static_cast<const r3n_pose_request16 *>(requests), n,
                        static_cast<const r3n_anim_rig16 *>(rigs), static_cast<const r3n_anim_joint80 *>(joints),
                        static_cast<const r3n_anim_clip16 *>(clips), static_cast<const r3n_anim_track80 *>(tracks), times, values, out);
     return (int)hipGetLastError();

@@ -108,7 +108,7 @@ struct r3n_ctx {
     DevBuf anim_rigs, anim_joints, anim_clips, anim_tracks, anim_times, anim_values, pose_requests;
     std::vector<r3n_anim_rig16> h_anim_rigs;
     std::vector<r3n_anim_clip16> h_anim_clips;
-    uint32_t n_pose_requests = 0, pose_matrix_end = 0;
+    uint32_t n_pose_requests = 0, pose_matrix_end = 0, anim_max_joints = 1;
     DevBuf big_uv[1 + R3N_AUX_STREAMS];
     DevBuf srgb_lut;  // Rgba8UnormSrgb code of every half in [0, 1): kernels_raster.h k_build_srgb_lut
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
@@ -621,7 +621,8 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
 }
 
 extern "C" int r3n_internal_pose_skeletons(const void *requests, uint32_t n, const void *rigs, const void *joints, const void *clips,
-                                           const void *tracks, const float *times, const float *values, float *out, hipStream_t stream);
+                                           const void *tracks, const float *times, const float *values, float *out, uint32_t max_joints,
+                                           hipStream_t stream);
 extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h);
 extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h, const void *src, uint32_t *dst, hipStream_t stream);
 
@@ -812,7 +813,7 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         Timed t(c, R3N_STAGE_POSE);
         const int e = r3n_internal_pose_skeletons(c->pose_requests.p, c->n_pose_requests, c->anim_rigs.p, c->anim_joints.p, c->anim_clips.p,
                                                   c->anim_tracks.p, c->anim_times.as<float>(), c->anim_values.as<float>(),
-                                                  c->skin_matrices.as<float>(), c->stream);
+                                                  c->skin_matrices.as<float>(), c->anim_max_joints, c->stream);
         c->n_pose_requests = 0;
         c->pose_matrix_end = 0;
         if (e != 0) return fail(c, R3N_ERR_HIP, std::string("k_pose_skeletons: ") + hipGetErrorString((hipError_t)e));
@@ -872,6 +873,8 @@ int r3n_animation_write(r3n_ctx *c, const r3n_anim_rig16 *rigs, uint32_t n_rigs,
     TRY(put(c->anim_values, values, (size_t)n_values * 4));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller owns the sources only for the duration of the call
     c->h_anim_rigs.assign(rigs, rigs + n_rigs);
+    c->anim_max_joints = 1;
+    for (uint32_t i = 0; i < n_rigs; ++i) c->anim_max_joints = std::max(c->anim_max_joints, rigs[i].n_joints);
     c->h_anim_clips.assign(clips, clips + n_clips);
     c->n_pose_requests = 0;
     c->pose_matrix_end = 0;

@@ -66,10 +66,58 @@ def run_cfg5(n=50000, steps=20):
     r.close()
 
 
+def run_cfg5_anim(n=50000, joints=24, steps=20):
+    """configs[4] with rend3-anim in front of the skinning pass: n instances of a `joints`-joint chain rig, every instance at
+    its own time of an 8-key clip (rotation + translation channels per joint); poses evaluated on the GPU (csrc/anim.hip),
+    no joint matrices cross PCIe (16 B per instance and frame: clip, time, matrix base)."""
+    from rend3_amd.scenes import skinned_cylinder
+    from rend3_amd import anim as pa
+    r = r3.Renderer(r3.host.LEFT, np.float32(16 / 9))
+    pos, idx, nrm, tang, ji, jw = skinned_cylinder(2)
+    ji = (ji.astype(np.int64) * (joints - 1)).astype(np.uint16)  # bind the two ends to the first / last joint of the chain
+    mesh = r.add_mesh(pos, idx, normals=nrm, tangents=tang, joint_indices=ji, joint_weights=jw)
+    rng = np.random.Generator(np.random.PCG64(0x5142))
+    sks = r.add_skeletons_bulk(mesh, [np.tile(r3.host.identity(), (joints, 1))] * n)
+    ident = r3.host.identity()
+    nodes = [dict(parent=(j - 1 if j else None), local_transform=ident, objects=[], skin=None, skeletons=[]) for j in range(joints)]
+    nodes[0]["skin"], nodes[0]["skeletons"] = 0, sks
+    keys = 8
+    channels = {}
+    for j in range(joints):
+        q = rng.normal(size=(keys, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        t = np.linspace(0, 2, keys).astype(np.float32)
+        channels[j] = dict(rotation=(t, q.astype(np.float32)), translation=(t, rng.normal(size=(keys, 3)).astype(np.float32)))
+    inst = dict(nodes=nodes, skins=[dict(joints=list(range(joints)), inverse_bind_matrices=np.tile(ident, (joints, 1)))], topological_order=list(range(joints)))
+    pa.AnimationData.from_gltf_scene(r, [dict(channels=channels, duration=np.float32(2.0))], inst)
+    sk_in, _ = r.skinning_buffers()
+    verts = int(sk_in[:, 9].sum())
+    rq = np.zeros(n, dtype=[("clip", np.uint32), ("time", np.float32), ("base", np.uint32), ("pad", np.uint32)])
+    rq["base"] = sk_in[:, 8]
+    def step(k):
+        rq["time"] = ((np.arange(n) * 0.00004 + 0.01 * k) % 2.0).astype(np.float32)
+        r._check(r.lib.r3n_pose_skeletons(r.ctx, r3._ffi.ptr(rq), n), "r3n_pose_skeletons")
+        r._check(r.lib.r3n_skinning(r.ctx, r3._ffi.ptr(sk_in), len(sk_in), None, n * joints), "r3n_skinning")
+    for k in range(3): step(k)
+    r.sync(); r.timing_enable(True); r.stage_times(reset=True)
+    t0 = time.perf_counter()
+    for k in range(steps): step(k)
+    r.sync(); wall = (time.perf_counter() - t0) / steps
+    st = r.stage_times(reset=True)
+    pose_ms, skin_ms = st["pose"][0] / steps, st["skinning"][0] / steps
+    # algorithmic bytes per joint: 80 B track + 80 B joint record + 64 B matrix out (keys are shared by all instances: cache)
+    print(json.dumps({"config": "configs[4] skinning + rend3-anim poses on the GPU", "skeletons": n, "joints_per_skeleton": joints,
+                      "keys_per_channel": keys, "pose_kernel_ms": round(pose_ms, 4), "skinning_kernel_ms": round(skin_ms, 4),
+                      "wall_ms_per_frame": round(1e3 * wall, 3), "joint_matrices_per_s": round(n * joints / (pose_ms * 1e-3)),
+                      "pose_algorithmic_GBps": round(n * joints * 224 / (pose_ms * 1e-3) / 1e9, 1), "vertices": verts}))
+    r.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg4", "cfg5"]
     if "cfg5" in which:
         run_cfg5()
+    if "cfg5anim" in which:
+        run_cfg5_anim()
     if "cfg2" in which:
         run("configs[1] scifi_like", lambda r: S.scifi_like(r, r3.host, r3.material_record), 1920, 1080, True)
     if "cfg4" in which:
