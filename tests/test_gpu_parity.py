@@ -479,6 +479,48 @@ def test_abi_error_behaviour(r3):
     slot = np.array([r.capacity], dtype=np.uint32)
     assert lib.r3n_objects_write(ctx, _ffi.ptr(slot), _ffi.ptr(rec), 1, r.capacity) == -1
     assert lib.r3n_objects_write(ctx, None, None, 0, 1) == -1
+    # encoded textures: formats outside the built set, levels outside the payload, misaligned level 0
+    payload = np.zeros(256, dtype=np.uint8)
+    desc = np.array([[0, 8, 8, 1, 16, 0, 0, 0]], dtype=np.uint32)
+    assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -5 and b"format" in lib.r3n_last_error(ctx)
+    desc[0, 4] = 14
+    assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 32) == -1   # 4 BC7 blocks need 64 B
+    desc[0, 0] = 2
+    assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -1
+    desc[0, 0], desc[0, 3] = 0, 5
+    assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -1   # an 8 x 8 image has 4 levels
+    desc[0, 3] = 4
+    assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == 0
+    # animation tables: parent / depth consistency, rig size, clip and key ranges; poses and skinning without matrices
+    rig = np.zeros(1, dtype=[("first", np.uint32), ("n", np.uint32), ("depth", np.uint32), ("pad", np.uint32)])
+    jt = np.zeros(2, dtype=[("parent", np.int32), ("depth", np.uint32), ("pad", np.uint32, 2), ("ibm", np.float32, 16)])
+    clip = np.zeros(1, dtype=[("rig", np.uint32), ("track", np.uint32), ("dur", np.float32), ("pad", np.uint32)])
+    trk = np.zeros(2, dtype=np.dtype([("animated", np.uint32), ("kf", np.uint32, 3), ("kc", np.uint32, 3), ("vf", np.uint32, 3),
+                                      ("bt", np.float32, 3), ("br", np.float32, 4), ("bs", np.float32, 3)]))
+    tv = np.zeros(8, dtype=f32)
+
+    def write():
+        return lib.r3n_animation_write(ctx, _ffi.ptr(rig), 1, _ffi.ptr(jt), 2, _ffi.ptr(clip), 1, _ffi.ptr(trk), 2, _ffi.ptr(tv), 8, _ffi.ptr(tv), 8)
+    rig[0] = (0, 2, 1, 0)
+    jt["parent"], jt["depth"] = [-1, 0], [0, 1]
+    assert write() == 0
+    jt["depth"] = [0, 0]
+    assert write() == -1 and b"depth" in lib.r3n_last_error(ctx)
+    jt["depth"], jt["parent"] = [0, 1], [-1, 2]
+    assert write() == -1
+    jt["parent"] = [-1, 0]
+    rig[0] = (0, 600, 1, 0)
+    assert write() == -6
+    rig[0] = (0, 2, 1, 0)
+    trk["kc"][1] = [0, 3, 0]   # 3 quaternion keys need 12 values, the pool has 8
+    assert write() == -1
+    trk["kc"][1] = [0, 2, 0]
+    assert write() == 0
+    rq = np.zeros(1, dtype=[("clip", np.uint32), ("time", np.float32), ("base", np.uint32), ("pad", np.uint32)])
+    rq["clip"] = 1
+    assert lib.r3n_pose_skeletons(ctx, _ffi.ptr(rq), 1) == -1
+    sk = np.zeros((1, 10), dtype=np.uint32)
+    assert lib.r3n_skinning(ctx, _ffi.ptr(sk), 1, None, 2) == -1 and b"no joint matrices" in lib.r3n_last_error(ctx)
     r.close()
 
 
