@@ -9,8 +9,10 @@ Third-party math: glam 0.25 (not in /root/reference): Vec3::lerp = a + (b - a) *
 - a) * s) with bias = +-1 by the sign of the dot product; normalize = v * (1 / length); Mat4::from_scale_rotation_
 translation via quat_to_axes (x2 = x + x ...); Mat4::to_scale_rotation_translation (determinant sign on the x scale,
 Quat::from_rotation_axes); Mat4 * Mat4 column by column, ((x*X + y*Y) + z*Z) + w*W.  Scalar (non-SIMD) association of the
-f32 sums.  PARITY UNPINNED against the reference's own output for this module: rend3 has no animation test or golden
-(only examples/animation); the restatement is pinned on closed-form cases in tests/test_anim.py instead.
+f32 sums.  PINNED on the reference's animation example screenshot (examples/src/animation: both scenes posed at t = 0,
+tests/test_oracle_goldens.py::test_animation_example: silhouette identical in all 100 031 covered pixels) and on closed-form
+cases (tests/test_anim.py).  The screenshot fixes the pose at t = 0 only; blending between keys rests on the closed-form
+cases.
 
 Every value is f32, one rounding per operation (numpy scalars)."""
 import numpy as np

@@ -186,7 +186,7 @@ class AnimationData:
                 tracks.append(trec)
         cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)  # noqa: E731
         self.n_skins = len(skins)
-        renderer.animation_write(rigs, cat(joints, joint_dt), clips, cat(tracks, track_dt), cat(times, f32), cat(values, f32))
+        self.clip_base = renderer.animation_add(rigs, cat(joints, joint_dt), clips, cat(tracks, track_dt), cat(times, f32), cat(values, f32))
 
     @classmethod
     def from_gltf_scene(cls, renderer, scene_animations, instance):
@@ -218,6 +218,6 @@ def pose_animation_frame(renderer, instance, animation_data, animation_index, ti
             renderer.set_object_transform(h, m)
     requests = []
     for si in range(animation_data.n_skins):
-        clip = animation_index * animation_data.n_skins + si
+        clip = animation_data.clip_base + animation_index * animation_data.n_skins + si
         requests += [(clip, t, sk) for sk in animation_data.skin_skeletons[si]]
     renderer.pose_skeletons(requests)

@@ -303,13 +303,28 @@ class Renderer:
         getattr(self, "_pose_state", {}).pop(sk, None)
         self.skeletons[sk]["matrices"] = np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)
 
-    def animation_write(self, rigs, joints, clips, tracks, times, values):
-        """r3n_animation_write: the rend3-anim tables (anim.AnimationData builds them; record layouts in include/r3n.h)."""
-        arrs = [np.ascontiguousarray(a) for a in (rigs, joints, clips, tracks, times, values)]
+    def animation_add(self, rigs, joints, clips, tracks, times, values):
+        """Register one AnimationData's tables (anim.AnimationData builds them; record layouts in include/r3n.h).  The
+        library holds ONE table set (r3n_animation_write), so the sets of all scene instances are concatenated here with
+        their indices rebased.  Returns the index of the set's first clip."""
+        sets = getattr(self, "_anim_sets", None)
+        if sets is None:
+            sets = self._anim_sets = [[np.zeros(0, dtype=a.dtype) for a in (rigs, joints, clips, tracks)] + [np.zeros(0, f32), np.zeros(0, f32)]]
+        cur = sets[0]
+        rigs, clips, tracks = rigs.copy(), clips.copy(), tracks.copy()
+        rigs["first"] += len(cur[1])
+        clips["rig"] += len(cur[0])
+        clips["track"] += len(cur[3])
+        tracks["kf"] += np.where(tracks["kc"] > 0, len(cur[4]), 0).astype(np.uint32)
+        tracks["vf"] += np.where(tracks["kc"] > 0, len(cur[5]), 0).astype(np.uint32)
+        clip_base = len(cur[2])
+        sets[0] = [np.concatenate([a, b]) for a, b in zip(cur, (rigs, joints, clips, tracks, np.asarray(times, f32), np.asarray(values, f32)))]
+        arrs = [np.ascontiguousarray(a) for a in sets[0]]
         args = []
         for a, rec in zip(arrs, (16, 80, 16, 80, 4, 4)):
             args += [_ffi.ptr(a) if a.size else None, a.nbytes // rec]
         self._check(self.lib.r3n_animation_write(self.ctx, *args), "r3n_animation_write")
+        return clip_base
 
     def pose_skeletons(self, requests):
         """rend3-anim poses: requests = [(clip, time, skeleton handle)].  The joint matrices are evaluated on the GPU

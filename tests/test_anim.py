@@ -85,8 +85,9 @@ def test_pose_skin_hierarchy_and_quirks():
 class FakeRenderer:
     handedness = 0
 
-    def animation_write(self, *tables):
+    def animation_add(self, *tables):
         self.tables = tables
+        return 0
 
 
 def load_animated(r, hm, mk, tmp_path):
@@ -222,3 +223,23 @@ def test_gpu_animated_gltf_frames_match_oracle(tmp_path):
     o.set_skeleton_joint_matrices(inst_o["skeletons"][0], ident)
     p.set_skeleton_joint_matrices(inst_p["skeletons"][0], ident)
     compare_frames(o.render(320, 192, **kw), p.render(320, 192, **kw), "explicit matrices after a pose")
+
+
+@pytest.mark.gpu
+def test_gpu_animation_example_matches_oracle():
+    """The reference's animation example (34-joint character + animated cube, tests/golden/animation/) at three times:
+    poses on the GPU, every frame bit-identical to the oracle at 640x360."""
+    import rend3_amd as r3
+    import test_oracle_goldens as G
+    from test_gpu_parity import compare_frames
+    o, p = OracleRenderer(oh.LEFT, f32(640) / f32(360)), r3.Renderer(oh.LEFT, f32(640) / f32(360))
+    so = G.build_animation_example(o, oh, omk)
+    sp = [(inst, anims, pa.AnimationData.from_gltf_scene(p, anims, inst)) for inst, anims in G.build_animation_example(p, r3.host, r3.material_record)]
+    assert [d.clip_base for _i, _a, d in sp] == [0, 1]  # one AnimationData per scene instance, sharing the library's tables
+    kw = dict(clear_color=(0.10, 0.05, 0.10, 1.0))
+    for t in (0.0, 3.3, 7.9):
+        for inst, anims in so:
+            oa.pose_animation_frame(o, inst, anims, 0, t)
+        for inst, _anims, data in sp:
+            pa.pose_animation_frame(p, inst, data, 0, t)
+        compare_frames(o.render(640, 360, **kw), p.render(640, 360, **kw), f"animation example t = {t}")
