@@ -55,6 +55,8 @@ def main():
                          "has base colour + normal + AO/roughness/metallic maps")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange path (RCCL all-reduce / all-gather) even with one rank: plumbing check")
+    ap.add_argument("--samples", type=int, default=1, choices=(1, 4),
+                    help="SampleCount of the viewport targets (the reference's scene_viewer default is 4); the headline metric is quoted at 1")
     ap.add_argument("--cpu-sample-frames", type=int, default=1)
     args = ap.parse_args()
 
@@ -100,7 +102,7 @@ def main():
 
     def frame(k, readback=False):
         r.set_camera_data(camera_path(r3.host, view0, k), info["camera"][1])
-        out = r.render(WIDTH, HEIGHT, ambient=AMBIENT, clear_color=CLEAR, readback=readback, base=base, exchange=exchange)
+        out = r.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR, readback=readback, base=base, exchange=exchange)
         if exchange is not None:
             exchange.gather_rows(WIDTH, HEIGHT, world)
         return out
@@ -203,7 +205,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2] stand-in: bistro_like (seed 0xB157), 3840x2160, "
-                                   "full PBR opaque + 4 directional shadow views (2048^2), camera dolly, "
+                                   "full PBR opaque + 4 directional shadow views (2048^2), camera dolly, " + ("MSAA x4, " if args.samples == 4 else "")
                                    + ("factor-only materials" if args.untextured else
                                       "130 materials with base colour + normal + AO/roughness/metallic maps (RGBA8, mips, trilinear)"),
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
@@ -241,11 +243,11 @@ def cpu_baseline(args, info):
     info_o = r3.scenes.bistro_like(o, oh, omk, n_objects=args.objects, target_tris=args.tris, textured=not args.untextured)
     view0 = info_o["camera"][0]
     o.set_camera_data(camera_path(oh, view0, 0), info_o["camera"][1])
-    o.render(WIDTH, HEIGHT, ambient=AMBIENT, clear_color=CLEAR)  # history frame (untimed)
+    o.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR)  # history frame (untimed)
     t0 = time.perf_counter()
     for k in range(args.cpu_sample_frames):
         o.set_camera_data(camera_path(oh, view0, 1 + k), info_o["camera"][1])
-        o.render(WIDTH, HEIGHT, ambient=AMBIENT, clear_color=CLEAR)
+        o.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR)
     dt = time.perf_counter() - t0
     return {"value": round(WIDTH * HEIGHT * args.cpu_sample_frames / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
             "kind": "port", "sample": f"{args.cpu_sample_frames} steady-state frame(s) of the same scene/camera path at "

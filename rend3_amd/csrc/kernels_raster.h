@@ -1329,9 +1329,9 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
 // pass resolve (base.rs:245-258) is their box average ((s0 + s1) + (s2 + s3)) * 0.25.
 // Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
 // (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
-// REC: the per-triangle records exist (S == 1 only): no vertex-stage code in the kernel at all.
+// REC: the per-triangle records exist: no vertex-stage code in the kernel at all.
 template <int S, bool TEX, bool REC = false>
-__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : ((S == 1 && REC) ? R3N_TEX_OCC : 1)) void k_resolve_opaque(ShadeArgs a) {
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
@@ -1366,26 +1366,43 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : ((S == 1 && REC) ? R3N_
         float col[S][4];
 #pragma unroll
         for (int sm = 0; sm < S; ++sm) ids[sm] = (uint32_t)(a.vis[pix * (size_t)S + (size_t)sm] & 0xFFFFFFFFull);
+        // The distinct triangles among the pixel's samples, each shaded ONCE (same triangle, same pixel centre: same
+        // value) by one copy of the fragment stage in a rolled loop: unrolling it per sample made the kernel four
+        // fragment stages long (instruction cache, registers) although interior pixels hold one triangle.
+        uint32_t first_of[S];  // index of the first sample with the same id
+        uint32_t n_unique = 0;
 #pragma unroll
         for (int sm = 0; sm < S; ++sm) {
-            int same = -1;
+            uint32_t f = (uint32_t)sm;
 #pragma unroll
-            for (int p = 0; p < sm; ++p)
-                if (ids[p] == ids[sm]) same = p;
-            if (same >= 0) {  // same triangle, same pixel centre: same value
+            for (int p = sm - 1; p >= 0; --p)
+                if (ids[p] == ids[sm]) f = (uint32_t)p;
+            first_of[sm] = f;
+            n_unique += f == (uint32_t)sm ? 1u : 0u;
+        }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) col[sm][c] = col[same][c];
-                continue;
-            }
+        for (int sm = 0; sm < S; ++sm)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) col[sm][c] = 0.0f;
+#pragma unroll 1
+        for (uint32_t k = 0, sm_at = 0; k < n_unique; ++k, ++sm_at) {
+            while (first_of[sm_at == 0u ? 0 : (sm_at == 1u ? 1 : (sm_at == 2u ? 2 : 3))] != sm_at) ++sm_at;  // next leader sample
+            const uint32_t id = sm_at == 0u ? ids[0] : (sm_at == 1u ? ids[1] : (sm_at == 2u ? ids[2] : ids[3]));
             float v[4];
-            if (ids[sm] == 0u) {
+            if (id == 0u) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
+            } else if (REC) {
+                fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, v);
             } else {
-                shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, ids[sm], x, y, v);
+                shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, v);
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];
+            for (int sm = 0; sm < S; ++sm)
+                if (first_of[sm] == sm_at) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];
+                }
         }
         if (a.samples_out != nullptr) {
 #pragma unroll

@@ -1182,16 +1182,16 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     }
     c->resolved_this_frame = true;
     const bool tex = c->n_textures > 0;
-    // one sample per pixel: the vertex stage runs once per visible triangle instead of once per pixel (256 B per
-    // triangle slot; skipped for worlds whose record array would pass 8 GiB)
-    if (c->samples == 1 && c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30)) {
+    // the vertex stage runs once per visible triangle instead of once per pixel / sample (256 B per triangle slot;
+    // skipped for worlds whose record array would pass 8 GiB)
+    if (c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30)) {
         TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
         TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, -1));
         a.tri_rec = c->tri_rec.as<TriRecord>();
         a.seen = c->tri_seen.as<unsigned char>();
         Timed t(c, R3N_STAGE_VERTEX, stream);
         HIP_TRY(c, hipMemsetAsync(a.seen, 0, (size_t)c->total_tris, stream));
-        const size_t first = (size_t)r0 * c->width, npx = (size_t)(r1 - r0) * c->width;
+        const size_t first = (size_t)r0 * c->width * c->samples, npx = (size_t)(r1 - r0) * c->width * c->samples;  // keys, not pixels
         hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, a.vis, a.seen, first, npx);
         const dim3 vgrid((unsigned)(((size_t)c->total_tris + 255) / 256));
         if (tex) hipLaunchKernelGGL(k_vertex_stage<true>, vgrid, dim3(256), 0, stream, a);
@@ -1200,7 +1200,10 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     {
         Timed t(c, R3N_STAGE_SHADE, stream);
         const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
-        if (c->samples == 4) {
+        if (c->samples == 4 && a.tri_rec != nullptr) {
+            if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true, true>), rgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_resolve_opaque<4, false, true>), rgrid, dim3(256), 0, stream, a);
+        } else if (c->samples == 4) {
             if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true>), rgrid, dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((k_resolve_opaque<4, false>), rgrid, dim3(256), 0, stream, a);
         } else if (a.tri_rec != nullptr) {
