@@ -225,11 +225,13 @@ def material_from_gltf(g, index, mk, r=None, image_cache=None):
     return rec, key
 
 
-def instance_scene(g, r, hm, mk, scale=1.0):
+def instance_scene(g, r, hm, mk, scale=1.0, enable_directional=True, directional_light_shadow_distance=100.0,
+                   directional_light_resolution=2048):
     """load_gltf + instance_loaded_scene (rend3-gltf/src/lib.rs:335-379, 493-562): node transforms in topological order
     under parent_transform = scale(s, s, -s for a left-handed renderer); one object per mesh primitive; a skeleton per
     primitive of a skinned node (joint matrices start as identity, add_mesh_by_index :411-457); winding flipped for
-    left-handed renderers (load_meshes :628-634).  Returns dict(objects=[handles], skeletons=[handles],
+    left-handed renderers (load_meshes :628-634); KHR_lights_punctual directional lights become
+    directional lights (GltfLoadSettings::enable_directional / directional_light_* defaults).  Returns dict(objects=[handles], skeletons=[handles],
     inverse_bind_matrices=[per skin], node_transforms)."""
     nodes = g.json.get("nodes", [])
     lh = r.handedness == 0
@@ -248,7 +250,7 @@ def instance_scene(g, r, hm, mk, scale=1.0):
     materials = {}
     image_cache = {}
     xf = [None] * len(nodes)
-    out = dict(objects=[], skeletons=[], inverse_bind_matrices=[], node_transforms=xf, topological_order=order,
+    out = dict(objects=[], skeletons=[], lights=[], inverse_bind_matrices=[], node_transforms=xf, topological_order=order,
                nodes=[dict(parent=parent_of.get(i), local_transform=None, objects=[], skin=None, skeletons=[]) for i in range(len(nodes))],
                skins=[dict(joints=list(sk["joints"])) for sk in g.json.get("skins", [])])
     for sk in g.json.get("skins", []):
@@ -260,6 +262,16 @@ def instance_scene(g, r, hm, mk, scale=1.0):
         parent = xf[parent_of[ni]] if ni in parent_of else root
         out["nodes"][ni]["local_transform"] = _node_local_matrix(node, hm)
         xf[ni] = hm.mat4_mul(parent, out["nodes"][ni]["local_transform"])
+        li = node.get("extensions", {}).get("KHR_lights_punctual", {}).get("light")
+        if li is not None and enable_directional:
+            # instance_loaded_scene :530-545: directional lights only; direction = transform.transform_vector3(-Z)
+            light = g.json["extensions"]["KHR_lights_punctual"]["lights"][li]
+            if light.get("type") == "directional":
+                m = xf[ni]
+                direction = tuple(np.float32(-m[8 + k]) for k in range(3))  # -(column 2): the matrix applied to (0, 0, -1, 0)
+                out["lights"].append(r.add_directional_light(color=tuple(light.get("color", [1.0, 1.0, 1.0])), intensity=light.get("intensity", 1.0),
+                                                             direction=direction, distance=directional_light_shadow_distance,
+                                                             resolution=directional_light_resolution))
         if "mesh" not in node:
             continue
         mi = node["mesh"]
