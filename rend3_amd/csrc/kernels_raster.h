@@ -125,6 +125,9 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 #ifndef R3N_PREREAD_SMALL
 #define R3N_PREREAD_SMALL 0
 #endif
+#ifndef R3N_PREREAD_MS
+#define R3N_PREREAD_MS 1   // multisampled targets, work-item kernel: read the pixel's keys before the atomics
+#endif
 #ifndef R3N_PREREAD_BIG
 #define R3N_PREREAD_BIG 0
 #endif
@@ -237,11 +240,24 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;
         }
         const size_t pix = ((size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x) * (size_t)S;
+#if R3N_ABLATE == 2
+        asm volatile("" : : "v"(zs[0]), "v"(zs[1]), "v"(zs[2]), "v"(zs[3]), "v"(mask), "v"(pix));
+        return;
+#endif
+        // PREREAD (the work-item kernel under MSAA): the pixel's four keys are 32 contiguous bytes; read them once and
+        // skip the atomics that cannot win.  Memory-side atomics are 65 % of that kernel at 4 samples (ablation,
+        // bench scene: 1.43 ms -> 0.50 ms without them); the read removes the overdrawn ones: 1.43 -> 1.04 ms.  Keys only
+        // grow, so a key that loses against a stale read loses against the current value too.
+        unsigned long long cur[S];
+        if (PREREAD) {
+#pragma unroll
+            for (int sm = 0; sm < S; ++sm) cur[sm] = a.vis[pix + (size_t)sm];
+        }
 #pragma unroll
         for (int sm = 0; sm < S; ++sm)
             if (mask & (1u << sm)) {
                 const unsigned long long key = ((unsigned long long)__float_as_uint(zs[sm]) << 32) | (unsigned long long)tw.slot1;
-                global_max_u64(&a.vis[pix + (size_t)sm], key);
+                if (!PREREAD || key > cur[sm]) global_max_u64(&a.vis[pix + (size_t)sm], key);
             }
     }
 }
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 }
                 const int b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                 const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
-                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX, BLEND>(a, w, x, y);
+                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (S > 1 && R3N_PREREAD_MS != 0), S, TEX, BLEND>(a, w, x, y);
             }
         } else if (R3N_ABLATE != 3) {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, R3N_PREREAD_BIG != 0, S, TEX, BLEND>(a, w, x, y);
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (S > 1 && R3N_PREREAD_MS != 0), S, TEX, BLEND>(a, w, x, y);
             }
         }
 #ifdef R3N_WAVE_TRACE
