@@ -126,7 +126,11 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 #define R3N_PREREAD_SMALL 0
 #endif
 #ifndef R3N_PREREAD_MS
-#define R3N_PREREAD_MS 1   // multisampled targets, work-item kernel: read the pixel's keys before the atomics
+#define R3N_PREREAD_MS 1        // work-item kernel on a multisampled viewport: read the pixel's keys before the atomics
+#endif
+#ifndef R3N_PREREAD_VIEWPORT
+#define R3N_PREREAD_VIEWPORT 0  // the same at one sample per pixel: the kernel alone gains (168 -> 152 us) but the frame with
+                                // frames in flight loses (1.18 -> 1.20 ms): off
 #endif
 #ifndef R3N_PREREAD_BIG
 #define R3N_PREREAD_BIG 0
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 }
                 const int b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                 const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
-                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (S > 1 && R3N_PREREAD_MS != 0), S, TEX, BLEND>(a, w, x, y);
+                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
         } else if (R3N_ABLATE != 3) {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (S > 1 && R3N_PREREAD_MS != 0), S, TEX, BLEND>(a, w, x, y);
+                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
         }
 #ifdef R3N_WAVE_TRACE
