@@ -246,6 +246,15 @@ int r3n_blend_order_write(r3n_ctx *ctx, const uint32_t *objects_back_to_front, u
 int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t directional_bytes,
                      const void *point_buffer, uint64_t point_bytes);
 
+/* TonemappingRoutine::new's output_format (rend3-routine/src/tonemapping.rs:29-106): *Srgb targets take the exact OETF of
+ * the fixed-function store (blit.wgsl fs_main_scene), other targets the shader's srgb_scene_to_display approximation
+ * (fs_main_monitor, math/color.wgsl:13-19, exponent 0.4166); Bgra8* targets hold blue first.  Default RGBA8_UNORM_SRGB. */
+#define R3N_OUTPUT_RGBA8_UNORM_SRGB 0u
+#define R3N_OUTPUT_BGRA8_UNORM_SRGB 1u
+#define R3N_OUTPUT_RGBA8_UNORM 2u
+#define R3N_OUTPUT_BGRA8_UNORM 3u
+int r3n_set_output_format(r3n_ctx *ctx, uint32_t format);
+
 /* ---- frame (node order of BaseRenderGraph::add_to_graph, rend3-routine/src/base.rs:135-185)
  * r3n_frame_begin: create_frame_uniforms (uniforms.rs:73-125) + render-target setup (base.rs:224-264) +
  * clear_shadow_buffers (clear.rs:4-20).  Clears colour to `clear_color`, depth and the shadow atlas to 0.0.

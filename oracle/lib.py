@@ -69,6 +69,7 @@ class OracleLib:
             "r3o_generate_mips": [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp],
             "r3o_srgb8_table": [vp],
             "r3o_tonemap": [vp, ctypes.c_uint64, vp, vp],
+            "r3o_tonemap_format": [vp, ctypes.c_uint64, vp, vp, ctypes.c_uint32],
             "r3o_skinning": [vp, vp, ctypes.c_uint32, vp],
         }.items():
             fn = getattr(c, name)

@@ -1386,15 +1386,28 @@ static float srgb_oetf(float x) {
     if (x <= 0.0031308f) return x * 12.92f;
     return 1.055f * powf(x, 1.0f / 2.4f) - 0.055f;
 }
-void r3o_tonemap(const uint16_t *hdr_in, uint64_t npix, float *out_f32, uint8_t *out_u8) {
+/* blit.wgsl fs_main_monitor (tonemapping.rs:44: targets whose format is not *Srgb): the shader applies
+ * math/color.wgsl:13-19 srgb_scene_to_display -- exponent 0.4166, not 1 / 2.4 -- and the unorm store clamps. */
+static float srgb_scene_to_display(float x) {
+    const float e = x > 0.0031308f ? 1.055f * powf(x, 0.4166f) - 0.055f : x * 12.92f;
+    if (!(e > 0.0f)) return 0.0f; /* unorm conversion: NaN and negatives -> 0 */
+    return e >= 1.0f ? 1.0f : e;
+}
+/* output_format: 0 Rgba8UnormSrgb, 1 Bgra8UnormSrgb, 2 Rgba8Unorm, 3 Bgra8Unorm (bit 0: B and R swapped in memory,
+ * bit 1: manual transfer function).  out_f32 stays in r, g, b, a order. */
+void r3o_tonemap_format(const uint16_t *hdr_in, uint64_t npix, float *out_f32, uint8_t *out_u8, uint32_t output_format) {
+    const int bgr = (output_format & 1u) != 0u, manual = (output_format & 2u) != 0u;
     for (uint64_t i = 0; i < npix; ++i) {
         for (int c = 0; c < 4; ++c) {
             float v = f16_to_f32(hdr_in[4 * i + c]);
-            float e = c < 3 ? srgb_oetf(v) : ((!(v > 0.0f)) ? 0.0f : (v >= 1.0f ? 1.0f : v));
+            float e = c < 3 ? (manual ? srgb_scene_to_display(v) : srgb_oetf(v)) : ((!(v > 0.0f)) ? 0.0f : (v >= 1.0f ? 1.0f : v));
             if (out_f32) out_f32[4 * i + c] = e;
-            if (out_u8) out_u8[4 * i + c] = (uint8_t)(e * 255.0f + 0.5f);
+            if (out_u8) out_u8[4 * i + ((bgr && c < 3) ? 2 - c : c)] = (uint8_t)(e * 255.0f + 0.5f);
         }
     }
+}
+void r3o_tonemap(const uint16_t *hdr_in, uint64_t npix, float *out_f32, uint8_t *out_u8) {
+    r3o_tonemap_format(hdr_in, npix, out_f32, out_u8, 0u);
 }
 
 /* ------------------------------------------------------------------ K8: GPU skinning (row S1) */

@@ -211,6 +211,9 @@ class OracleRenderer:
         return inputs, (np.ascontiguousarray(np.concatenate(mats)) if mats else np.zeros((0, 16), dtype=f32))
 
     # ------------------------------------------------------------------ world edits
+    def set_output_format(self, fmt):
+        self.output_format = int(fmt)
+
     def add_texture_2d(self, rgba8, srgb=True, mip_count=1, mip_source="uploaded"):
         """Renderer::add_texture_2d (rend3/src/renderer/mod.rs) with Texture{data, format, size, mip_count, mip_source}:
         rgba8 = (H, W, 4) u8 (mip 0, or every mip concatenated row-major when mip_source == "uploaded" and
@@ -547,7 +550,7 @@ class OracleRenderer:
                       len(blend_obj), lib.ptr(hdr16))
         rgba_f = np.zeros((height, width, 4), dtype=f32)
         rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
-        lib.r3o_tonemap(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8))
+        lib.r3o_tonemap_format(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8), getattr(self, "output_format", 0))
 
         out.update(header=hdr, frame_uniforms=fu, baked=baked, visible=visible, tri_base=tri_base,
                    residual=residual, vis=vis, atlas=atlas, atlas_size=atlas_size, hdr16=hdr16, rgba_f32=rgba_f,

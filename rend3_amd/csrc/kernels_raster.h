@@ -755,6 +755,7 @@ struct ShadeArgs {
     ushort4 *hdr_out;          // Rgba16Float
     uchar4 *ldr_out;           // Rgba8UnormSrgb: the tonemap blit fused into the resolve (one HDR round trip less)
     const unsigned char *srgb_lut;
+    bool out_bgr;              // Bgra8* output target
     TextureArgs tex;
     ushort4 *samples_out;      // S == 4 and a transparent pass follows: the per-sample colours (else null)
     TriRecord *tri_rec;        // S == 1: per-triangle vertex-stage records by canonical slot (else null)
@@ -929,11 +930,19 @@ R3N_DEV unsigned char srgb8_of_half(const unsigned char *__restrict__ lut, unsig
     return lut[h];
 }
 // blit.wgsl fs_main_scene into an Rgba8UnormSrgb target: exact OETF of the Rgba16Float-rounded value
-R3N_DEV uchar4 tonemap_half4(const unsigned char *__restrict__ lut, ushort4 h) {
+// bgr: the target is a Bgra8* format (blue first in memory)
+R3N_DEV uchar4 tonemap_half4(const unsigned char *__restrict__ lut, ushort4 h, bool bgr = false) {
     const float al = (float)__builtin_bit_cast(_Float16, h.w);
     const float a = (!(al > 0.0f)) ? 0.0f : (al >= 1.0f ? 1.0f : al);
-    return make_uchar4(srgb8_of_half(lut, h.x), srgb8_of_half(lut, h.y), srgb8_of_half(lut, h.z),
-                       (unsigned char)(a * 255.0f + 0.5f));
+    const unsigned char r = srgb8_of_half(lut, h.x), g = srgb8_of_half(lut, h.y), b = srgb8_of_half(lut, h.z);
+    return make_uchar4(bgr ? b : r, g, bgr ? r : b, (unsigned char)(a * 255.0f + 0.5f));
+}
+// math/color.wgsl:13-19 srgb_scene_to_display + the unorm store's clamp: what blit.wgsl fs_main_monitor writes into a
+// target whose format is not *Srgb (tonemapping.rs:44)
+R3N_DEV float srgb_scene_to_display(float x) {
+    const float e = x > 0.0031308f ? 1.055f * powf(x, 0.4166f) - 0.055f : x * 12.92f;
+    if (!(e > 0.0f)) return 0.0f;
+    return e >= 1.0f ? 1.0f : e;
 }
 
 R3N_DEV ushort4 pack_half4(const float v[4]) {
@@ -1376,7 +1385,7 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
         if (id == 0u) {
             const ushort4 hc = pack_half4(a.clear);
             a.hdr_out[pix] = hc;
-            a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc);
+            a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc, a.out_bgr);
             return;
         }
         if (REC) fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
@@ -1433,7 +1442,7 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
     }
     const ushort4 ho = pack_half4(out);
     a.hdr_out[pix] = ho;
-    a.ldr_out[pix] = tonemap_half4(a.srgb_lut, ho);
+    a.ldr_out[pix] = tonemap_half4(a.srgb_lut, ho, a.out_bgr);
 }
 
 // ------------------------------------------------------------------------------------------------ transparent pass
@@ -1505,7 +1514,8 @@ __global__ __launch_bounds__(256) void k_resolve_samples(const ushort4 *__restri
 // 2 pixels per thread: one 16-byte load, one 8-byte store.
 __global__ __launch_bounds__(256) void k_tonemap(const ushort4 *__restrict__ hdr, uchar4 *__restrict__ out,
                                                  float4 *__restrict__ out_f32, size_t first_pixel, size_t n_pixels,
-                                                 const unsigned char *__restrict__ srgb_lut) {
+                                                 const unsigned char *__restrict__ srgb_lut, uint32_t output_format) {
+    const bool bgr = (output_format & 1u) != 0u, manual = (output_format & 2u) != 0u;
     const size_t pair = (size_t)blockIdx.x * 256u + threadIdx.x;
     const size_t i0 = first_pixel + pair * 2u;
     if (pair * 2u >= n_pixels) return;
@@ -1522,11 +1532,12 @@ __global__ __launch_bounds__(256) void k_tonemap(const ushort4 *__restrict__ hdr
     uchar4 o8[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        o8[k] = tonemap_half4(srgb_lut, h[k]);
+        o8[k] = tonemap_half4(srgb_lut, h[k], bgr);
         if (out_f32 != nullptr && (k == 0 || two)) {  // float view of the same target (readback tap only)
             const float r = (float)__builtin_bit_cast(_Float16, h[k].x), g = (float)__builtin_bit_cast(_Float16, h[k].y);
             const float b = (float)__builtin_bit_cast(_Float16, h[k].z), al = (float)__builtin_bit_cast(_Float16, h[k].w);
-            out_f32[i0 + (size_t)k] = make_float4(srgb_oetf(r), srgb_oetf(g), srgb_oetf(b),
+            out_f32[i0 + (size_t)k] = make_float4(manual ? srgb_scene_to_display(r) : srgb_oetf(r), manual ? srgb_scene_to_display(g) : srgb_oetf(g),
+                                                  manual ? srgb_scene_to_display(b) : srgb_oetf(b),
                                                   (!(al > 0.0f)) ? 0.0f : (al >= 1.0f ? 1.0f : al));
         }
     }

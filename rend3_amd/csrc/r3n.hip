@@ -110,7 +110,8 @@ struct r3n_ctx {
     std::vector<r3n_anim_clip16> h_anim_clips;
     uint32_t n_pose_requests = 0, pose_matrix_end = 0, anim_max_joints = 1;
     DevBuf big_uv[1 + R3N_AUX_STREAMS];
-    DevBuf srgb_lut;  // Rgba8UnormSrgb code of every half in [0, 1): kernels_raster.h k_build_srgb_lut
+    DevBuf srgb_lut;  // 8-bit output code of every half in [0, 1): kernels_raster.h k_build_srgb_lut (or r3n_set_output_format)
+    uint32_t output_format = R3N_OUTPUT_RGBA8_UNORM_SRGB;
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
     uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {0, 0, 0, 0, 0};
     uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (80 B) per work sub-queue (R3N_BIGQ of them)
@@ -1142,6 +1143,7 @@ static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     a.hdr_out = c->hdr16.as<ushort4>();
     a.ldr_out = c->out8.as<uchar4>();
     a.srgb_lut = c->srgb_lut.as<unsigned char>();
+    a.out_bgr = (c->output_format & 1u) != 0u;
     a.tex = texture_args(c);
     a.samples_out = nullptr;
     a.tri_rec = nullptr;
@@ -1357,7 +1359,7 @@ static int launch_tonemap(r3n_ctx *c, float4 *f32_out) {
     Timed t(c, R3N_STAGE_TONEMAP);
     const size_t pairs = (n + 1) / 2;
     hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, c->stream, c->hdr16.as<ushort4>(),
-                       c->out8.as<uchar4>(), f32_out, first, n, c->srgb_lut.as<unsigned char>());
+                       c->out8.as<uchar4>(), f32_out, first, n, c->srgb_lut.as<unsigned char>(), c->output_format);
     return check_launch(c, "k_tonemap");
 }
 
@@ -1372,6 +1374,33 @@ int r3n_hdr_write(r3n_ctx *c, const uint16_t *rgba16f, uint64_t first_pixel, uin
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the source only for the duration of the call
     }
     c->resolved_this_frame = false;  // the fused blit no longer matches the HDR target
+    return R3N_OK;
+}
+
+int r3n_set_output_format(r3n_ctx *c, uint32_t format) {
+    if (!c || format > R3N_OUTPUT_BGRA8_UNORM) return fail(c, R3N_ERR_INVALID_ARG, "set_output_format: unknown format");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));
+    if (((format ^ c->output_format) & 2u) != 0u) {  // the transfer function changes: rebuild the half -> 8-bit table
+        if (format & 2u) {
+            // blit.wgsl fs_main_monitor: 1.055 * pow(x, 0.4166) - 0.055 (math/color.wgsl:13-19).  Built on the host so that
+            // the table is what libm gives the oracle too (a device powf may differ in the last bit on a rounding boundary)
+            std::vector<unsigned char> lut(R3N_SRGB_LUT_SIZE);
+            for (uint32_t h = 0; h < R3N_SRGB_LUT_SIZE; ++h) {
+                const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+                const float x = e == 0u ? std::ldexp((float)m, -24) : std::ldexp((float)(m | 1024u), (int)e - 25);
+                float v = x > 0.0031308f ? 1.055f * std::pow(x, 0.4166f) - 0.055f : x * 12.92f;
+                v = !(v > 0.0f) ? 0.0f : (v >= 1.0f ? 1.0f : v);
+                lut[h] = (unsigned char)(v * 255.0f + 0.5f);
+            }
+            HIP_TRY(c, hipMemcpy(c->srgb_lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice));
+        } else {
+            hipLaunchKernelGGL(k_build_srgb_lut, dim3((R3N_SRGB_LUT_SIZE + 255u) / 256u), dim3(256), 0, c->stream, c->srgb_lut.as<unsigned char>());
+            TRY(check_launch(c, "k_build_srgb_lut"));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    c->output_format = format;
     return R3N_OK;
 }
 

@@ -611,6 +611,11 @@ class Renderer:
         self._check(self.lib.r3n_readback_mesh(self.ctx, byte_offset, _ffi.ptr(out), out.nbytes), "r3n_readback_mesh")
         return out
 
+    def set_output_format(self, fmt):
+        """TonemappingRoutine's output_format: 0 Rgba8UnormSrgb (default), 1 Bgra8UnormSrgb, 2 Rgba8Unorm, 3 Bgra8Unorm."""
+        self._check(self.lib.r3n_set_output_format(self.ctx, int(fmt)), "r3n_set_output_format")
+        self.output_format = int(fmt)
+
     def readback_joint_matrices(self):
         """The joint matrices the last skinning pass read (host-provided and GPU-posed), (n, 16) f32."""
         n = sum(len(sk["matrices"]) for sk in self.skeletons)

@@ -707,14 +707,19 @@ def test_transparent_pass_multi_frame(r3, handedness, samples, textured):
         compare_frames(fo, fp, f"transparent frame {f}")
 
 
-def test_tonemap_every_half_value(r3):
-    """blit.wgsl + the Rgba8UnormSrgb store over EVERY Rgba16Float bit pattern (all 65536 halves in every channel,
-    NaN / inf / negative / denormal included): the device's sRGB table and the stand-alone blit kernel against the
-    oracle's direct evaluation, byte for byte; the float view within 1 ulp-scale tolerance of the same formula."""
+@pytest.mark.parametrize("output_format", [0, 1, 2, 3])
+def test_tonemap_every_half_value(r3, output_format):
+    """blit.wgsl + the 8-bit store over EVERY Rgba16Float bit pattern (all 65536 halves in every channel, NaN / inf /
+    negative / denormal included), for the four output formats of TonemappingRoutine (Rgba8 / Bgra8, *Srgb targets with
+    the exact OETF, plain unorm targets with the shader's srgb_scene_to_display, exponent 0.4166): the device's table and
+    the stand-alone blit kernel against the oracle's direct evaluation, byte for byte; the float view within 1 ulp-scale
+    tolerance of the same formula."""
     from rend3_amd import _ffi
     from oracle import lib as olib
     lib = _ffi.lib()
     r = r3.Renderer(oh.LEFT)
+    assert lib.r3n_set_output_format(r.ctx, 4) == -1
+    r.set_output_format(output_format)
     w = h = 256
     fu = r3.host.frame_uniforms(r.camera, (0, 0, 0, 0), (w, h))
     clear = np.zeros(4, dtype=f32)
@@ -731,7 +736,25 @@ def test_tonemap_every_half_value(r3):
     o = olib.get()
     exp8 = np.zeros((w * h, 4), dtype=np.uint8)
     expf = np.zeros((w * h, 4), dtype=f32)
-    o.r3o_tonemap(o.ptr(hdr), w * h, o.ptr(expf), o.ptr(exp8))
+    o.r3o_tonemap_format(o.ptr(hdr), w * h, o.ptr(expf), o.ptr(exp8), output_format)
     bad = np.nonzero((got8 != exp8).any(axis=1))[0]
     assert len(bad) == 0, (len(bad), hdr[bad[:5]], got8[bad[:5]], exp8[bad[:5]])
-    assert np.allclose(gotf, expf, rtol=0, atol=2e-7)
+    assert np.allclose(gotf, expf, rtol=0, atol=2e-7 if output_format < 2 else 1e-6, equal_nan=True)
+    r.close()
+
+
+def test_output_formats_on_a_frame(r3):
+    """A lit frame into a Bgra8Unorm target (the fused blit of the resolve: swizzle + manual transfer function), then
+    back to the default: both equal the oracle's tonemap of the same HDR buffer."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    scenes.build_random_scene(o, oh, omk, 120, 0xF0F0, lights=1)
+    scenes.build_random_scene(p, oh, r3.material_record, 120, 0xF0F0, lights=1)
+    for r in (o, p):
+        r.set_camera_data(oh.look_at_lh((3.0, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    for fmt in (3, 0):
+        o.output_format = fmt
+        p.set_output_format(fmt)
+        fo = o.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"output format {fmt}")
+    assert (fo["rgba8"][..., :3].max(axis=2) > 40).mean() > 0.05

@@ -404,3 +404,28 @@ def test_animation_example():
             assert diff.mean() <= 2.0 and (diff <= 1).mean() >= 0.95, (diff.mean(), (diff <= 1).mean())
         else:
             assert diff[:, 640:].mean() <= 0.4, diff[:, 640:].mean()
+
+
+def test_tonemap_output_formats():
+    """TonemappingRoutine's two fragment entry points (tonemapping.rs:44, blit.wgsl:19-31): *Srgb targets store the exact
+    OETF, plain unorm targets get math/color.wgsl's srgb_scene_to_display (exponent 0.4166); Bgra8* targets hold blue
+    first.  KATs: SURVEY section 8c's sRGB(0.25, 0.5, 0.75) -> [137, 188, 225] on the exact path; the manual path
+    differs from it by at most 1 code anywhere in [0, 1] and is monotone."""
+    from oracle import lib as olib
+    o = olib.get()
+    px = np.array([[0.25, 0.5, 0.75, 1.0]], dtype=np.float16).view(np.uint16)
+    outs = {}
+    for fmt in range(4):
+        out8 = np.zeros((1, 4), np.uint8)
+        o.r3o_tonemap_format(o.ptr(px), 1, None, o.ptr(out8), fmt)
+        outs[fmt] = out8[0].tolist()
+    assert outs[0] == [137, 188, 225, 255] and outs[1] == [225, 188, 137, 255]
+    assert outs[3] == outs[2][2::-1] + [255] and max(abs(a - b) for a, b in zip(outs[0], outs[2])) <= 1
+    halves = np.arange(0x3C01, dtype=np.uint16)   # [0, 1]
+    hdr = np.stack([halves, halves, halves, halves], axis=1).copy()
+    exact, manual = np.zeros((len(halves), 4), np.uint8), np.zeros((len(halves), 4), np.uint8)
+    o.r3o_tonemap_format(o.ptr(hdr), len(halves), None, o.ptr(exact), 0)
+    o.r3o_tonemap_format(o.ptr(hdr), len(halves), None, o.ptr(manual), 2)
+    assert (np.diff(manual[:, 0].astype(int)) >= 0).all() and manual[0, 0] == 0 and manual[-1, 0] == 255
+    assert np.abs(exact[:, 0].astype(int) - manual[:, 0].astype(int)).max() <= 1
+    assert (exact[:, 0] != manual[:, 0]).any()  # 0.4166 is not 1 / 2.4
