@@ -184,7 +184,7 @@ typedef struct r3n_anim_clip16 {
     uint32_t _pad;
 } r3n_anim_clip16;
 typedef struct r3n_anim_track80 {
-    uint32_t animated;        /* 0: the clip has no channel for this joint's node -> local matrix IDENTITY (:220) */
+    uint32_t animated;        /* 0: the clip has no channel for this joint's node -> local matrix IDENTITY (:220); else nonzero */
     uint32_t key_first[3];    /* translation, rotation, scale: first key time (index into `times`) */
     uint32_t key_count[3];    /* 0: channel absent -> bind component */
     uint32_t value_first[3];  /* first value (index into `values`: 3 floats per vec3 key, 4 per quaternion key, xyzw) */

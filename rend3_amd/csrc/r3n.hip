@@ -869,7 +869,19 @@ int r3n_animation_write(r3n_ctx *c, const r3n_anim_rig16 *rigs, uint32_t n_rigs,
     TRY(put(c->anim_rigs, rigs, (size_t)n_rigs * sizeof *rigs));
     TRY(put(c->anim_joints, joints, (size_t)n_joints * sizeof *joints));
     TRY(put(c->anim_clips, clips, (size_t)n_clips * sizeof *clips));
-    TRY(put(c->anim_tracks, tracks, (size_t)n_tracks * sizeof *tracks));
+    // device copy of the tracks: bit 0 of `animated` = animated, bits 1..3 = "the translation / rotation / scale key times
+    // are non-decreasing", which lets the kernel bisect instead of scan (same result: the first key later than t)
+    std::vector<r3n_anim_track80> dev_tracks(tracks, tracks + n_tracks);
+    for (auto &t : dev_tracks) {
+        uint32_t flags = t.animated ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) {
+            bool sorted = true;
+            for (uint32_t i = 1; i < t.key_count[k] && sorted; ++i) sorted = times[t.key_first[k] + i - 1u] <= times[t.key_first[k] + i];
+            if (sorted) flags |= 2u << k;
+        }
+        t.animated = flags;
+    }
+    TRY(put(c->anim_tracks, dev_tracks.data(), (size_t)n_tracks * sizeof *tracks));
     TRY(put(c->anim_times, times, (size_t)n_times * 4));
     TRY(put(c->anim_values, values, (size_t)n_values * 4));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller owns the sources only for the duration of the call

@@ -159,6 +159,10 @@ def random_rig_case(rng, n_joints, n_extra_nodes=2):
                 continue
             k = 1 if rng.random() < 0.08 else int(rng.integers(2, 7))
             times = np.sort(rng.uniform(0.0 if rng.random() < 0.7 else 0.4, 3.0, k)).astype(f32)
+            if k > 2 and rng.random() < 0.15:
+                times[[0, k - 1]] = times[[k - 1, 0]]   # an unsorted channel: the reference's linear scan decides, not bisection
+            if k > 3 and rng.random() < 0.15:
+                times[1] = times[2]                      # duplicate key times
             vals = rng.normal(size=(k, width)).astype(f32)
             if path == "rotation":
                 vals = (vals / np.linalg.norm(vals, axis=1, keepdims=True)).astype(f32)

@@ -112,12 +112,59 @@ def run_cfg5_anim(n=50000, joints=24, steps=20):
     r.close()
 
 
+def run_cfg5_asset(n=5000, steps=20):
+    """configs[4], "34-joint / 2324-vertex variant" (SURVEY section 8d): the reference's animation example character
+    (tests/golden/animation/scene.gltf) x n skeleton instances, each at its own time of the asset's clip: GPU poses + skinning."""
+    import os
+    from rend3_amd.gltf import Gltf, instance_scene, load_animations
+    from rend3_amd import anim as pa
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "animation")
+    r = r3.Renderer(r3.host.LEFT, np.float32(16 / 9))
+    g = Gltf(os.path.join(root, "scene.gltf"))
+    inst = instance_scene(g, r, r3.host, r3.material_record)
+    anims = load_animations(g)
+    first = inst["skeletons"][0]
+    mesh = r.skeletons[first]["mesh"]
+    joints = len(r.skeletons[first]["matrices"])
+    more = r.add_skeletons_bulk(mesh, [np.tile(r3.host.identity(), (joints, 1))] * (n - 1))
+    node = next(nd for nd in inst["nodes"] if nd["skin"] == 0)
+    node["skeletons"] += more
+    data = pa.AnimationData.from_gltf_scene(r, anims, inst)
+    sks = data.skin_skeletons[0]
+    sk_in, _ = r.skinning_buffers()
+    verts = int(sk_in[:, 9].sum())
+    rq = np.zeros(len(sks), dtype=[("clip", np.uint32), ("time", np.float32), ("base", np.uint32), ("pad", np.uint32)])
+    rq["clip"] = data.clip_base
+    rq["base"] = sk_in[sks, 8]
+    dur = float(anims[0]["duration"])
+    def step(k):
+        rq["time"] = ((np.arange(len(sks)) * 0.0023 + 0.016 * k) % dur).astype(np.float32)
+        r._check(r.lib.r3n_pose_skeletons(r.ctx, r3._ffi.ptr(rq), len(rq)), "r3n_pose_skeletons")
+        r._check(r.lib.r3n_skinning(r.ctx, r3._ffi.ptr(sk_in), len(sk_in), None, len(sks) * joints), "r3n_skinning")
+    for k in range(3): step(k)
+    r.sync(); r.timing_enable(True); r.stage_times(reset=True)
+    t0 = time.perf_counter()
+    for k in range(steps): step(k)
+    r.sync(); wall = (time.perf_counter() - t0) / steps
+    st = r.stage_times(reset=True)
+    pose_ms, skin_ms = st["pose"][0] / steps, st["skinning"][0] / steps
+    print(json.dumps({"config": "configs[4] 34-joint asset (animation example character) x instances", "skeletons": len(sks),
+                      "joints_per_skeleton": joints, "vertices": verts, "pose_kernel_ms": round(pose_ms, 4),
+                      "skinning_kernel_ms": round(skin_ms, 4), "wall_ms_per_frame": round(1e3 * wall, 3),
+                      "joint_matrices_per_s": round(len(sks) * joints / (pose_ms * 1e-3)),
+                      "vertices_per_s": round(verts / (skin_ms * 1e-3)),
+                      "skinning_algorithmic_GBps": round(verts * 96 / (skin_ms * 1e-3) / 1e9, 1)}))
+    r.close()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg4", "cfg5"]
     if "cfg5" in which:
         run_cfg5()
     if "cfg5anim" in which:
         run_cfg5_anim()
+    if "cfg5asset" in which:
+        run_cfg5_asset()
     if "cfg2" in which:
         run("configs[1] scifi_like", lambda r: S.scifi_like(r, r3.host, r3.material_record), 1920, 1080, True)
     if "cfg4" in which:
