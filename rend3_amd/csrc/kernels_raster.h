@@ -277,6 +277,9 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 #ifndef R3N_SMALL_OCC
 #define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
 #endif
+#ifndef R3N_MS_OCC
+#define R3N_MS_OCC 4   // the same for the multisampled record-based resolve (5 spills: 1.19 vs 0.99 ms; 3: 1.03)
+#endif
 #ifndef R3N_TEX_OCC
 #define R3N_TEX_OCC 5  // min waves per SIMD asked of the textured record-based resolve (launch bound)
 #endif
@@ -761,7 +764,12 @@ struct ShadeArgs {
     TriRecord *tri_rec;        // S == 1: per-triangle vertex-stage records by canonical slot (else null)
     unsigned char *seen;       // ... and which slots own a pixel this frame
     uint32_t total_tris;
+    // S == 4, split resolve: pixels whose samples belong to more than one triangle hand their extra triangles to a
+    // second, dense pass (R3N_EDGEQ sub-lists of pixel << 3 | leader sample << 1 | last-entry-of-the-pixel)
+    uint32_t *edge_list, *edge_count;
+    uint32_t edge_capacity;    // entries per sub-list
 };
+#define R3N_EDGEQ 32u
 
 struct LdsDirLight {
     float m[16];      // light.view_proj * uniforms.inv_view (opaque.wgsl:491)
@@ -1359,8 +1367,8 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
 // Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
 // (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
 // REC: the per-triangle records exist: no vertex-stage code in the kernel at all.
-template <int S, bool TEX, bool REC = false>
-__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)) void k_resolve_opaque(ShadeArgs a) {
+template <int S, bool TEX, bool REC = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TEX_OCC : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
@@ -1377,8 +1385,9 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
     const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
     const uint32_t x = blockIdx.x * 16u + (ln & 7u) + 8u * (wv & 1u);
     const uint32_t y = a.row_begin + blockIdx.y * 16u + (ln >> 3) + 8u * (wv >> 1);
-    if (x >= a.width || y >= a.row_end) return;
-    const size_t pix = (size_t)y * a.width + x;
+    const bool inside = x < a.width && y < a.row_end;
+    if (!inside && !SPLIT) return;  // SPLIT: every thread of the workgroup takes part in the queue reservation below
+    const size_t pix = inside ? (size_t)y * a.width + x : 0u;
     float out[4];
     if (S == 1) {
         const uint32_t id = (uint32_t)(a.vis[pix] & 0xFFFFFFFFull);
@@ -1394,7 +1403,7 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
         uint32_t ids[S];
         float col[S][4];
 #pragma unroll
-        for (int sm = 0; sm < S; ++sm) ids[sm] = (uint32_t)(a.vis[pix * (size_t)S + (size_t)sm] & 0xFFFFFFFFull);
+        for (int sm = 0; sm < S; ++sm) ids[sm] = inside ? (uint32_t)(a.vis[pix * (size_t)S + (size_t)sm] & 0xFFFFFFFFull) : 0u;
         // The distinct triangles among the pixel's samples, each shaded ONCE (same triangle, same pixel centre: same
         // value) by one copy of the fragment stage in a rolled loop: unrolling it per sample made the kernel four
         // fragment stages long (instruction cache, registers) although interior pixels hold one triangle.
@@ -1413,8 +1422,40 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
         for (int sm = 0; sm < S; ++sm)
 #pragma unroll
             for (int c = 0; c < 4; ++c) col[sm][c] = 0.0f;
+        // SPLIT: this kernel shades only the triangle of sample 0 -- every lane busy once -- and queues the pixel's
+        // other triangles (edge pixels, a minority) for k_resolve_edges, which runs them densely; k_resolve_edge_pixels
+        // then averages.  Unsplit, a wavefront pays a whole fragment stage for every extra triangle of its worst pixel.
+        uint32_t edge_base = 0;
+        bool edge_fits = true;
+        if (SPLIT) {
+            __shared__ uint32_t s_extra, s_base;
+            if (threadIdx.x == 0u) s_extra = 0u;
+            __syncthreads();
+            const uint32_t extra = n_unique - 1u;
+            uint32_t my_off = 0;
+            if (extra) my_off = atomicAdd(&s_extra, extra);
+            __syncthreads();
+            const uint32_t q = (blockIdx.y * gridDim.x + blockIdx.x) % R3N_EDGEQ;
+            if (threadIdx.x == 0u && s_extra) s_base = atomicAdd(&a.edge_count[q], s_extra);
+            __syncthreads();
+            edge_base = s_base + my_off;
+            edge_fits = edge_base + extra <= a.edge_capacity;  // else: shade everything here (never drop work)
+            if (extra && edge_fits) {
+                uint32_t *dst = a.edge_list + (size_t)q * a.edge_capacity + edge_base;
+                uint32_t last = 0;
+#pragma unroll
+                for (int sm = 1; sm < S; ++sm)
+                    if (first_of[sm] == (uint32_t)sm) last = (uint32_t)sm;
+                uint32_t w = 0;
+#pragma unroll
+                for (int sm = 1; sm < S; ++sm)
+                    if (first_of[sm] == (uint32_t)sm) dst[w++] = ((uint32_t)pix << 3) | ((uint32_t)sm << 1) | (last == (uint32_t)sm ? 1u : 0u);
+            }
+        }
+        if (!inside) return;  // (after the workgroup barriers)
+        const uint32_t n_here = (SPLIT && edge_fits) ? 1u : n_unique;
 #pragma unroll 1
-        for (uint32_t k = 0, sm_at = 0; k < n_unique; ++k, ++sm_at) {
+        for (uint32_t k = 0, sm_at = 0; k < n_here; ++k, ++sm_at) {
             while (first_of[sm_at == 0u ? 0 : (sm_at == 1u ? 1 : (sm_at == 2u ? 2 : 3))] != sm_at) ++sm_at;  // next leader sample
             const uint32_t id = sm_at == 0u ? ids[0] : (sm_at == 1u ? ids[1] : (sm_at == 2u ? ids[2] : ids[3]));
             float v[4];
@@ -1433,7 +1474,14 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
                     for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];
                 }
         }
-        if (a.samples_out != nullptr) {
+        if (SPLIT && edge_fits && n_unique > 1u) {
+            // edge pixel: park the samples of the first triangle; the other passes finish the pixel
+#pragma unroll
+            for (int sm = 0; sm < S; ++sm)
+                if (first_of[sm] == 0u) a.samples_out[pix * (size_t)S + (size_t)sm] = pack_half4(col[sm]);
+            return;
+        }
+        if (!SPLIT && a.samples_out != nullptr) {
 #pragma unroll
             for (int sm = 0; sm < S; ++sm) a.samples_out[pix * (size_t)S + (size_t)sm] = pack_half4(col[sm]);
         }
@@ -1443,6 +1491,73 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? R3N_TEX_OCC : 1)
     const ushort4 ho = pack_half4(out);
     a.hdr_out[pix] = ho;
     a.ldr_out[pix] = tonemap_half4(a.srgb_lut, ho, a.out_bgr);
+}
+
+// Split MSAA resolve, pass B: one thread per queued (pixel, leader sample): shade that triangle at the pixel centre and
+// park the half-rounded colour in every sample it owns.  Pass C (k_resolve_edge_pixels): the entry flagged as its
+// pixel's last one averages the four parked samples -- the same box resolve expression as everywhere else.
+template <bool TEX, bool REC>
+__global__ __launch_bounds__(256, REC ? R3N_TEX_OCC : 1) void k_resolve_edges(ShadeArgs a) {
+    __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
+    __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
+    __shared__ float s_decode[512];
+    if (TEX) {
+        s_decode[threadIdx.x] = a.tex.decode[threadIdx.x];
+        s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
+        a.tex.decode = s_decode;
+    }
+    uint32_t n_dir, n_point;
+    stage_lights(a, s_dir, s_point, n_dir, n_point);
+    const uint32_t q = blockIdx.x % R3N_EDGEQ;
+    const uint32_t n = min(a.edge_count[q], a.edge_capacity);
+    const uint32_t *list = a.edge_list + (size_t)q * a.edge_capacity;
+    const uint32_t stride = (gridDim.x / R3N_EDGEQ) * 256u;
+    for (uint32_t i = (blockIdx.x / R3N_EDGEQ) * 256u + threadIdx.x; i < n; i += stride) {
+        const uint32_t e = list[i];
+        const size_t pix = e >> 3;
+        const uint32_t leader = (e >> 1) & 3u;
+        uint32_t ids[4];
+#pragma unroll
+        for (int sm = 0; sm < 4; ++sm) ids[sm] = (uint32_t)(a.vis[pix * 4u + (size_t)sm] & 0xFFFFFFFFull);
+        const uint32_t id = leader == 1u ? ids[1] : (leader == 2u ? ids[2] : ids[3]);
+        const uint32_t x = (uint32_t)(pix % a.width), y = (uint32_t)(pix / a.width);
+        float v[4];
+        if (id == 0u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
+        } else if (REC) {
+            fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, v);
+        } else {
+            shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, v);
+        }
+        const ushort4 h = pack_half4(v);
+#pragma unroll
+        for (int sm = 1; sm < 4; ++sm)
+            if ((uint32_t)sm >= leader && ids[sm] == id) a.samples_out[pix * 4u + (size_t)sm] = h;  // samples led by `leader`
+    }
+}
+__global__ __launch_bounds__(256) void k_resolve_edge_pixels(ShadeArgs a) {
+    const uint32_t q = blockIdx.x % R3N_EDGEQ;
+    const uint32_t n = min(a.edge_count[q], a.edge_capacity);
+    const uint32_t *list = a.edge_list + (size_t)q * a.edge_capacity;
+    const uint32_t stride = (gridDim.x / R3N_EDGEQ) * 256u;
+    for (uint32_t i = (blockIdx.x / R3N_EDGEQ) * 256u + threadIdx.x; i < n; i += stride) {
+        const uint32_t e = list[i];
+        if (!(e & 1u)) continue;
+        const size_t pix = e >> 3;
+        float col[4][4], out[4];
+#pragma unroll
+        for (int sm = 0; sm < 4; ++sm) {
+            const ushort4 h = a.samples_out[pix * 4u + (size_t)sm];
+            col[sm][0] = (float)__builtin_bit_cast(_Float16, h.x); col[sm][1] = (float)__builtin_bit_cast(_Float16, h.y);
+            col[sm][2] = (float)__builtin_bit_cast(_Float16, h.z); col[sm][3] = (float)__builtin_bit_cast(_Float16, h.w);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = ((col[0][c] + col[1][c]) + (col[2][c] + col[3][c])) * 0.25f;
+        const ushort4 ho = pack_half4(out);
+        a.hdr_out[pix] = ho;
+        a.ldr_out[pix] = tonemap_half4(a.srgb_lut, ho, a.out_bgr);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ transparent pass

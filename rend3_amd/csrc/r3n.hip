@@ -105,6 +105,7 @@ struct r3n_ctx {
     DevBuf tex_descs, tex_texels, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
     // rend3-anim tables (row N4) and the pose requests queued for the next r3n_skinning
+    DevBuf edge_list, edge_count;  // split MSAA resolve (kernels_raster.h k_resolve_edges)
     DevBuf anim_rigs, anim_joints, anim_clips, anim_tracks, anim_times, anim_values, pose_requests;
     std::vector<r3n_anim_rig16> h_anim_rigs;
     std::vector<r3n_anim_clip16> h_anim_clips;
@@ -482,7 +483,7 @@ void r3n_destroy(r3n_ctx *c) {
                       &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
-                      &c->anim_times, &c->anim_values, &c->pose_requests};
+                      &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -1091,6 +1092,9 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.big_capacity = c->big_capacity;
     a.big_uv = c->big_uv[lane].as<r3n_big_uv>();
     a.tex = texture_args(c);
+#ifndef R3N_MSAA_SPLIT
+#define R3N_MSAA_SPLIT 1  // MSAA resolve in three passes (first triangle per pixel / queued edge triangles / edge pixel average)
+#endif
 #ifndef R3N_BIG_GRID
 #define R3N_BIG_GRID 8192  // 4x the resident wave count (8 waves per SIMD at < 64 VGPRs): the hardware dispatcher
                            // then balances the uneven item costs (measured on the bench scene, shadow views:
@@ -1214,7 +1218,28 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     {
         Timed t(c, R3N_STAGE_SHADE, stream);
         const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
-        if (c->samples == 4 && a.tri_rec != nullptr) {
+        const uint64_t npix_all = (uint64_t)c->width * c->height;
+        if (c->samples == 4 && a.tri_rec != nullptr && a.samples_out == nullptr && npix_all < (1ull << 29) && R3N_MSAA_SPLIT) {
+            // split resolve: first triangle of every pixel here, the extra triangles of edge pixels in a dense second pass
+            const uint32_t cap = (uint32_t)((uint64_t)(r1 - r0) * c->width * 3u / R3N_EDGEQ) + 4096u;
+            TRY(ensure(c, c->samples16, (size_t)npix_all * 4 * 8, false, -1));
+            TRY(ensure(c, c->edge_list, (size_t)cap * R3N_EDGEQ * 4, false, -1));
+            TRY(ensure(c, c->edge_count, R3N_EDGEQ * 4, false, 0));
+            a.samples_out = c->samples16.as<ushort4>();
+            a.edge_list = c->edge_list.as<uint32_t>();
+            a.edge_count = c->edge_count.as<uint32_t>();
+            a.edge_capacity = cap;
+            HIP_TRY(c, hipMemsetAsync(a.edge_count, 0, R3N_EDGEQ * 4, stream));
+            const dim3 egrid(R3N_EDGEQ * 64u);
+            if (tex) {
+                hipLaunchKernelGGL((k_resolve_opaque<4, true, true, true>), rgrid, dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((k_resolve_edges<true, true>), egrid, dim3(256), 0, stream, a);
+            } else {
+                hipLaunchKernelGGL((k_resolve_opaque<4, false, true, true>), rgrid, dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((k_resolve_edges<false, true>), egrid, dim3(256), 0, stream, a);
+            }
+            hipLaunchKernelGGL(k_resolve_edge_pixels, egrid, dim3(256), 0, stream, a);
+        } else if (c->samples == 4 && a.tri_rec != nullptr) {
             if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true, true>), rgrid, dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((k_resolve_opaque<4, false, true>), rgrid, dim3(256), 0, stream, a);
         } else if (c->samples == 4) {
