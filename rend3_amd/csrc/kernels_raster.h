@@ -1440,6 +1440,10 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
             __syncthreads();
             edge_base = s_base + my_off;
             edge_fits = edge_base + extra <= a.edge_capacity;  // else: shade everything here (never drop work)
+            if (extra && !edge_fits) {  // the slots this pixel reserved inside the list stay empty
+                for (uint32_t k = edge_base; k < min(edge_base + extra, a.edge_capacity); ++k)
+                    a.edge_list[(size_t)q * a.edge_capacity + k] = 0xFFFFFFFFu;
+            }
             if (extra && edge_fits) {
                 uint32_t *dst = a.edge_list + (size_t)q * a.edge_capacity + edge_base;
                 uint32_t last = 0;
@@ -1514,6 +1518,7 @@ __global__ __launch_bounds__(256, REC ? R3N_TEX_OCC : 1) void k_resolve_edges(Sh
     const uint32_t stride = (gridDim.x / R3N_EDGEQ) * 256u;
     for (uint32_t i = (blockIdx.x / R3N_EDGEQ) * 256u + threadIdx.x; i < n; i += stride) {
         const uint32_t e = list[i];
+        if (e == 0xFFFFFFFFu) continue;  // reserved by a pixel that did not fit and shaded itself
         const size_t pix = e >> 3;
         const uint32_t leader = (e >> 1) & 3u;
         uint32_t ids[4];
@@ -1543,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_resolve_edge_pixels(ShadeArgs a) {
     const uint32_t stride = (gridDim.x / R3N_EDGEQ) * 256u;
     for (uint32_t i = (blockIdx.x / R3N_EDGEQ) * 256u + threadIdx.x; i < n; i += stride) {
         const uint32_t e = list[i];
-        if (!(e & 1u)) continue;
+        if (e == 0xFFFFFFFFu || !(e & 1u)) continue;
         const size_t pix = e >> 3;
         float col[4][4], out[4];
 #pragma unroll

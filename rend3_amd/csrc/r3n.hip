@@ -106,6 +106,7 @@ struct r3n_ctx {
     uint32_t n_textures = 0;
     // rend3-anim tables (row N4) and the pose requests queued for the next r3n_skinning
     DevBuf edge_list, edge_count;  // split MSAA resolve (kernels_raster.h k_resolve_edges)
+    uint32_t edge_capacity_override = 0;
     DevBuf anim_rigs, anim_joints, anim_clips, anim_tracks, anim_times, anim_values, pose_requests;
     std::vector<r3n_anim_rig16> h_anim_rigs;
     std::vector<r3n_anim_clip16> h_anim_clips;
@@ -420,6 +421,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
+    if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->shade_done[0], hipEventDisableTiming) != hipSuccess ||
@@ -1221,7 +1223,8 @@ int r3n_resolve_opaque(r3n_ctx *c) {
         const uint64_t npix_all = (uint64_t)c->width * c->height;
         if (c->samples == 4 && a.tri_rec != nullptr && a.samples_out == nullptr && npix_all < (1ull << 29) && R3N_MSAA_SPLIT) {
             // split resolve: first triangle of every pixel here, the extra triangles of edge pixels in a dense second pass
-            const uint32_t cap = (uint32_t)((uint64_t)(r1 - r0) * c->width * 3u / R3N_EDGEQ) + 4096u;
+            uint32_t cap = (uint32_t)((uint64_t)(r1 - r0) * c->width * 3u / R3N_EDGEQ) + 4096u;
+            if (c->edge_capacity_override) cap = c->edge_capacity_override;  // R3N_EDGE_CAPACITY: exercises the overflow path in tests
             TRY(ensure(c, c->samples16, (size_t)npix_all * 4 * 8, false, -1));
             TRY(ensure(c, c->edge_list, (size_t)cap * R3N_EDGEQ * 4, false, -1));
             TRY(ensure(c, c->edge_count, R3N_EDGEQ * 4, false, 0));

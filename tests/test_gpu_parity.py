@@ -558,6 +558,21 @@ def test_msaa_random_scene_multi_frame(r3, handedness):
         compare_frames(fo, fp, f"msaa random scene frame {f}")
 
 
+def test_msaa_edge_queue_overflow(r3, monkeypatch):
+    """The split MSAA resolve queues the extra triangles of edge pixels; with the queues shrunk to 8 entries per
+    sub-list (R3N_EDGE_CAPACITY) almost every edge pixel overflows and shades itself in the first pass: same frame."""
+    monkeypatch.setenv("R3N_EDGE_CAPACITY", "8")
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    scenes.build_random_scene(o, oh, omk, 200, 0xED6E, lights=1, with_cutout=True)
+    scenes.build_random_scene(p, oh, r3.material_record, 200, 0xED6E, lights=1, with_cutout=True)
+    for f in range(2):
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh((3.0 + f, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, 192, samples=4, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, samples=4, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"edge queue overflow frame {f}")
+
+
 def test_golden_textured_quad_example(r3):
     """examples/src/textured_quad/mod.rs at 1280x720 (row N2): albedo texture, nearest sampler, sRGB decode -- HIP ==
     oracle bit for bit, and the HIP image against the reference's screenshot (Threshold::Mean(0.0): RGB exact)."""
