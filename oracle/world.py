@@ -304,6 +304,18 @@ class OracleRenderer:
         self.materials.append((np.asarray(record, dtype=f32), key))
         return len(self.materials) - 1
 
+    def update_material(self, handle, record, key=None):
+        """Renderer::update_material (rend3/src/renderer/mod.rs): replaces the material's data; the transparency key of a
+        material cannot change through an update in the reference (archetype), so `key` defaults to the existing one."""
+        self.materials[handle] = (np.asarray(record, dtype=f32), self.materials[handle][1] if key is None else key)
+
+    def update_directional_light(self, handle, **changes):
+        """Renderer::update_directional_light with a DirectionalLightChange (only the given fields change)."""
+        self.dir_lights[handle].update(changes)
+
+    def update_point_light(self, handle, **changes):
+        self.point_lights[handle].update(changes)
+
     def _alloc_handle(self):
         if self.free_handles:
             return self.free_handles.pop(0)

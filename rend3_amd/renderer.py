@@ -417,6 +417,23 @@ class Renderer:
                     "r3n_materials_write")
         return idx
 
+    def update_material(self, handle, record, key=None):
+        """Renderer::update_material: rewrites the material's 208-B record in place (r3n_materials_write orders itself
+        after a resolve still in flight)."""
+        key = self.materials[handle][1] if key is None else key
+        self.materials[handle] = (np.asarray(record, dtype=f32), key)
+        slots = np.array([handle], dtype=np.uint32)
+        rec = np.ascontiguousarray(record, dtype=f32).reshape(1, 52)
+        keys = np.array([key], dtype=np.uint8)
+        self._check(self.lib.r3n_materials_write(self.ctx, _ffi.ptr(slots), _ffi.ptr(rec), _ffi.ptr(keys), 1), "r3n_materials_write")
+
+    def update_directional_light(self, handle, **changes):
+        """Renderer::update_directional_light with a DirectionalLightChange (only the given fields change)."""
+        self.dir_lights[handle].update(changes)
+
+    def update_point_light(self, handle, **changes):
+        self.point_lights[handle].update(changes)
+
     def _alloc_handle(self):
         if self.free_handles:
             return self.free_handles.pop(0)

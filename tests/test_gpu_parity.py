@@ -687,6 +687,10 @@ def test_frames_in_flight_world_mutation(r3):
             if f == 4:
                 mesh, mat = extra[id(r)]
                 r.add_object(mesh, mat, oh.translation((-3.0, 2.0, 1.0)))
+                mk = omk if r is o else r3.material_record
+                r.update_material(mat, mk(albedo=(0.1, 0.8, 0.3, 1.0), roughness=0.7, metallic=1.0))
+            if f == 5:
+                r.update_directional_light(0, intensity=5.0, direction=(0.4, -1.0, 0.3))
         last = f == frames - 1
         fo = o.render(W, H, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
         fp = p.render(W, H, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0), readback=last)
