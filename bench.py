@@ -96,6 +96,7 @@ def main():
         r.set_object_range(begin, end)
         exchange = parallel.Exchange(r, device)
         rows = parallel.row_ranges(HEIGHT, world)
+        exchange.rows_equal = HEIGHT % world == 0
         r._check(r.lib.r3n_set_row_range(r.ctx, rows[rank][0], rows[rank][1]), "r3n_set_row_range")
 
     base = r3.BaseRenderGraph(r)

@@ -8,10 +8,10 @@ visibility key orders by depth first, so MAX of keys is exactly the depth-tested
   "shadow": the f32 shadow atlas                  (after the shadow depth draws)
   "pass1" : the 64-bit visibility keys            (before Hi-Z: every rank culls against the GLOBAL pass-1 depth,
                                                    which keeps the per-triangle visible set bit-exact)
-  "pass2" : the 64-bit visibility keys            (before the resolve)
+  "pass2" : the 64-bit visibility keys            (before the resolve; a reduce-scatter to the row owners when the rows
+                                                   split evenly: nobody needs the other ranks' rows any more)
 
-After "pass2" every rank holds the full keys; screen rows are split across ranks for resolve + tonemap and the
-Rgba8 rows are all-gathered.
+Screen rows are split across ranks for resolve + tonemap and the Rgba8 rows are all-gathered.
 """
 import numpy as np
 
@@ -53,6 +53,23 @@ def allreduce_max_(tensor, group=None):
     return tensor
 
 
+def reduce_scatter_max_rows_(tensor, rank, world_size, group=None):
+    """Element-wise MAX over ranks, delivered only where it is needed: afterwards rank r's r-th equal chunk of `tensor`
+    holds the reduced values (the rows it resolves); the other chunks keep this rank's own partial values.  Half the
+    traffic of an all-reduce.  Backends without reduce-scatter (gloo) fall back to the all-reduce."""
+    import torch
+    import torch.distributed as dist
+    assert tensor.numel() % world_size == 0
+    chunk = tensor.numel() // world_size
+    if tensor.is_cuda and hasattr(dist, "reduce_scatter_tensor"):
+        out = torch.empty(chunk, dtype=tensor.dtype, device=tensor.device)
+        dist.reduce_scatter_tensor(out, tensor, op=dist.ReduceOp.MAX, group=group)
+        tensor[rank * chunk:(rank + 1) * chunk].copy_(out)
+    else:
+        dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+    return tensor
+
+
 def allgather_rows_(full, rank, world_size, group=None):
     """`full` is the whole flat image; rank r has valid data in its r-th equal chunk.  Gathers every chunk in place."""
     import torch.distributed as dist
@@ -91,6 +108,7 @@ class Exchange:
         self.device = device
         self.stream = torch.cuda.ExternalStream(renderer.lib.r3n_stream(renderer.ctx), device=device)
         self._ct = ctypes
+        self.rows_equal = False  # set by the caller when every rank resolves an equal, contiguous block of rows
 
     def _buffers(self):
         ct = self._ct
@@ -109,6 +127,10 @@ class Exchange:
             if what == "shadow":
                 if atlas_n:
                     allreduce_max_(device_tensor(atlas, atlas_n, "<f4", self.device), self.group)
+            elif what == "pass2" and self.rows_equal:
+                # only the rows this rank resolves have to be complete from here on
+                world = dist.get_world_size(self.group)
+                reduce_scatter_max_rows_(device_tensor(vis, vis_n, "<i8", self.device), dist.get_rank(self.group), world, self.group)
             else:
                 allreduce_max_(device_tensor(vis, vis_n, "<i8", self.device), self.group)
 

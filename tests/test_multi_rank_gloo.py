@@ -90,6 +90,11 @@ def _worker(rank, world, port, q):
             img.zero_()
             img[r0 * W * 4:r1 * W * 4] = keep[r0 * W * 4:r1 * W * 4]
             parallel.allgather_rows_(img, rank, world)
+            # pass-2 exchange as a reduce-scatter to the row owners (falls back to the all-reduce on gloo): own rows complete
+            keys = torch.from_numpy(got["vis"].copy().reshape(-1).view(np.int64))
+            parallel.reduce_scatter_max_rows_(keys, rank, world)
+            n = keys.numel() // world
+            assert np.array_equal(keys.numpy()[rank * n:(rank + 1) * n].view(np.uint64), ref["vis"].reshape(-1)[rank * n:(rank + 1) * n])
             assert np.array_equal(img.numpy().reshape(H, W, 4), ref["rgba8"]), f"gather frame {f}"
         q.put((rank, "ok"))
     except Exception as exc:  # noqa: BLE001
