@@ -573,6 +573,37 @@ def test_msaa_edge_queue_overflow(r3, monkeypatch):
         compare_frames(fo, fp, f"edge queue overflow frame {f}")
 
 
+def test_exchange_path_single_rank(r3):
+    """The multi-GPU exchange plumbing on one GPU: a one-rank RCCL process group, the context's buffers wrapped as torch
+    tensors on the context's own stream (rend3_amd/parallel.py Exchange), MAX all-reduces of the shadow atlas and the pass-1
+    keys, the reduce-scatter of the pass-2 keys, row range + row gather: the frames still equal the oracle's.  (World
+    size 2 is covered on the CPU with gloo, tests/test_multi_rank_gloo.py.)"""
+    import torch
+    import torch.distributed as dist
+    from rend3_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+        scenes.build_random_scene(o, oh, omk, 150, 0xE8C4, lights=2, with_cutout=True)
+        scenes.build_random_scene(p, oh, r3.material_record, 150, 0xE8C4, lights=2, with_cutout=True)
+        ex = parallel.Exchange(p, torch.device("cuda", 0))
+        ex.rows_equal = True
+        p.set_object_range(0, p.capacity)
+        p._check(p.lib.r3n_set_row_range(p.ctx, 0, 192), "r3n_set_row_range")
+        for f in range(3):
+            for r in (o, p):
+                r.set_camera_data(oh.look_at_lh((3.0 + f, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+            fo = o.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+            fp = p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0), exchange=ex)
+            ex.gather_rows(320, 192, 1)
+            compare_frames(fo, fp, f"exchange path frame {f}")
+        p.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_golden_textured_quad_example(r3):
     """examples/src/textured_quad/mod.rs at 1280x720 (row N2): albedo texture, nearest sampler, sRGB decode -- HIP ==
     oracle bit for bit, and the HIP image against the reference's screenshot (Threshold::Mean(0.0): RGB exact)."""
