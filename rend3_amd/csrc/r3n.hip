@@ -1102,7 +1102,10 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
                            // then balances the uneven item costs (measured on the bench scene, shadow views:
                            // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
 #endif
-    const uint32_t small_grid = 2048;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
+#ifndef R3N_SMALL_GRID
+#define R3N_SMALL_GRID 2048
+#endif
+    const uint32_t small_grid = R3N_SMALL_GRID;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
     TRY(fork_lane(c, lane));
     HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
     if (viewport) {
