@@ -403,9 +403,14 @@ class Renderer:
         self.tex_used = end
         desc = np.array([[start, w, h, mips, fmt, 0, 0, 0]], dtype=np.uint32)
         self.tex_descs = np.ascontiguousarray(np.concatenate([self.tex_descs, desc]))
-        self._check(self.lib.r3n_textures_write_encoded(self.ctx, _ffi.ptr(self.tex_descs), len(self.tex_descs),
-                                                        _ffi.ptr(self.tex_pool), self.tex_used), "r3n_textures_write_encoded")
+        self._tex_dirty = True  # the array is re-sent once, when the next frame is evaluated (TextureManager::evaluate)
         return len(self.tex_descs) - 1
+
+    def _flush_textures(self):
+        if getattr(self, "_tex_dirty", False):
+            self._check(self.lib.r3n_textures_write_encoded(self.ctx, _ffi.ptr(self.tex_descs), len(self.tex_descs),
+                                                            _ffi.ptr(self.tex_pool), self.tex_used), "r3n_textures_write_encoded")
+            self._tex_dirty = False
 
     def add_material(self, record, key=OPAQUE):
         idx = len(self.materials)
@@ -546,6 +551,10 @@ class Renderer:
 
     # ------------------------------------------------------------------ per-frame evaluation
     def evaluate_instructions(self):
+        self._flush_textures()
+        return self._evaluate_instructions()
+
+    def _evaluate_instructions(self):
         """Renderer::evaluate_instructions (rend3/src/renderer/eval.rs:9-187), path subset: flush dirty objects,
         evaluate lights -> shadow cameras + atlas + light buffers."""
         for h in self.pending_free:
@@ -644,6 +653,7 @@ class Renderer:
     def readback_texels(self):
         """The decoded RGBA8 texels of every texture (levels back to back, array order) as (n, 4) u8.  In the library's
         pool every texture starts on a 4-texel boundary (r3n_textures_write_encoded); the gaps are dropped here."""
+        self._flush_textures()
         sizes = [sum(max(1, int(d[1]) >> k) * max(1, int(d[2]) >> k) for k in range(int(d[3]))) for d in self.tex_descs]
         starts, cur = [], 0
         for n in sizes:

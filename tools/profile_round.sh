@@ -23,3 +23,7 @@ R3N_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WA
 cd "$root"
 find "$out" -name "*.csv" -size +20M -delete   # keep the merge-back small: per-dispatch traces of long runs
 ls -R "$out" | head -50
+# 4. kernel trace without frames in flight: the pass whose per-kernel averages match the bench's HIP-event stage times
+cd /tmp
+R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_serial" -o kts -- $B --steps 30 --warmup 5 > "$out/bench_under_rocprof_serial.json" 2> "$out/kts.err"
+cd "$root"
