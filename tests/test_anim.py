@@ -231,7 +231,7 @@ def test_gpu_animated_gltf_frames_match_oracle(tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_animation_example_matches_oracle():
-    """The reference's animation example (34-joint character + animated cube, tests/golden/animation/) at three times:
+    """The reference's animation example (34-joint character + animated cube, tests/golden/animation-*.glb) at three times:
     poses on the GPU, every frame bit-identical to the oracle at 640x360."""
     import rend3_amd as r3
     import test_oracle_goldens as G

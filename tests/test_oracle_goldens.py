@@ -365,12 +365,13 @@ def test_skinning_example():
 def build_animation_example(r, hm, mk):
     """examples/src/animation/mod.rs:43-106: scene.gltf (a 34-joint skinned character, one JPEG texture) and cube_3.gltf
     (an animated node), left-handed, one directional light; returns [(instance, animations)] for the poser.
-    Assets: tests/golden/animation/ (CC-BY, see its LICENSE), copied from the reference's example resources."""
+    Assets: tests/golden/animation-*.glb (CC-BY, animation-LICENSE.txt), packed from the reference's example resources by
+    tests/golden/make_animation_fixture.py."""
     from rend3_amd.gltf import Gltf, instance_scene, load_animations
     r.set_camera_data(hm.mat4_mul(hm.from_euler_xyz(0.0, 0.0, 0.0), hm.translation((0.0, -1.5, 5.0))), ("perspective", 60.0, 0.1))
     out = []
-    for name in ("scene.gltf", "cube_3.gltf"):
-        g = Gltf(os.path.join(GOLD, "animation", name))
+    for name in ("animation-character.glb", "animation-cube.glb"):
+        g = Gltf(os.path.join(GOLD, name))
         out.append((instance_scene(g, r, hm, mk), load_animations(g)))
     r.add_directional_light(color=(1, 1, 1), intensity=5.0, direction=(-1.0, -4.0, 2.0), distance=400.0, resolution=2048)
     return out

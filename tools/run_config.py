@@ -114,13 +114,13 @@ def run_cfg5_anim(n=50000, joints=24, steps=20):
 
 def run_cfg5_asset(n=5000, steps=20):
     """configs[4], "34-joint / 2324-vertex variant" (SURVEY section 8d): the reference's animation example character
-    (tests/golden/animation/scene.gltf) x n skeleton instances, each at its own time of the asset's clip: GPU poses + skinning."""
+    (tests/golden/animation-character.glb) x n skeleton instances, each at its own time of the asset's clip: GPU poses + skinning."""
     import os
     from rend3_amd.gltf import Gltf, instance_scene, load_animations
     from rend3_amd import anim as pa
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "animation")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     r = r3.Renderer(r3.host.LEFT, np.float32(16 / 9))
-    g = Gltf(os.path.join(root, "scene.gltf"))
+    g = Gltf(os.path.join(root, "animation-character.glb"))
     inst = instance_scene(g, r, r3.host, r3.material_record)
     anims = load_animations(g)
     first = inst["skeletons"][0]
