@@ -89,7 +89,7 @@ typedef struct r3n_material208 {
 } r3n_material208;
 
 /* One entry of the bindless texture array (rend3/src/managers/texture.rs; Texture in rend3-types/src/lib.rs:
- * data, format, size, mip_count).  RGBA8 only in this slice; `offset` = first texel (u32) of mip 0 in the texel
+ * data, format, size, mip_count).  For r3n_textures_write: RGBA8 texels, `offset` = first texel (u32) of mip 0 in the texel
  * pool, the mips follow contiguously; material records refer to entry i as texture id i + 1 (0 = none). */
 typedef struct r3n_texture_desc32 {
     uint32_t offset;

@@ -602,7 +602,7 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
     if (!c || (n && (!descs || !texels))) return fail(c, R3N_ERR_INVALID_ARG, "textures write: null");
     for (uint32_t i = 0; i < n; ++i) {
         const r3n_texture_desc32 &d = descs[i];
-        if (d.format > R3N_TEXTURE_RGBA8_UNORM_SRGB) return fail(c, R3N_ERR_UNSUPPORTED, "textures write: only RGBA8 formats are built (row N2)");
+        if (d.format > R3N_TEXTURE_RGBA8_UNORM_SRGB) return fail(c, R3N_ERR_UNSUPPORTED, "textures write: RGBA8 texels only here; other formats go through r3n_textures_write_encoded");
         if (!d.width || !d.height || !d.mips || d.width > 65535u || d.height > 65535u) return fail(c, R3N_ERR_INVALID_ARG, "textures write: bad extent");
         uint32_t max_mips = 0;
         for (uint32_t m = std::max(d.width, d.height); m; m >>= 1) ++max_mips;

@@ -1,4 +1,4 @@
-// texture.h -- material textures (row N2, first slice: albedo), device side.
+// texture.h -- material textures (row N2), device side: the sampler over the decoded RGBA8 texel pool.
 //
 // Reference behaviour restated (file:line):
 //   rend3/src/managers/texture.rs            one bindless array of every 2D texture of the world

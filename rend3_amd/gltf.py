@@ -1,8 +1,9 @@
-"""Minimal glTF 2.0 / GLB reader (row N1 of SURVEY.md section 8f, first slice): container parsing and accessor decoding
-into numpy arrays -- enough to feed meshes, skins and factor-only PBR materials of binary glTF files into the
-Renderer-shaped API.  Follows what the reference reads through the `gltf` crate in
-rend3-gltf/src/lib.rs:607-678 (load_meshes: positions, normals, tangents, uv0/1, colours, joints, weights, indices) and
-examples/src/static_gltf/mod.rs:5-41.  Textures / images / KTX2 / DDS (row N2) are not handled.
+"""glTF 2.0 / GLB reader and scene instancer (row N1 of SURVEY.md section 8f): container parsing, accessor decoding
+into numpy arrays, node hierarchy, skins, materials with their textures (PNG / JPEG through PIL, KTX2 / DDS through
+containers.py), KHR_lights_punctual directional lights and animations, fed into the Renderer-shaped API the way
+rend3-gltf does (rend3-gltf/src/lib.rs: load_meshes :607-678, load_materials_and_textures :806-943, load_image
+:984-1130, load_animations :724-773, instance_loaded_scene :493-562; examples/src/static_gltf/mod.rs:5-41).
+Not read: cameras, morph targets, sparse accessors.
 """
 import json
 import os
