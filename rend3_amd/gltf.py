@@ -3,7 +3,7 @@ into numpy arrays, node hierarchy, skins, materials with their textures (PNG / J
 containers.py), KHR_lights_punctual directional lights and animations, fed into the Renderer-shaped API the way
 rend3-gltf does (rend3-gltf/src/lib.rs: load_meshes :607-678, load_materials_and_textures :806-943, load_image
 :984-1130, load_animations :724-773, instance_loaded_scene :493-562; examples/src/static_gltf/mod.rs:5-41).
-Not read: cameras, morph targets, sparse accessors.
+Not read: cameras, morph targets; TEXCOORD_1 is decoded but not uploaded (no shader of the path reads it).
 """
 import json
 import os
@@ -44,29 +44,38 @@ class Gltf:
             else:
                 self.buffers.append(open(os.path.join(os.path.dirname(path), b["uri"]), "rb").read())
 
-    def accessor(self, index):
-        a = self.json["accessors"][index]
-        assert "sparse" not in a, "sparse accessors are not supported"
-        dt = np.dtype(_COMPONENT[a["componentType"]])
-        width = _WIDTH[a["type"]]
-        count = a["count"]
-        if "bufferView" not in a:
-            return np.zeros((count, width), dtype=dt)
-        bv = self.json["bufferViews"][a["bufferView"]]
+    def _read(self, view_index, byte_offset, dt, width, count):
+        bv = self.json["bufferViews"][view_index]
         buf = self.buffers[bv["buffer"]]
-        base = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        base = bv.get("byteOffset", 0) + byte_offset
         elem = dt.itemsize * width
         stride = bv.get("byteStride", 0) or elem
         if stride == elem:
-            arr = np.frombuffer(buf, dtype=dt, count=count * width, offset=base).reshape(count, width)
+            return np.frombuffer(buf, dtype=dt, count=count * width, offset=base).reshape(count, width).copy()
+        raw = np.frombuffer(buf, dtype=np.uint8, count=(count - 1) * stride + elem, offset=base)
+        idx = (np.arange(count)[:, None] * stride + np.arange(elem)[None, :]).reshape(-1)
+        return raw[idx].view(dt).reshape(count, width).copy()
+
+    def accessor(self, index, raw=False):
+        """Accessor data as (count, width): floats as stored; normalised integers converted to f32 (glTF 2.0 section
+        3.6.2.4) unless `raw`; sparse accessors (section 3.6.2.5) applied over the base view (or zeros)."""
+        a = self.json["accessors"][index]
+        dt = np.dtype(_COMPONENT[a["componentType"]])
+        width = _WIDTH[a["type"]]
+        count = a["count"]
+        if "bufferView" in a:
+            arr = self._read(a["bufferView"], a.get("byteOffset", 0), dt, width, count)
         else:
-            raw = np.frombuffer(buf, dtype=np.uint8, count=(count - 1) * stride + elem, offset=base)
-            idx = (np.arange(count)[:, None] * stride + np.arange(elem)[None, :]).reshape(-1)
-            arr = raw[idx].view(dt).reshape(count, width)
-        if a.get("normalized") and dt != np.float32:
+            arr = np.zeros((count, width), dtype=dt)
+        if "sparse" in a:
+            sp = a["sparse"]
+            idt = np.dtype(_COMPONENT[sp["indices"]["componentType"]])
+            where = self._read(sp["indices"]["bufferView"], sp["indices"].get("byteOffset", 0), idt, 1, sp["count"]).reshape(-1)
+            arr[where.astype(np.int64)] = self._read(sp["values"]["bufferView"], sp["values"].get("byteOffset", 0), dt, width, sp["count"])
+        if a.get("normalized") and dt != np.float32 and not raw:
             info = np.iinfo(dt)
             arr = np.maximum(arr.astype(np.float32) / np.float32(info.max), -1.0 if info.min < 0 else 0.0)
-        return arr.copy()
+        return arr
 
     def primitive(self, mesh=0, primitive=0):
         """Attribute arrays of one primitive, as the reference's loaders read them (u32 indices, f32 attributes)."""
@@ -80,6 +89,21 @@ class Gltf:
             out["tangents"] = self.accessor(at["TANGENT"]).astype(np.float32)[:, :3]  # Vec4::truncate
         if "TEXCOORD_0" in at:
             out["uv0"] = self.accessor(at["TEXCOORD_0"]).astype(np.float32)
+        if "TEXCOORD_1" in at:
+            out["uv1"] = self.accessor(at["TEXCOORD_1"]).astype(np.float32)
+        if "COLOR_0" in at:
+            # read_colors(0).into_rgba_u8() (gltf crate, mesh/util/colors.rs: f32 -> (clamp(x, 0, 1) * 255) as u8, u16 -> x >> 8,
+            # RGB gets alpha 255)
+            c = self.accessor(at["COLOR_0"], raw=True)
+            if c.dtype == np.float32:
+                c8 = (np.clip(c, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+            elif c.dtype == np.uint16:
+                c8 = (c >> 8).astype(np.uint8)
+            else:
+                c8 = c.astype(np.uint8)
+            if c8.shape[1] == 3:
+                c8 = np.concatenate([c8, np.full((len(c8), 1), 255, dtype=np.uint8)], axis=1)
+            out["colors"] = c8
         if "JOINTS_0" in at:
             out["joints"] = self.accessor(at["JOINTS_0"]).astype(np.uint16)
             out["weights"] = self.accessor(at["WEIGHTS_0"]).astype(np.float32)
@@ -282,7 +306,7 @@ def instance_scene(g, r, hm, mk, scale=1.0, enable_directional=True, directional
                 idx = p["indices"].reshape(-1, 3)[:, ::-1].reshape(-1) if lh else p["indices"]
                 meshes[(mi, pi)] = (r.add_mesh(p["positions"], idx, normals=p.get("normals"), tangents=p.get("tangents"),
                                                joint_indices=p.get("joints"), joint_weights=p.get("weights"),
-                                               uv0=p.get("uv0"), mesh_handedness=r.handedness), p["material"])
+                                               uv0=p.get("uv0"), colors=p.get("colors"), mesh_handedness=r.handedness), p["material"])
             mesh, mat_index = meshes[(mi, pi)]
             if mat_index not in materials:
                 rec, key = material_from_gltf(g, mat_index, mk, r, image_cache)
