@@ -277,6 +277,9 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 #ifndef R3N_SMALL_OCC
 #define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
 #endif
+#ifndef R3N_XCD_REMAP
+#define R3N_XCD_REMAP 0  // resolve tiles in contiguous per-XCD bands: measured, no gain (shade 595 -> 593 us, frame 1.184 -> 1.193 ms)
+#endif
 #ifndef R3N_MS_OCC
 #define R3N_MS_OCC 4   // the same for the multisampled record-based resolve (5 spills: 1.19 vs 0.99 ms; 3: 1.03)
 #endif
@@ -1383,8 +1386,19 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
     // each wavefront shades an 8x8 pixel quad of the 16x16 tile (fewer distinct triangles / atlas texels per wave
     // than a 16x4 strip; measured 3 % faster)
     const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-    const uint32_t x = blockIdx.x * 16u + (ln & 7u) + 8u * (wv & 1u);
-    const uint32_t y = a.row_begin + blockIdx.y * 16u + (ln >> 3) + 8u * (wv >> 1);
+#if R3N_XCD_REMAP
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id; remap so that every XCD shades a contiguous band of
+    // tiles (its L2 then holds one band's triangle records, texels and shadow texels instead of a slice of all of them).
+    const uint32_t nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t per = (nb + 7u) / 8u;
+    uint32_t tile = (lin & 7u) * per + (lin >> 3);
+    if (tile >= nb) tile = lin;  // (only when nb is not a multiple of 8: the tail keeps its place)
+    const uint32_t bx = tile % gridDim.x, by = tile / gridDim.x;
+#else
+    const uint32_t bx = blockIdx.x, by = blockIdx.y;
+#endif
+    const uint32_t x = bx * 16u + (ln & 7u) + 8u * (wv & 1u);
+    const uint32_t y = a.row_begin + by * 16u + (ln >> 3) + 8u * (wv >> 1);
     const bool inside = x < a.width && y < a.row_end;
     if (!inside && !SPLIT) return;  // SPLIT: every thread of the workgroup takes part in the queue reservation below
     const size_t pix = inside ? (size_t)y * a.width + x : 0u;
