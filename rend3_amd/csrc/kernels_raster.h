@@ -281,7 +281,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 #define R3N_XCD_REMAP 0  // resolve tiles in contiguous per-XCD bands: measured, no gain (shade 595 -> 593 us, frame 1.184 -> 1.193 ms)
 #endif
 #ifndef R3N_MS_OCC
-#define R3N_MS_OCC 4   // the same for the multisampled record-based resolve (5 spills: 1.19 vs 0.99 ms; 3: 1.03)
+#define R3N_MS_OCC 5   // the same for the multisampled record-based resolve (lean split pass: 0.86 ms at 5, 0.92 at 4)
 #endif
 #ifndef R3N_TEX_OCC
 #define R3N_TEX_OCC 5  // min waves per SIMD asked of the textured record-based resolve (launch bound)
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
             if (threadIdx.x == 0u && s_extra) s_base = atomicAdd(&a.edge_count[q], s_extra);
             __syncthreads();
             edge_base = s_base + my_off;
-            edge_fits = edge_base + extra <= a.edge_capacity;  // else: shade everything here (never drop work)
+            edge_fits = extra == 0u || edge_base + extra <= a.edge_capacity;  // else: shade everything here (never drop work)
             if (extra && !edge_fits) {  // the slots this pixel reserved inside the list stay empty
                 for (uint32_t k = edge_base; k < min(edge_base + extra, a.edge_capacity); ++k)
                     a.edge_list[(size_t)q * a.edge_capacity + k] = 0xFFFFFFFFu;
@@ -1471,7 +1471,41 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
             }
         }
         if (!inside) return;  // (after the workgroup barriers)
-        const uint32_t n_here = (SPLIT && edge_fits) ? 1u : n_unique;
+        if (SPLIT && edge_fits) {
+            // the common case, kept lean: only the first triangle is shaded here, so nothing per sample has to stay in
+            // registers across the fragment stage except which samples it owns
+            uint32_t mask0 = 0;
+#pragma unroll
+            for (int sm = 0; sm < S; ++sm) mask0 |= first_of[sm] == 0u ? 1u << sm : 0u;
+            const uint32_t id0 = ids[0];
+            const bool single = n_unique == 1u;
+            float v[4];
+            if (id0 == 0u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
+            } else if (REC) {
+                fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id0 - 1u], x, y, v);
+            } else {
+                shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id0, x, y, v);
+            }
+            const ushort4 h = pack_half4(v);
+            if (!single) {  // edge pixel: park the samples of the first triangle; the other passes finish the pixel
+#pragma unroll
+                for (int sm = 0; sm < S; ++sm)
+                    if ((mask0 >> sm) & 1u) a.samples_out[pix * (size_t)S + (size_t)sm] = h;
+                return;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // box resolve of four equal samples, same expression as everywhere
+                const float cf = (float)(_Float16)v[c];
+                out[c] = ((cf + cf) + (cf + cf)) * 0.25f;
+            }
+            const ushort4 ho = pack_half4(out);
+            a.hdr_out[pix] = ho;
+            a.ldr_out[pix] = tonemap_half4(a.srgb_lut, ho, a.out_bgr);
+            return;
+        }
+        const uint32_t n_here = n_unique;
 #pragma unroll 1
         for (uint32_t k = 0, sm_at = 0; k < n_here; ++k, ++sm_at) {
             while (first_of[sm_at == 0u ? 0 : (sm_at == 1u ? 1 : (sm_at == 2u ? 2 : 3))] != sm_at) ++sm_at;  // next leader sample
@@ -1491,13 +1525,6 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
 #pragma unroll
                     for (int c = 0; c < 4; ++c) col[sm][c] = (float)(_Float16)v[c];
                 }
-        }
-        if (SPLIT && edge_fits && n_unique > 1u) {
-            // edge pixel: park the samples of the first triangle; the other passes finish the pixel
-#pragma unroll
-            for (int sm = 0; sm < S; ++sm)
-                if (first_of[sm] == 0u) a.samples_out[pix * (size_t)S + (size_t)sm] = pack_half4(col[sm]);
-            return;
         }
         if (!SPLIT && a.samples_out != nullptr) {
 #pragma unroll
