@@ -190,6 +190,10 @@ class Renderer:
         self.tex_descs = np.zeros((0, 8), dtype=np.uint32)  # r3n_texture_desc32 rows
         self.tex_pool = np.zeros(4, dtype=np.uint8)   # every texture's levels in ITS format (bytes)
         self.tex_used = 0
+        self._tex_dirty = False
+        self._pose_state = {}      # skeleton handle -> (clip, time): rend3-anim poses re-evaluated in front of every skinning pass
+        self._anim_sets = None     # concatenated rend3-anim tables of every AnimationData (animation_add)
+        self.output_format = 0
         self.capacity = 16  # FreelistDerivedBuffer::STARTING_SIZE
         self.object_meta = {}
         self.free_handles, self.pending_free, self.deferred_removals = [], [], []
@@ -300,14 +304,14 @@ class Renderer:
         return list(range(first, first + n))
 
     def set_skeleton_joint_matrices(self, sk, joint_matrices):
-        getattr(self, "_pose_state", {}).pop(sk, None)
+        self._pose_state.pop(sk, None)
         self.skeletons[sk]["matrices"] = np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)
 
     def animation_add(self, rigs, joints, clips, tracks, times, values):
         """Register one AnimationData's tables (anim.AnimationData builds them; record layouts in include/r3n.h).  The
         library holds ONE table set (r3n_animation_write), so the sets of all scene instances are concatenated here with
         their indices rebased.  Returns the index of the set's first clip."""
-        sets = getattr(self, "_anim_sets", None)
+        sets = self._anim_sets
         if sets is None:
             sets = self._anim_sets = [[np.zeros(0, dtype=a.dtype) for a in (rigs, joints, clips, tracks)] + [np.zeros(0, f32), np.zeros(0, f32)]]
         cur = sets[0]
@@ -331,13 +335,11 @@ class Renderer:
         (csrc/anim.hip) in front of every skinning pass, straight into the buffer the skinning kernel reads, until the
         skeleton gets another pose or explicit matrices (Renderer::set_skeleton_joint_matrices semantics: the last
         value set stays)."""
-        if not hasattr(self, "_pose_state"):
-            self._pose_state = {}
         for clip, time, sk in requests:
             self._pose_state[sk] = (int(clip), np.float32(time))
 
     def _pose_requests(self):
-        state = getattr(self, "_pose_state", {})
+        state = self._pose_state
         rq = np.zeros(len(state), dtype=[("clip", np.uint32), ("time", np.float32), ("base", np.uint32), ("pad", np.uint32)])
         for i, (sk, (clip, time)) in enumerate(sorted(state.items())):
             rq[i] = (clip, time, int(self._skin_inputs[sk][8]), 0)
@@ -407,7 +409,7 @@ class Renderer:
         return len(self.tex_descs) - 1
 
     def _flush_textures(self):
-        if getattr(self, "_tex_dirty", False):
+        if self._tex_dirty:
             self._check(self.lib.r3n_textures_write_encoded(self.ctx, _ffi.ptr(self.tex_descs), len(self.tex_descs),
                                                             _ffi.ptr(self.tex_pool), self.tex_used), "r3n_textures_write_encoded")
             self._tex_dirty = False
