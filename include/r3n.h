@@ -95,7 +95,11 @@ typedef struct r3n_texture_desc32 {
     uint32_t offset;
     uint32_t width, height, mips;
     uint32_t format; /* R3N_TEXTURE_* */
-    uint32_t _pad[3];
+    uint32_t stored_mips; /* r3n_textures_write_encoded only: 0 = all `mips` levels are in the payload (MipmapSource::Uploaded);
+                             k < mips = the first k levels are, the others are GENERATED on the GPU (MipmapSource::Generated,
+                             rend3/src/util/mipmap.rs + mipmap.wgsl: Linear / ClampToEdge blit per level in the texture's
+                             format); uncompressed formats only */
+    uint32_t _pad[2];
 } r3n_texture_desc32;
 #define R3N_TEXTURE_RGBA8_UNORM 0u
 #define R3N_TEXTURE_RGBA8_UNORM_SRGB 1u
@@ -384,7 +388,6 @@ void r3n_host_projection(int kind, const float *params, int rh, float aspect_rat
 void r3n_host_frustum_from_matrix(const float *m, float *planes20);
 /* MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + rend3/shaders/mipmap.wgsl): fills mips 1.. of an
  * RGBA8 chain whose mip 0 is in place; Linear / ClampToEdge blit per level in the texture's own format. */
-void r3n_host_generate_mips(uint32_t format, uint32_t width, uint32_t height, uint32_t mips, uint32_t *texels);
 int r3n_host_frustum_contains_sphere(const float *planes20, const float center[3], float radius);
 /* BoundingSphere::{from_mesh, apply_transform}, frustum.rs:15-56 */
 void r3n_host_bounding_sphere_from_mesh(const float *positions, uint64_t vertex_count, float out_center[3],

@@ -82,7 +82,6 @@ SIGNATURES = {
     "r3n_host_calculate_normals": (None, [vp, u64, vp, u64, cint, vp]),
     "r3n_host_shadow_camera": (None, [vp, cfloat, u32, vp, cint, vp, vp]),
     "r3n_host_allocate_shadow_atlas": (u32, [vp, vp, u32, u32, vp, vp]),
-    "r3n_host_generate_mips": (None, [u32, u32, u32, u32, vp]),
 }
 
 _LIB = None

@@ -349,56 +349,4 @@ uint32_t r3n_host_allocate_shadow_atlas(const uint32_t *handles, const uint16_t 
     return written;
 }
 
-// MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + rend3/shaders/mipmap.wgsl): level l is a blit of level
-// l - 1 through a Linear / ClampToEdge sampler at the destination texel centres into the texture's own format, so an
-// sRGB texture is decoded, filtered and re-encoded per level.  float -> unorm8: x * 255 + 0.5, truncated.
-void r3n_host_generate_mips(uint32_t format, uint32_t width, uint32_t height, uint32_t mips, uint32_t *texels) {
-    float decode[256];
-    for (int i = 0; i < 256; ++i) {
-        const float e = (float)i / 255.0f;
-        decode[i] = e > 0.04045f ? std::pow((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f;
-    }
-    auto dim = [](uint32_t d, uint32_t k) { const uint32_t v = d >> k; return v ? v : 1u; };
-    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
-    auto encode_srgb = [](float x) {
-        if (!(x > 0.0f)) return 0.0f;
-        if (x >= 1.0f) return 1.0f;
-        if (x <= 0.0031308f) return x * 12.92f;
-        return 1.055f * std::pow(x, 1.0f / 2.4f) - 0.055f;
-    };
-    uint64_t src = 0;
-    for (uint32_t l = 1; l < mips; ++l) {
-        const uint32_t sw = dim(width, l - 1), sh = dim(height, l - 1), dw = dim(width, l), dh = dim(height, l);
-        const uint64_t dst = src + (uint64_t)sw * sh;
-        for (uint32_t y = 0; y < dh; ++y)
-            for (uint32_t x = 0; x < dw; ++x) {
-                const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
-                const float tx = u * (float)sw - 0.5f, ty = v * (float)sh - 0.5f;
-                const float fx0 = std::floor(tx), fy0 = std::floor(ty);
-                const float fx = tx - fx0, fy = ty - fy0;
-                const int ix = (int)fx0, iy = (int)fy0;
-                const uint32_t x0 = (uint32_t)clampi(ix, (int)sw - 1), x1 = (uint32_t)clampi(ix + 1, (int)sw - 1);
-                const uint32_t y0 = (uint32_t)clampi(iy, (int)sh - 1), y1 = (uint32_t)clampi(iy + 1, (int)sh - 1);
-                const uint32_t t[4] = {texels[src + (uint64_t)y0 * sw + x0], texels[src + (uint64_t)y0 * sw + x1],
-                                       texels[src + (uint64_t)y1 * sw + x0], texels[src + (uint64_t)y1 * sw + x1]};
-                uint32_t out = 0;
-                for (int c = 0; c < 4; ++c) {
-                    const bool srgb = format == R3N_TEXTURE_RGBA8_UNORM_SRGB && c < 3;
-                    float q[4];
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t b = (t[k] >> (8 * c)) & 0xFFu;
-                        q[k] = srgb ? decode[b] : (float)b / 255.0f;
-                    }
-                    const float top = q[0] * (1.0f - fx) + q[1] * fx;
-                    const float bot = q[2] * (1.0f - fx) + q[3] * fx;
-                    const float r = top * (1.0f - fy) + bot * fy;
-                    const float e = srgb ? encode_srgb(r) : std::fmin(std::fmax(r, 0.0f), 1.0f);
-                    out |= (uint32_t)(e * 255.0f + 0.5f) << (8 * c);
-                }
-                texels[dst + (uint64_t)y * dw + x] = out;
-            }
-        src = dst;
-    }
-}
-
 }  // extern "C"

@@ -112,6 +112,7 @@ struct r3n_ctx {
     std::vector<r3n_anim_clip16> h_anim_clips;
     uint32_t n_pose_requests = 0, pose_matrix_end = 0, anim_max_joints = 1;
     DevBuf big_uv[1 + R3N_AUX_STREAMS];
+    DevBuf srgb_thr;  // 255 floats: smallest linear value whose Rgba8UnormSrgb code is >= c (GPU mip generation)
     DevBuf srgb_lut;  // 8-bit output code of every half in [0, 1): kernels_raster.h k_build_srgb_lut (or r3n_set_output_format)
     uint32_t output_format = R3N_OUTPUT_RGBA8_UNORM_SRGB;
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
@@ -459,6 +460,25 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
             decode[256 + i] = e > 0.04045f ? std::pow((e + 0.055f) / 1.055f, 2.4f) : e / 12.92f;
         }
         ok = hipMemcpyAsync(c->srgb8_decode.p, decode, sizeof decode, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        // encode thresholds for the GPU mip chain: thr[c - 1] = the smallest float x with (uint8)(oetf(x) * 255 + 0.5) >= c,
+        // by bisection over the float bit patterns of [0, 1] with the libm expression the oracle uses
+        static float thr[255];
+        auto code_of = [](float x) {
+            float e = !(x > 0.0f) ? 0.0f : (x >= 1.0f ? 1.0f : (x <= 0.0031308f ? x * 12.92f : 1.055f * std::pow(x, 1.0f / 2.4f) - 0.055f));
+            return (uint32_t)(e * 255.0f + 0.5f);
+        };
+        for (uint32_t cc = 1; cc <= 255; ++cc) {
+            uint32_t lo = 0u, hi = 0x3F800000u;  // code_of(hi) = 255 >= cc
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2u;
+                float x;
+                std::memcpy(&x, &mid, 4);
+                if (code_of(x) >= cc) hi = mid; else lo = mid + 1u;
+            }
+            std::memcpy(&thr[cc - 1u], &lo, 4);
+        }
+        ok = ok && ensure(c, c->srgb_thr, sizeof thr, false, -1) == R3N_OK &&
+             hipMemcpyAsync(c->srgb_thr.p, thr, sizeof thr, hipMemcpyHostToDevice, c->stream) == hipSuccess;
         ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
         if (!ok) c->err = "k_build_srgb_lut failed";
     }
@@ -482,7 +502,7 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
                       &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count};
@@ -627,6 +647,8 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
 extern "C" int r3n_internal_pose_skeletons(const void *requests, uint32_t n, const void *rigs, const void *joints, const void *clips,
                                            const void *tracks, const float *times, const float *values, float *out, uint32_t max_joints,
                                            hipStream_t stream);
+extern "C" int r3n_internal_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const uint32_t *src,
+                                         uint32_t *dst, const float *decode, const float *thr, hipStream_t stream);
 extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h);
 extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h, const void *src, uint32_t *dst, hipStream_t stream);
 
@@ -641,10 +663,14 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         uint32_t max_mips = 0;
         for (uint32_t m = std::max(d.width, d.height); m; m >>= 1) ++max_mips;
         if (d.mips > max_mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): more mips than the extent has");
+        if (d.stored_mips > d.mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): more stored levels than mips");
+        const uint32_t stored = d.stored_mips ? d.stored_mips : d.mips;
+        if (stored < d.mips && d.format >= R3N_TEXTURE_BC1_RGBA_UNORM)
+            return fail(c, R3N_ERR_UNSUPPORTED, "textures write (encoded): mips are generated for uncompressed formats only (block formats are not render targets)");
         uint64_t end = d.offset, texels = 0;
         for (uint32_t k = 0; k < d.mips; ++k) {
             const uint32_t w = std::max(1u, d.width >> k), h = std::max(1u, d.height >> k);
-            end += r3n_internal_level_bytes(d.format, w, h);
+            if (k < stored) end += r3n_internal_level_bytes(d.format, w, h);
             texels += (uint64_t)w * h;
         }
         if (end > payload_bytes) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): levels outside the payload");
@@ -655,6 +681,7 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
                           d.format == R3N_TEXTURE_BC3_RGBA_UNORM_SRGB || d.format == R3N_TEXTURE_BC7_RGBA_UNORM_SRGB;
         n_texels = (n_texels + 3u) & ~3ull;  // 16-byte-aligned texture starts: the block decoder stores whole rows
         internal[i] = d;
+        internal[i].stored_mips = 0;
         internal[i].offset = (uint32_t)n_texels;
         internal[i].format = srgb ? R3N_TEXTURE_RGBA8_UNORM_SRGB : R3N_TEXTURE_RGBA8_UNORM;
         n_texels += texels;
@@ -670,12 +697,21 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         if (e == hipSuccess) e = hipMemcpyAsync(c->tex_descs.p, internal.data(), (size_t)n * sizeof(r3n_texture_desc32), hipMemcpyHostToDevice, c->stream);
         for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
             uint64_t src = descs[i].offset, dst = internal[i].offset;
+            const uint32_t stored = descs[i].stored_mips ? descs[i].stored_mips : descs[i].mips;
             for (uint32_t k = 0; k < descs[i].mips && e == hipSuccess; ++k) {
                 const uint32_t w = std::max(1u, descs[i].width >> k), h = std::max(1u, descs[i].height >> k);
-                // block-compressed and 32-bit sources are read as dwords: every level of those formats is a multiple of 4 B
-                e = (hipError_t)r3n_internal_decode_level(descs[i].format, w, h, static_cast<const char *>(staged) + src,
-                                                          c->tex_texels.as<uint32_t>() + dst, c->stream);
-                src += r3n_internal_level_bytes(descs[i].format, w, h);
+                if (k < stored) {
+                    // block-compressed and 32-bit sources are read as dwords: every level of those formats is a multiple of 4 B
+                    e = (hipError_t)r3n_internal_decode_level(descs[i].format, w, h, static_cast<const char *>(staged) + src,
+                                                              c->tex_texels.as<uint32_t>() + dst, c->stream);
+                    src += r3n_internal_level_bytes(descs[i].format, w, h);
+                } else {  // MipmapSource::Generated: blit of the level above, in the texture's format
+                    const uint32_t sw = std::max(1u, descs[i].width >> (k - 1u)), sh = std::max(1u, descs[i].height >> (k - 1u));
+                    e = (hipError_t)r3n_internal_generate_mip(internal[i].format == R3N_TEXTURE_RGBA8_UNORM_SRGB, sw, sh, w, h,
+                                                              c->tex_texels.as<uint32_t>() + dst - (uint64_t)sw * sh,
+                                                              c->tex_texels.as<uint32_t>() + dst, c->srgb8_decode.as<float>(),
+                                                              c->srgb_thr.as<float>(), c->stream);
+                }
                 dst += (uint64_t)w * h;
             }
         }

@@ -261,7 +261,61 @@ __global__ __launch_bounds__(256) void k_expand_texels(uint32_t format, uint64_t
     dst[i] = v;
 }
 
+// MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + rend3/shaders/mipmap.wgsl, K11): level l is a blit of
+// level l - 1 through a Linear / ClampToEdge sampler at the destination texel centres into the texture's own format, so
+// an sRGB texture is decoded, filtered and re-encoded per level.  One thread per destination texel.  float -> unorm8:
+// x * 255 + 0.5, truncated.  The sRGB encode is a search in a 255-entry table of thresholds (thr[c - 1] = the smallest
+// float whose code is >= c, found on the host with the same libm expression the oracle evaluates), not a device powf:
+// the codes then agree with the oracle for every input.
+__global__ __launch_bounds__(256) void k_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
+                                                      const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                      const float *__restrict__ decode, const float *__restrict__ thr) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= dw * dh) return;
+    const uint32_t x = g % dw, y = g / dw;
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    const float tx = u * (float)sw - 0.5f, ty = v * (float)sh - 0.5f;
+    const float fx0 = floorf(tx), fy0 = floorf(ty);
+    const float fx = tx - fx0, fy = ty - fy0;
+    const int ix = (int)fx0, iy = (int)fy0;
+    auto clampi = [](int a, int hi) { return a < 0 ? 0 : (a > hi ? hi : a); };
+    const uint32_t x0 = (uint32_t)clampi(ix, (int)sw - 1), x1 = (uint32_t)clampi(ix + 1, (int)sw - 1);
+    const uint32_t y0 = (uint32_t)clampi(iy, (int)sh - 1), y1 = (uint32_t)clampi(iy + 1, (int)sh - 1);
+    const uint32_t t[4] = {src[(size_t)y0 * sw + x0], src[(size_t)y0 * sw + x1], src[(size_t)y1 * sw + x0], src[(size_t)y1 * sw + x1]};
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool s = srgb != 0u && c < 3;
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = decode[(s ? 256u : 0u) + ((t[k] >> (8 * c)) & 0xFFu)];
+        const float top = q[0] * (1.0f - fx) + q[1] * fx;
+        const float bot = q[2] * (1.0f - fx) + q[3] * fx;
+        const float r = top * (1.0f - fy) + bot * fy;
+        uint32_t code;
+        if (s) {
+            uint32_t lo = 0, hi = 255;  // code = number of thresholds <= r (NaN compares false: code 0, like the formula)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (r >= thr[mid]) lo = mid + 1u; else hi = mid;
+            }
+            code = lo;
+        } else {
+            const float e = fminf(fmaxf(r, 0.0f), 1.0f);
+            code = (uint32_t)(e * 255.0f + 0.5f);
+        }
+        out |= code << (8 * c);
+    }
+    dst[g] = out;
+}
+
 }  // namespace
+
+extern "C" int r3n_internal_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const uint32_t *src,
+                                         uint32_t *dst, const float *decode, const float *thr, hipStream_t stream) {
+    hipLaunchKernelGGL(k_generate_mip, dim3((dw * dh + 255u) / 256u), dim3(256), 0, stream, srgb, sw, sh, dw, dh, src, dst, decode, thr);
+    return (int)hipGetLastError();
+}
 
 // bytes of one w x h level in `format`; 0 for an unknown format
 extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h) {

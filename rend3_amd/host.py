@@ -273,23 +273,19 @@ def mip_chain_texels(w, h, mips):
 
 def prepare_texture(rgba8, srgb, mip_count, mip_source):
     """Texture upload path of rend3/src/managers/texture.rs: mip count check (MipmapCount::Maximum =
-    Extent3d::max_mips), contiguous mip layout and, for MipmapSource::Generated, the blit chain of
-    util/mipmap.rs (r3n_host_generate_mips).  Returns (u32 texels of the whole chain, width, height, mips)."""
+    Extent3d::max_mips).  Returns (RGBA8 bytes of the stored levels, width, height, mips, stored levels); for
+    MipmapSource::Generated only level 0 is stored and the library builds the chain on the GPU (util/mipmap.rs)."""
     a = np.ascontiguousarray(rgba8, dtype=np.uint8)
     if a.ndim != 3 or a.shape[2] != 4:
         raise ValueError("texture data must be (H, W, 4) u8")
     if mip_source != "generated" and mip_count != 1:
-        raise ValueError("uploaded mip chains are not supported by this helper")
+        raise ValueError("uploaded mip chains go through add_texture_2d_encoded")
     h, w = a.shape[:2]
     max_mips = int(max(w, h)).bit_length()
     mips = max_mips if mip_count == "maximum" else int(mip_count)
     if not 1 <= mips <= max_mips:
         raise ValueError("mip_count out of range")
-    out = np.zeros(mip_chain_texels(w, h, mips), dtype=np.uint32)
-    out[: w * h] = a.reshape(-1, 4).view(np.uint32).reshape(-1)
-    if mips > 1:
-        _ffi.lib().r3n_host_generate_mips(1 if srgb else 0, w, h, mips, _ffi.ptr(out))
-    return out, w, h, mips
+    return a.reshape(-1), w, h, mips, 1 if mips > 1 else 0
 
 
 def blend_draw_order(camera_location, object_indices, locations):

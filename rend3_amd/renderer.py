@@ -363,38 +363,27 @@ class Renderer:
         """Renderer::add_texture_2d with Texture{data, format, size, mip_count, mip_source}: rgba8 = (H, W, 4) u8;
         format Rgba8UnormSrgb | Rgba8Unorm; mip_count int or "maximum"; mip_source "uploaded" | "generated".
         The whole bindless array is re-sent (r3n_textures_write_encoded).  Returns the texture handle (index)."""
-        data, w, h, mips = host.prepare_texture(rgba8, srgb, mip_count, mip_source)
-        return self._append_texture(data.view(np.uint8), w, h, mips, 1 if srgb else 0)
+        data, w, h, mips, stored = host.prepare_texture(rgba8, srgb, mip_count, mip_source)
+        return self._append_texture(data, w, h, mips, 1 if srgb else 0, stored)
 
     def add_texture_2d_encoded(self, fmt, width, height, levels, generate_mips=False):
         """Renderer::add_texture_2d for the other formats rend3-gltf's loader produces (containers.py ids = R3N_TEXTURE_*):
         `levels` = the stored levels' bytes, largest first.  generate_mips: MipmapCount::Maximum + MipmapSource::Generated
         (single-level uncompressed files, rend3-gltf/src/lib.rs:1031-1036); the chain is then built from the expanded
-        RGBA8 level, which gives every channel the values the format's own blit chain would.  Block-compressed data
-        goes to the GPU as stored and is decoded there."""
+        RGBA8 level (on the GPU, like the expansion itself), which gives every channel the values the format's own blit
+        chain would.  Block-compressed data goes to the GPU as stored and is decoded there."""
         from . import containers
         if generate_mips:
             if containers.is_block_format(fmt) or len(levels) != 1:
                 raise ValueError("mips are generated for single-level uncompressed textures only")
-            a = np.frombuffer(levels[0], dtype=np.uint8)
-            rgba = np.zeros((height, width, 4), dtype=np.uint8)
-            rgba[..., 3] = 255
-            if fmt == containers.R8:
-                rgba[..., 0] = a.reshape(height, width)
-            elif fmt == containers.RG8:
-                rgba[..., :2] = a.reshape(height, width, 2)
-            elif fmt in (containers.BGRA8, containers.BGRA8_SRGB):
-                rgba[...] = a.reshape(height, width, 4)[..., [2, 1, 0, 3]]
-            else:
-                rgba[...] = a.reshape(height, width, 4)
-            srgb = fmt in (containers.RGBA8_SRGB, containers.BGRA8_SRGB)
-            return self.add_texture_2d(rgba, srgb=srgb, mip_count="maximum", mip_source="generated")
+            mips = int(max(width, height)).bit_length()
+            return self._append_texture(np.frombuffer(levels[0], dtype=np.uint8), width, height, mips, fmt, 1 if mips > 1 else 0)
         for k, lv in enumerate(levels):
             if len(lv) != containers.level_bytes(fmt, max(1, width >> k), max(1, height >> k)):
                 raise ValueError(f"level {k}: wrong byte count for its extent")
         return self._append_texture(np.frombuffer(b"".join(levels), dtype=np.uint8), width, height, len(levels), fmt)
 
-    def _append_texture(self, data_u8, w, h, mips, fmt):
+    def _append_texture(self, data_u8, w, h, mips, fmt, stored=0):
         start = (self.tex_used + 3) & ~3  # level 0 of every texture starts on a 4-byte boundary
         end = start + len(data_u8)
         if end > len(self.tex_pool):
@@ -403,7 +392,7 @@ class Renderer:
             self.tex_pool = grown
         self.tex_pool[start:end] = data_u8
         self.tex_used = end
-        desc = np.array([[start, w, h, mips, fmt, 0, 0, 0]], dtype=np.uint32)
+        desc = np.array([[start, w, h, mips, fmt, stored, 0, 0]], dtype=np.uint32)
         self.tex_descs = np.ascontiguousarray(np.concatenate([self.tex_descs, desc]))
         self._tex_dirty = True  # the array is re-sent once, when the next frame is evaluated (TextureManager::evaluate)
         return len(self.tex_descs) - 1

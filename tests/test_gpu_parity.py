@@ -637,6 +637,40 @@ def test_textured_scene_multi_frame(r3, handedness, samples):
         compare_frames(fo, fp, f"textured scene frame {f}")
 
 
+def test_generated_mip_chains_match_oracle(r3):
+    """MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + mipmap.wgsl, K11): the chain the library builds on the
+    GPU at upload (Linear / ClampToEdge blit per level in the texture's own format; sRGB levels decoded, filtered and
+    re-encoded through the threshold table) against the oracle's, every level byte for byte: sRGB and linear formats,
+    even / odd / degenerate extents, and R8 / RG8 / BGRA8 sources expanded first."""
+    import test_texture_formats as T
+    o, p = both(r3)
+    rng = np.random.default_rng(5)
+    want = []
+    for (w, h, srgb) in [(64, 64, True), (37, 19, True), (128, 40, False), (1, 7, True), (5, 1, False), (256, 256, True)]:
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if (w, h) == (256, 256):  # every code next to every other: exercises the encode thresholds densely
+            img[..., 0] = np.arange(256, dtype=np.uint8)[None, :]
+            img[..., 1] = np.arange(256, dtype=np.uint8)[:, None]
+        p.add_texture_2d(img, srgb=srgb, mip_count="maximum", mip_source="generated")
+        t = o.add_texture_2d(img, srgb=srgb, mip_count="maximum", mip_source="generated")
+        d = o.tex_descs[t]
+        n = sum(max(1, w >> k) * max(1, h >> k) for k in range(int(d[3])))
+        want.append(o.tex_pool[int(d[0]): int(d[0]) + n].view(np.uint8).reshape(-1, 4))
+    for fmt, width in ((T.C.R8, 1), (T.C.RG8, 2), (T.C.BGRA8_SRGB, 4)):
+        w, h = 23, 10
+        raw = rng.integers(0, 256, (h, w, width), dtype=np.uint8)
+        p.add_texture_2d_encoded(fmt, w, h, [raw.tobytes()], generate_mips=True)
+        t = o.add_texture_2d_encoded(fmt, w, h, [raw.tobytes()], generate_mips=True)
+        d = o.tex_descs[t]
+        n = sum(max(1, w >> k) * max(1, h >> k) for k in range(int(d[3])))
+        want.append(o.tex_pool[int(d[0]): int(d[0]) + n].view(np.uint8).reshape(-1, 4))
+    got = p.readback_texels()
+    want = np.concatenate(want)
+    assert got.shape == want.shape
+    bad = (got != want).any(axis=1)
+    assert not bad.any(), f"{bad.sum()} of {len(bad)} texels differ, first at {np.nonzero(bad)[0][:4]}: {got[bad][:4].tolist()} vs {want[bad][:4].tolist()}"
+
+
 def test_texture_decode_matches_oracle(r3):
     """Row N2, formats: every source format r3n_textures_write_encoded accepts, decoded / expanded on the GPU
     (csrc/texture_decode.hip) against the oracle's decoders (oracle/bcn.c, pinned on an independent decoder's output):
