@@ -2,18 +2,36 @@
 
 -ffp-contract=off: every f32 operation rounds once (no FMA contraction) -- the arithmetic contract the
 bit-exact visible-set parity rests on.  Division and sqrt stay correctly rounded
-(hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+(hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  The opt-in FAST shading variants (r3n_config.shade_mode)
+are separate kernels inside shade.hip that enable contraction / approximate reciprocals locally.
+
+Every translation unit is compiled on its own (in parallel) and the objects are linked; only the units whose
+dependencies changed are recompiled.
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 SO = os.path.join(HERE, "librend3_amd.so")
-SOURCES = ["r3n.hip", "blend_sort.hip", "texture_decode.hip", "anim.hip", "host.cpp"]
-DEPS = SOURCES + ["layouts.h", "device_math.h", "texture.h", "kernels_cull.h", "kernels_raster.h", "bc7_tables.h", "../../include/r3n.h"]
+COMMON = ["layouts.h", "device_math.h", "../../include/r3n.h"]
+# translation unit -> the headers it includes (besides COMMON)
+UNITS = {
+    "r3n.hip": ["texture.h", "kernels_cull.h", "kernels_raster.h", "kernels_shade.h"],
+    "shade.hip": ["texture.h", "kernels_shade.h"],
+    "shade_ms.hip": ["texture.h", "kernels_shade.h"],
+    "shade_blend.hip": ["texture.h", "kernels_shade.h"],
+    "blend_sort.hip": [],
+    "texture_decode.hip": ["bc7_tables.h"],
+    "anim.hip": [],
+    "host.cpp": [],
+}
+SOURCES = list(UNITS)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():
@@ -23,27 +41,56 @@ def hipcc():
     raise RuntimeError("hipcc not found: rend3_amd needs ROCm's hipcc to build its gfx950 kernels")
 
 
+def _deps(unit):
+    return [os.path.join(CSRC, d) for d in [unit] + UNITS[unit] + COMMON]
+
+
+def _obj(unit, obj_dir=OBJ):
+    return os.path.join(obj_dir, unit.replace(".", "_") + ".o")
+
+
+def _stale(unit, obj_dir=OBJ):
+    o = _obj(unit, obj_dir)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in _deps(unit))
+
+
 def up_to_date():
     if not os.path.exists(SO):
         return False
     t = os.path.getmtime(SO)
-    return all(os.path.getmtime(os.path.join(CSRC, d)) <= t for d in DEPS)
+    return all(os.path.getmtime(d) <= t for u in UNITS for d in _deps(u))
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
+def build(force=False, verbose=False, extra=None, out=SO, obj_dir=OBJ):
+    """extra: additional compiler flags (variant builds, tools/variants.py); they go into their own object directory."""
+    if extra is None:
+        extra = os.environ.get("R3N_EXTRA_CXXFLAGS", "").split()
+    if not force and not extra and out == SO and up_to_date():
         return SO
-    extra = os.environ.get("R3N_EXTRA_CXXFLAGS", "").split()
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", SO] + extra + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    os.makedirs(obj_dir, exist_ok=True)
+    todo = [u for u in UNITS if force or extra or _stale(u, obj_dir)]
+
+    def compile_unit(u):
+        cmd = [hipcc()] + FLAGS + extra + ["-c", "-o", _obj(u, obj_dir), os.path.join(CSRC, u)]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        return u, subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
+        results = list(pool.map(compile_unit, todo))
+    for u, res in results:
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {u}:\n" + res.stdout + res.stderr)
+        if verbose:
+            sys.stderr.write(res.stderr)
+    link = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + [_obj(u, obj_dir) for u in UNITS]
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    if verbose:
-        sys.stderr.write(res.stderr)
-    return SO
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    return out
 
 
 if __name__ == "__main__":

@@ -12,6 +12,8 @@
 
 #include "kernels_cull.h"
 #include "kernels_raster.h"
+#define R3N_SHADE_DECL_ONLY
+#include "kernels_shade.h"
 
 namespace {
 
@@ -154,6 +156,7 @@ int fail(r3n_ctx *c, int code, const std::string &msg) {
 
 int sync_all(r3n_ctx *c);
 int join_shade(r3n_ctx *c);
+int join_lanes(r3n_ctx *c);
 
 // Grow-only device buffer.  preserve: keep old contents; fill: byte value for the newly allocated tail.
 int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
@@ -164,6 +167,10 @@ int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
     HIP_TRY(c, hipMalloc(&np, want));
     size_t kept = 0;
     if (preserve && b.p && b.bytes) {
+        // a lane or the shade stream may still be writing the old allocation: the snapshot must come after them
+        int r = join_lanes(c);
+        if (r == R3N_OK) r = join_shade(c);
+        if (r != R3N_OK) { (void)hipFree(np); return r; }
         HIP_TRY(c, hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, c->stream));
         kept = b.bytes;
     }
@@ -448,8 +455,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
              ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK &&
              ensure(c, c->big_uv[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_uv), false, -1) == R3N_OK;
     if (ok) {
-        hipLaunchKernelGGL(k_build_srgb_lut, dim3((R3N_SRGB_LUT_SIZE + 255u) / 256u), dim3(256), 0, c->stream,
-                           c->srgb_lut.as<unsigned char>());
+        (void)r3n_internal_build_srgb_lut(c->srgb_lut.as<unsigned char>(), c->stream);
         // sRGB8 -> linear decode table for texture fetches: built on the HOST (libm powf, like the oracle's), because
         // every entry feeds f32 filtering arithmetic directly -- a last-ulp difference between libm and the device
         // math library in any of the 256 entries would show up as 1-ulp HDR differences
@@ -575,6 +581,14 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
     }
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t nt = records[i].enabled ? records[i].index_count / 3u : 0u;
+        // A slot rewritten in place with another triangle count (not reachable through rend3's own API, where a handle is
+        // disabled for a frame before it is reused, but legal through this ABI) must not index last frame's result bits
+        // with this frame's triangle numbers: it counts as "not batched last frame" (batching.rs:226).
+        if (c->h_ntri[slots[i]] != 0u && nt != c->h_ntri[slots[i]] && c->viewport.has_prev) {
+            DevBuf &pb = c->viewport.slot_base[1 - c->viewport.cur];
+            if (pb.p && (size_t)(slots[i] + 1u) * 4u <= pb.bytes)
+                HIP_TRY(c, hipMemsetAsync(pb.as<uint32_t>() + slots[i], 0xFF, 4, c->stream));
+        }
         c->total_tris = c->total_tris - c->h_ntri[slots[i]] + nt;
         c->h_ntri[slots[i]] = nt;
         c->h_material[slots[i]] = records[i].material_index;
@@ -818,8 +832,15 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         const r3n_skinning_input40 &in = inputs[i];
         if (in.joint_indices_offset == R3N_INVALID || in.joint_weight_offset == R3N_INVALID)
             return fail(c, R3N_ERR_INVALID_ARG, "skinning: skeleton without joint indices / weights (SkeletonCreationError)");
-        if ((uint64_t)in.joint_weight_offset / 4 + (uint64_t)in.vertex_count * 4 > mesh_words)
-            return fail(c, R3N_ERR_INVALID_ARG, "skinning: attribute range outside the mesh buffer");
+        // every attribute run the kernel touches: (byte offset, words per vertex); INVALID inputs read zeros, INVALID outputs are skipped
+        const uint32_t runs[9][2] = {{in.base_position_offset, 3}, {in.base_normal_offset, 3}, {in.base_tangent_offset, 3},
+                                     {in.joint_indices_offset, 2}, {in.joint_weight_offset, 4}, {in.updated_position_offset, 3},
+                                     {in.updated_normal_offset, 3}, {in.updated_tangent_offset, 3}, {R3N_INVALID, 0}};
+        for (const auto &run : runs) {
+            if (run[0] == R3N_INVALID) continue;
+            if ((run[0] & 3u) != 0u || (uint64_t)run[0] / 4 + (uint64_t)in.vertex_count * run[1] > mesh_words)
+                return fail(c, R3N_ERR_INVALID_ARG, "skinning: attribute range outside the mesh buffer");
+        }
         if (in.joint_matrix_base_offset >= n_joints) return fail(c, R3N_ERR_INVALID_ARG, "skinning: joint matrix base out of range");
     }
     // skeleton records change rarely: rebuild the wave -> skeleton map only when they do
@@ -1228,7 +1249,8 @@ int r3n_resolve_opaque(r3n_ctx *c) {
             if (c->aux_used[k]) {  // the shadow atlas must be complete
                 HIP_TRY(c, hipEventRecord(c->join_ev[k], c->aux[k]));
                 HIP_TRY(c, hipStreamWaitEvent(c->shade, c->join_ev[k], 0));
-                c->aux_used[k] = false;
+                // aux_used[k] stays set: r3n_frame_end still has to order the MAIN stream behind the lanes, because the
+                // next frame's r3n_uniform_bake uploads the shadow camera headers (single-buffered) on the main stream
             }
     } else {
         TRY(join_lanes(c));  // the shadow atlas must be complete
@@ -1249,19 +1271,15 @@ int r3n_resolve_opaque(r3n_ctx *c) {
         a.tri_rec = c->tri_rec.as<TriRecord>();
         a.seen = c->tri_seen.as<unsigned char>();
         Timed t(c, R3N_STAGE_VERTEX, stream);
-        HIP_TRY(c, hipMemsetAsync(a.seen, 0, (size_t)c->total_tris, stream));
         const size_t first = (size_t)r0 * c->width * c->samples, npx = (size_t)(r1 - r0) * c->width * c->samples;  // keys, not pixels
-        hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, a.vis, a.seen, first, npx);
-        const dim3 vgrid((unsigned)(((size_t)c->total_tris + 255) / 256));
-        if (tex) hipLaunchKernelGGL(k_vertex_stage<true>, vgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(k_vertex_stage<false>, vgrid, dim3(256), 0, stream, a);
+        HIP_TRY(c, (hipError_t)r3n_internal_shade_prepass(&a, tex ? 1 : 0, first, npx, stream));
     }
     {
         Timed t(c, R3N_STAGE_SHADE, stream);
-        const dim3 rgrid((c->width + 15u) / 16u, (r1 - r0 + 15u) / 16u);
         const uint64_t npix_all = (uint64_t)c->width * c->height;
+        bool split = false;
         if (c->samples == 4 && a.tri_rec != nullptr && a.samples_out == nullptr && npix_all < (1ull << 29) && R3N_MSAA_SPLIT) {
-            // split resolve: first triangle of every pixel here, the extra triangles of edge pixels in a dense second pass
+            // split resolve: first triangle of every pixel, the extra triangles of edge pixels in a dense second pass
             uint32_t cap = (uint32_t)((uint64_t)(r1 - r0) * c->width * 3u / R3N_EDGEQ) + 4096u;
             if (c->edge_capacity_override) cap = c->edge_capacity_override;  // R3N_EDGE_CAPACITY: exercises the overflow path in tests
             TRY(ensure(c, c->samples16, (size_t)npix_all * 4 * 8, false, -1));
@@ -1272,28 +1290,9 @@ int r3n_resolve_opaque(r3n_ctx *c) {
             a.edge_count = c->edge_count.as<uint32_t>();
             a.edge_capacity = cap;
             HIP_TRY(c, hipMemsetAsync(a.edge_count, 0, R3N_EDGEQ * 4, stream));
-            const dim3 egrid(R3N_EDGEQ * 64u);
-            if (tex) {
-                hipLaunchKernelGGL((k_resolve_opaque<4, true, true, true>), rgrid, dim3(256), 0, stream, a);
-                hipLaunchKernelGGL((k_resolve_edges<true, true>), egrid, dim3(256), 0, stream, a);
-            } else {
-                hipLaunchKernelGGL((k_resolve_opaque<4, false, true, true>), rgrid, dim3(256), 0, stream, a);
-                hipLaunchKernelGGL((k_resolve_edges<false, true>), egrid, dim3(256), 0, stream, a);
-            }
-            hipLaunchKernelGGL(k_resolve_edge_pixels, egrid, dim3(256), 0, stream, a);
-        } else if (c->samples == 4 && a.tri_rec != nullptr) {
-            if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true, true>), rgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_resolve_opaque<4, false, true>), rgrid, dim3(256), 0, stream, a);
-        } else if (c->samples == 4) {
-            if (tex) hipLaunchKernelGGL((k_resolve_opaque<4, true>), rgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_resolve_opaque<4, false>), rgrid, dim3(256), 0, stream, a);
-        } else if (a.tri_rec != nullptr) {
-            if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_resolve_opaque<1, false, true>), rgrid, dim3(256), 0, stream, a);
-        } else {
-            if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, false>), rgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_resolve_opaque<1, false, false>), rgrid, dim3(256), 0, stream, a);
+            split = true;
         }
+        HIP_TRY(c, (hipError_t)r3n_internal_resolve(&a, c->samples, tex ? 1 : 0, a.tri_rec != nullptr ? 1 : 0, split ? 1 : 0, stream));
     }
     TRY(check_launch(c, "k_resolve_opaque"));
     if (on_shade) {
@@ -1413,17 +1412,11 @@ static int forward_blend(r3n_ctx *c) {
     if (S == 4 && !c->samples16.p) return fail(c, R3N_ERR_STATE, "forward: r3n_blend_order_write must precede r3n_resolve_opaque");
     {
         Timed t(c, R3N_STAGE_SHADE, stream);
-        const dim3 g((n_frag + 255u) / 256u);
         const bool tex = c->n_textures > 0;
+        HIP_TRY(c, (hipError_t)r3n_internal_blend_apply(&sa, &ba, S, tex ? 1 : 0, stream));
         if (S == 4) {
-            if (tex) hipLaunchKernelGGL((k_blend_apply<4, true>), g, dim3(256), 0, stream, sa, ba);
-            else hipLaunchKernelGGL((k_blend_apply<4, false>), g, dim3(256), 0, stream, sa, ba);
             const size_t first = (size_t)r0 * c->width, npx = (size_t)(r1 - r0) * c->width;
-            hipLaunchKernelGGL(k_resolve_samples, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream,
-                               c->samples16.as<ushort4>(), c->hdr16.as<ushort4>(), first, npx);
-        } else {
-            if (tex) hipLaunchKernelGGL((k_blend_apply<1, true>), g, dim3(256), 0, stream, sa, ba);
-            else hipLaunchKernelGGL((k_blend_apply<1, false>), g, dim3(256), 0, stream, sa, ba);
+            HIP_TRY(c, (hipError_t)r3n_internal_resolve_samples(c->samples16.as<ushort4>(), c->hdr16.as<ushort4>(), first, npx, stream));
         }
     }
     c->resolved_this_frame = false;  // the fused blit shows the HDR target before blending: r3n_tonemap re-runs it
@@ -1436,10 +1429,9 @@ static int launch_tonemap(r3n_ctx *c, float4 *f32_out) {
     if (r1 <= r0) return R3N_OK;
     const size_t first = (size_t)r0 * c->width, n = (size_t)(r1 - r0) * c->width;
     Timed t(c, R3N_STAGE_TONEMAP);
-    const size_t pairs = (n + 1) / 2;
-    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, c->stream, c->hdr16.as<ushort4>(),
-                       c->out8.as<uchar4>(), f32_out, first, n, c->srgb_lut.as<unsigned char>(), c->output_format);
-    return check_launch(c, "k_tonemap");
+    HIP_TRY(c, (hipError_t)r3n_internal_tonemap(c->hdr16.as<ushort4>(), c->out8.as<uchar4>(), f32_out, first, n, c->srgb_lut.as<unsigned char>(),
+                                                c->output_format, c->stream));
+    return R3N_OK;
 }
 
 int r3n_hdr_write(r3n_ctx *c, const uint16_t *rgba16f, uint64_t first_pixel, uint64_t n_pixels) {
@@ -1474,8 +1466,7 @@ int r3n_set_output_format(r3n_ctx *c, uint32_t format) {
             }
             HIP_TRY(c, hipMemcpy(c->srgb_lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice));
         } else {
-            hipLaunchKernelGGL(k_build_srgb_lut, dim3((R3N_SRGB_LUT_SIZE + 255u) / 256u), dim3(256), 0, c->stream, c->srgb_lut.as<unsigned char>());
-            TRY(check_launch(c, "k_build_srgb_lut"));
+            HIP_TRY(c, (hipError_t)r3n_internal_build_srgb_lut(c->srgb_lut.as<unsigned char>(), c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }

@@ -417,6 +417,8 @@ class Renderer:
         """Renderer::update_material: rewrites the material's 208-B record in place (r3n_materials_write orders itself
         after a resolve still in flight)."""
         key = self.materials[handle][1] if key is None else key
+        if key != self.materials[handle][1]:
+            self._blend_cache = None  # the material moved into / out of the transparent pass
         self.materials[handle] = (np.asarray(record, dtype=f32), key)
         slots = np.array([handle], dtype=np.uint32)
         rec = np.ascontiguousarray(record, dtype=f32).reshape(1, 52)

@@ -20,17 +20,16 @@ def build(specs):
     from rend3_amd import build as b
     os.makedirs(VDIR, exist_ok=True)
     for f in os.listdir(VDIR):
-        os.remove(os.path.join(VDIR, f))
-    procs = []
-    for spec in specs:
+        if f.endswith(".so"):
+            os.remove(os.path.join(VDIR, f))
+    for spec in specs:  # every variant compiles its translation units in parallel (rend3_amd/build.py)
         name, _, flags = spec.partition("=")
-        out = os.path.join(VDIR, f"lib_{name}.so")
-        cmd = [b.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-function", "-o", out] + [f for f in flags.split(",") if f] + [os.path.join(b.CSRC, s) for s in b.SOURCES]
-        procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for name, p in procs:
-        out, _ = p.communicate()
-        print(name, "ok" if p.returncode == 0 else "FAILED\n" + out)
+        try:
+            b.build(force=True, extra=[f for f in flags.split(",") if f] or ["-DR3N_VARIANT_BASE"], out=os.path.join(VDIR, f"lib_{name}.so"),
+                    obj_dir=os.path.join(VDIR, f"obj_{name}"))
+            print(name, "ok")
+        except RuntimeError as e:
+            print(name, "FAILED\n" + str(e))
 
 
 def run(steps):
