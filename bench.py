@@ -5,14 +5,19 @@
   (N > 1: launched as python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one whole frame of the hot path over the synthetic Bistro-like scene of BASELINE.json configs[2]
-(rend3_amd/scenes.py::bistro_like: ~3 000 objects, ~2.8 M triangles, 130 PBR materials, 4 directional lights with
-2048^2 shadow views, 3840x2160, camera dollying down the street so the residual pass has real work):
+(rend3_amd/scenes.py::bistro_like: ~3 000 objects each owning its geometry -- ~2.8 M unique triangles, a ~216 MB mesh
+buffer --, 130 PBR materials, 4 directional lights with 2048^2 shadow views, 3840x2160, camera dollying down the street
+so the residual pass has real work; --instanced is the round-1 variant whose 11 shared meshes fit in L2):
   per shadow view: uniform bake -> object frustum cull + slot scan -> triangle cull + compaction -> depth raster;
   viewport: bake -> raster predicted -> Hi-Z -> cull -> raster residual -> PBR resolve -> tonemap.
 All inputs are resident in HBM before the timed region; per-frame camera blocks (a few KB) are precomputed on the
 host and uploaded through the C ABI exactly as the Rust side would.  value = W*H*K / time (whole job, all ranks).
-Prints ONE JSON line on rank 0.
+At N=1 the first two frames (camera steps 0 and 1) are rendered with a read-back of step 1, and the CPU oracle -- which
+renders the same steps for the `cpu_baseline` figure anyway -- checks that frame: visible-object sets, per-triangle
+pass / residual sets, visibility keys, shadow atlas and the Rgba16Float target bit for bit, the tonemapped framebuffer
+within 1e-3 (`"parity"` in the JSON line).  Prints ONE JSON line on rank 0.
 """
+import hashlib
 import argparse
 import json
 import math
@@ -27,6 +32,45 @@ WIDTH, HEIGHT = 3840, 2160
 AMBIENT = (0.1, 0.1, 0.1, 1.0)
 CLEAR = (0.25, 0.45, 0.8, 1.0)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK_TFLOPS = 157.3  # same guide: peak FP32 vector rate (packed FMA: 2 lanes x 2 flop per lane-slot and issue cycle)
+
+
+def kernel_sources_sha():
+    """sha256 over the library's kernel sources: profiles/traffic.json is stamped with it when the PMC passes are taken
+    (tools/make_traffic.py), and the counters are only quoted by a build of the same sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rend3_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def compare_frames(fo, fp):
+    """Oracle frame `fo` against the HIP frame `fp` (read-back dicts): what must be bit-exact is counted, the tonemapped
+    framebuffer is measured.  Same checks as tests/test_gpu_parity.py::compare_frames."""
+    import numpy as np
+    n = len(fo["pass"])
+    enabled = fo["objects"][:, 29] != 0
+    out = {
+        "baked_matrices_equal": bool(np.array_equal(fo["baked"].view(np.uint32)[enabled], fp["baked"].view(np.uint32)[enabled])),
+        "visible_objects_differ": int((fo["visible"] != fp["visible"]).sum()),
+        "pass_triangles_differ": int((fo["pass"] != fp["pass"][:n]).sum()),
+        "residual_triangles_differ": int((fo["residual"] != fp["residual"][:n]).sum()),
+        "shadow_views_sets_differ": int(sum(int((so["visible"] != sp["visible"]).sum()) + int((so["pass"] != sp["pass"][: len(so["pass"])]).sum())
+                                            for so, sp in zip(fo["shadows"], fp["shadows"]))),
+        "visibility_keys_differ_px": int((fo["vis"] != fp["vis"]).sum()),
+        "shadow_atlas_differ_texels": int((fo["atlas"].view(np.uint32) != fp["atlas"].view(np.uint32)).sum()),
+        "hdr_f16_differ_px": int((fo["hdr16"] != fp["hdr16"]).any(axis=2).sum()),
+        "framebuffer_max_abs": float(np.abs(fo["rgba_f32"] - fp["rgba_f32"]).max()),
+        "rgba8_max_lsb": int(np.abs(fo["rgba8"].astype(np.int16) - fp["rgba8"].astype(np.int16)).max()),
+        "visible_objects": int(fo["visible"].sum()), "pass_triangles": int(fo["pass"].sum()),
+        "residual_triangles": int(fo["residual"].sum()), "covered_px": int((fo["vis"] != 0).sum()),
+    }
+    out["ok"] = bool(out["baked_matrices_equal"] and all(out[k] == 0 for k in out if k.endswith(("_differ", "_differ_px", "_differ_texels")))
+                     and out["framebuffer_max_abs"] <= 1e-3 and out["rgba8_max_lsb"] <= 1)
+    return out
 
 
 def camera_path(hm, view0, step):
@@ -34,12 +78,6 @@ def camera_path(hm, view0, step):
     d = 0.15 * step
     yaw = 0.02 * math.sin(0.25 * step)
     return hm.mat4_mul(hm.mat4_mul(hm.rotation_y(yaw), hm.translation((0.0, 0.0, d))), view0)
-
-
-def build_scene(r3, objects, tris, width, height):
-    r = r3.Renderer(r3.host.RIGHT, float(width) / float(height))
-    info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=objects, target_tris=tris)
-    return r, info
 
 
 def main():
@@ -57,7 +95,10 @@ def main():
                     help="run the multi-GPU exchange path (RCCL all-reduce / all-gather) even with one rank: plumbing check")
     ap.add_argument("--samples", type=int, default=1, choices=(1, 4),
                     help="SampleCount of the viewport targets (the reference's scene_viewer default is 4); the headline metric is quoted at 1")
-    ap.add_argument("--cpu-sample-frames", type=int, default=1)
+    ap.add_argument("--cpu-sample-frames", type=int, default=5, help="steady-state oracle frames timed for cpu_baseline (median)")
+    ap.add_argument("--instanced", action="store_true",
+                    help="the round-1 stand-in: 3 000 objects instancing 11 shared meshes (1.5 MB of geometry, L2-resident) instead "
+                         "of one mesh per object (~216 MB)")
     args = ap.parse_args()
 
     import numpy as np
@@ -85,8 +126,9 @@ def main():
     # ---------------------------------------------------------------- scene: replicated on every rank
     r = r3.Renderer(r3.host.RIGHT, np.float32(WIDTH) / np.float32(HEIGHT), device=local_rank)
     info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=args.objects, target_tris=args.tris,
-                                 textured=not args.untextured)
+                                 textured=not args.untextured, unique=not args.instanced)
     view0 = info["camera"][0]
+    hbm_measured = r.hbm_copy_rate(1 << 30, 5)
     exchange = None
     if distributed:
         counts = np.zeros(r.capacity, dtype=np.int64)
@@ -113,13 +155,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---------------------------------------------------------------- parity frames (N=1): camera steps 0 and 1, read-back of step 1
+    check = world == 1 and not args.no_cpu_baseline and not args.force_exchange
+    hip_frame1 = None
+    step0 = 0
+    if check:
+        frame(0)
+        hip_frame1 = frame(1, readback=True)
+        step0 = 2
     # ---------------------------------------------------------------- warmup + timed region
     for k in range(args.warmup):
-        frame(k)
+        frame(step0 + k)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        frame(args.warmup + k)
+        frame(step0 + args.warmup + k)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -136,21 +186,31 @@ def main():
     r.stage_times(reset=True)
     n_inst = min(args.steps, 20)
     for k in range(n_inst):
-        frame(args.warmup + args.steps + k)
+        frame(step0 + args.warmup + args.steps + k)
     r.sync()
     stages = r.stage_times(reset=True)
     r.timing_enable(False)
     r.set_multi_stream(True)
-    last = frame(args.warmup + args.steps + n_inst, readback=(world == 1))
+    last = frame(step0 + args.warmup + args.steps + n_inst, readback=(world == 1))
 
     result = None
-    traffic, valu_busy = {}, {}
-    try:  # HBM bytes per launch from the committed PMC passes (collected separately, see profiles/r01_summary.md)
+    # HBM bytes / VALU instructions per launch from the PMC passes (collected in their own rocprofv3 runs, tools/profile_round.sh
+    # + tools/make_traffic.py).  Quoted only when they were taken on these kernel sources and this workload variant.
+    traffic, valu_busy, valu_insts, traffic_note = {}, {}, {}, "no PMC pass on record"
+    variant = ("instanced" if args.instanced else "unique") + ("-untextured" if args.untextured else "-textured") + f"-s{args.samples}"
+    try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             committed = json.load(fh)
+        if committed.get("kernel_sources_sha") != kernel_sources_sha():
+            traffic_note = "stale: PMC passes were taken on other kernel sources (" + str(committed.get("kernel_sources_sha")) + ")"
+        elif committed.get("variant") != variant:
+            traffic_note = "PMC passes on record are for workload variant " + str(committed.get("variant"))
+        else:
             traffic = committed.get("bytes_per_launch", {})
             valu_busy = committed.get("valu_busy", {})
-    except OSError:
+            valu_insts = committed.get("valu_insts_per_launch", {})
+            traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* passes of " + str(committed.get("taken", "?")) + ", same kernel sources"
+    except (OSError, ValueError):
         pass
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -160,9 +220,30 @@ def main():
         launches = {s: n / n_inst for s, (_ms, n) in stages.items()}
         cull_ms = stage_ms["bake"] + stage_ms["object_cull"] + stage_ms["triangle_cull"]
         tri_cull_ms_per_launch = stage_ms["triangle_cull"] / max(launches["triangle_cull"], 1)
-        # roofline objects: algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 5) / average launch duration
-        # from HIP events recorded on the context's stream around that kernel's launches (instrumented pass above)
-        roof = roof_cull = None
+        # roofline objects: algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 5: the minimum traffic the
+        # inputs and outputs imply, not this implementation's) / average launch duration from HIP events recorded on the
+        # context's stream around that kernel's launches (instrumented pass above, single stream).
+        rooflines = {}
+
+        def roofline_of(kernel, stage, bytes_per_launch, traffic_key, note, extra=None):
+            ms = stage_ms[stage] / max(launches[stage], 1)
+            ach = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            d = {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(traffic_key) if world == 1 else None,
+                 "peak_measured": round(hbm_measured, 1), "frac_of_measured_peak": round(ach / hbm_measured, 5) if hbm_measured else None,
+                 "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(ms, 5), "ms_per_frame": round(stage_ms[stage], 5),
+                 "traffic_source": traffic_note, "note": note}
+            vi = valu_insts.get(traffic_key) if world == 1 else None
+            if vi:  # SQ_INSTS_VALU wave-instructions per launch x 64 lanes / launch time against the vector peak: the peak counts a
+                # packed FMA as 4 flop per lane-slot, a plain (non-packed, non-fused) f32 op is 1 -- so 0.25 is the ceiling of such code
+                lane_ops = vi * 64.0 / (ms * 1e-3) / 1e12
+                d["valu"] = {"insts_per_launch": int(vi), "lane_ops_T_per_s": round(lane_ops, 2), "peak_tflops": VALU_PEAK_TFLOPS,
+                             "frac_of_vector_peak": round(lane_ops / VALU_PEAK_TFLOPS, 4), "busy": valu_busy.get(traffic_key)}
+            if extra:
+                d.update(extra)
+            rooflines[stage] = d
+            return d
+
         if last is not None:
             vis_tris = 0
             per_launch = []
@@ -177,35 +258,33 @@ def main():
                 # triangle cull: 48 B in + 12 B * pass + 12 B * new + 0.25 B out per triangle slot the launch processes
                 per_launch.append(48.0 * t_in + 12.0 * n_pass + 12.0 * n_new + 0.25 * t_in)
                 vis_tris += t_in
-            bytes_per_launch = float(np.mean(per_launch))
-            achieved = bytes_per_launch / (tri_cull_ms_per_launch * 1e-3) / 1e9
-            roof_cull = {"kernel": "k_triangle_cull", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic.get("k_triangle_cull") if world == 1 else None,
-                         "bytes_per_launch": int(bytes_per_launch), "ms_per_launch": round(tri_cull_ms_per_launch, 5),
-                         "triangles_per_launch": vis_tris // len(cams)}
-        # dominant kernel by GPU time: the deferred PBR resolve (one launch per frame).  Its HBM floor is 8 B key read +
-        # 8 B Rgba16Float write per pixel (">= 16 B / shaded pixel") + 4 B for the Rgba8UnormSrgb
-        # blit fused into it.  The kernel is VALU-bound, not HBM-bound (SQ_ACTIVE_INST_VALU = the whole SIMD issue
-        # capacity of the launch, profiles/r01_summary.md), so the fraction of the HBM roofline is small by construction.
-        shade_ms = stage_ms["shade"] / max(launches["shade"], 1)
-        shade_bytes = 20.0 * WIDTH * HEIGHT / world
-        ach = shade_bytes / (shade_ms * 1e-3) / 1e9
-        roof = {"kernel": "k_resolve_opaque", "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get("k_resolve_opaque") if world == 1 else None,
-                "bytes_per_launch": int(shade_bytes),
-                "ms_per_launch": round(shade_ms, 5),
-                "valu_busy": valu_busy.get("k_resolve_opaque" if not args.untextured else "k_resolve_opaque_untextured") if world == 1 else None,
-                "note": "dominant kernel by time; VALU-bound, not HBM-bound: valu_busy = SQ_ACTIVE_INST_VALU / SIMD issue cycles of the "
-                        "launch (SQ counter pass, profiles/r01_summary.md section 2); about "
-                        + ("1500" if args.untextured else "2400") + " vector instructions per pixel (4 lights x (5-tap PCF + GGX)"
-                        + ("" if args.untextured else ", 3 trilinear maps, tangent frame") + ", all IEEE div/sqrt); bytes = key + HDR + sRGB per pixel, texels excluded"}
+            roofline_of("k_triangle_cull", "triangle_cull", float(np.mean(per_launch)), "k_triangle_cull",
+                        "48 B in + 12 B per passing + 12 B per newly visible + 0.25 B out per triangle of the frustum-visible objects, mean over the 5 cameras",
+                        {"triangles_per_launch": vis_tris // len(cams)})
+            # shadow views: <= 72 B per drawn triangle (8 B list entry + 12 B indices + 36 B positions, + setup hand-over) and 4 B per
+            # covered atlas texel (the final depth: overdraw is this implementation's, not the algorithm's)
+            drawn = float(np.mean([int(c["pass"].sum()) for c in last["shadows"]])) if last["shadows"] else 0.0
+            covered = float((last["atlas"] != 0).sum()) / max(len(last["shadows"]), 1)
+            for stage, kname in (("shadow_raster", "k_raster_small<depth>"), ("shadow_raster_big", "k_raster_big<depth>")):
+                if launches.get(stage):
+                    roofline_of(kname, stage, 56.0 * drawn + 4.0 * covered, kname,
+                                "per shadow view: 56 B per drawn triangle + 4 B per covered texel, charged to each of the view's raster launches "
+                                "(both walk the same triangles / texels between them)", {"drawn_triangles": int(drawn), "covered_texels": int(covered)})
+        # the deferred PBR resolve (one launch per frame).  HBM floor: 8 B key read + 8 B Rgba16Float write per pixel (BASELINE.md
+        # section 5: ">= 16 B / shaded pixel") + 4 B for the Rgba8UnormSrgb blit fused into it.  VALU-bound, not HBM-bound, so its
+        # fraction of the HBM roofline is small by construction; `valu` says how close it is to its own bound.
+        roofline_of("k_resolve_opaque", "shade", 20.0 * WIDTH * HEIGHT / world, "k_resolve_opaque",
+                    "8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; VALU-bound: 4 lights x "
+                    "(5-tap PCF + GGX)" + ("" if args.untextured else ", 3 trilinear maps, tangent frame"))
+        dominant = max(rooflines, key=lambda st: stage_ms[st])
+        roof = dict(rooflines[dominant], dominant_by="largest kernel time per frame in the HIP-event stage table")
         result = {
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2] stand-in: bistro_like (seed 0xB157), 3840x2160, "
+            "config": {"workload": "BASELINE.json configs[2] stand-in: bistro_like (seed 0xB157, "
+                                   + ("11 instanced meshes" if args.instanced else "every object owns its geometry") + "), 3840x2160, "
                                    "full PBR opaque + 4 directional shadow views (2048^2), camera dolly, " + ("MSAA x4, " if args.samples == 4 else "")
                                    + ("factor-only materials" if args.untextured else
                                       "130 materials with base colour + normal + AO/roughness/metallic maps (RGBA8, mips, trilinear)"),
@@ -217,12 +296,17 @@ def main():
             "stage_ms_per_frame": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_launches_per_frame": launches,
             "roofline": roof,
-            "roofline_triangle_cull": roof_cull,
+            "rooflines": {k: v for k, v in rooflines.items() if k != dominant},
+            "hbm_copy_rate_measured_GBps": round(hbm_measured, 1),
+            "mesh_buffer_bytes": info.get("mesh_bytes"), "unique_triangles": info.get("unique_triangles"),
         }
 
     # ---------------------------------------------------------------- CPU baseline: the oracle ("port"), rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, info)
+        cb, parity = cpu_baseline(args, hip_frame1)
+        result["cpu_baseline"] = cb
+        result["parity"] = parity
+        result["vs_cpu_baseline"] = round(result["value"] / cb["value"], 1) if cb["value"] else None
     if rank == 0:
         print(json.dumps(result))
     r.close()
@@ -230,10 +314,12 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, info):
-    """The C oracle (oracle/r3o.c, OpenMP over objects/rows) timed on the host cores on a bounded sample of the same
-    workload: the same scene and camera path, `--cpu-sample-frames` steady-state frames at 4K after one history frame.
-    kind "port": the reference itself (Rust + wgpu on lavapipe) cannot be built here."""
+def cpu_baseline(args, hip_frame1):
+    """The C oracle (oracle/r3o.c; OpenMP over objects / triangles / rows in every stage) on the host cores, on a bounded sample
+    of the same workload: the same scene and camera path, camera step 0 as the history frame, then `--cpu-sample-frames` timed
+    steady-state frames at 4K -- median frame time and the stage split of BASELINE.md section 3.  kind "port": the reference
+    itself (Rust + wgpu on lavapipe) cannot be built here.  The frame of camera step 1 is also what the
+    HIP path's read-back of the same step is checked against (`parity`)."""
     import numpy as np
     from oracle import host as oh
     from oracle.world import OracleRenderer, material_record as omk
@@ -241,18 +327,30 @@ def cpu_baseline(args, info):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     o = OracleRenderer(oh.RIGHT, np.float32(WIDTH) / np.float32(HEIGHT))
-    info_o = r3.scenes.bistro_like(o, oh, omk, n_objects=args.objects, target_tris=args.tris, textured=not args.untextured)
+    info_o = r3.scenes.bistro_like(o, oh, omk, n_objects=args.objects, target_tris=args.tris, textured=not args.untextured,
+                                   unique=not args.instanced)
     view0 = info_o["camera"][0]
     o.set_camera_data(camera_path(oh, view0, 0), info_o["camera"][1])
     o.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR)  # history frame (untimed)
-    t0 = time.perf_counter()
-    for k in range(args.cpu_sample_frames):
+    times, splits, parity = [], [], None
+    for k in range(max(args.cpu_sample_frames, 1)):
         o.set_camera_data(camera_path(oh, view0, 1 + k), info_o["camera"][1])
-        o.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR)
-    dt = time.perf_counter() - t0
-    return {"value": round(WIDTH * HEIGHT * args.cpu_sample_frames / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
-            "kind": "port", "sample": f"{args.cpu_sample_frames} steady-state frame(s) of the same scene/camera path at "
-                                      f"{WIDTH}x{HEIGHT} (oracle C, OpenMP cull+shade, single-thread raster), {dt:.1f} s"}
+        t0 = time.perf_counter()
+        fo = o.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR)
+        times.append(time.perf_counter() - t0)
+        splits.append(dict(o.stage_s))
+        if k == 0 and hip_frame1 is not None:
+            parity = dict(compare_frames(fo, hip_frame1), frame="camera step 1 of the bench's camera path (first frame with temporal history), "
+                                                                f"{WIDTH}x{HEIGHT}, oracle vs HIP read-back")
+        del fo
+    med = float(np.median(times))
+    split = {k: round(float(np.median([sp[k] for sp in splits])), 3) for k in splits[0]}
+    cb = {"value": round(WIDTH * HEIGHT / med / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+          "s_per_frame_median": round(med, 3), "stage_s_median": split,
+          "sample": f"median of {len(times)} steady-state frame(s) (camera steps 1..{len(times)}) of the same scene/camera path at "
+                    f"{WIDTH}x{HEIGHT}, after one history frame; oracle C with OpenMP in every stage on {cores} threads; "
+                    f"{sum(times):.1f} s of CPU wall time"}
+    return cb, parity
 
 
 if __name__ == "__main__":

@@ -373,6 +373,11 @@ int r3n_timing_enable(r3n_ctx *ctx, int enable);
  * stream (enable = 0).  Only between frames. */
 int r3n_set_multi_stream(r3n_ctx *ctx, int enable);
 int r3n_stage_times(r3n_ctx *ctx, double ms[R3N_STAGE_COUNT], uint64_t launches[R3N_STAGE_COUNT], int reset);
+/* Measured HBM streaming rate of this device, the denominator BASELINE.md section 5 asks for ("measured on the target
+ * box, not taken from the datasheet"): a float4 grid-stride copy of `bytes` (>= 64 MiB, well past the 256 MiB Infinity
+ * Cache when 1 GiB) repeated `repeats` times, HIP-event timed; *gb_per_s = (bytes read + bytes written) / best time.
+ * Allocates and frees two scratch buffers; synchronises. */
+int r3n_hbm_copy_rate(r3n_ctx *ctx, uint64_t bytes, uint32_t repeats, double *gb_per_s);
 
 /* ---- host-side mirror of the reference's CPU math on the path (rend3_amd/csrc/host.cpp).
  * In a real integration these stay in Rust (rend3 core); they exist here so the standalone harness, the
@@ -386,8 +391,7 @@ void r3n_host_look_at(const float eye[3], const float center[3], const float up[
 void r3n_host_projection(int kind, const float *params, int rh, float aspect_ratio, float *out);
 /* Frustum::from_matrix, rend3/src/util/frustum.rs:96-145: 5 planes x vec4 */
 void r3n_host_frustum_from_matrix(const float *m, float *planes20);
-/* MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + rend3/shaders/mipmap.wgsl): fills mips 1.. of an
- * RGBA8 chain whose mip 0 is in place; Linear / ClampToEdge blit per level in the texture's own format. */
+/* Frustum::contains_sphere, rend3/src/util/frustum.rs:148-161: 1 when the sphere touches or is inside all 5 planes */
 int r3n_host_frustum_contains_sphere(const float *planes20, const float center[3], float radius);
 /* BoundingSphere::{from_mesh, apply_transform}, frustum.rs:15-56 */
 void r3n_host_bounding_sphere_from_mesh(const float *positions, uint64_t vertex_count, float out_center[3],

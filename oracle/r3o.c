@@ -764,6 +764,18 @@ static float fetch_color_alpha(const r3o_object *ob, const uint32_t *mesh, uint3
 static const float SAMPLE_POS_1[1][2] = {{0.5f, 0.5f}};
 static const float SAMPLE_POS_4[4][2] = {{0.375f, 0.125f}, {0.875f, 0.375f}, {0.125f, 0.625f}, {0.625f, 0.875f}};
 
+/* The two rasterisers run their triangle loops under OpenMP.  Depth test GreaterEqual + write is a max over
+ * (depth, slot) keys, which is order-independent, so the threads merge through compare-and-swap max and the result
+ * equals the serial loop's (depth bits of non-negative floats order like the floats; -0 is canonicalised to +0). */
+static inline void atomic_max_u64(uint64_t *dst, uint64_t v) {
+    uint64_t cur = __atomic_load_n(dst, __ATOMIC_RELAXED);
+    while (v > cur && !__atomic_compare_exchange_n(dst, &cur, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+static inline void atomic_max_u32(uint32_t *dst, uint32_t v) {
+    uint32_t cur = __atomic_load_n(dst, __ATOMIC_RELAXED);
+    while (v > cur && !__atomic_compare_exchange_n(dst, &cur, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
 void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objects, const uint32_t *mesh,
                            const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
                            const uint32_t *tri_base, const uint32_t *list_obj, const uint32_t *list_tri,
@@ -774,6 +786,7 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
     init_srgb8();
     float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f;
     int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+#pragma omp parallel for schedule(dynamic, 64)
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t o = list_obj[i], t = list_tri[i];
         const r3o_object *ob = &objects[o];
@@ -807,6 +820,7 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
                     if (!edge_eval(&ts, (float)x + spos[sm][0], (float)y + spos[sm][1], E)) continue;
                     float z = frag_depth(&ts, E);
                     if (!(z >= 0.0f && z <= 1.0f)) continue;
+                    if (z == 0.0f) z = 0.0f; /* -0 -> +0 */
                     zs[sm] = z;
                     mask |= 1u << sm;
                 }
@@ -829,8 +843,7 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
                     if (!(mask & (1u << sm))) continue;
                     uint32_t zb; memcpy(&zb, &zs[sm], 4);
                     uint64_t k64 = ((uint64_t)zb << 32) | (uint64_t)(slot + 1u);
-                    uint64_t *dst = &vis[((uint64_t)y * w + (uint64_t)x) * samples + sm];
-                    if (k64 > *dst) *dst = k64;
+                    atomic_max_u64(&vis[((uint64_t)y * w + (uint64_t)x) * samples + sm], k64);
                 }
             }
     }
@@ -849,6 +862,7 @@ void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, c
     init_srgb8();
     float half = (float)vp_size / 2.0f;
     int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
+#pragma omp parallel for schedule(dynamic, 64)
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t o = list_obj[i], t = list_tri[i];
         const r3o_object *ob = &objects[o];
@@ -891,8 +905,9 @@ void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, c
                     }
                     if (material_alpha(mat, ta, a) < mat->alpha_cutout) continue;
                 }
-                float *dst = &atlas[(uint64_t)(vp_y + (uint32_t)y) * atlas_w + vp_x + (uint32_t)x];
-                if (z >= *dst) *dst = z;
+                if (z == 0.0f) z = 0.0f; /* -0 -> +0 */
+                uint32_t zb; memcpy(&zb, &z, 4);
+                atomic_max_u32((uint32_t *)&atlas[(uint64_t)(vp_y + (uint32_t)y) * atlas_w + vp_x + (uint32_t)x], zb);
             }
     }
 }
@@ -1397,6 +1412,7 @@ static float srgb_scene_to_display(float x) {
  * bit 1: manual transfer function).  out_f32 stays in r, g, b, a order. */
 void r3o_tonemap_format(const uint16_t *hdr_in, uint64_t npix, float *out_f32, uint8_t *out_u8, uint32_t output_format) {
     const int bgr = (output_format & 1u) != 0u, manual = (output_format & 2u) != 0u;
+#pragma omp parallel for schedule(static)
     for (uint64_t i = 0; i < npix; ++i) {
         for (int c = 0; c < 4; ++c) {
             float v = f16_to_f32(hdr_in[4 * i + c]);

@@ -11,6 +11,8 @@ Mirrors, at the level the hot path needs:
   MeshManager (SoA attribute runs + indices in one u32 buffer)          rend3/src/managers/mesh.rs:123-184
   temporal two-pass culling state                                       SURVEY.md App. B.4
 """
+import time
+
 import numpy as np
 
 from . import host
@@ -191,7 +193,7 @@ class OracleRenderer:
         for a in range(3):  # position, normal, tangent copies private to the skeleton (skeleton.rs:110-113)
             if m.attr_off[a] != INVALID:
                 out_off[a] = 4 * len(self.mesh_words)
-                self.mesh_words = np.concatenate([self.mesh_words, np.zeros(3 * m.vertex_count, dtype=np.uint32)])
+                self._mesh_append([np.zeros(3 * m.vertex_count, dtype=np.uint32)])
         self.skeletons.append(dict(mesh=mesh, out_off=out_off, matrices=np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)))
         return len(self.skeletons) - 1
 
@@ -258,6 +260,20 @@ class OracleRenderer:
         return (lib.ptr(np.ascontiguousarray(self.tex_descs)) if len(self.tex_descs) else None, len(self.tex_descs),
                 lib.ptr(self.tex_pool))
 
+    def _mesh_append(self, chunks):
+        """mesh_words is a view of a buffer that grows geometrically (thousands of meshes: no quadratic re-copy)."""
+        used = len(self.mesh_words)
+        need = used + sum(len(c) for c in chunks)
+        buf = getattr(self, "_mesh_buf", None)
+        if buf is None or need > len(buf):
+            grown = np.zeros(max(need, 2 * (len(buf) if buf is not None else 0), 1024), dtype=np.uint32)
+            grown[:used] = self.mesh_words
+            self._mesh_buf = buf = grown
+        for c in chunks:
+            buf[used:used + len(c)] = c
+            used += len(c)
+        self.mesh_words = buf[:used]
+
     def add_mesh(self, positions, indices=None, normals=None, colors=None, mesh_handedness=host.LEFT, tangents=None,
                  joint_indices=None, joint_weights=None, uv0=None):
         positions = np.ascontiguousarray(positions, dtype=f32).reshape(-1, 3)
@@ -269,7 +285,7 @@ class OracleRenderer:
         normals = np.ascontiguousarray(normals, dtype=f32).reshape(-1, 3)
         m = _Mesh()
         m.attr_off = [INVALID] * 6
-        chunks = [self.mesh_words]
+        chunks = []
         cursor = len(self.mesh_words)
 
         def push(words):
@@ -295,7 +311,7 @@ class OracleRenderer:
             m.weight_off = 4 * push(np.ascontiguousarray(joint_weights, dtype=f32).reshape(-1, 4).view(np.uint32).reshape(-1))
         m.first_index = push(indices)
         m.index_count = len(indices)
-        self.mesh_words = np.concatenate(chunks)
+        self._mesh_append(chunks)
         m.centre, m.radius = host.bounding_sphere_from_mesh(positions)
         self.meshes.append(m)
         return len(self.meshes) - 1
@@ -458,6 +474,18 @@ class OracleRenderer:
         the visibility keys ("pass1", "pass2") at the points DESIGN.md section 6 names."""
         assert samples in (1, 4), "SampleCount::One | SampleCount::Four (rend3-types/src/lib.rs SampleCount)"
         lib = self.lib
+        # wall-clock per stage of this frame (BASELINE.md section 3 split), read by bench.py's cpu_baseline leg
+        stage_s = self.stage_s = {k: 0.0 for k in ("bake", "cull", "hiz", "shadow_depth", "forward_raster", "shade", "tonemap")}
+
+        class _Span:
+            def __init__(self, name):
+                self.name = name
+
+            def __enter__(self):
+                self.t0 = time.perf_counter()
+
+            def __exit__(self, *exc):
+                stage_s[self.name] += time.perf_counter() - self.t0
         # Renderer::evaluate_instructions (renderer/eval.rs): last frame's removals become real
         for h in self.pending_free:
             self.objects[h] = 0
@@ -485,14 +513,17 @@ class OracleRenderer:
         for si, sh in enumerate(shadows):
             hdr = host.camera_header(sh["camera"], si, (sh["size"], sh["size"]), 1, cap, lib)
             baked = np.zeros((cap, 32), dtype=f32)
-            lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
-            visible, tri_base, pass_bits, _ = self._cull(("shadow", si), hdr, baked, None, 0, 0)
-            lo, lt = self._list_from_bits(pass_bits, tri_base)
+            with _Span("bake"):
+                lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
+            with _Span("cull"):
+                visible, tri_base, pass_bits, _ = self._cull(("shadow", si), hdr, baked, None, 0, 0)
+                lo, lt = self._list_from_bits(pass_bits, tri_base)
             if self.skip_shadow_draw:  # test probe only: leaves the atlas at its 0.0 clear, so every compare passes
                 lo, lt = lo[:0], lt[:0]
-            lib.r3o_raster_depth(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words), lib.ptr(baked),
-                                 lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(lo), lib.ptr(lt), len(lo),
-                                 lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"], *self._tex_args())
+            with _Span("shadow_depth"):
+                lib.r3o_raster_depth(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words), lib.ptr(baked),
+                                     lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(lo), lib.ptr(lt), len(lo),
+                                     lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"], *self._tex_args())
             out["shadows"].append(dict(header=hdr, visible=visible, tri_base=tri_base, **{"pass": pass_bits}))
         if exchange is not None and shadows:
             exchange("shadow", atlas)
@@ -500,15 +531,17 @@ class OracleRenderer:
         # 7. viewport bake
         hdr = host.camera_header(cam, None, (width, height), samples, cap, lib)
         baked = np.zeros((cap, 32), dtype=f32)
-        lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
+        with _Span("bake"):
+            lib.r3o_uniform_bake(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(baked))
         vis = np.zeros((height, width) if samples == 1 else (height, width, samples), dtype=np.uint64)
         tri_base_now, _ = self.tri_base()
 
         def draw(lo, lt):
             if len(lo):
-                lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
-                                          lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
-                                          lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, *self._tex_args(), lib.ptr(vis))
+                with _Span("forward_raster"):
+                    lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
+                                              lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
+                                              lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, *self._tex_args(), lib.ptr(vis))
 
         # 8. pass 1: last frame's predicted triangles (forward.rs:224-232)
         predicted = self.cam_state.get("predicted_list")
@@ -521,16 +554,19 @@ class OracleRenderer:
         # 9. Hi-Z from pass-1 depth (hi_z.rs:161-234)
         nm = lib.r3o_hiz_mip_count(width, height)
         pyr = np.zeros(int(lib.r3o_hiz_mip_offset(width, height, nm)), dtype=f32)
-        lib.r3o_vis_to_depth(lib.ptr(vis), width * height, samples, lib.ptr(pyr))
-        lib.r3o_hiz_build(lib.ptr(pyr), width, height)
+        with _Span("hiz"):
+            lib.r3o_vis_to_depth(lib.ptr(vis), width * height, samples, lib.ptr(pyr))
+            lib.r3o_hiz_build(lib.ptr(pyr), width, height)
         out["depth_pass1"] = pyr[: width * height].reshape(height, width).copy()
         out["hiz"] = pyr
         # 10. cull (culler.rs:531-659)
-        visible, tri_base, pass_bits, residual = self._cull("viewport", hdr, baked, pyr, width, height)
+        with _Span("cull"):
+            visible, tri_base, pass_bits, residual = self._cull("viewport", hdr, baked, pyr, width, height)
+            resid_list = self._list_from_bits(residual, tri_base)
+            self.cam_state["predicted_list"] = self._list_from_bits(pass_bits, tri_base)
         assert np.array_equal(tri_base, tri_base_now)
         # 11. pass 2: residual triangles
-        draw(*self._list_from_bits(residual, tri_base))
-        self.cam_state["predicted_list"] = self._list_from_bits(pass_bits, tri_base)
+        draw(*resid_list)
         if exchange is not None:
             exchange("pass2", vis)
 
@@ -554,15 +590,17 @@ class OracleRenderer:
         blend_obj = np.ascontiguousarray(np.concatenate(bo)) if bo else np.zeros(0, dtype=np.uint32)
         blend_tri = np.ascontiguousarray(np.concatenate(bt)) if bt else np.zeros(0, dtype=np.uint32)
         out["blend_list"] = (blend_obj, blend_tri)
-        lib.r3o_shade(lib.ptr(vis), width, height, samples, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
-                      lib.ptr(self.mesh_words), lib.ptr(baked), lib.ptr(mats), lib.ptr(tri_base), n_dir,
-                      lib.ptr(dir_arr) if n_dir else None, n_pt, lib.ptr(pt_arr) if n_pt else None,
-                      lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), *self._tex_args(),
-                      lib.ptr(blend_obj) if len(blend_obj) else None, lib.ptr(blend_tri) if len(blend_tri) else None,
-                      len(blend_obj), lib.ptr(hdr16))
+        with _Span("shade"):
+            lib.r3o_shade(lib.ptr(vis), width, height, samples, lib.ptr(fu), lib.ptr(hdr), lib.ptr(self.objects),
+                          lib.ptr(self.mesh_words), lib.ptr(baked), lib.ptr(mats), lib.ptr(tri_base), n_dir,
+                          lib.ptr(dir_arr) if n_dir else None, n_pt, lib.ptr(pt_arr) if n_pt else None,
+                          lib.ptr(atlas), atlas_size[0], atlas_size[1], lib.ptr(clear), *self._tex_args(),
+                          lib.ptr(blend_obj) if len(blend_obj) else None, lib.ptr(blend_tri) if len(blend_tri) else None,
+                          len(blend_obj), lib.ptr(hdr16))
         rgba_f = np.zeros((height, width, 4), dtype=f32)
         rgba8 = np.zeros((height, width, 4), dtype=np.uint8)
-        lib.r3o_tonemap_format(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8), getattr(self, "output_format", 0))
+        with _Span("tonemap"):
+            lib.r3o_tonemap_format(lib.ptr(hdr16), width * height, lib.ptr(rgba_f), lib.ptr(rgba8), getattr(self, "output_format", 0))
 
         out.update(header=hdr, frame_uniforms=fu, baked=baked, visible=visible, tri_base=tri_base,
                    residual=residual, vis=vis, atlas=atlas, atlas_size=atlas_size, hdr16=hdr16, rgba_f32=rgba_f,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "r3n_timing_enable": (cint, [vp, cint]),
     "r3n_stage_times": (cint, [vp, vp, vp, cint]),
     "r3n_set_multi_stream": (cint, [vp, cint]),
+    "r3n_hbm_copy_rate": (cint, [vp, u64, u32, vp]),
     "r3n_host_mat4_mul": (None, [vp, vp, vp]),
     "r3n_host_mat4_inverse": (None, [vp, vp]),
     "r3n_host_look_at": (None, [vp, vp, vp, cint, vp]),

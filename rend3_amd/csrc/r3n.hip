@@ -1727,6 +1727,40 @@ int r3n_set_multi_stream(r3n_ctx *c, int enable) {
     return R3N_OK;
 }
 
+__global__ __launch_bounds__(256) static void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+
+int r3n_hbm_copy_rate(r3n_ctx *c, uint64_t bytes, uint32_t repeats, double *gb_per_s) {
+    if (!c || !gb_per_s || bytes < (64ull << 20) || repeats == 0) return fail(c, R3N_ERR_INVALID_ARG, "hbm_copy_rate: bytes >= 64 MiB, repeats >= 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t n = bytes / 16;
+    int rc = R3N_OK;
+    float best = 0.0f;
+    if (hipMalloc(&a, n * 16) != hipSuccess || hipMalloc(&b, n * 16) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess || hipMemsetAsync(a, 1, n * 16, c->stream) != hipSuccess) {
+        rc = fail(c, R3N_ERR_HIP, "hbm_copy_rate: scratch allocation failed");
+    } else {
+        for (uint32_t r = 0; r <= repeats && rc == R3N_OK; ++r) {  // first pass untimed (page mapping, clocks)
+            (void)hipEventRecord(e0, c->stream);
+            hipLaunchKernelGGL(k_copy_f4, dim3(256 * 32), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n);
+            (void)hipEventRecord(e1, c->stream);
+            float ms = 0.0f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(c, R3N_ERR_HIP, "hbm_copy_rate: timing failed");
+            else if (r > 0 && (best == 0.0f || ms < best)) best = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (rc == R3N_OK) *gb_per_s = best > 0.0f ? 2.0 * (double)(n * 16) / ((double)best * 1e-3) / 1e9 : 0.0;
+    return rc;
+}
+
 int r3n_stage_times(r3n_ctx *c, double ms[R3N_STAGE_COUNT], uint64_t launches[R3N_STAGE_COUNT], int reset) {
     if (!c) return R3N_ERR_INVALID_ARG;
     TRY(drain_timing(c));

@@ -684,6 +684,12 @@ class Renderer:
         self._check(self.lib.r3n_stage_times(self.ctx, _ffi.ptr(ms), _ffi.ptr(n), 1 if reset else 0), "r3n_stage_times")
         return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(_ffi.STAGES)}
 
+    def hbm_copy_rate(self, nbytes=1 << 30, repeats=5):
+        """GB/s of a float4 copy of `nbytes` on this device (read + write bytes): the measured HBM roofline denominator."""
+        out = ctypes.c_double(0.0)
+        self._check(self.lib.r3n_hbm_copy_rate(self.ctx, int(nbytes), int(repeats), ctypes.byref(out)), "r3n_hbm_copy_rate")
+        return float(out.value)
+
     def sync(self):
         self._check(self.lib.r3n_sync(self.ctx), "r3n_sync")
 

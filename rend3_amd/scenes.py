@@ -99,31 +99,36 @@ class Pcg32:
 
 
 
-def subdivided_box(n, sx=1.0, sy=1.0, sz=1.0):
+def subdivided_box(n, sx=1.0, sy=1.0, sz=1.0, share=True):
     """Box whose 6 faces are n x n quads (12 n^2 triangles), wound like the reference cube
-    (examples/src/cube/mod.rs:39-46): front-facing from outside for a left-handed renderer."""
+    (examples/src/cube/mod.rs:39-46): front-facing from outside for a left-handed renderer.
+    share=False: every quad owns its four vertices (24 n^2 vertices, two per triangle -- the vertex : triangle ratio of
+    meshes with per-face attributes / UV seams) instead of sharing the (n + 1)^2 grid vertices of its face."""
     faces = [((0, 0, 1), (1, 0, 0), (0, 1, 0)), ((0, 0, -1), (-1, 0, 0), (0, 1, 0)), ((1, 0, 0), (0, 0, -1), (0, 1, 0)),
              ((-1, 0, 0), (0, 0, 1), (0, 1, 0)), ((0, 1, 0), (1, 0, 0), (0, 0, -1)), ((0, -1, 0), (1, 0, 0), (0, 0, 1))]
     pos, nrm, idx = [], [], []
     ts = np.linspace(-1.0, 1.0, n + 1)
     for nvec, u, v in faces:
         nvec, u, v = (np.array(a, dtype=np.float64) for a in (nvec, u, v))
-        base = len(pos)
-        for b in ts:
-            for a in ts:
-                pos.append(nvec + a * u + b * v)
-                nrm.append(nvec)
         # orientation: (u x v) . n > 0 means a,b,c order (a -> a+1 -> a+n+1) is CCW seen from outside
         ccw = float(np.dot(np.cross(u, v), nvec)) > 0
-        for j in range(n):
-            for i in range(n):
-                a0 = base + j * (n + 1) + i
-                b0, c0, d0 = a0 + 1, a0 + n + 1, a0 + n + 2
-                tri = [(a0, b0, c0), (b0, d0, c0)] if ccw else [(a0, c0, b0), (b0, c0, d0)]
-                for t in tri:
-                    idx += [t[0], t[1], t[2]]
-    pos = np.array(pos, dtype=f32) * np.array([sx, sy, sz], dtype=f32)
-    return pos, np.array(idx, dtype=np.uint32), np.array(nrm, dtype=f32)
+        grid = nvec[None, None, :] + ts[None, :, None] * u[None, None, :] + ts[:, None, None] * v[None, None, :]  # [b][a]
+        base = sum(len(p_) for p_ in pos)
+        if share:
+            pos.append(grid.reshape(-1, 3))
+            j, i = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+            a0 = (base + j * (n + 1) + i).reshape(-1)
+            b0, c0, d0 = a0 + 1, a0 + n + 1, a0 + n + 2
+        else:
+            quads = np.stack([grid[:-1, :-1], grid[:-1, 1:], grid[1:, :-1], grid[1:, 1:]], axis=2)  # [j][i][corner a,b,c,d]
+            pos.append(quads.reshape(-1, 3))
+            a0 = base + 4 * np.arange(n * n)
+            b0, c0, d0 = a0 + 1, a0 + 2, a0 + 3
+        tri = np.stack([a0, b0, c0, b0, d0, c0], axis=1) if ccw else np.stack([a0, c0, b0, b0, c0, d0], axis=1)
+        idx.append(tri.reshape(-1))
+        nrm.append(np.tile(nvec, (len(pos[-1]), 1)))
+    pos = np.concatenate(pos).astype(f32) * np.array([sx, sy, sz], dtype=f32)
+    return pos, np.concatenate(idx).astype(np.uint32), np.concatenate(nrm).astype(f32)
 
 
 def _flip(idx):
@@ -198,40 +203,72 @@ def procedural_textures(n_albedo=16, n_normal=8, n_orm=8, size=1024, seed=0x7E57
 
 
 def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=130, seed=0xB157, shadow_res=2048,
-                n_lights=4, textured=False):
+                n_lights=4, textured=False, unique=True, tex_size=1024):
     """BASELINE.json configs[2] stand-in (SURVEY.md section 8d cfg 3): street canyon with real occlusion, ~3 000 objects,
     ~2.8 M triangles (log-normal per object), 130 PBR materials (roughness U[0.2,0.9], metallic in {0,1} p=0.2),
     4 directional lights with 2048^2 shadow views, distance 100, ambient 0.1 (applied by the caller),
     Bistro test camera of examples/src/scene_viewer/mod.rs:727-751.  Right-handed like scene_viewer (:435).
-    textured: every material gets a base colour, a normal and a packed AO / roughness / metallic map (1024^2 / 512^2
-    RGBA8 with full mip chains, trilinear) from a pool of 32 procedural textures, like the scanned material set of the
-    real asset; meshes then carry box-projected texture coordinates and tangents.
-    Returns dict(objects, triangles, camera=(view, projection))."""
+    unique (default): EVERY object owns its geometry, like the real asset (~2.8 M unique triangles): its mesh is one of
+    the 11 shapes below with per-quad vertices for the boxes (two vertices per triangle) and a smooth per-object
+    deformation (a sine field of the vertex position, so coincident vertices move together and the surface stays
+    watertight); the mesh buffer then holds ~150 MB (textured: position + normal + tangent + uv per vertex) instead of the
+    1.5 MB of the instanced variant, and the cull / raster / vertex-stage gathers go to HBM instead of hitting a
+    cache-resident mesh library.  unique=False: the 11 meshes are instanced (round-1 workload, labelled as such).
+    textured: every material gets a base colour, a normal and a packed AO / roughness / metallic map (tex_size^2 /
+    (tex_size/2)^2 RGBA8 with full mip chains, trilinear) from a pool of 32 procedural textures, like the scanned material
+    set of the real asset; meshes then carry box-projected texture coordinates and tangents.
+    Returns dict(objects, triangles, camera=(view, projection), mesh_bytes, unique_triangles)."""
     rng = Pcg32(seed)
     rh = r.handedness == RIGHT
     fix = (lambda i: _flip(i)) if rh else (lambda i: i)  # generators emit LH-front-facing winding
 
     # ---- mesh library: triangle counts from 12 to 20 480
     lib = []
+    templates = []  # unique: (positions, indices, normals, uv, tangents) of every shape; instanced: the mesh handle
+    deform_rng = Pcg32(seed ^ 0xD3F0, seq=77)  # its own stream: object placement is identical with and without `unique`
+    mesh_bytes = [0]
+    unique_tris = [0]
 
-    def add(p, i, nr):
+    def upload(p, i, nr, uv, tan):
+        mesh_bytes[0] += 4 * (p.size + nr.size + i.size + (uv.size + tan.size if textured else 0))
+        unique_tris[0] += len(i) // 3
         if not textured:
-            return r.add_mesh(p, fix(i), normals=nr)
-        uv, tan = planar_uv_tangent(p, nr, 2.0)
-        return r.add_mesh(p, fix(i), normals=nr, uv0=uv, tangents=tan)
+            return r.add_mesh(p, i, normals=nr)
+        return r.add_mesh(p, i, normals=nr, uv0=uv, tangents=tan)
+
+    def add(kind, ntri, p, i, nr):
+        i = fix(i)
+        uv, tan = planar_uv_tangent(p, nr, 2.0) if textured else (None, None)
+        if unique:
+            templates.append((p, i, nr, uv, tan))
+            lib.append((kind, ntri, len(templates) - 1))
+        else:
+            lib.append((kind, ntri, upload(p, i, nr, uv, tan)))
+
+    def instance_mesh(entry):
+        """The mesh handle an object of library entry `entry` draws: the shared one, or its own deformed copy."""
+        if not unique:
+            return entry[2]
+        p, i, nr, uv, tan = templates[entry[2]]
+        # smooth displacement field d(x) = amp * sin(K x + phase) per axis: a function of position only
+        k = np.array([[deform_rng.uniform(1.5, 6.0) for _ in range(3)] for _ in range(3)], dtype=f32)
+        ph = np.array([deform_rng.uniform(0.0, 2.0 * math.pi) for _ in range(3)], dtype=f32)
+        amp = f32(deform_rng.uniform(0.004, 0.02))
+        q = (p + amp * np.sin(p @ k.T + ph)).astype(f32)
+        return upload(q, i, nr, uv, tan)
 
     for n in (1, 2, 4, 8, 16, 32):
-        p, i, nr = subdivided_box(n)
-        lib.append(("box", 12 * n * n, add(p, i, nr)))
+        p, i, nr = subdivided_box(n, share=not unique)
+        add("box", 12 * n * n, p, i, nr)
     for sub in (1, 2, 3, 4, 5):
         p, i, nr = icosphere(sub)
-        lib.append(("sphere", 20 * 4 ** sub, add(p, i, nr)))
+        add("sphere", 20 * 4 ** sub, p, i, nr)
     boxes = [m for m in lib if m[0] == "box"]
     spheres = [m for m in lib if m[0] == "sphere"]
 
     tex = None
     if textured:
-        imgs = procedural_textures()
+        imgs = procedural_textures(size=tex_size)
         tex = {"albedo": [r.add_texture_2d(im, srgb=True, mip_count="maximum", mip_source="generated") for im in imgs["albedo"]],
                "normal": [r.add_texture_2d(im, srgb=False, mip_count="maximum", mip_source="generated") for im in imgs["normal"]],
                "orm": [r.add_texture_2d(im, srgb=False, mip_count="maximum", mip_source="generated") for im in imgs["orm"]]}
@@ -313,7 +350,7 @@ def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=13
 
     total = 0
     for mesh, m in objs:
-        r.add_object(mesh[2], mats[rng.randint(len(mats))], m)
+        r.add_object(instance_mesh(mesh), mats[rng.randint(len(mats))], m)
         total += mesh[1]
 
     # ---- lights (scene_viewer/mod.rs:736-737 + 3 rotated copies), shadow distance 100, resolution 2048
@@ -325,7 +362,8 @@ def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=13
                                 direction=d, distance=100.0, resolution=shadow_res)
     projection = ("perspective", 60.0, 0.1)
     r.set_camera_data(view, projection)
-    return dict(objects=len(objs), triangles=total, camera=(view, projection))
+    return dict(objects=len(objs), triangles=total, camera=(view, projection), mesh_bytes=mesh_bytes[0],
+                unique_triangles=unique_tris[0])
 
 
 def _gauss(rng):

@@ -791,6 +791,31 @@ def test_transparent_pass_multi_frame(r3, handedness, samples, textured):
         compare_frames(fo, fp, f"transparent frame {f}")
 
 
+def test_material_key_flip_between_frames(r3):
+    """A material's transparency key rewritten between frames through the raw material write (the reference fixes a material's
+    archetype, this ABI does not): BLEND -> OPAQUE -> BLEND.  The host mirror's cached blend-object list must follow, else the
+    objects of that material are drawn by no pass at all (or by two)."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    for r, mk in ((o, omk), (p, r3.material_record)):
+        scenes.build_random_scene(r, oh, mk, 80, 0xF11B, lights=1)
+    scenes.add_blend_objects(o, oh, omk, 0xB1E2E)
+    scenes.add_blend_objects(p, oh, r3.material_record, 0xB1E2E)
+    blend_mats = [i for i, (_rec, key) in enumerate(o.materials) if key == scenes.BLEND]
+    assert blend_mats
+    for r in (o, p):
+        r.set_camera_data(oh.look_at_lh((-2.0, 1.0, -3.0), (0.0, 0.5, 8.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    sizes = []
+    for f, key in enumerate((scenes.BLEND, scenes.OPAQUE, scenes.BLEND, scenes.BLEND)):
+        for r in (o, p):
+            for m in blend_mats[:3]:
+                r.update_material(m, r.materials[m][0], key=key)
+        fo = o.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"key flip frame {f}")
+        sizes.append(len(fo["blend_list"][0]))
+    assert sizes[1] < sizes[0] and sizes[2] > sizes[1]
+
+
 @pytest.mark.parametrize("output_format", [0, 1, 2, 3])
 def test_tonemap_every_half_value(r3, output_format):
     """blit.wgsl + the 8-bit store over EVERY Rgba16Float bit pattern (all 65536 halves in every channel, NaN / inf /
@@ -842,3 +867,57 @@ def test_output_formats_on_a_frame(r3):
         fp = p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
         compare_frames(fo, fp, f"output format {fmt}")
     assert (fo["rgba8"][..., :3].max(axis=2) > 40).mean() > 0.05
+
+
+# ------------------------------------------------------------------ the benchmarked workload (BASELINE.json configs[2])
+def _config3_pair(r3, w, h, **kw):
+    """bench.py's scene on both sides: rend3_amd/scenes.py::bistro_like with every object owning its geometry."""
+    import rend3_amd.scenes as S
+    o, p = both(r3, oh.RIGHT, f32(w) / f32(h))
+    io = S.bistro_like(o, oh, omk, unique=True, **kw)
+    ip = S.bistro_like(p, r3.host, r3.material_record, unique=True, **kw)
+    assert io["triangles"] == ip["triangles"] == io["unique_triangles"]
+    return o, p, io
+
+
+def test_config3_bistro_like(r3):
+    """The benchmarked frame at a size the oracle finishes in seconds: bench.py's scene generator (street canyon, unique
+    geometry per object), textured (base colour + normal + AO/roughness/metallic maps, trilinear), 4 directional lights
+    with their shadow views, bench.py's camera dolly over three frames (so the predicted pass, the Hi-Z cull against it
+    and the residual pass all carry history), 1920x1080 -- every frame bit-exact like the small scenes: L1 / L2 sets of
+    the five cameras, keys, atlas, HDR; framebuffer within 1e-3.  Reference: examples/src/scene_viewer/mod.rs:727-751
+    (camera, light, resolution of the Bistro test)."""
+    import bench
+    w, h = 1920, 1080
+    o, p, info = _config3_pair(r3, w, h, n_objects=1200, target_tris=300_000, textured=True, tex_size=256, shadow_res=1024)
+    assert info["triangles"] > 400_000
+    view0, proj = info["camera"]
+    for k in range(3):
+        o.set_camera_data(bench.camera_path(oh, view0, k), proj)
+        p.set_camera_data(bench.camera_path(r3.host, view0, k), proj)
+        fo = o.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+        fp = p.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+        compare_frames(fo, fp, f"config 3 frame {k}")
+        assert len(fo["shadows"]) == 4 and all(s["pass"].sum() > 1000 for s in fo["shadows"])
+    assert fo["residual"].sum() > 0 and fo["pass"].sum() > 10_000  # the dolly keeps the residual pass busy
+    assert (fo["vis"] != 0).mean() > 0.9
+
+
+def test_config3_4k_frame(r3):
+    """bench.py's workload at its full size -- 3840x2160, ~3 000 objects / ~2.8 M unique triangles, 4 shadow views of
+    2048^2 -- with factor-only materials (the textured fragment stage is covered above at 1080p; at 4K it would only
+    add oracle time): camera steps 0 and 1, both bit-exact.  Exercises what only the full size reaches: the 13-level
+    Hi-Z pyramid with its odd-dimension tail, work items from > 32 px triangles in coarse mode, the 2 Mi-entry work
+    queue under the ground tiles that cross the near plane, 4096^2 atlas."""
+    import bench
+    w, h = bench.WIDTH, bench.HEIGHT
+    o, p, info = _config3_pair(r3, w, h, textured=False)
+    assert info["triangles"] > 2_500_000 and info["mesh_bytes"] > 100_000_000
+    view0, proj = info["camera"]
+    for k in range(2):
+        o.set_camera_data(bench.camera_path(oh, view0, k), proj)
+        p.set_camera_data(bench.camera_path(r3.host, view0, k), proj)
+        fo = o.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+        fp = p.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+        compare_frames(fo, fp, f"config 3 at 4K, frame {k}")
+    assert fo["hiz"].size > w * h and fo["residual"].sum() > 0
