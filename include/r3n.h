@@ -201,10 +201,20 @@ typedef struct r3n_pose_request16 {
     uint32_t _pad;
 } r3n_pose_request16;
 
+/* Arithmetic of the PBR fragment stage (r3n_resolve_opaque).  EXACT (default): every f32 operation rounds once, IEEE division and
+ * square root -- the contract under which visibility, HDR and framebuffer are bit-identical to the CPU oracle.  FAST (opt-in):
+ * fused multiply-add and hardware reciprocal / rsqrt in interpolation, texture filtering and BRDF; coverage, depth, level of
+ * detail, shadow coordinates and comparisons stay exact.  The framebuffer then stays within the north-star tolerance
+ * (|delta| <= 1e-3 after tonemap), not bit-identical.  Honoured by the single-sample resolve; MSAA always runs EXACT. */
+#define R3N_SHADE_EXACT 0u
+#define R3N_SHADE_FAST 1u
+
 typedef struct r3n_config {
     uint32_t struct_size;      /* sizeof(r3n_config) */
     uint32_t max_big_items;    /* raster work-queue capacity (0 = default 4 Mi items) */
-    uint64_t reserved[3];
+    uint32_t shade_mode;       /* R3N_SHADE_EXACT | R3N_SHADE_FAST */
+    uint32_t _pad;
+    uint64_t reserved[2];
 } r3n_config;
 
 /* ---- lifetime (replaces rend3::create_iad + BaseRenderGraph::new / PbrRoutine::new state:
@@ -258,6 +268,8 @@ int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t dire
 #define R3N_OUTPUT_RGBA8_UNORM 2u
 #define R3N_OUTPUT_BGRA8_UNORM 3u
 int r3n_set_output_format(r3n_ctx *ctx, uint32_t format);
+/* switches the fragment-stage arithmetic (R3N_SHADE_*) for the resolves enqueued from now on */
+int r3n_set_shade_mode(r3n_ctx *ctx, uint32_t mode);
 
 /* ---- frame (node order of BaseRenderGraph::add_to_graph, rend3-routine/src/base.rs:135-185)
  * r3n_frame_begin: create_frame_uniforms (uniforms.rs:73-125) + render-target setup (base.rs:224-264) +
@@ -337,6 +349,9 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 /* work-queue occupancy of the rasteriser: big_items[i] = number of >8x8 px work items the i-th r3n_forward call of
  * the last frame produced (performance diagnostics only) */
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
+/* triangle references binned into each 64 x 64 texel tile of a shadow view by the last frame (row-major, tiles_x per row;
+ * performance diagnostics only) */
+int r3n_readback_shadow_tile_counts(r3n_ctx *ctx, r3n_camera shadow_view, uint32_t *counts, uint32_t n, uint32_t *tiles_x);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
 int r3n_readback_joint_matrices(r3n_ctx *ctx, uint32_t first_matrix, float *dst, uint32_t n_matrices); /* what the last r3n_skinning read */

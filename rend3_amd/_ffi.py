@@ -36,6 +36,7 @@ SIGNATURES = {
     "r3n_animation_write": (cint, [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32]),
     "r3n_pose_skeletons": (cint, [vp, vp, u32]),
     "r3n_set_output_format": (cint, [vp, u32]),
+    "r3n_set_shade_mode": (cint, [vp, u32]),
     "r3n_blend_order_write": (cint, [vp, vp, u32]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "r3n_readback_triangle_sets": (cint, [vp, u32, vp, vp, u64]),
     "r3n_readback_draw_calls": (cint, [vp, u32, vp]),
     "r3n_readback_raster_stats": (cint, [vp, vp]),
+    "r3n_readback_shadow_tile_counts": (cint, [vp, u32, vp, u32, vp]),
     "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
     "r3n_readback_mesh": (cint, [vp, u64, vp, u64]),
     "r3n_readback_texels": (cint, [vp, u64, vp, u64]),

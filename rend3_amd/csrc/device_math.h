@@ -16,7 +16,57 @@ R3N_DEV void mul_vec4(const float *__restrict__ m, float x, float y, float z, fl
 // position variant: w == 1 still multiplies (keeps the op sequence identical to the contract)
 R3N_DEV void mul_point(const float *__restrict__ m, const float v[3], float o[4]) { mul_vec4(m, v[0], v[1], v[2], 1.0f, o); }
 
+// Two floats in one register pair: `*` and `+` on this type compile to v_pk_mul_f32 / v_pk_add_f32 -- one issue slot for both
+// lanes' operations, each still rounded once, so packing is invisible to the arithmetic contract.
+typedef float f2 __attribute__((ext_vector_type(2)));
+R3N_DEV f2 splat2(float v) { return (f2){v, v}; }
+
+// Arithmetic policy of the shading code (kernels_shade.h, texture.h).
+//   MathExact  the contract of DESIGN.md section 2: a * b + c rounds twice (the TU is built with -ffp-contract=off), division and
+//              square root are the correctly rounded IEEE operations.  Bit-identical to the oracle.
+//   MathFast   opt-in (r3n_config.shade_mode = R3N_SHADE_FAST): fused multiply-add, v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp).
+//              Not bit-identical; the framebuffer stays within the north-star tolerance (1e-3 after tonemap), tested.
+struct MathExact {
+    static constexpr bool fast = false;
+    static R3N_DEV float mad(float a, float b, float c) { return a * b + c; }
+    static R3N_DEV f2 mad(f2 a, f2 b, f2 c) { return a * b + c; }
+    static R3N_DEV float rcp(float x) { return 1.0f / x; }
+    static R3N_DEV float div(float a, float b) { return a / b; }
+    static R3N_DEV float sqrt(float x) { return sqrtf(x); }
+    static R3N_DEV float rsqrt(float x) { return 1.0f / sqrtf(x); }
+};
+struct MathFast {
+    static constexpr bool fast = true;
+    static R3N_DEV float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static R3N_DEV f2 mad(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+    static R3N_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static R3N_DEV float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static R3N_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static R3N_DEV float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+};
+
 R3N_DEV float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+// policy forms: same value as the plain ones under MathExact (the additions only swap commutative operands)
+template <class M> R3N_DEV float dot3m(const float a[3], const float b[3]) { return M::mad(a[2], b[2], M::mad(a[1], b[1], a[0] * b[0])); }
+template <class M> R3N_DEV void normalize3m(float v[3]) {
+    const float r = M::rsqrt(dot3m<M>(v, v));
+    v[0] *= r; v[1] *= r; v[2] *= r;
+}
+// m * (x,y,z,w) as two row pairs: ((c0*x + c1*y) + c2*z) + c3*w per row
+template <class M> R3N_DEV void mul_vec4m(const float *__restrict__ m, float x, float y, float z, float w, float o[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const f2 c0 = {m[r], m[r + 1]}, c1 = {m[4 + r], m[5 + r]}, c2 = {m[8 + r], m[9 + r]}, c3 = {m[12 + r], m[13 + r]};
+        const f2 t = M::mad(c3, splat2(w), M::mad(c2, splat2(z), M::mad(c1, splat2(y), c0 * splat2(x))));
+        o[r] = t.x; o[r + 1] = t.y;
+    }
+}
+template <class M> R3N_DEV void mat3_mul_vec3m(const float *__restrict__ c0, const float *__restrict__ c1, const float *__restrict__ c2,
+                                               const float v[3], float o[3]) {
+    const f2 t = M::mad((f2){c2[0], c2[1]}, splat2(v[2]), M::mad((f2){c1[0], c1[1]}, splat2(v[1]), (f2){c0[0], c0[1]} * splat2(v[0])));
+    o[0] = t.x; o[1] = t.y;
+    o[2] = M::mad(c2[2], v[2], M::mad(c1[2], v[1], c0[2] * v[0]));
+}
 R3N_DEV float sat(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 R3N_DEV void normalize3(float v[3]) {
     float r = 1.0f / sqrtf(dot3(v, v));
@@ -60,11 +110,23 @@ R3N_DEV uint32_t mip_dim(uint32_t d, uint32_t k) {
 }
 
 // vertex_attributes.wgsl:51-58
+// Dword-aligned groups of 2 / 3 / 4 words read with ONE load instruction (global_load_dwordx2/3/4 take 4-byte alignment on
+// gfx950): the mesh buffer's vec3 attributes and index triples are 12-byte records at arbitrary word offsets, and fetched
+// word by word a triangle cost twelve memory instructions instead of four.
+struct __attribute__((packed, aligned(4))) r3n_words2 { uint32_t x, y; };
+struct __attribute__((packed, aligned(4))) r3n_words3 { uint32_t x, y, z; };
+struct __attribute__((packed, aligned(4))) r3n_words4 { uint32_t x, y, z, w; };
 R3N_DEV void fetch_vec3(const uint32_t *__restrict__ mesh, uint32_t byte_off, uint32_t vtx, float o[3]) {
     const uint32_t w = byte_off / 4u + vtx * 3u;
-    o[0] = __uint_as_float(mesh[w]);
-    o[1] = __uint_as_float(mesh[w + 1u]);
-    o[2] = __uint_as_float(mesh[w + 2u]);
+    const r3n_words3 v = *reinterpret_cast<const r3n_words3 *>(mesh + w);
+    o[0] = __uint_as_float(v.x);
+    o[1] = __uint_as_float(v.y);
+    o[2] = __uint_as_float(v.z);
+}
+// the three vertex indices of a triangle (index buffer words first .. first + 2)
+R3N_DEV void fetch_indices3(const uint32_t *__restrict__ mesh, uint32_t first, uint32_t idx[3]) {
+    const r3n_words3 v = *reinterpret_cast<const r3n_words3 *>(mesh + first);
+    idx[0] = v.x; idx[1] = v.y; idx[2] = v.z;
 }
 
 // ---- homogeneous triangle setup (DESIGN.md "Rasteriser contract") --------------------------------

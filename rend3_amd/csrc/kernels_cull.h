@@ -16,9 +16,8 @@
 // ------------------------------------------------------------------------------------------------ K1
 // 4 threads per object: thread c bakes column c of model_view and model_view_proj.  Consecutive threads
 // read consecutive 16-byte columns (fully coalesced) and write two 16-byte columns.
-__global__ __launch_bounds__(256) void k_uniform_bake(const r3n_camera_header240 *__restrict__ hdr,
-                                                      const r3n_object128 *__restrict__ objects,
-                                                      r3n_baked128 *__restrict__ baked) {
+R3N_DEV void uniform_bake_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
+                                r3n_baked128 *__restrict__ baked) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t obj = gid >> 2, c = gid & 3u;
     if (obj >= hdr->object_count) return;            // uniform_prep.wgsl:15-17
@@ -29,6 +28,11 @@ __global__ __launch_bounds__(256) void k_uniform_bake(const r3n_camera_header240
     mul_vec4(hdr->view_proj, col.x, col.y, col.z, col.w, mvp);
     reinterpret_cast<float4 *>(baked[obj].model_view)[c] = make_float4(mv[0], mv[1], mv[2], mv[3]);
     reinterpret_cast<float4 *>(baked[obj].model_view_proj)[c] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+}
+__global__ __launch_bounds__(256) void k_uniform_bake(const r3n_camera_header240 *__restrict__ hdr,
+                                                      const r3n_object128 *__restrict__ objects,
+                                                      r3n_baked128 *__restrict__ baked) {
+    uniform_bake_body(hdr, objects, baked);
 }
 
 // ------------------------------------------------------------------------------------------------ object pass
@@ -43,12 +47,9 @@ R3N_DEV uint32_t wave_reduce_add(uint32_t v) {
 }
 
 // Pass A: frustum test (batching.rs:146, frustum.rs:148-161) + per-block totals.
-__global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240 *__restrict__ hdr,
-                                                      const r3n_object128 *__restrict__ objects,
-                                                      const uint8_t *__restrict__ material_keys, uint32_t n_materials,
-                                                      uint32_t range_begin, uint32_t range_end,
-                                                      uint8_t *__restrict__ vis_flags,
-                                                      ObjBlockSums *__restrict__ block_sums) {
+R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
+                                const uint8_t *__restrict__ material_keys, uint32_t n_materials, uint32_t range_begin,
+                                uint32_t range_end, uint8_t *__restrict__ vis_flags, ObjBlockSums *__restrict__ block_sums) {
     __shared__ uint32_t red[4][6];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t cap = hdr->object_count;
@@ -99,6 +100,14 @@ __global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240
         dst[k] = s;
     }
 }
+__global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240 *__restrict__ hdr,
+                                                      const r3n_object128 *__restrict__ objects,
+                                                      const uint8_t *__restrict__ material_keys, uint32_t n_materials,
+                                                      uint32_t range_begin, uint32_t range_end,
+                                                      uint8_t *__restrict__ vis_flags,
+                                                      ObjBlockSums *__restrict__ block_sums) {
+    object_count_body(hdr, objects, material_keys, n_materials, range_begin, range_end, vis_flags, block_sums);
+}
 
 struct ObjBlockOffsets {
     uint32_t visible, waves, tris_all;
@@ -106,11 +115,9 @@ struct ObjBlockOffsets {
 
 // Pass B: one block scans the per-block totals, derives region bases and resets the append counters
 // (culler.rs:642 clear_buffer + cull.wgsl:47-61 init_draw_calls).
-__global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__restrict__ block_sums, uint32_t nblocks,
-                                                      ObjBlockOffsets *__restrict__ block_off,
-                                                      r3n_cull_counts *__restrict__ counts,
-                                                      r3n_vis_entry *__restrict__ vis_list,
-                                                      r3n_sub_counts *__restrict__ sub_counts) {
+R3N_DEV void object_scan_body(const ObjBlockSums *__restrict__ block_sums, uint32_t nblocks, ObjBlockOffsets *__restrict__ block_off,
+                               r3n_cull_counts *__restrict__ counts, r3n_vis_entry *__restrict__ vis_list,
+                               r3n_sub_counts *__restrict__ sub_counts) {
     __shared__ uint32_t sh[3][1024];
     __shared__ uint32_t carry[3];
     __shared__ uint32_t ktot[3];
@@ -168,6 +175,13 @@ __global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__rest
         vis_list[carry[0]].wave_start = carry[1];
     }
 }
+__global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__restrict__ block_sums, uint32_t nblocks,
+                                                      ObjBlockOffsets *__restrict__ block_off,
+                                                      r3n_cull_counts *__restrict__ counts,
+                                                      r3n_vis_entry *__restrict__ vis_list,
+                                                      r3n_sub_counts *__restrict__ sub_counts) {
+    object_scan_body(block_sums, nblocks, block_off, counts, vis_list, sub_counts);
+}
 
 R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -181,13 +195,10 @@ R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
 // Pass C: scatter visible objects into the work list (object-slot order => deterministic layout).
 // slot_base[i] = first triangle slot of object i in this frame's result bitmask, or INVALID when the object
 // was not batched (== "not in current_invocation_map", batching.rs:226,230).  tri_base[i] = canonical base.
-__global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header240 *__restrict__ hdr,
-                                                        const r3n_object128 *__restrict__ objects,
-                                                        const uint8_t *__restrict__ vis_flags,
-                                                        const ObjBlockOffsets *__restrict__ block_off,
-                                                        r3n_vis_entry *__restrict__ vis_list,
-                                                        uint32_t *__restrict__ slot_base,
-                                                        uint32_t *__restrict__ tri_base) {
+R3N_DEV void object_scatter_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
+                                  const uint8_t *__restrict__ vis_flags, const ObjBlockOffsets *__restrict__ block_off,
+                                  r3n_vis_entry *__restrict__ vis_list, uint32_t *__restrict__ slot_base,
+                                  uint32_t *__restrict__ tri_base) {
     __shared__ uint32_t wtot[4][3];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t cap = hdr->object_count;
@@ -215,6 +226,15 @@ __global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header2
         if (tri_base != nullptr) tri_base[i] = p2 + s2 - ntri;
     }
 }
+__global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header240 *__restrict__ hdr,
+                                                        const r3n_object128 *__restrict__ objects,
+                                                        const uint8_t *__restrict__ vis_flags,
+                                                        const ObjBlockOffsets *__restrict__ block_off,
+                                                        r3n_vis_entry *__restrict__ vis_list,
+                                                        uint32_t *__restrict__ slot_base,
+                                                        uint32_t *__restrict__ tri_base) {
+    object_scatter_body(hdr, objects, vis_flags, block_off, vis_list, slot_base, tri_base);
+}
 
 // ------------------------------------------------------------------------------------------------ K8 skinning
 // skinning.wgsl:37-94.  One launch for all skeletons: wave slot w (64 vertices) belongs to skeleton wave_skeleton[w]
@@ -233,11 +253,11 @@ __global__ __launch_bounds__(256) void k_skinning(uint32_t *__restrict__ mesh, c
     const r3n_skinning_input40 in = inputs[sk];
     const uint32_t idx = (w - wave_first[sk]) * 64u + lane;
     if (idx >= in.vertex_count) return;
-    const uint32_t j0 = mesh[in.joint_indices_offset / 4u + idx * 2u], j1 = mesh[in.joint_indices_offset / 4u + idx * 2u + 1u];
+    const r3n_words2 jj = *reinterpret_cast<const r3n_words2 *>(mesh + in.joint_indices_offset / 4u + idx * 2u);
+    const uint32_t j0 = jj.x, j1 = jj.y;
     const uint32_t ji[4] = {j0 & 0xFFFFu, (j0 >> 16) & 0xFFFFu, j1 & 0xFFFFu, (j1 >> 16) & 0xFFFFu};
-    float jw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) jw[i] = __uint_as_float(mesh[in.joint_weight_offset / 4u + idx * 4u + (uint32_t)i]);
+    const r3n_words4 jww = *reinterpret_cast<const r3n_words4 *>(mesh + in.joint_weight_offset / 4u + idx * 4u);
+    const float jw[4] = {__uint_as_float(jww.x), __uint_as_float(jww.y), __uint_as_float(jww.z), __uint_as_float(jww.w)};
     float pos[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f}, tan[3] = {0.0f, 0.0f, 0.0f};
     if (in.base_position_offset != R3N_INVALID) fetch_vec3(mesh, in.base_position_offset, idx, pos);
     if (in.base_normal_offset != R3N_INVALID) fetch_vec3(mesh, in.base_normal_offset, idx, nrm);
@@ -269,15 +289,15 @@ __global__ __launch_bounds__(256) void k_skinning(uint32_t *__restrict__ mesh, c
     normalize3(ta);
     if (in.updated_position_offset != R3N_INVALID) {
         const uint32_t o = in.updated_position_offset / 4u + idx * 3u;
-        mesh[o] = __float_as_uint(pa[0]); mesh[o + 1u] = __float_as_uint(pa[1]); mesh[o + 2u] = __float_as_uint(pa[2]);
+        *reinterpret_cast<r3n_words3 *>(mesh + o) = r3n_words3{__float_as_uint(pa[0]), __float_as_uint(pa[1]), __float_as_uint(pa[2])};
     }
     if (in.updated_normal_offset != R3N_INVALID) {
         const uint32_t o = in.updated_normal_offset / 4u + idx * 3u;
-        mesh[o] = __float_as_uint(na[0]); mesh[o + 1u] = __float_as_uint(na[1]); mesh[o + 2u] = __float_as_uint(na[2]);
+        *reinterpret_cast<r3n_words3 *>(mesh + o) = r3n_words3{__float_as_uint(na[0]), __float_as_uint(na[1]), __float_as_uint(na[2])};
     }
     if (in.updated_tangent_offset != R3N_INVALID) {
         const uint32_t o = in.updated_tangent_offset / 4u + idx * 3u;
-        mesh[o] = __float_as_uint(ta[0]); mesh[o + 1u] = __float_as_uint(ta[1]); mesh[o + 2u] = __float_as_uint(ta[2]);
+        *reinterpret_cast<r3n_words3 *>(mesh + o) = r3n_words3{__float_as_uint(ta[0]), __float_as_uint(ta[1]), __float_as_uint(ta[2])};
     }
 }
 
@@ -319,12 +339,8 @@ R3N_DEV float hiz_sample_min(const HizView &hz, float u, float v, uint32_t mip) 
     return m;
 }
 
-// cull.wgsl:264-324
-R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3], uint32_t flags, bool shadow,
-                             float res_x, float res_y, const HizView &hz) {
-    float p[3][4];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mul_point(mvp, v[k], p[k]);
+// cull.wgsl:264-324, from the clip-space positions p[k] = model_view_proj * vertex k
+R3N_DEV bool execute_culling_clip(const float p[3][4], uint32_t flags, bool shadow, float res_x, float res_y, const HizView &hz) {
     const float det = det3_xyw(p[0], p[1], p[2]);
     if (flags & R3N_PCU_POSITIVE_AREA_VISIBLE) {
         if (det <= 0.0f) return false;
@@ -367,6 +383,13 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
     const float occ = hiz_sample_min(hz, uv[0], uv[1], mip);
     if (depth < occ) return false;
     return true;
+}
+R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3], uint32_t flags, bool shadow,
+                             float res_x, float res_y, const HizView &hz) {
+    float p[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mul_point(mvp, v[k], p[k]);
+    return execute_culling_clip(p, flags, shadow, res_x, res_y, hz);
 }
 
 #define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
@@ -444,8 +467,10 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
                     const uint32_t first = ob->first_index + tri * 3u;
                     const uint32_t pos_off = ob->vertex_attribute_start_offsets[0];
                     float v[3][3];
+                    uint32_t idx[3];
+                    fetch_indices3(a.mesh, first, idx);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, pos_off, a.mesh[first + (uint32_t)k], v[k]);
+                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, pos_off, idx[k], v[k]);
                     pass = execute_culling(a.baked[obj].model_view_proj, v, flags, shadow, res_x, res_y, a.hiz);
                 }
                 ballot = __ballot(pass);

@@ -89,9 +89,9 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
     uint32_t idx[3];
     float p[3][4];
+    fetch_indices3(a.mesh, first, idx);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        idx[k] = a.mesh[first + (uint32_t)k];
         float v[3];
         fetch_vec3(a.mesh, pos_off, idx[k], v);
         mul_point(a.baked[obj].model_view_proj, v, p[k]);
@@ -287,7 +287,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
-__global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs a) {
+R3N_DEV void raster_small_body(const RasterArgs &a) {
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
     const uint32_t n = a.sub_counts[a.key * R3N_SUBQ + q];
@@ -345,6 +345,18 @@ __global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs 
             }
         }
     }
+}
+
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
+__global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs a) {
+    raster_small_body<DEPTH_ONLY, S, TEX>(a);
+}
+// The same over several targets at once: blockIdx.y picks the view's argument block (kernels_shadow.h: the shadow views'
+// fallback lists, one launch for all views).
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
+__global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small_views(const RasterArgs *__restrict__ views) {
+    const RasterArgs a = views[blockIdx.y];
+    raster_small_body<DEPTH_ONLY, S, TEX>(a);
 }
 
 // Transparent pass, stage 1 (row N3): one thread per triangle of the blend-key objects, in DRAW ORDER -- objects back
@@ -438,7 +450,7 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 __device__ uint32_t g_wave_trace[4][32768][4];
 #endif
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false>
-__global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
+R3N_DEV void raster_big_body(RasterArgs a) {
 #ifdef R3N_WAVE_TRACE
     const uint32_t trace_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
     uint32_t trace_items = 0, trace_steps = 0;
@@ -596,6 +608,15 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
         t[0] = trace_t0; t[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); t[2] = trace_items; t[3] = trace_steps;
     }
 #endif
+}
+
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false>
+__global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
+    raster_big_body<DEPTH_ONLY, S, TEX, BLEND>(a);
+}
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
+__global__ __launch_bounds__(256) void k_raster_big_views(const RasterArgs *__restrict__ views) {
+    raster_big_body<DEPTH_ONLY, S, TEX, false>(views[blockIdx.y]);
 }
 
 // ------------------------------------------------------------------------------------------------ clears

@@ -7,6 +7,8 @@
 //   opaque.wgsl:91-135 (VS), :203-551 (FS), math/brdf.wgsl, shadow/pcf.wgsl
 //   blit.wgsl:22-31, tonemapping.rs:44 (Rgba8UnormSrgb target => exact sRGB OETF)
 #pragma once
+#include <type_traits>
+
 #include "device_math.h"
 #include "texture.h"
 
@@ -21,6 +23,10 @@
 #endif
 #ifndef R3N_SKIP_OCCLUDED
 #define R3N_SKIP_OCCLUDED 1
+#endif
+#ifndef R3N_SHADE_ABLATE
+#define R3N_SHADE_ABLATE 0  // diagnostics only (tools/variants.py): bit 0 textures return a constant, bit 1 no texture coordinates /
+                            // derivatives, bit 2 no shadow lookup, bit 3 no lights, bit 4 no tangent frame -- cost of each part
 #endif
 
 // ------------------------------------------------------------------------------------------------ K6 resolve
@@ -97,29 +103,7 @@ struct LdsPointLight {
     float radius;
 };
 
-// shadow/pcf.wgsl + comparison sampler (samplers.rs:24,42-57): bilinear, GreaterEqual, Repeat
-R3N_DEV float sample_compare(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref,
-                             int ox, int oy) {
-    const float tx = (u * (float)aw - 0.5f) + (float)ox;
-    const float ty = (v * (float)ah - 0.5f) + (float)oy;
-    const float fx0 = floorf(tx), fy0 = floorf(ty);
-    float fx = tx - fx0, fy = ty - fy0;
-    const long long ix = (fx0 == fx0 && fabsf(fx0) < 1e9f) ? (long long)fx0 : 0ll;
-    const long long iy = (fy0 == fy0 && fabsf(fy0) < 1e9f) ? (long long)fy0 : 0ll;
-    if (!(fx == fx)) fx = 0.0f;
-    if (!(fy == fy)) fy = 0.0f;
-    const long long w = (long long)aw, h = (long long)ah;
-    const uint32_t x0 = (uint32_t)(((ix % w) + w) % w), x1 = (uint32_t)((((ix + 1) % w) + w) % w);
-    const uint32_t y0 = (uint32_t)(((iy % h) + h) % h), y1 = (uint32_t)((((iy + 1) % h) + h) % h);
-    const float c00 = ref >= atlas[(size_t)y0 * aw + x0] ? 1.0f : 0.0f;
-    const float c10 = ref >= atlas[(size_t)y0 * aw + x1] ? 1.0f : 0.0f;
-    const float c01 = ref >= atlas[(size_t)y1 * aw + x0] ? 1.0f : 0.0f;
-    const float c11 = ref >= atlas[(size_t)y1 * aw + x1] ? 1.0f : 0.0f;
-    const float top = c00 * (1.0f - fx) + c10 * fx;
-    const float bot = c01 * (1.0f - fx) + c11 * fx;
-    return top * (1.0f - fy) + bot * fy;
-}
-
+// shadow/pcf.wgsl + comparison sampler (samplers.rs:24,42-57): bilinear, GreaterEqual, Repeat.
 // Texel coordinates + bilinear weights of one comparison tap, exactly as sample_compare derives them.
 struct PcfTap {
     int ix, iy;  // |floor| < 1e9 fits
@@ -150,7 +134,8 @@ R3N_DEV float pcf_texel_cmp(const float *__restrict__ atlas, uint32_t aw, uint32
 // shadow/pcf.wgsl: mean of 5 bilinear comparison taps (centre, +-1 texel in x and y).  The 5 taps touch 20 texels
 // of which only 12 are distinct (a 4x4 block without its corners): the comparisons are fetched once and every tap
 // then applies its own weights -- same values, same operation order as five independent sample_compare calls.
-R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
+template <class M>
+R3N_DEV float shadow_pcf5_general(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
     const PcfTap c = pcf_tap(aw, ah, u, v, 0, 0);
     // cmp[dy][dx] for texel (c.ix - 1 + dx, c.iy - 1 + dy); corners are never needed on the regular path
     uint32_t xs[4];
@@ -183,10 +168,48 @@ R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t
             c00 = pcf_texel_cmp(atlas, aw, ah, t.ix, t.iy, ref);     c10 = pcf_texel_cmp(atlas, aw, ah, t.ix + 1, t.iy, ref);
             c01 = pcf_texel_cmp(atlas, aw, ah, t.ix, t.iy + 1, ref); c11 = pcf_texel_cmp(atlas, aw, ah, t.ix + 1, t.iy + 1, ref);
         }
-        const float top = c00 * (1.0f - t.fx) + c10 * t.fx;
-        const float bot = c01 * (1.0f - t.fx) + c11 * t.fx;
-        r = r + (top * (1.0f - t.fy) + bot * t.fy);
+        // top = c00 * (1 - fx) + c10 * fx, bot = c01 * (1 - fx) + c11 * fx as one packed pair
+        const f2 tb = M::mad((f2){c10, c11}, splat2(t.fx), (f2){c00, c01} * splat2(1.0f - t.fx));
+        r = r + M::mad(tb.y, t.fy, tb.x * (1.0f - t.fy));
     }
+    return r * 0.2f;
+}
+
+// The same five taps when nothing unusual happens -- every floor is a small integer, the +-1 texel taps land one texel
+// away, the 4x4 block lies inside the atlas: ONE test for the whole lookup instead of one per tap and per texel, 32-bit offsets
+// from the uniform atlas pointer, no Repeat wrap.  Same comparisons, weights and summation order as the general form.
+template <class M>
+R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
+    const float tx0 = u * (float)aw - 0.5f, ty0 = v * (float)ah - 0.5f;
+    const float txp = tx0 + 1.0f, txm = tx0 + -1.0f, typ = ty0 + 1.0f, tym = ty0 + -1.0f;
+    const float f0x = floorf(tx0), fpx = floorf(txp), fmx = floorf(txm);
+    const float f0y = floorf(ty0), fpy = floorf(typ), fmy = floorf(tym);
+    const bool regular = fpx == f0x + 1.0f && fmx == f0x - 1.0f && fpy == f0y + 1.0f && fmy == f0y - 1.0f &&
+                         f0x >= 1.0f && f0x <= (float)aw - 3.0f && f0y >= 1.0f && f0y <= (float)ah - 3.0f &&
+                         ((unsigned long long)aw * ah <= (1ull << 30));  // (NaN fails every comparison)
+    if (!regular) return shadow_pcf5_general<M>(atlas, aw, ah, u, v, ref);
+    const float fx0 = tx0 - f0x, fxp = txp - fpx, fxm = txm - fmx;
+    const float fy0 = ty0 - f0y, fyp = typ - fpy, fym = tym - fmy;
+    // cmp[dy][dx] for texel (cx - 1 + dx, cy - 1 + dy); the corners are never read
+    const uint32_t row = aw << 2;
+    const uint32_t base = (__umul24((uint32_t)(int)f0y - 1u, aw) + ((uint32_t)(int)f0x - 1u)) << 2;  // byte offset of texel (cx - 1, cy - 1)
+    const char *ap = reinterpret_cast<const char *>(atlas);
+    auto cmp = [&](uint32_t dy, uint32_t dx) { return ref >= *reinterpret_cast<const float *>(ap + (base + dy * row + (dx << 2))) ? 1.0f : 0.0f; };
+    const float c01 = cmp(0, 1), c02 = cmp(0, 2);
+    const float c10 = cmp(1, 0), c11 = cmp(1, 1), c12 = cmp(1, 2), c13 = cmp(1, 3);
+    const float c20 = cmp(2, 0), c21 = cmp(2, 1), c22 = cmp(2, 2), c23 = cmp(2, 3);
+    const float c31 = cmp(3, 1), c32 = cmp(3, 2);
+    // tap(a, b, c, d, fx, fy) = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy, (top, bot) as a packed pair
+    auto tap = [&](float a, float b, float c, float d, float fx, float fy) {
+        const f2 tb = M::mad((f2){b, d}, splat2(fx), (f2){a, c} * splat2(1.0f - fx));
+        return M::mad(tb.y, fy, tb.x * (1.0f - fy));
+    };
+    float r = 0.0f;
+    r = r + tap(c11, c12, c21, c22, fx0, fy0);  // ( 0,  0)
+    r = r + tap(c21, c22, c31, c32, fx0, fyp);  // ( 0, +1)
+    r = r + tap(c01, c02, c11, c12, fx0, fym);  // ( 0, -1)
+    r = r + tap(c12, c13, c22, c23, fxp, fy0);  // (+1,  0)
+    r = r + tap(c10, c11, c20, c21, fxm, fy0);  // (-1,  0)
     return r * 0.2f;
 }
 
@@ -196,32 +219,38 @@ struct PixelData {
 
 #define R3N_PI 3.14159265359f
 
-// opaque.wgsl:440-468
+// opaque.wgsl:440-468.  The r and g channels run as one packed pair, b on its own.
+template <class M>
 R3N_DEV void surface_shading(const float l[3], const float intensity[3], const PixelData &px, const float v[3],
                              float occlusion, float out[3]) {
     float h[3] = {v[0] + l[0], v[1] + l[1], v[2] + l[2]};
-    normalize3(h);
-    const float nov = fabsf(dot3(px.normal, v)) + 0.00001f;
-    const float nol = sat(dot3(px.normal, l));
-    const float noh = sat(dot3(px.normal, h));
-    const float loh = sat(dot3(l, h));
+    normalize3m<M>(h);
+    const float nov = fabsf(dot3m<M>(px.normal, v)) + 0.00001f;
+    const float nol = sat(dot3m<M>(px.normal, l));
+    const float noh = sat(dot3m<M>(px.normal, h));
+    const float loh = sat(dot3m<M>(l, h));
     const float c165[3] = {16.5f, 16.5f, 16.5f};
-    const float f90 = sat(dot3(px.f0, c165));
+    const float f90 = sat(dot3m<M>(px.f0, c165));
     const float a = px.roughness, a2 = a * a;
-    const float f = (noh * a2 - noh) * noh + 1.0f;
-    const float d = a2 / ((R3N_PI * f) * f);
+    const float f = M::mad(M::mad(noh, a2, -noh), noh, 1.0f);             // (noh * a2 - noh) * noh + 1
+    const float d = M::div(a2, (R3N_PI * f) * f);
     const float x = 1.0f - loh, x2 = x * x, x5 = (x2 * x2) * x;
-    const float ggxl = nov * sqrtf((-nol * a2 + nol) * nol + a2);
-    const float ggxv = nol * sqrtf((-nov * a2 + nov) * nov + a2);
-    const float vis = 0.5f / (ggxl + ggxv);
+    const float ggxl = nov * M::sqrt(M::mad(M::mad(-nol, a2, nol), nol, a2));  // (-nol * a2 + nol) * nol + a2
+    const float ggxv = nol * M::sqrt(M::mad(M::mad(-nov, a2, nov), nov, a2));
+    const float vis = M::div(0.5f, ggxl + ggxv);
     const float k = nol * occlusion;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float fres = px.f0[c] + (f90 - px.f0[c]) * x5;
-        const float fr = (d * vis) * fres;
-        const float fd = px.diffuse[c] * (1.0f / R3N_PI);
-        const float color = fd + fr;
-        out[c] = (color * intensity[c]) * k;
+    const float dv = d * vis;
+    {
+        const f2 f0 = {px.f0[0], px.f0[1]};
+        const f2 fres = M::mad(splat2(f90) - f0, splat2(x5), f0);          // f0 + (f90 - f0) * x5
+        const f2 color = M::mad(splat2(dv), fres, (f2){px.diffuse[0], px.diffuse[1]} * splat2(1.0f / R3N_PI));  // fd + fr
+        const f2 o = (color * (f2){intensity[0], intensity[1]}) * splat2(k);
+        out[0] = o.x; out[1] = o.y;
+    }
+    {
+        const float fres = M::mad(f90 - px.f0[2], x5, px.f0[2]);
+        const float color = M::mad(dv, fres, px.diffuse[2] * (1.0f / R3N_PI));
+        out[2] = (color * intensity[2]) * k;
     }
 }
 
@@ -314,9 +343,9 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
 #pragma unroll
         for (int k = 0; k < 10; ++k) any_tex = any_tex || mat.textures[k] != 0u;
     }
+    fetch_indices3(a.mesh, first, idx);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        idx[k] = a.mesh[first + (uint32_t)k];
         float v[3];
         fetch_vec3(a.mesh, pos_off, idx[k], v);
         mul_point(a.baked[obj].model_view_proj, v, p[k]);
@@ -356,8 +385,30 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
         for (int c = 0; c < 3; ++c) r.e[i][c] = ts.e[i][c];
 }
 
+// (lam0 * a0 + lam1 * a1) + lam2 * a2 for a pair of attribute channels
+template <class M> R3N_DEV f2 interp2(const float lam[3], f2 a0, f2 a1, f2 a2) {
+    return M::mad(splat2(lam[2]), a2, M::mad(splat2(lam[1]), a1, splat2(lam[0]) * a0));
+}
+template <class M> R3N_DEV float interp1(const float lam[3], float a0, float a1, float a2) {
+    return M::mad(lam[2], a2, M::mad(lam[1], a1, lam[0] * a0));
+}
+template <class M> R3N_DEV void interp_vec3(const float lam[3], const float a[3][3], float o[3]) {
+    const f2 xy = interp2<M>(lam, (f2){a[0][0], a[0][1]}, (f2){a[1][0], a[1][1]}, (f2){a[2][0], a[2][1]});
+    o[0] = xy.x; o[1] = xy.y;
+    o[2] = interp1<M>(lam, a[0][2], a[1][2], a[2][2]);
+}
+template <class M> R3N_DEV void interp_vec4(const float lam[3], const float a[3][4], float o[4]) {
+    const f2 xy = interp2<M>(lam, (f2){a[0][0], a[0][1]}, (f2){a[1][0], a[1][1]}, (f2){a[2][0], a[2][1]});
+    const f2 zw = interp2<M>(lam, (f2){a[0][2], a[0][3]}, (f2){a[1][2], a[1][3]}, (f2){a[2][2], a[2][3]});
+    o[0] = xy.x; o[1] = xy.y; o[2] = zw.x; o[3] = zw.y;
+}
+
 // opaque.wgsl FS (:203-551) for the triangle record `r` at the centre of pixel (x, y).
-template <bool TEX>
+// M = MathExact: the arithmetic contract, bit-identical to the oracle.  M = MathFast (opt-in): fused multiply-adds and
+// hardware reciprocal / rsqrt in the interpolation, filtering and BRDF arithmetic; the edge functions, the level-of-detail /
+// footprint selection, the shadow coordinates and the depth comparisons stay exact so that no pixel changes triangle, mip
+// level or shadow texel -- the result differs from the exact one by rounding only.
+template <bool TEX, class M = MathExact>
 R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
                             uint32_t n_point, const TriRecord &r, uint32_t x, uint32_t y, float out[4]) {
     const r3n_material208 &mat = a.materials[r.material];
@@ -369,17 +420,16 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     ts.z[0] = ts.z[1] = ts.z[2] = 0.0f; ts.det = 1.0f; ts.valid = true;  // not used by the fragment stage
     float E[3];
     (void)edge_eval(ts, (float)x + 0.5f, (float)y + 0.5f, E);
+    // barycentrics and the view-space position: exact arithmetic under both policies.  The position feeds the shadow
+    // coordinates and the comparison depth, and without a depth bias (reference behaviour) a lit surface compares against its
+    // own rasterised depth -- a last-bit change of the position flips comparisons all over it.
     const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
     const float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
     float vpos[4], nrm[3], col[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * r.vp[0][c] + lam[1] * r.vp[1][c]) + lam[2] * r.vp[2][c];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * r.vn[0][c] + lam[1] * r.vn[1][c]) + lam[2] * r.vn[2][c];
-    if ((mat.flags & R3N_FLAGS_ALBEDO_ACTIVE) && (mat.flags & R3N_FLAGS_ALBEDO_BLEND)) {  // the only reader of vs_out.color
-#pragma unroll
-        for (int c = 0; c < 4; ++c) col[c] = (lam[0] * r.vc[0][c] + lam[1] * r.vc[1][c]) + lam[2] * r.vc[2][c];
-    }
+    interp_vec4<MathExact>(lam, r.vp, vpos);
+    interp_vec3<M>(lam, r.vn, nrm);
+    if ((mat.flags & R3N_FLAGS_ALBEDO_ACTIVE) && (mat.flags & R3N_FLAGS_ALBEDO_BLEND))  // the only reader of vs_out.color
+        interp_vec4<M>(lam, r.vc, col);
 
     // fragment stage (opaque.wgsl:203-424).  Texture slots (managers/material.rs:25-29 order): 0 albedo, 1 normal,
     // 2 roughness, 3 metallic, 4 reflectance, 5 clear coat, 6 clear coat roughness, 7 emissive, 8 anisotropy, 9 AO
@@ -392,17 +442,24 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     }
     float coords[2] = {0.0f, 0.0f}, ddx[2] = {0.0f, 0.0f}, ddy[2] = {0.0f, 0.0f};
     const bool nearest = (mflags & R3N_FLAGS_NEAREST) != 0u;
-    if (TEX && any_tex) {  // opaque.wgsl:207-209
-        const float self_raw[2] = {(lam[0] * r.uv[0][0] + lam[1] * r.uv[1][0]) + lam[2] * r.uv[2][0],
-                                   (lam[0] * r.uv[0][1] + lam[1] * r.uv[1][1]) + lam[2] * r.uv[2][1]};
-        frag_coords(ts, r.uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
+    if (TEX && any_tex && !(R3N_SHADE_ABLATE & 2)) {  // opaque.wgsl:207-209
+        const f2 sr = interp2<M>(lam, (f2){r.uv[0][0], r.uv[0][1]}, (f2){r.uv[1][0], r.uv[1][1]}, (f2){r.uv[2][0], r.uv[2][1]});
+        const float self_raw[2] = {sr.x, sr.y};
+        frag_coords<M>(ts, r.uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
     }
-    auto tex = [&](int slot, float dst[4]) { tex_sample_grad(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    // tex4: all four channels; tex3: the callers that read r, g, b only (alpha neither decoded nor filtered)
+#if R3N_SHADE_ABLATE & 1
+    auto tex4 = [&](int slot, float dst[4]) { dst[0] = coords[0]; dst[1] = coords[1]; dst[2] = ddx[0] + ddy[0]; dst[3] = ddx[1] + ddy[1] + (float)slot; };
+    auto tex3 = tex4;
+#else
+    auto tex4 = [&](int slot, float dst[4]) { tex_sample_grad<M, true>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    auto tex3 = [&](int slot, float dst[4]) { tex_sample_grad<M, false>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+#endif
     auto has = [&](int slot) { return TEX && mat.textures[slot] != 0u; };
     if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
-        if (has(0)) tex(0, px.albedo);
+        if (has(0)) tex4(0, px.albedo);
         if (mflags & R3N_FLAGS_ALBEDO_BLEND) {
             if (mflags & R3N_FLAGS_ALBEDO_VERTEX_SRGB) {
 #pragma unroll
@@ -417,84 +474,86 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         px.albedo[0] = px.albedo[1] = px.albedo[2] = 0.0f;
         px.albedo[3] = 1.0f;
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) px.albedo[c] *= mat.albedo[c];
+    {
+        const f2 rg = (f2){px.albedo[0], px.albedo[1]} * (f2){mat.albedo[0], mat.albedo[1]};
+        const f2 ba = (f2){px.albedo[2], px.albedo[3]} * (f2){mat.albedo[2], mat.albedo[3]};
+        px.albedo[0] = rg.x; px.albedo[1] = rg.y; px.albedo[2] = ba.x; px.albedo[3] = ba.y;
+    }
 
     if (mflags & R3N_FLAGS_UNLIT) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
     } else {
         // --- normal (opaque.wgsl:246-273)
-        if (has(1)) {
+        if (has(1) && !(R3N_SHADE_ABLATE & 16)) {
             float t[4], n[3];
-            tex(1, t);
+            tex4(1, t);
             if (mflags & R3N_FLAGS_BICOMPONENT_NORMAL) {
                 float b0 = (mflags & R3N_FLAGS_SWIZZLED_NORMAL) ? t[3] : t[0], b1 = t[1];  // texture_read.ag : .rg
-                b0 = b0 * 2.0f - 1.0f;
-                b1 = b1 * 2.0f - 1.0f;
+                b0 = M::mad(b0, 2.0f, -1.0f);
+                b1 = M::mad(b1, 2.0f, -1.0f);
                 n[0] = b0; n[1] = b1;
-                n[2] = sqrtf((1.0f - b0 * b0) - b1 * b1);
+                n[2] = M::sqrt((1.0f - b0 * b0) - b1 * b1);
             } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) n[c] = t[c] * 2.0f - 1.0f;
-                normalize3(n);
+                for (int c = 0; c < 3; ++c) n[c] = M::mad(t[c], 2.0f, -1.0f);
+                normalize3m<M>(n);
             }
             if (mflags & R3N_FLAGS_YDOWN_NORMAL) n[1] = -n[1];
             float tng[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) tng[c] = (lam[0] * r.vt[0][c] + lam[1] * r.vt[1][c]) + lam[2] * r.vt[2][c];
+            interp_vec3<M>(lam, r.vt, tng);
             float nn[3] = {nrm[0], nrm[1], nrm[2]};
-            normalize3(nn);
-            normalize3(tng);
+            normalize3m<M>(nn);
+            normalize3m<M>(tng);
             const float bt[3] = {nn[1] * tng[2] - tng[1] * nn[2], nn[2] * tng[0] - tng[2] * nn[0], nn[0] * tng[1] - tng[0] * nn[1]};
-            mat3_mul_vec3(tng, bt, nn, n, px.normal);  // tbn * normal
+            mat3_mul_vec3m<M>(tng, bt, nn, n, px.normal);  // tbn * normal
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) px.normal[c] = nrm[c];
         }
-        normalize3(px.normal);
+        normalize3m<M>(px.normal);
         // --- AO, metallic, roughness (opaque.wgsl:277-351)
         float ao = mat.ambient_occlusion, pr = mat.roughness, metallic = mat.metallic;
         if (mflags & R3N_FLAGS_AOMR_COMBINED) {
             if (has(2)) {
                 float t[4];
-                tex(2, t);
+                tex3(2, t);
                 ao = mat.ambient_occlusion * t[0];
                 pr = mat.roughness * t[1];
                 metallic = mat.metallic * t[2];
             }
         } else if (mflags & R3N_FLAGS_AOMR_BW_SPLIT) {
             float t[4];
-            if (has(2)) { tex(2, t); pr = mat.roughness * t[0]; }
-            if (has(3)) { tex(3, t); metallic = mat.metallic * t[0]; }
-            if (has(9)) { tex(9, t); ao = mat.ambient_occlusion * t[0]; }
+            if (has(2)) { tex3(2, t); pr = mat.roughness * t[0]; }
+            if (has(3)) { tex3(3, t); metallic = mat.metallic * t[0]; }
+            if (has(9)) { tex3(9, t); ao = mat.ambient_occlusion * t[0]; }
         } else {
             float t[4];
             if (has(2)) {
-                tex(2, t);
+                tex3(2, t);
                 const bool sw = (mflags & R3N_FLAGS_AOMR_SWIZZLED_SPLIT) != 0u;
                 pr = mat.roughness * (sw ? t[1] : t[0]);
                 metallic = mat.metallic * (sw ? t[2] : t[1]);
             }
-            if (has(9)) { tex(9, t); ao = mat.ambient_occlusion * t[0]; }
+            if (has(9)) { tex3(9, t); ao = mat.ambient_occlusion * t[0]; }
         }
         // --- reflectance (opaque.wgsl:355-359)
         float reflectance = mat.reflectance;
-        if (has(4)) { float t[4]; tex(4, t); reflectance = mat.reflectance * t[0]; }
+        if (has(4)) { float t[4]; tex3(4, t); reflectance = mat.reflectance * t[0]; }
         // --- clear coat (opaque.wgsl:363-391)
         float cc = mat.clear_coat, ccpr = mat.clear_coat_roughness;
         if (mflags & R3N_FLAGS_CC_GLTF_COMBINED) {
             if (has(5)) {
                 float t[4];
-                tex(5, t);
+                tex3(5, t);
                 cc = mat.clear_coat * t[0];
                 ccpr = mat.clear_coat_roughness * t[1];
             }
         } else {
             float t[4];
-            if (has(5)) { tex(5, t); cc = mat.clear_coat * t[0]; }
+            if (has(5)) { tex3(5, t); cc = mat.clear_coat * t[0]; }
             if (has(6)) {
-                tex(6, t);
+                tex3(6, t);
                 ccpr = mat.clear_coat_roughness * ((mflags & R3N_FLAGS_CC_GLTF_SPLIT) ? t[1] : t[0]);
             }
         }
@@ -503,24 +562,26 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         for (int c = 0; c < 3; ++c) px.emissive[c] = mat.emissive[c];
         if (has(7)) {
             float t[4];
-            tex(7, t);
+            tex3(7, t);
 #pragma unroll
             for (int c = 0; c < 3; ++c) px.emissive[c] = mat.emissive[c] * t[c];
         }
+        const float omm = 1.0f - metallic;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * (1.0f - metallic);
+        for (int c = 0; c < 3; ++c) px.diffuse[c] = px.albedo[c] * omm;
         const float refl = (0.16f * reflectance) * reflectance;
+        const float refl_omm = refl * omm;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) px.f0[c] = px.albedo[c] * metallic + (refl * (1.0f - metallic));
+        for (int c = 0; c < 3; ++c) px.f0[c] = M::mad(px.albedo[c], metallic, refl_omm);
         if (cc != 0.0f) {
             const float base_pr = fmaxf(pr, ccpr);
-            pr = pr * (1.0f - cc) + base_pr * cc;
+            pr = M::mad(base_pr, cc, pr * (1.0f - cc));
         }
         px.roughness = pr * pr;
         px.ao = ao;
 
         float vv[3] = {vpos[0], vpos[1], vpos[2]};
-        normalize3(vv);
+        normalize3m<M>(vv);
 #pragma unroll
         for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
         float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
@@ -534,19 +595,20 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
                           (((fabsf(px.f0[2]) + fabsf(px.diffuse[0])) + (fabsf(px.diffuse[1]) + fabsf(px.diffuse[2]))) + fabsf(px.ao));
         const bool skip_ok = px.roughness >= 1e-9f && px.roughness <= 1e9f && mag < 1e30f;
 #endif
-        for (uint32_t i = 0; i < n_dir; ++i) {
+        for (uint32_t i = 0; i < ((R3N_SHADE_ABLATE & 8) ? 0u : n_dir); ++i) {
             const LdsDirLight &L = s_dir[i];
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
             // (D <= 1/(pi a^2), V <= 0.5/(nov a), nov >= 1e-5), so the light adds exactly +0: skip the shadow lookup
             // and the BRDF.  `+= 0.0f` keeps the -0 -> +0 behaviour of the full expression.
-            const float nl_raw = dot3(px.normal, L.l);
+            const float nl_raw = dot3m<M>(px.normal, L.l);
             if (px.roughness > 0.0f && nl_raw == nl_raw && sat(nl_raw) == 0.0f) {  // (a NaN normal must stay NaN)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) color[c] += 0.0f;
                 continue;
             }
+            // shadow coordinates: exact arithmetic under both policies (they select shadow texels and feed a comparison)
             float sn[4];
-            mul_vec4(L.m, vpos[0], vpos[1], vpos[2], vpos[3], sn);
+            mul_vec4m<MathExact>(L.m, vpos[0], vpos[1], vpos[2], vpos[3], sn);
             const float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
             const float local[2] = {fl[0], 1.0f - fl[1]};
             float tl[2] = {L.offset[0], L.offset[1]};
@@ -558,8 +620,8 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             tr[0] -= border[0]; tr[1] -= border[1];
             float shadow = 1.0f;
             // opaque.wgsl:509-514 (quirk: `any`, un-atlased coords vs atlas-space bounds -- reproduced)
-            if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f)
-                shadow = shadow_pcf5(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], sn[2]);
+            if (!(R3N_SHADE_ABLATE & 4) && (fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f)
+                shadow = shadow_pcf5<M>(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], sn[2]);
 #if R3N_SKIP_OCCLUDED
             if (skip_ok && L.sane != 0.0f && shadow * px.ao == 0.0f) {
 #pragma unroll
@@ -568,21 +630,21 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             }
 #endif
             float res[3];
-            surface_shading(L.l, L.color, px, vv, shadow * px.ao, res);
+            surface_shading<M>(L.l, L.color, px, vv, shadow * px.ao, res);
 #pragma unroll
             for (int c = 0; c < 3; ++c) color[c] += res[c];
         }
         for (uint32_t i = 0; i < n_point; ++i) {
             const LdsPointLight &P = s_point[i];
             const float delta[3] = {P.vpos[0] - vpos[0], P.vpos[1] - vpos[1], P.vpos[2] - vpos[2]};
-            const float d = sqrtf(dot3(delta, delta));
-            const float s = sat(d / P.radius);
+            const float d = M::sqrt(dot3m<M>(delta, delta));
+            const float s = sat(M::div(d, P.radius));
             const float s2 = s * s, is2 = 1.0f - s2;
-            const float att = is2 * is2 / (1.0f + s2);
+            const float att = M::div(is2 * is2, 1.0f + s2);
             const float inten[3] = {P.color[0] * att, P.color[1] * att, P.color[2] * att};
-            const float l[3] = {delta[0] / d, delta[1] / d, delta[2] / d};
+            const float l[3] = {M::div(delta[0], d), M::div(delta[1], d), M::div(delta[2], d)};
             float res[3];
-            surface_shading(l, inten, px, vv, px.ao, res);
+            surface_shading<M>(l, inten, px, vv, px.ao, res);
 #pragma unroll
             for (int c = 0; c < 3; ++c) color[c] += (res[c] > 0.0f ? res[c] : 0.0f);
         }
@@ -592,12 +654,12 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     }
 }
 
-template <bool TEX>
+template <bool TEX, class M = MathExact>
 R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
                             uint32_t n_point, uint32_t id, uint32_t x, uint32_t y, float out[4]) {
     TriRecord r;
     vertex_stage<TEX>(a, id, r);
-    fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, r, x, y, out);
+    fragment_stage<TEX, M>(a, s_dir, s_point, n_dir, n_point, r, x, y, out);
 }
 
 // Flags the triangles that own at least one pixel (plain byte stores: every writer writes 1).
@@ -668,8 +730,11 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
 // Register budget: the untextured single-sample variant is VALU-bound and measurably faster at 5 waves per SIMD
 // (<= 96 VGPRs: 347 vs 375 us on the bench scene) -- the second launch-bound asks for that.
 // REC: the per-triangle records exist: no vertex-stage code in the kernel at all.
-template <int S, bool TEX, bool REC = false, bool SPLIT = false>
+// FAST: the MathFast policy in the fragment stage (opt-in, r3n_config.shade_mode); instantiated for the record-based
+// single-sample resolve.
+template <int S, bool TEX, bool REC = false, bool SPLIT = false, bool FAST = false>
 __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TEX_OCC : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
+    typedef typename std::conditional<FAST, MathFast, MathExact>::type M;
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
@@ -709,8 +774,8 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
             a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc, a.out_bgr);
             return;
         }
-        if (REC) fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
-        else shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
+        if (REC) fragment_stage<TEX, M>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
+        else shade_fragment<TEX, M>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
     } else {
         uint32_t ids[S];
         float col[S][4];
@@ -782,9 +847,9 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
             } else if (REC) {
-                fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id0 - 1u], x, y, v);
+                fragment_stage<TEX, M>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id0 - 1u], x, y, v);
             } else {
-                shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id0, x, y, v);
+                shade_fragment<TEX, M>(a, s_dir, s_point, n_dir, n_point, id0, x, y, v);
             }
             const ushort4 h = pack_half4(v);
             if (!single) {  // edge pixel: park the samples of the first triangle; the other passes finish the pixel
@@ -813,9 +878,9 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = a.clear[c];
             } else if (REC) {
-                fragment_stage<TEX>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, v);
+                fragment_stage<TEX, M>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, v);
             } else {
-                shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, id, x, y, v);
+                shade_fragment<TEX, M>(a, s_dir, s_point, n_dir, n_point, id, x, y, v);
             }
 #pragma unroll
             for (int sm = 0; sm < S; ++sm)
@@ -1006,7 +1071,8 @@ int r3n_internal_build_srgb_lut(unsigned char *lut, hipStream_t stream);
 // memset of a.seen + k_mark_visible over keys [first_key, first_key + n_keys) + k_vertex_stage over a.total_tris slots
 int r3n_internal_shade_prepass(const ShadeArgs *a, int tex, size_t first_key, size_t n_keys, hipStream_t stream);
 // the resolve of rows [a.row_begin, a.row_end): samples 1 | 4; rec = a.tri_rec holds this frame's records; split = three-pass MSAA resolve
-int r3n_internal_resolve(const ShadeArgs *a, uint32_t samples, int tex, int rec, int split, hipStream_t stream);
+// fast: R3N_SHADE_FAST (honoured by the single-sample record-based resolve; the other variants always run the exact arithmetic)
+int r3n_internal_resolve(const ShadeArgs *a, uint32_t samples, int tex, int rec, int split, int fast, hipStream_t stream);
 int r3n_internal_blend_apply(const ShadeArgs *a, const BlendApplyArgs *b, uint32_t samples, int tex, hipStream_t stream);
 int r3n_internal_resolve_samples(const ushort4 *samples, ushort4 *hdr_out, size_t first_pixel, size_t n_pixels, hipStream_t stream);
 int r3n_internal_tonemap(const ushort4 *hdr, uchar4 *out, float4 *out_f32, size_t first_pixel, size_t n_pixels, const unsigned char *srgb_lut,

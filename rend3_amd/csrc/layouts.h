@@ -137,6 +137,7 @@ struct r3n_sub_counts {
 #define R3N_SLOT_TABLE_SHIFT 8  // canonical triangle slots per bucket of the slot -> object table
 
 #define R3N_MAX_HIZ_MIPS 16
+#define R3N_TEX_LEVELS 16  // extents <= 65535: at most 16 levels per texture (level-offset table of the sampler)
 struct r3n_hiz_desc {
     uint32_t width, height, mips, _pad;
     uint32_t offset[R3N_MAX_HIZ_MIPS];  // element offset of each mip

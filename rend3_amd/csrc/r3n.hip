@@ -12,6 +12,7 @@
 
 #include "kernels_cull.h"
 #include "kernels_raster.h"
+#include "kernels_shadow.h"
 #define R3N_SHADE_DECL_ONLY
 #include "kernels_shade.h"
 
@@ -35,6 +36,10 @@ struct CamState {
     DevBuf slot_base[2], mask[2], predicted[2], sub_counts[2], counts[2];
     uint32_t subcap[2] = {0, 0};  // list entries reserved per (material key, sub-list)
     DevBuf residual;
+    // shadow views (kernels_shadow.h): triangle records, tile lists and the fallback list's counters; the stages the host
+    // has asked for since the last flush (they are issued batched over all views, flush_shadows)
+    DevBuf recs, tile_count, tile_list, fb_counts;
+    bool pend_bake = false, pend_cull = false, pend_draw[2] = {false, false};
 };
 
 std::string g_create_error;
@@ -104,8 +109,9 @@ struct r3n_ctx {
     std::vector<uint32_t> h_blend_order;
     uint32_t n_blend = 0, blend_tris = 0;
     uint32_t frag_capacity = 32u << 20;  // fragments (24 B each incl. the sort's double buffers), allocated on first use
-    DevBuf tex_descs, tex_texels, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
+    DevBuf tex_descs, tex_texels, tex_level_off, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
+    uint64_t n_texels = 0;
     // rend3-anim tables (row N4) and the pose requests queued for the next r3n_skinning
     DevBuf edge_list, edge_count;  // split MSAA resolve (kernels_raster.h k_resolve_edges)
     uint32_t edge_capacity_override = 0;
@@ -117,11 +123,15 @@ struct r3n_ctx {
     DevBuf srgb_thr;  // 255 floats: smallest linear value whose Rgba8UnormSrgb code is >= c (GPU mip generation)
     DevBuf srgb_lut;  // 8-bit output code of every half in [0, 1): kernels_raster.h k_build_srgb_lut (or r3n_set_output_format)
     uint32_t output_format = R3N_OUTPUT_RGBA8_UNORM_SRGB;
+    uint32_t shade_mode = R3N_SHADE_EXACT;
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
     uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {0, 0, 0, 0, 0};
     uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (80 B) per work sub-queue (R3N_BIGQ of them)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
+    DevBuf shadow_views[3], shadow_rargs[2];  // device arrays of the batched shadow stages: ShadowView per stage, RasterArgs per key
+    bool shadow_pending = false;
+    bool shadow_tiles = false;  // R3N_SHADOW_TILES=1: the batched tile-owned shadow path (kernels_shadow.h) instead of the per-view one
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
     // pinned staging ring for small per-frame uploads (headers, uniforms, light buffers): the caller owns its
@@ -303,7 +313,7 @@ CamState *find_cam(r3n_ctx *c, r3n_camera cam, bool create) {
 void free_cam(CamState &s) {
     DevBuf *bufs[] = {&s.d_hdr, &s.baked, &s.vis_flags, &s.vis_list, &s.block_sums, &s.block_off, &s.slot_base[0],
                       &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.sub_counts[0],
-                      &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual};
+                      &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual, &s.recs, &s.tile_count, &s.tile_list, &s.fb_counts};
     for (DevBuf *b : bufs)
         if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
 }
@@ -414,6 +424,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     c->device = hip_device;
     if (config && config->struct_size >= sizeof(r3n_config) && config->max_big_items)
         c->big_capacity = std::max(1024u, config->max_big_items / R3N_BIGQ);
+    if (config && config->struct_size >= sizeof(r3n_config) && config->shade_mode <= R3N_SHADE_FAST) c->shade_mode = config->shade_mode;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
@@ -429,6 +440,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
+    if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) c->shadow_tiles = e4[0] == '1';
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
@@ -448,7 +460,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         }
     // empty light buffers: count = 0
     bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->srgb8_decode, 512 * 4, false, -1) == R3N_OK &&
-              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
+              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->tex_level_off, 64, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
               ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
     for (int lane = 0; ok && lane < 1 + R3N_AUX_STREAMS; ++lane)
         ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
@@ -508,10 +520,11 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->srgb8_decode,
+                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
-                      &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count};
+                      &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
+                      &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1]};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -629,7 +642,27 @@ static TextureArgs texture_args(r3n_ctx *c) {
     t.count = c->n_textures;
     t.texels = c->tex_texels.as<uint32_t>();
     t.decode = c->srgb8_decode.as<float>();
+    t.level_off = c->tex_level_off.as<uint32_t>();
+    t.small_pool = c->n_texels <= (1ull << 30) ? 1u : 0u;  // byte offsets into the pool fit 32 bits: the sampler's short path
     return t;
+}
+
+// First texel (pool index) of every level of every texture: R3N_TEX_LEVELS entries per texture, so that the sampler does not
+// walk the chain.  `descs` = the descriptors as the device holds them (offsets in texels).
+static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, uint64_t n_texels) {
+    std::vector<uint32_t> off((size_t)std::max(n, 1u) * R3N_TEX_LEVELS, 0u);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t at = descs[i].offset;
+        for (uint32_t k = 0; k < R3N_TEX_LEVELS; ++k) {
+            off[(size_t)i * R3N_TEX_LEVELS + k] = (uint32_t)at;
+            if (k < descs[i].mips) at += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k);
+        }
+    }
+    TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
+    HIP_TRY(c, hipMemcpyAsync(c->tex_level_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
+    c->n_texels = n_texels;
+    return R3N_OK;
 }
 
 int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, const uint32_t *texels, uint64_t n_texels) {
@@ -654,6 +687,7 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
         HIP_TRY(c, hipMemcpyAsync(c->tex_texels.p, texels, n_texels * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the sources only for the duration of the call
     }
+    TRY(upload_level_offsets(c, descs, n, n_texels));
     c->n_textures = n;
     return R3N_OK;
 }
@@ -734,6 +768,7 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         if (e != hipSuccess) return fail(c, R3N_ERR_HIP, std::string("textures write (encoded): ") + hipGetErrorString(e));
         if (e2 != hipSuccess) return fail(c, R3N_ERR_HIP, std::string("textures write (encoded): ") + hipGetErrorString(e2));
     }
+    TRY(upload_level_offsets(c, internal.data(), n, n_texels));
     c->n_textures = n;
     return R3N_OK;
 }
@@ -974,6 +1009,177 @@ int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t 
     return R3N_OK;
 }
 
+#ifndef R3N_MSAA_SPLIT
+#define R3N_MSAA_SPLIT 1  // MSAA resolve in three passes (first triangle per pixel / queued edge triangles / edge pixel average)
+#endif
+#ifndef R3N_BIG_GRID
+#define R3N_BIG_GRID 8192  // 4x the resident wave count (8 waves per SIMD at < 64 VGPRs): the hardware dispatcher
+                           // then balances the uneven item costs (measured on the bench scene, shadow views:
+                           // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
+#endif
+#ifndef R3N_SMALL_GRID
+#define R3N_SMALL_GRID 2048
+#endif
+#define R3N_FB_SMALL_GRID 1024  // the shadow views' fallback lists are short: smaller grids (x views)
+#define R3N_FB_BIG_GRID 2048
+
+// Issues the shadow views' pending stages, every stage ONE launch over all views (kernels_shadow.h).  Called where the reference's
+// node order moves on from the shadow nodes (the viewport's uniform bake, base.rs:156) and wherever their results are needed.
+static TextureArgs texture_args(r3n_ctx *c);
+static int flush_shadows(r3n_ctx *c) {
+    if (!c->shadow_pending) return R3N_OK;
+    c->shadow_pending = false;
+    std::vector<std::pair<uint32_t, CamState *>> batch;
+    for (auto &kv : c->shadows)
+        if (kv.second.pend_bake || kv.second.pend_cull || kv.second.pend_draw[0] || kv.second.pend_draw[1]) batch.push_back({kv.first, &kv.second});
+    if (batch.empty() || c->capacity == 0) {
+        for (auto &b : batch) b.second->pend_bake = b.second->pend_cull = b.second->pend_draw[0] = b.second->pend_draw[1] = false;
+        return R3N_OK;
+    }
+    const int lane = c->multi_stream ? 1 : 0;
+    hipStream_t stream = lane_stream(c, lane);
+    const uint32_t cap = c->capacity, nblocks = (cap + 255u) / 256u;
+    const uint32_t mw = max_waves(c);
+    const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
+    const uint32_t subcap = ((chunks + R3N_SUBQ - 1u) / R3N_SUBQ) * (R3N_CHUNK_WAVES * 64u);
+    const size_t list_bytes = (size_t)3 * R3N_SUBQ * subcap * sizeof(r3n_tri_ref);
+    // ---- sizes first (allocations run on the main stream), then the descriptors
+    std::vector<ShadowView> hv[3];  // [bake | cull | draw]
+    std::vector<RasterArgs> hr[2];  // fallback / cutout draws per key
+    uint32_t max_tiles = 1;
+    for (auto &b : batch) {
+        CamState &s = *b.second;
+        const int cur = s.cur;
+        TRY(ensure(c, s.vis_flags, cap, false, -1));
+        TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
+        TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
+        TRY(ensure(c, s.block_off, (size_t)nblocks * sizeof(ObjBlockOffsets), false, -1));
+        TRY(ensure(c, s.slot_base[cur], (size_t)cap * 4u, true, 0xFF));
+        TRY(ensure(c, s.sub_counts[cur], sizeof(r3n_sub_counts), false, 0));
+        TRY(ensure(c, s.counts[cur], sizeof(r3n_cull_counts), false, 0));
+        TRY(ensure(c, s.mask[cur], (size_t)mw * 8u, false, -1));
+        TRY(ensure(c, s.predicted[cur], list_bytes, false, -1));
+        TRY(ensure(c, s.recs, (size_t)mw * 64u * sizeof(r3n_shadow_tri), false, -1));
+        const uint32_t tiles_x = std::max(1u, (s.vp_size + R3N_STILE - 1u) / R3N_STILE);
+        TRY(ensure(c, s.tile_count, (size_t)tiles_x * tiles_x * 4u, false, 0));
+        TRY(ensure(c, s.tile_list, (size_t)tiles_x * tiles_x * R3N_STILE_CAP * 4u, false, -1));
+        TRY(ensure(c, s.fb_counts, 3u * R3N_SUBQ * 4u, false, 0));
+        s.subcap[cur] = subcap;
+        max_tiles = std::max(max_tiles, tiles_x * tiles_x);
+        ShadowView v{};
+        v.hdr = s.d_hdr.as<r3n_camera_header240>();
+        v.baked = s.baked.as<r3n_baked128>();
+        v.vis_flags = s.vis_flags.as<uint8_t>();
+        v.block_sums = s.block_sums.as<ObjBlockSums>();
+        v.block_off = s.block_off.as<ObjBlockOffsets>();
+        v.vis_list = s.vis_list.as<r3n_vis_entry>();
+        v.slot_base = s.slot_base[cur].as<uint32_t>();
+        v.counts = s.counts[cur].as<r3n_cull_counts>();
+        v.sub_counts = s.sub_counts[cur].as<r3n_sub_counts>();
+        v.mask = s.mask[cur].as<unsigned long long>();
+        v.recs = s.recs.as<r3n_shadow_tri>();
+        v.tile_count = s.tile_count.as<uint32_t>();
+        v.tile_list = s.tile_list.as<uint32_t>();
+        v.fallback = s.predicted[cur].as<r3n_tri_ref>();
+        v.fb_counts = s.fb_counts.as<uint32_t>();
+        v.subcap = subcap;
+        v.vp_x = s.vp_x; v.vp_y = s.vp_y; v.vp_size = s.vp_size; v.tiles_x = tiles_x;
+        if (s.pend_bake) hv[0].push_back(v);
+        if (s.pend_cull) hv[1].push_back(v);
+        if (s.pend_draw[0]) hv[2].push_back(v);
+        for (uint32_t key = 0; key < 2u; ++key) {
+            if (!s.pend_draw[key]) continue;
+            const uint32_t slot = (uint32_t)hr[key].size();  // its own work queue: at most R3N_AUX_STREAMS views per raster launch
+            const int qlane = 1 + (int)(slot % R3N_AUX_STREAMS);
+            RasterArgs a{};
+            a.hdr = v.hdr;
+            a.objects = c->objects.as<r3n_object128>();
+            a.mesh = c->mesh.as<uint32_t>();
+            a.baked = v.baked;
+            a.materials = c->materials.as<r3n_material208>();
+            a.material_keys = c->material_keys.as<uint8_t>();
+            a.n_materials = c->n_materials;
+            a.tri_base = c->tri_base.as<uint32_t>();
+            a.list = v.fallback;
+            a.sub_counts = v.fb_counts;
+            a.subcap = subcap;
+            a.key = key;
+            a.big_items = c->big_items[qlane].as<r3n_big_item>();
+            const uint32_t fwd = std::min(c->forward_index_lane[qlane]++, 63u);
+            a.big_count = c->big_count[qlane].as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
+            a.big_capacity = c->big_capacity;
+            a.big_uv = c->big_uv[qlane].as<r3n_big_uv>();
+            a.tex = texture_args(c);
+            a.vp_x = s.vp_x; a.vp_y = s.vp_y; a.vp_w = s.vp_size; a.vp_h = s.vp_size; a.target_pitch = c->atlas_w;
+            a.depth = c->atlas.as<uint32_t>();
+            hr[key].push_back(a);
+        }
+        s.pend_bake = s.pend_cull = s.pend_draw[0] = s.pend_draw[1] = false;
+    }
+    auto upload = [&](DevBuf &dst, const void *src, size_t bytes) -> int {
+        TRY(ensure(c, dst, std::max<size_t>(bytes, 256), false, -1));
+        for (size_t off = 0; off < bytes; off += r3n_ctx::kStageSlotBytes)
+            TRY(upload_small(c, static_cast<char *>(dst.p) + off, static_cast<const char *>(src) + off, std::min<size_t>(r3n_ctx::kStageSlotBytes, bytes - off)));
+        return R3N_OK;
+    };
+    for (int st = 0; st < 3; ++st)
+        if (!hv[st].empty()) TRY(upload(c->shadow_views[st], hv[st].data(), hv[st].size() * sizeof(ShadowView)));
+    for (int key = 0; key < 2; ++key)
+        if (!hr[key].empty()) TRY(upload(c->shadow_rargs[key], hr[key].data(), hr[key].size() * sizeof(RasterArgs)));
+    TRY(fork_lane(c, lane));  // after the header / descriptor uploads and the frame's clears (main stream)
+    ShadowBatchArgs a{};
+    a.objects = c->objects.as<r3n_object128>();
+    a.mesh = c->mesh.as<uint32_t>();
+    a.material_keys = c->material_keys.as<uint8_t>();
+    a.n_materials = c->n_materials;
+    a.range_begin = c->range_begin; a.range_end = c->range_end;
+    a.atlas = c->atlas.as<uint32_t>();
+    a.atlas_pitch = c->atlas_w;
+    if (!hv[0].empty()) {
+        a.views = c->shadow_views[0].as<ShadowView>();
+        Timed t(c, R3N_STAGE_BAKE, stream);
+        hipLaunchKernelGGL(k_shadow_bake, dim3((cap * 4u + 255u) / 256u, (unsigned)hv[0].size()), dim3(256), 0, stream, a);
+    }
+    if (!hv[1].empty()) {
+        a.views = c->shadow_views[1].as<ShadowView>();
+        const unsigned nv = (unsigned)hv[1].size();
+        {
+            Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
+            hipLaunchKernelGGL(k_shadow_object_count, dim3(nblocks, nv), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_shadow_object_scan, dim3(1, nv), dim3(1024), 0, stream, a, nblocks);
+            hipLaunchKernelGGL(k_shadow_object_scatter, dim3(nblocks, nv), dim3(256), 0, stream, a);
+        }
+        {
+            Timed t(c, R3N_STAGE_TRIANGLE_CULL, stream);
+            hipLaunchKernelGGL(k_shadow_cull_bin, dim3(std::max(1u, std::min(chunks, 4096u)), nv), dim3(256), 0, stream, a);
+        }
+    }
+    if (!hv[2].empty()) {
+        a.views = c->shadow_views[2].as<ShadowView>();
+        Timed t(c, R3N_STAGE_SHADOW_RASTER, stream);
+        hipLaunchKernelGGL(k_shadow_tiles, dim3(max_tiles, (unsigned)hv[2].size()), dim3(R3N_STILE_THREADS), 0, stream, a);
+    }
+    TRY(check_launch(c, "shadow batch"));
+    // what the tiles declined (opaque key) and the cutout key: general rasteriser over the fallback lists, AFTER the tile stores
+    for (uint32_t key = 0; key < 2u; ++key) {
+        const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
+        for (size_t first = 0; first < hr[key].size(); first += R3N_AUX_STREAMS) {
+            const unsigned nv = (unsigned)std::min<size_t>(R3N_AUX_STREAMS, hr[key].size() - first);
+            const RasterArgs *views = c->shadow_rargs[key].as<RasterArgs>() + first;
+            for (unsigned k = 0; k < nv; ++k) HIP_TRY(c, hipMemsetAsync(hr[key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
+            Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream);
+            if (tex) {
+                hipLaunchKernelGGL((k_raster_small_views<true, 1, true>), dim3(R3N_FB_SMALL_GRID, nv), dim3(256), 0, stream, views);
+                hipLaunchKernelGGL((k_raster_big_views<true, 1, true>), dim3(R3N_FB_BIG_GRID, nv), dim3(256), 0, stream, views);
+            } else {
+                hipLaunchKernelGGL((k_raster_small_views<true, 1, false>), dim3(R3N_FB_SMALL_GRID, nv), dim3(256), 0, stream, views);
+                hipLaunchKernelGGL((k_raster_big_views<true, 1, false>), dim3(R3N_FB_BIG_GRID, nv), dim3(256), 0, stream, views);
+            }
+        }
+    }
+    return check_launch(c, "shadow fallback raster");
+}
+
 int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr) {
     if (!c || !hdr) return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: null");
     CamState *s = find_cam(c, cam, true);
@@ -989,6 +1195,12 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     TRY(upload_small(c, s->d_hdr.p, hdr, sizeof *hdr));
     // per-camera buffer regrow preserves old matrices (disabled slots keep stale data, App. D.2)
     TRY(ensure(c, s->baked, (size_t)c->capacity * sizeof(r3n_baked128), true, 0));
+    if (cam != R3N_CAMERA_VIEWPORT && c->shadow_tiles) {  // shadow views: issued batched over all views (flush_shadows)
+        s->pend_bake = true;
+        c->shadow_pending = true;
+        return R3N_OK;
+    }
+    if (cam == R3N_CAMERA_VIEWPORT) TRY(flush_shadows(c));  // reference order (base.rs:148-156): the shadow nodes precede the viewport's
     const int lane = cam_lane(c, cam);
     TRY(fork_lane(c, lane));  // after the header upload (main stream)
     hipStream_t stream = lane_stream(c, lane);
@@ -1007,6 +1219,13 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     if (c->capacity == 0) return R3N_OK;  // culler.rs:705-707
     HIP_TRY(c, hipSetDevice(c->device));
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
+    if (!viewport && c->shadow_tiles) {  // shadow views: issued batched over all views (flush_shadows)
+        s->pend_cull = true;
+        c->shadow_pending = true;
+        s->culled = true;
+        s->last = s->cur;
+        return R3N_OK;
+    }
     const int cur = s->cur, prev = 1 - cur;
     const int lane = cam_lane(c, cam);
     hipStream_t stream = lane_stream(c, lane);
@@ -1114,6 +1333,17 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         return forward_blend(c);
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!viewport && c->shadow_tiles) {
+        // shadow views (base.rs:366-396: opaque_depth and cutout_depth over CullingSource::Residual): issued batched over all
+        // views by flush_shadows -- tile rasteriser for the opaque key, the general one for cutouts and what the tiles decline
+        if (source != R3N_SOURCE_RESIDUAL) return fail(c, R3N_ERR_UNSUPPORTED, "forward: shadow views draw the residual source (base.rs:366-396)");
+        if (!s->culled) return R3N_OK;
+        if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
+            return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
+        s->pend_draw[key] = true;
+        c->shadow_pending = true;
+        return R3N_OK;
+    }
     int idx;
     const r3n_tri_ref *list;
     const uint32_t *sub_counts;
@@ -1151,17 +1381,6 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.big_capacity = c->big_capacity;
     a.big_uv = c->big_uv[lane].as<r3n_big_uv>();
     a.tex = texture_args(c);
-#ifndef R3N_MSAA_SPLIT
-#define R3N_MSAA_SPLIT 1  // MSAA resolve in three passes (first triangle per pixel / queued edge triangles / edge pixel average)
-#endif
-#ifndef R3N_BIG_GRID
-#define R3N_BIG_GRID 8192  // 4x the resident wave count (8 waves per SIMD at < 64 VGPRs): the hardware dispatcher
-                           // then balances the uneven item costs (measured on the bench scene, shadow views:
-                           // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
-#endif
-#ifndef R3N_SMALL_GRID
-#define R3N_SMALL_GRID 2048
-#endif
     const uint32_t small_grid = R3N_SMALL_GRID;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
     TRY(fork_lane(c, lane));
     HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
@@ -1237,6 +1456,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     if (r1 <= r0) return R3N_OK;
     CamState &s = c->viewport;
     if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
+    TRY(flush_shadows(c));  // the resolve reads the shadow atlas
     // frames in flight: the resolve goes to the shade stream, ordered after this frame's viewport chain (main stream up
     // to here) and shadow views (lanes); the main stream is free to start the next frame.  Not when a transparent pass
     // follows (it continues on the main stream with the HDR target) or while stage timing is on.
@@ -1292,7 +1512,8 @@ int r3n_resolve_opaque(r3n_ctx *c) {
             HIP_TRY(c, hipMemsetAsync(a.edge_count, 0, R3N_EDGEQ * 4, stream));
             split = true;
         }
-        HIP_TRY(c, (hipError_t)r3n_internal_resolve(&a, c->samples, tex ? 1 : 0, a.tri_rec != nullptr ? 1 : 0, split ? 1 : 0, stream));
+        HIP_TRY(c, (hipError_t)r3n_internal_resolve(&a, c->samples, tex ? 1 : 0, a.tri_rec != nullptr ? 1 : 0, split ? 1 : 0,
+                                                    c->shade_mode == R3N_SHADE_FAST ? 1 : 0, stream));
     }
     TRY(check_launch(c, "k_resolve_opaque"));
     if (on_shade) {
@@ -1474,6 +1695,12 @@ int r3n_set_output_format(r3n_ctx *c, uint32_t format) {
     return R3N_OK;
 }
 
+int r3n_set_shade_mode(r3n_ctx *c, uint32_t mode) {
+    if (!c || mode > R3N_SHADE_FAST) return fail(c, R3N_ERR_INVALID_ARG, "set_shade_mode: unknown mode");
+    c->shade_mode = mode;  // read when the next resolve is enqueued
+    return R3N_OK;
+}
+
 int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
     if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "tonemap: outside a frame");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1495,6 +1722,8 @@ int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
 
 int r3n_frame_end(r3n_ctx *c) {
     if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "frame_end: no frame in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(flush_shadows(c));
     TRY(join_lanes(c));  // the next frame's clears (main stream) must not overtake this frame's shadow work
     auto flip = [](CamState &s) {
         if (s.culled) { s.cur = 1 - s.cur; s.has_prev = true; }
@@ -1514,6 +1743,7 @@ int r3n_set_object_range(r3n_ctx *c, uint32_t begin, uint32_t end) {
 }
 int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atlas, uint64_t *atlas_count) {
     if (!c || !c->vis.p) return fail(c, R3N_ERR_STATE, "exchange_buffers: no frame targets yet");
+    TRY(flush_shadows(c));
     TRY(join_lanes(c));  // collectives are ordered on the main stream
     if (vis) *vis = c->vis.p;
     if (vis_count) *vis_count = (uint64_t)c->width * c->height * c->samples;
@@ -1537,6 +1767,7 @@ int r3n_output_buffer(r3n_ctx *c, void **rgba8, uint64_t *bytes) {
 // ------------------------------------------------------------------------------------------------ readbacks
 static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(flush_shadows(c));
     TRY(join_lanes(c));
     TRY(join_shade(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1622,6 +1853,15 @@ int r3n_readback_raster_stats(r3n_ctx *c, uint32_t big_items[64]) {
             for (int q = 0; q < R3N_BIGQ; ++q) big_items[base + f] += raw[f * R3N_BIGQ + q];
     }
     return R3N_OK;
+}
+
+int r3n_readback_shadow_tile_counts(r3n_ctx *c, r3n_camera cam, uint32_t *counts, uint32_t n, uint32_t *tiles_x) {
+    CamState *s = c ? find_cam(c, cam, false) : nullptr;
+    if (!s || cam == R3N_CAMERA_VIEWPORT || !s->tile_count.p || !counts) return fail(c, R3N_ERR_STATE, "readback_shadow_tile_counts: shadow view never drawn");
+    const uint32_t tx = std::max(1u, (s->vp_size + R3N_STILE - 1u) / R3N_STILE);
+    if (n < tx * tx) return fail(c, R3N_ERR_INVALID_ARG, "readback_shadow_tile_counts: buffer too small");
+    if (tiles_x) *tiles_x = tx;
+    return d2h(c, counts, s->tile_count.p, (size_t)tx * tx * 4u);
 }
 
 int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity) {
@@ -1727,8 +1967,15 @@ int r3n_set_multi_stream(r3n_ctx *c, int enable) {
     return R3N_OK;
 }
 
+// four independent 16-byte loads in flight per thread and iteration
 __global__ __launch_bounds__(256) static void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+    const size_t stride = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3u * stride < n; i += 4u * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2u * stride], d = src[i + 3u * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2u * stride] = c; dst[i + 3u * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 int r3n_hbm_copy_rate(r3n_ctx *c, uint64_t bytes, uint32_t repeats, double *gb_per_s) {
@@ -1744,9 +1991,10 @@ int r3n_hbm_copy_rate(r3n_ctx *c, uint64_t bytes, uint32_t repeats, double *gb_p
         hipEventCreate(&e1) != hipSuccess || hipMemsetAsync(a, 1, n * 16, c->stream) != hipSuccess) {
         rc = fail(c, R3N_ERR_HIP, "hbm_copy_rate: scratch allocation failed");
     } else {
-        for (uint32_t r = 0; r <= repeats && rc == R3N_OK; ++r) {  // first pass untimed (page mapping, clocks)
+        const unsigned grids[3] = {256u * 8u, 256u * 16u, 256u * 32u};  // the best of a few grid sizes counts
+        for (uint32_t r = 0; r <= 3u * repeats && rc == R3N_OK; ++r) {  // first pass untimed (page mapping, clocks)
             (void)hipEventRecord(e0, c->stream);
-            hipLaunchKernelGGL(k_copy_f4, dim3(256 * 32), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n);
+            hipLaunchKernelGGL(k_copy_f4, dim3(grids[r % 3u]), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n);
             (void)hipEventRecord(e1, c->stream);
             float ms = 0.0f;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(c, R3N_ERR_HIP, "hbm_copy_rate: timing failed");

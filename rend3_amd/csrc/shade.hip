@@ -28,11 +28,14 @@ int r3n_internal_shade_prepass(const ShadeArgs *ap, int tex, size_t first_key, s
     return launch_status();
 }
 
-int r3n_internal_resolve(const ShadeArgs *ap, uint32_t samples, int tex, int rec, int split, hipStream_t stream) {
+int r3n_internal_resolve(const ShadeArgs *ap, uint32_t samples, int tex, int rec, int split, int fast, hipStream_t stream) {
     if (samples == 4) return r3n_internal_resolve_ms(ap, tex, rec, split, stream);  // shade_ms.hip
     const ShadeArgs &a = *ap;
     const dim3 rgrid((a.width + 15u) / 16u, (a.row_end - a.row_begin + 15u) / 16u);
-    if (rec) {
+    if (rec && fast) {
+        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, false, true, false, true>), rgrid, dim3(256), 0, stream, a);
+    } else if (rec) {
         if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_resolve_opaque<1, false, true>), rgrid, dim3(256), 0, stream, a);
     } else {

@@ -24,6 +24,8 @@ struct TextureArgs {
                                   // give.  The resolve stages them in LDS: a texel decode is then 4 LDS reads instead of
                                   // 4 IEEE divisions.  (Measured alternative: a pre-decoded float4 pool, 4x the memory,
                                   // same speed -- the kernel is bound by VALU work, not by the decode.)
+    const uint32_t *level_off;    // R3N_TEX_LEVELS entries per texture: pool index of the first texel of each level
+    uint32_t small_pool;          // 1: the pool holds <= 2^30 texels, so a texel's BYTE offset fits 32 bits
 };
 
 R3N_DEV uint32_t tex_mip_dim(uint32_t d, uint32_t k) {
@@ -98,84 +100,189 @@ R3N_DEV void tex_footprint(const r3n_texture_desc32 &d, bool nearest, float u, f
     tex_level_footprint(w, h, u, v, f.l[0]);
     if (frac > 0.0f) tex_level_footprint(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), u, v, f.l[1]);
 }
-R3N_DEV void tex_texel(const TextureArgs &t, bool srgb, const uint32_t *__restrict__ lvl, uint32_t i, float o[4]) {
+// A decoded texel / filtered sample as two channel pairs: the bilinear and trilinear blends below then run as packed f32
+// operations (v_pk_mul_f32 / v_pk_add_f32: two channels per issue slot, each operation rounded once like its scalar form).
+struct Texel4 {
+    f2 rg, ba;
+};
+// NEED_A = false: the caller reads r, g, b only (AO / roughness / metallic, emissive ...): alpha is neither decoded nor filtered
+template <bool NEED_A>
+R3N_DEV Texel4 tex_texel(const TextureArgs &t, bool srgb, const uint32_t *__restrict__ lvl, uint32_t i) {
     const uint32_t v = lvl[i];
     const float *rgb = t.decode + (srgb ? 256 : 0);
-    o[0] = rgb[v & 0xFFu]; o[1] = rgb[(v >> 8) & 0xFFu]; o[2] = rgb[(v >> 16) & 0xFFu]; o[3] = t.decode[v >> 24];
+    Texel4 o;
+    o.rg = (f2){rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu]};
+    o.ba = (f2){rgb[(v >> 16) & 0xFFu], NEED_A ? t.decode[v >> 24] : 0.0f};
+    return o;
 }
-R3N_DEV void tex_bilinear(const TextureArgs &t, bool srgb, size_t lvl_off, const TexFootprint::Lvl &l, float o[4]) {
-    float c00[4], c10[4], c01[4], c11[4];
+template <class M> R3N_DEV f2 mix2(f2 a, f2 b, float t, float one_minus_t) {  // a * (1 - t) + b * t
+    return M::mad(b, splat2(t), a * splat2(one_minus_t));
+}
+template <class M, bool NEED_A>
+R3N_DEV Texel4 tex_bilinear(const TextureArgs &t, bool srgb, size_t lvl_off, const TexFootprint::Lvl &l) {
     const uint32_t *lvl = t.texels + lvl_off;
-    tex_texel(t, srgb, lvl, l.i00, c00); tex_texel(t, srgb, lvl, l.i10, c10);
-    tex_texel(t, srgb, lvl, l.i01, c01); tex_texel(t, srgb, lvl, l.i11, c11);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float top = c00[c] * (1.0f - l.fx) + c10[c] * l.fx;
-        const float bot = c01[c] * (1.0f - l.fx) + c11[c] * l.fx;
-        o[c] = top * (1.0f - l.fy) + bot * l.fy;
+    const Texel4 c00 = tex_texel<NEED_A>(t, srgb, lvl, l.i00), c10 = tex_texel<NEED_A>(t, srgb, lvl, l.i10);
+    const Texel4 c01 = tex_texel<NEED_A>(t, srgb, lvl, l.i01), c11 = tex_texel<NEED_A>(t, srgb, lvl, l.i11);
+    const float omx = 1.0f - l.fx, omy = 1.0f - l.fy;
+    Texel4 o;
+    o.rg = mix2<M>(mix2<M>(c00.rg, c10.rg, l.fx, omx), mix2<M>(c01.rg, c11.rg, l.fx, omx), l.fy, omy);
+    if (NEED_A) {
+        o.ba = mix2<M>(mix2<M>(c00.ba, c10.ba, l.fx, omx), mix2<M>(c01.ba, c11.ba, l.fx, omx), l.fy, omy);
+    } else {  // blue alone
+        const float top = M::mad(c10.ba.x, l.fx, c00.ba.x * omx), bot = M::mad(c11.ba.x, l.fx, c01.ba.x * omx);
+        o.ba = (f2){M::mad(bot, l.fy, top * omy), 0.0f};
     }
+    return o;
 }
-R3N_DEV void tex_apply(const TextureArgs &t, const r3n_texture_desc32 &d, const TexFootprint &f, float o[4]) {
+template <class M, bool NEED_A>
+R3N_DEV Texel4 tex_apply(const TextureArgs &t, const r3n_texture_desc32 &d, const TexFootprint &f) {
     const size_t lvl = (size_t)d.offset + f.level_off;
     const bool srgb = d.format == 1u;
-    if (f.nearest) {
-        tex_texel(t, srgb, t.texels + lvl, f.l[0].i00, o);
-        return;
-    }
-    tex_bilinear(t, srgb, lvl, f.l[0], o);
+    if (f.nearest) return tex_texel<NEED_A>(t, srgb, t.texels + lvl, f.l[0].i00);
+    Texel4 o = tex_bilinear<M, NEED_A>(t, srgb, lvl, f.l[0]);
     if (f.frac > 0.0f) {
-        float hi[4];
-        tex_bilinear(t, srgb, lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level), f.l[1], hi);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = o[c] * (1.0f - f.frac) + hi[c] * f.frac;
+        const Texel4 hi = tex_bilinear<M, NEED_A>(t, srgb, lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level), f.l[1]);
+        const float omf = 1.0f - f.frac;
+        o.rg = mix2<M>(o.rg, hi.rg, f.frac, omf);
+        if (NEED_A) o.ba = mix2<M>(o.ba, hi.ba, f.frac, omf);
+        else o.ba.x = M::mad(hi.ba.x, f.frac, o.ba.x * omf);
     }
+    return o;
 }
+// One level of the short path: bilinear footprint of a power-of-two level whose coordinates are tame.  Returns false when
+// the general code has to take over (a floor beyond 2^24 or NaN: then `floor + 1` and the integer increment part ways).
+struct TexLvlFast {
+    uint32_t o00, o10, o01, o11;  // BYTE offsets of the four texels in the pool
+    float fx, fy;
+};
+R3N_DEV bool tex_level_fast(uint32_t w, uint32_t h, uint32_t base, float u, float v, TexLvlFast &l) {
+    const float tx = u * (float)w - 0.5f, ty = v * (float)h - 0.5f;
+    const float fx0 = floorf(tx), fy0 = floorf(ty);
+    l.fx = tx - fx0; l.fy = ty - fy0;
+    const int ix = (int)fx0, iy = (int)fy0;
+    // power-of-two extent: the mask is the floor-modulo of Repeat addressing, for negative indices too
+    const uint32_t x0 = (uint32_t)ix & (w - 1u), x1 = (uint32_t)(ix + 1) & (w - 1u);
+    const uint32_t y0 = __umul24((uint32_t)iy & (h - 1u), w), y1 = __umul24((uint32_t)(iy + 1) & (h - 1u), w);  // extents <= 65535
+    l.o00 = (base + y0 + x0) << 2; l.o10 = (base + y0 + x1) << 2;
+    l.o01 = (base + y1 + x0) << 2; l.o11 = (base + y1 + x1) << 2;
+    return fabsf(fx0) < 16777216.0f && fabsf(fy0) < 16777216.0f;  // NaN compares false
+}
+template <bool NEED_A>
+R3N_DEV Texel4 tex_texel_at(const TextureArgs &t, const float *__restrict__ rgb, uint32_t byte_off) {
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t.texels) + byte_off);  // uniform base + 32-bit offset
+    Texel4 o;
+    o.rg = (f2){rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu]};
+    o.ba = (f2){rgb[(v >> 16) & 0xFFu], NEED_A ? t.decode[v >> 24] : 0.0f};
+    return o;
+}
+template <class M, bool NEED_A>
+R3N_DEV Texel4 tex_bilinear_fast(const TextureArgs &t, const float *__restrict__ rgb, const TexLvlFast &l) {
+    const Texel4 c00 = tex_texel_at<NEED_A>(t, rgb, l.o00), c10 = tex_texel_at<NEED_A>(t, rgb, l.o10);
+    const Texel4 c01 = tex_texel_at<NEED_A>(t, rgb, l.o01), c11 = tex_texel_at<NEED_A>(t, rgb, l.o11);
+    const float omx = 1.0f - l.fx, omy = 1.0f - l.fy;
+    Texel4 o;
+    o.rg = mix2<M>(mix2<M>(c00.rg, c10.rg, l.fx, omx), mix2<M>(c01.rg, c11.rg, l.fx, omx), l.fy, omy);
+    if (NEED_A) {
+        o.ba = mix2<M>(mix2<M>(c00.ba, c10.ba, l.fx, omx), mix2<M>(c01.ba, c11.ba, l.fx, omx), l.fy, omy);
+    } else {
+        const float top = M::mad(c10.ba.x, l.fx, c00.ba.x * omx), bot = M::mad(c11.ba.x, l.fx, c01.ba.x * omx);
+        o.ba = (f2){M::mad(bot, l.fy, top * omy), 0.0f};
+    }
+    return o;
+}
+
 // textureSampleGrad(textures[id - 1], nearest ? nearest_sampler : primary_sampler, (u, v), ddx, ddy).
+// The level of detail and the footprint are the same exact arithmetic under both policies (a fused operation must not move a
+// sample to another mip level or texel); M only governs the blends.
+// Short path (what scanned material sets hit): linear sampler, power-of-two extents, tame coordinates, pool below 4 GiB.  Same
+// values as the general path -- masks instead of remainders, the level's first texel from a table instead of a walk over
+// the chain, 32-bit byte offsets from the uniform pool pointer -- with one branch per sample instead of one per texel.
 // (Sharing one footprint between the maps of a material that have the same extent was measured: slower -- the cached
 // footprint stays live across the whole fragment stage and costs an occupancy step.)
+template <class M = MathExact, bool NEED_A = true>
 R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, float u, float v, const float ddx[2],
                              const float ddy[2], float o[4]) {
     if (id == 0u || id > t.count) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const r3n_texture_desc32 d = t.descs[id - 1u];
+    const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
+    if (!nearest && pow2 && t.small_pool != 0u) {
+        // level of detail exactly as tex_footprint derives it
+        const float W = (float)d.width, H = (float)d.height;
+        const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
+        const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
+        uint32_t level = 0;
+        float frac = 0.0f;
+        if (rho > 1.0f && rho < INFINITY) {
+            const uint32_t bits = __float_as_uint(rho);
+            level = (bits >> 23) - 127u;
+            frac = (float)(bits & 0x7FFFFFu) / 8388608.0f;
+        } else if (rho == INFINITY) {
+            level = d.mips;
+        }
+        if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
+        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
+        const float *rgb = t.decode + (d.format == 1u ? 256 : 0);
+        TexLvlFast l0, l1;
+        bool tame = tex_level_fast(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
+        const bool two = frac > 0.0f;  // then level + 1 <= mips - 1
+        if (two) tame = tex_level_fast(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
+        if (tame) {
+            Texel4 r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
+            if (two) {
+                const Texel4 hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
+                const float omf = 1.0f - frac;
+                r.rg = mix2<M>(r.rg, hi.rg, frac, omf);
+                if (NEED_A) r.ba = mix2<M>(r.ba, hi.ba, frac, omf);
+                else r.ba.x = M::mad(hi.ba.x, frac, r.ba.x * omf);
+            }
+            o[0] = r.rg.x; o[1] = r.rg.y; o[2] = r.ba.x; o[3] = r.ba.y;
+            return;
+        }
+    }
     TexFootprint f;
     tex_footprint(d, nearest, u, v, ddx, ddy, f);
-    tex_apply(t, d, f, o);
+    const Texel4 r = tex_apply<M, NEED_A>(t, d, f);
+    o[0] = r.rg.x; o[1] = r.rg.y; o[2] = r.ba.x; o[3] = r.ba.y;
 }
 
 // vertex_attributes.wgsl: vec2<f32> texture coordinates (attribute 3); a missing attribute reads (0, 0)
 R3N_DEV void fetch_uv0(const uint32_t *__restrict__ mesh, uint32_t byte_off, uint32_t vtx, float o[2]) {
     if (byte_off == R3N_INVALID) { o[0] = o[1] = 0.0f; return; }
     const uint32_t w = byte_off / 4u + vtx * 2u;
-    o[0] = __uint_as_float(mesh[w]);
-    o[1] = __uint_as_float(mesh[w + 1u]);
+    const r3n_words2 t = *reinterpret_cast<const r3n_words2 *>(mesh + w);
+    o[0] = __uint_as_float(t.x);
+    o[1] = __uint_as_float(t.y);
 }
 // perspective-correct interpolation of a vec2 attribute at the centre of pixel (px, py), covered or not
+template <class M = MathExact>
 R3N_DEV void interp_vec2(const TriSetup &ts, const float a[3][2], int px, int py, float o[2]) {
     float E[3];
     (void)edge_eval(ts, (float)px + 0.5f, (float)py + 0.5f, E);
-    const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+    const float rs = M::rcp((E[0] + E[1]) + E[2]);
     const float l0 = E[0] * rs, l1 = E[1] * rs, l2 = E[2] * rs;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) o[c] = (l0 * a[0][c] + l1 * a[1][c]) + l2 * a[2][c];
+    const f2 r = M::mad(splat2(l2), (f2){a[2][0], a[2][1]}, M::mad(splat2(l1), (f2){a[1][0], a[1][1]}, splat2(l0) * (f2){a[0][0], a[0][1]}));
+    o[0] = r.x; o[1] = r.y;
 }
 // (uv_transform * vec3(uv, 1)).xy; mat3x3 stored as three padded vec4 columns
+template <class M = MathExact>
 R3N_DEV void uv_transform(const float *m, const float uv[2], float o[2]) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) o[c] = (m[c] * uv[0] + m[4 + c] * uv[1]) + m[8 + c] * 1.0f;
+    const f2 r = M::mad((f2){m[8], m[9]}, splat2(1.0f), M::mad((f2){m[4], m[5]}, splat2(uv[1]), (f2){m[0], m[1]} * splat2(uv[0])));
+    o[0] = r.x; o[1] = r.y;
 }
 // Fragment-stage texture coordinates of pixel (x, y) and their derivatives: differences inside the pixel's 2x2 quad
 // ("fine": same row for dpdx, same column for dpdy), every operand evaluated like its own (helper) invocation.
 // m = uv_transform0 or nullptr (depth.wgsl uses the raw coordinates).  Only the two quad neighbours are evaluated
 // here; the pixel's own value comes from `self_raw` (its interpolated coordinates) when the caller already has them.
+template <class M = MathExact>
 R3N_DEV void frag_coords(const TriSetup &ts, const float uv[3][2], const float *m, int x, int y, float coords[2],
                          float ddx[2], float ddy[2], const float *self_raw = nullptr) {
     float raw[2], self[2], nx[2], ny[2];
-    if (self_raw) { raw[0] = self_raw[0]; raw[1] = self_raw[1]; } else interp_vec2(ts, uv, x, y, raw);
-    if (m) uv_transform(m, raw, self); else { self[0] = raw[0]; self[1] = raw[1]; }
-    interp_vec2(ts, uv, x ^ 1, y, raw);
-    if (m) uv_transform(m, raw, nx); else { nx[0] = raw[0]; nx[1] = raw[1]; }
-    interp_vec2(ts, uv, x, y ^ 1, raw);
-    if (m) uv_transform(m, raw, ny); else { ny[0] = raw[0]; ny[1] = raw[1]; }
+    if (self_raw) { raw[0] = self_raw[0]; raw[1] = self_raw[1]; } else interp_vec2<M>(ts, uv, x, y, raw);
+    if (m) uv_transform<M>(m, raw, self); else { self[0] = raw[0]; self[1] = raw[1]; }
+    interp_vec2<M>(ts, uv, x ^ 1, y, raw);
+    if (m) uv_transform<M>(m, raw, nx); else { nx[0] = raw[0]; nx[1] = raw[1]; }
+    interp_vec2<M>(ts, uv, x, y ^ 1, raw);
+    if (m) uv_transform<M>(m, raw, ny); else { ny[0] = raw[0]; ny[1] = raw[1]; }
     coords[0] = self[0]; coords[1] = self[1];
     // value at the odd pixel of the pair minus value at the even one
 #pragma unroll

@@ -635,6 +635,11 @@ class Renderer:
         self._check(self.lib.r3n_set_output_format(self.ctx, int(fmt)), "r3n_set_output_format")
         self.output_format = int(fmt)
 
+    def set_shade_mode(self, mode):
+        """0 = R3N_SHADE_EXACT (default, bit-identical to the oracle), 1 = R3N_SHADE_FAST (fused / approximate shading arithmetic,
+        framebuffer within 1e-3 after tonemap)."""
+        self._check(self.lib.r3n_set_shade_mode(self.ctx, int(mode)), "r3n_set_shade_mode")
+
     def readback_joint_matrices(self):
         """The joint matrices the last skinning pass read (host-provided and GPU-posed), (n, 16) f32."""
         n = sum(len(sk["matrices"]) for sk in self.skeletons)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Folds the rocprofv3 --pmc passes of tools/gpu_pmc.sh into profiles-style JSON: per kernel and launch HBM bytes
+(FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction for wide coalesced loads -- calibrated in the same run on
+k_mark_visible / k_hiz_head, whose byte counts are known -- plus WRITE_SIZE; both counters are in KiB), VALU wave-instructions,
+VALU busy fraction and instruction-cache figures.  Stamped with the sha of the kernel sources so that bench.py quotes the
+figures only for a build of the same sources.   usage: make_traffic.py <gpurun_out/tag> [bench args...]"""
+import csv
+import datetime
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def per_kernel(path):
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(path)):
+        a = acc[r["Kernel_Name"]][r["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: {c: v[1] / v[0] for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def short(name):
+    base = name.split("(")[0].replace("void ", "").strip()
+    return base
+
+
+def main():
+    out = sys.argv[1]
+    args = sys.argv[2:]
+    passes = {}
+    for name in ("fetch", "write", "sq", "ic", "mix", "mix2"):
+        files = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
+        passes[name] = per_kernel(files[0]) if files else {}
+    kernels = sorted(set().union(*[set(p) for p in passes.values()]))
+    table = {}
+    for k in kernels:
+        f = passes["fetch"].get(k, {}).get("FETCH_SIZE")
+        w = passes["write"].get(k, {}).get("WRITE_SIZE")
+        sq = passes["sq"].get(k, {})
+        ic = passes["ic"].get(k, {})
+        row = {}
+        if f is not None and w is not None:
+            row["fetch_bytes_x2"] = int(2 * f * 1024)
+            row["write_bytes"] = int(w * 1024)
+            row["hbm_bytes"] = row["fetch_bytes_x2"] + row["write_bytes"]
+        if sq:
+            row.update({c.lower(): v for c, v in sq.items()})
+            if sq.get("GRBM_GUI_ACTIVE") and sq.get("SQ_ACTIVE_INST_VALU") is not None:
+                # SQ_ACTIVE_INST_VALU is in quad-cycles summed over the SIMDs; capacity = 256 CU x 4 SIMD x (GUI_ACTIVE / 8 XCDs) / 4
+                row["valu_busy"] = round(sq["SQ_ACTIVE_INST_VALU"] / (256 * 4 * (sq["GRBM_GUI_ACTIVE"] / 8.0) / 4.0), 4)
+        if ic:
+            row.update({c.lower(): v for c, v in ic.items()})
+        for extra_pass in ("mix", "mix2"):
+            row.update({c.lower(): v for c, v in passes[extra_pass].get(k, {}).items()})
+        table[short(k)] = row
+    variant = ("instanced" if "--instanced" in args else "unique") + ("-untextured" if "--untextured" in args else "-textured") + \
+              ("-s4" if "--samples" in args and args[args.index("--samples") + 1] == "4" else "-s1") + \
+              ("-fast" if "--shade-mode" in args and args[args.index("--shade-mode") + 1] == "fast" else "")
+    import bench
+    pick = {"k_resolve_opaque": [k for k in table if k.startswith("k_resolve_opaque")],
+            "k_triangle_cull": [k for k in table if k.startswith("k_triangle_cull")],
+            "k_raster_small<depth>": [k for k in table if k.startswith("k_raster_small<true")],
+            "k_raster_big<depth>": [k for k in table if k.startswith("k_raster_big<true")],
+            "k_shadow_tiles": [k for k in table if k.startswith("k_shadow_tiles")]}
+    doc = {"source": "tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter set per run; FETCH_SIZE x2 (gfx950 wide-load correction) + WRITE_SIZE",
+           "taken": datetime.date.today().isoformat(), "variant": variant, "kernel_sources_sha": bench.kernel_sources_sha(),
+           "bytes_per_launch": {}, "valu_busy": {}, "valu_insts_per_launch": {}, "kernels": table}
+    for key, names in pick.items():
+        if names and "hbm_bytes" in table[names[0]]:
+            doc["bytes_per_launch"][key] = table[names[0]]["hbm_bytes"]
+        if names and "valu_busy" in table[names[0]]:
+            doc["valu_busy"][key] = table[names[0]]["valu_busy"]
+        if names and "sq_insts_valu" in table[names[0]]:
+            doc["valu_insts_per_launch"][key] = int(table[names[0]]["sq_insts_valu"])
+    json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    for k, row in table.items():
+        print(k[:60], {a: (round(b, 3) if isinstance(b, float) else b) for a, b in row.items()})
+
+
+if __name__ == "__main__":
+    main()
