@@ -145,6 +145,7 @@ def main():
         begin, end = parallel.partition_objects(counts, world)[rank]
         r.set_object_range(begin, end)
         exchange = parallel.Exchange(r, device)
+        exchange.assign_shadow_views(len(r.dir_lights))  # shadow views by view: view v whole on rank v mod N
         rows = parallel.row_ranges(HEIGHT, world)
         exchange.rows_equal = HEIGHT % world == 0
         r._check(r.lib.r3n_set_row_range(r.ctx, rows[rank][0], rows[rank][1]), "r3n_set_row_range")
@@ -193,11 +194,17 @@ def main():
     r.timing_enable(True)
     r.stage_times(reset=True)
     n_inst = min(args.steps, 20)
+    if exchange is not None:
+        exchange.timed = True
     for k in range(n_inst):
         frame(step0 + args.warmup + args.steps + k)
     r.sync()
     stages = r.stage_times(reset=True)
     r.timing_enable(False)
+    exchange_ms = None
+    if exchange is not None:  # HIP events on the context's stream around every collective of the instrumented frames
+        exchange.timed = False
+        exchange_ms = {k: round(v / n_inst, 4) for k, v in exchange.drain_timings().items()}
     r.set_multi_stream(True)
     last = frame(step0 + args.warmup + args.steps + n_inst, readback=(world == 1))
 
@@ -299,7 +306,8 @@ def main():
                                       "130 materials with base colour + normal + AO/roughness/metallic maps (RGBA8, mips, trilinear)"),
                        "shade_mode": args.shade_mode,
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
-                       "parallelism": "single GPU" if world == 1 else f"object-range sharding x{world}, RCCL max all-reduce of depth keys"},
+                       "parallelism": "single GPU" if world == 1 else f"viewport objects by slot range x{world}, shadow views by view (broadcast), RCCL MAX all-reduce of "
+                                                                             "the pass-1 depth plane, MAX reduce-scatter of the pass-2 keys, row all-gather"},
             "fps": round(args.steps / elapsed, 2),
             "culled_objects_per_s": round(info["objects"] * cameras / (cull_ms * 1e-3), 1) if cull_ms > 0 else None,
             "culled_mtris_per_s": round(info["triangles"] * cameras / (cull_ms * 1e-3) / 1e6, 1) if cull_ms > 0 else None,
@@ -308,6 +316,8 @@ def main():
             "roofline": roof,
             "rooflines": {k: v for k, v in rooflines.items() if k != dominant},
             "hbm_copy_rate_measured_GBps": round(hbm_measured, 1),
+            "exchange_ms_per_frame": exchange_ms,
+            "exchange_bytes_per_frame": dict(exchange.bytes) if exchange is not None else None,
             "mesh_buffer_bytes": info.get("mesh_bytes"), "unique_triangles": info.get("unique_triangles"),
         }
 

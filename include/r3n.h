@@ -330,6 +330,13 @@ int r3n_frame_end(r3n_ctx *ctx);
 int r3n_set_object_range(r3n_ctx *ctx, uint32_t begin, uint32_t end);
 /* Device pointers + sizes of the exchange buffers, for RCCL (all-reduce MAX over ranks):
  * the 64-bit visibility/depth keys (width*height u64, as int64 non-negative) and the f32 shadow atlas. */
+/* this camera's own object-slot range, overriding r3n_set_object_range for it (a shadow view owned whole by one rank draws
+ * every object there and nothing elsewhere); begin == end == 0xFFFFFFFF returns the camera to the global range */
+int r3n_set_camera_object_range(r3n_ctx *ctx, r3n_camera camera, uint32_t begin, uint32_t end);
+/* the pass-1 exchange of single-sample targets: only DEPTH has to be global for the Hi-Z cull (33 MB at 4K instead of 66 MB of
+ * keys).  Derives mip 0 of the Hi-Z pyramid (f32 depth plane) from the keys and returns its device address; after the callers'
+ * element-wise MAX all-reduce of the plane on r3n_stream(), r3n_hi_z builds the pyramid from it. */
+int r3n_exchange_depth(r3n_ctx *ctx, void **depth_f32, uint64_t *count);
 int r3n_exchange_buffers(r3n_ctx *ctx, void **visibility_keys, uint64_t *visibility_count,
                          void **shadow_atlas, uint64_t *shadow_atlas_count);
 /* Device pointer of the tonemapped Rgba8 image (width*height*4 bytes) and the rows [row_begin,row_end) this

@@ -183,6 +183,7 @@ class OracleRenderer:
         self.cam_state = {}  # camera specifier -> temporal state
         self.frame_index = 0
         self.object_range = None
+        self.shadow_views_owned = None  # multi-rank: set of shadow views this rank renders (whole); None = all, by object range
         self.skeletons = []  # dict(mesh, out_off[3], matrices)
 
     # ------------------------------------------------------------------ skeletons (rend3/src/managers/skeleton.rs:67-163)
@@ -434,7 +435,8 @@ class OracleRenderer:
         cap = self.capacity
         visible = np.zeros(cap, dtype=np.uint8)
         lib.r3o_frustum_cull(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(visible))
-        if self.object_range is not None:  # multi-rank sharding: this rank owns object slots [begin, end)
+        whole_view = self.shadow_views_owned is not None and isinstance(spec, tuple)  # an owned shadow view draws every object
+        if self.object_range is not None and not whole_view:  # multi-rank sharding: this rank owns object slots [begin, end)
             b, e = self.object_range
             # ... of the opaque / cutout objects; blend objects are culled and drawn by every rank (ordered blending
             # cannot be merged by a MAX reduce)
@@ -511,6 +513,9 @@ class OracleRenderer:
             lib.r3o_skinning(lib.ptr(self.mesh_words), lib.ptr(sk_in), len(sk_in), lib.ptr(sk_m))
         # 4-6. shadow views: bake, cull, depth draw (base.rs:148-153)
         for si, sh in enumerate(shadows):
+            if self.shadow_views_owned is not None and si not in self.shadow_views_owned:
+                out["shadows"].append(None)  # rendered by its owner rank; the atlas rectangle arrives through the exchange
+                continue
             hdr = host.camera_header(sh["camera"], si, (sh["size"], sh["size"]), 1, cap, lib)
             baked = np.zeros((cap, 32), dtype=f32)
             with _Span("bake"):
@@ -526,7 +531,7 @@ class OracleRenderer:
                                      lib.ptr(atlas), atlas_size[0], sh["offset"][0], sh["offset"][1], sh["size"], *self._tex_args())
             out["shadows"].append(dict(header=hdr, visible=visible, tri_base=tri_base, **{"pass": pass_bits}))
         if exchange is not None and shadows:
-            exchange("shadow", atlas)
+            exchange("shadow", atlas, shadows=shadows)
 
         # 7. viewport bake
         hdr = host.camera_header(cam, None, (width, height), samples, cap, lib)
@@ -549,13 +554,15 @@ class OracleRenderer:
             lo, lt = predicted
             keep = lo < cap
             draw(np.ascontiguousarray(lo[keep]), np.ascontiguousarray(lt[keep]))
-        if exchange is not None:
-            exchange("pass1", vis)
+        if exchange is not None and samples != 1:
+            exchange("pass1", vis)  # multisampled: the keys (min over samples and max over ranks do not commute)
         # 9. Hi-Z from pass-1 depth (hi_z.rs:161-234)
         nm = lib.r3o_hiz_mip_count(width, height)
         pyr = np.zeros(int(lib.r3o_hiz_mip_offset(width, height, nm)), dtype=f32)
         with _Span("hiz"):
             lib.r3o_vis_to_depth(lib.ptr(vis), width * height, samples, lib.ptr(pyr))
+            if exchange is not None and samples == 1:
+                exchange("pass1_depth", pyr[: width * height])  # only the depth plane has to be global for the Hi-Z cull
             lib.r3o_hiz_build(lib.ptr(pyr), width, height)
         out["depth_pass1"] = pyr[: width * height].reshape(height, width).copy()
         out["hiz"] = pyr

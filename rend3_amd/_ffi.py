@@ -52,6 +52,8 @@ SIGNATURES = {
     "r3n_frame_end": (cint, [vp]),
     "r3n_set_object_range": (cint, [vp, u32, u32]),
     "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
+    "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
+    "r3n_exchange_depth": (cint, [vp, vp, vp]),
     "r3n_set_row_range": (cint, [vp, u32, u32]),
     "r3n_output_buffer": (cint, [vp, vp, vp]),
     "r3n_readback_visible_objects": (cint, [vp, u32, vp, u32]),

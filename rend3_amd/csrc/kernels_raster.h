@@ -668,7 +668,9 @@ __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__re
             float v = 0.0f;
             if (x < d.width && y < d.height) {
                 const size_t pix = (size_t)y * d.width + x;
-                if (samples == 1u) {
+                if (samples == 0u) {  // mip 0 was filled in before this launch (the cross-rank depth merge, r3n_exchange_depth)
+                    v = pyr[pix];
+                } else if (samples == 1u) {
                     v = __uint_as_float((uint32_t)(vis[pix] >> 32));
                 } else {
                     v = 1.0f;

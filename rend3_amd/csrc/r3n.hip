@@ -40,6 +40,8 @@ struct CamState {
     // has asked for since the last flush (they are issued batched over all views, flush_shadows)
     DevBuf recs, tile_count, tile_list, fb_counts;
     bool pend_bake = false, pend_cull = false, pend_draw[2] = {false, false};
+    bool range_set = false;      // r3n_set_camera_object_range: this camera's own object range (multi-GPU: shadow views owned whole)
+    uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
 };
 
 std::string g_create_error;
@@ -103,6 +105,7 @@ struct r3n_ctx {
     bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
+    bool hiz_plane_ready = false;  // mip 0 already holds the (merged) pass-1 depth: r3n_exchange_depth
     // transparent pass (row N3)
     DevBuf tri_rec, tri_seen;  // per-triangle vertex-stage records of the resolve (kernels_raster.h TriRecord)
     DevBuf blend_order, blend_rank_base, frag_keys[2], frag_vals[2], frag_count, sort_temp, samples16;
@@ -849,6 +852,7 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     for (auto &f : c->forward_index_lane) f = 0;
     c->resolved_this_frame = false;
     c->blended_this_frame = false;
+    c->hiz_plane_ready = false;
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
@@ -1084,6 +1088,8 @@ static int flush_shadows(r3n_ctx *c) {
         v.fb_counts = s.fb_counts.as<uint32_t>();
         v.subcap = subcap;
         v.vp_x = s.vp_x; v.vp_y = s.vp_y; v.vp_size = s.vp_size; v.tiles_x = tiles_x;
+        v.range_begin = s.range_set ? s.range_begin : c->range_begin;
+        v.range_end = s.range_set ? s.range_end : c->range_end;
         if (s.pend_bake) hv[0].push_back(v);
         if (s.pend_cull) hv[1].push_back(v);
         if (s.pend_draw[0]) hv[2].push_back(v);
@@ -1132,7 +1138,6 @@ static int flush_shadows(r3n_ctx *c) {
     a.mesh = c->mesh.as<uint32_t>();
     a.material_keys = c->material_keys.as<uint8_t>();
     a.n_materials = c->n_materials;
-    a.range_begin = c->range_begin; a.range_end = c->range_end;
     a.atlas = c->atlas.as<uint32_t>();
     a.atlas_pitch = c->atlas_w;
     if (!hv[0].empty()) {
@@ -1250,7 +1255,7 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     TRY(ensure(c, s->predicted[cur], list_bytes, false, -1));
     if (viewport) TRY(ensure(c, s->residual, list_bytes, false, -1));
     TRY(fork_lane(c, lane));
-    TRY(run_object_pass(c, *s, cur, c->range_begin, c->range_end, nullptr, stream));
+    TRY(run_object_pass(c, *s, cur, s->range_set ? s->range_begin : c->range_begin, s->range_set ? s->range_end : c->range_end, nullptr, stream));
     TriCullArgs a{};
     a.hdr = s->d_hdr.as<r3n_camera_header240>();
     a.objects = c->objects.as<r3n_object128>();
@@ -1290,7 +1295,8 @@ int r3n_hi_z(r3n_ctx *c) {
            (c->width >> levels) >= 2u && (c->height >> levels) >= 2u)
         ++levels;
     hipLaunchKernelGGL(k_hiz_head, dim3((c->width + 31u) / 32u, (c->height + 31u) / 32u), dim3(256), 0, c->stream,
-                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->samples);
+                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples);
+    c->hiz_plane_ready = false;
     if (levels + 1u < c->hizd.mips)
         hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, c->stream, c->hiz.as<float>(), c->hizd, levels + 1u);
     return check_launch(c, "hi_z");
@@ -1739,6 +1745,34 @@ int r3n_frame_end(r3n_ctx *c) {
 int r3n_set_object_range(r3n_ctx *c, uint32_t begin, uint32_t end) {
     if (!c || begin > end) return fail(c, R3N_ERR_INVALID_ARG, "set_object_range: begin > end");
     c->range_begin = begin; c->range_end = end;
+    return R3N_OK;
+}
+int r3n_set_camera_object_range(r3n_ctx *c, r3n_camera cam, uint32_t begin, uint32_t end) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    CamState *s = find_cam(c, cam, true);
+    if (!s) return fail(c, R3N_ERR_INVALID_ARG, "set_camera_object_range: bad camera");
+    if (begin == 0xFFFFFFFFu && end == 0xFFFFFFFFu) { s->range_set = false; return R3N_OK; }  // follow r3n_set_object_range again
+    if (begin > end) return fail(c, R3N_ERR_INVALID_ARG, "set_camera_object_range: begin > end");
+    s->range_set = true; s->range_begin = begin; s->range_end = end;
+    return R3N_OK;
+}
+// Pass-1 depth for the Hi-Z exchange (single-sample targets): mip 0 of the pyramid is derived from the keys now and its address
+// handed out; the r3n_hi_z that follows builds the upper levels from that plane (MAX-merged across ranks in between) instead of
+// from this rank's keys.
+int r3n_exchange_depth(r3n_ctx *c, void **depth_f32, uint64_t *count) {
+    if (!c || !c->in_frame || !c->vis.p) return fail(c, R3N_ERR_STATE, "exchange_depth: outside a frame");
+    if (c->samples != 1) return fail(c, R3N_ERR_UNSUPPORTED, "exchange_depth: single-sample targets only (a multisampled pass-1 exchange carries the keys)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->width * c->height;
+    {
+        Timed t(c, R3N_STAGE_HIZ);
+        hipLaunchKernelGGL(k_hiz_mip0, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535u * 16u)), dim3(256), 0, c->stream,
+                           c->vis.as<unsigned long long>(), c->hiz.as<float>(), n);
+    }
+    TRY(check_launch(c, "k_hiz_mip0"));
+    c->hiz_plane_ready = true;
+    if (depth_f32) *depth_f32 = c->hiz.p;
+    if (count) *count = n;
     return R3N_OK;
 }
 int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atlas, uint64_t *atlas_count) {

@@ -1,15 +1,19 @@
 """Multi-GPU object-range sharding (the reference is single-device, so this layer is new).
 
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests).  Every rank holds
-the full mesh/object/material buffers and culls + rasterises only its contiguous object-slot range.  The path has
-three real exchange steps per frame, all element-wise MAX all-reduces (reverse-Z: nearest == max; the 64-bit
-visibility key orders by depth first, so MAX of keys is exactly the depth-tested composite):
+the full mesh/object/material buffers.  The VIEWPORT's opaque / cutout objects are split into contiguous object-slot
+ranges (balanced by triangle count); the SHADOW VIEWS are split by view -- view v is rendered whole by rank v mod N and by
+nobody else.  Exchange steps per frame (reverse-Z: nearest == max; the 64-bit visibility key orders by depth first, so
+MAX of keys is exactly the depth-tested composite):
 
-  "shadow": the f32 shadow atlas                  (after the shadow depth draws)
-  "pass1" : the 64-bit visibility keys            (before Hi-Z: every rank culls against the GLOBAL pass-1 depth,
-                                                   which keeps the per-triangle visible set bit-exact)
-  "pass2" : the 64-bit visibility keys            (before the resolve; a reduce-scatter to the row owners when the rows
-                                                   split evenly: nobody needs the other ranks' rows any more)
+  "shadow": every view's atlas rectangle is broadcast from its owner        (16 MiB per 2048^2 view, received once)
+  "pass1" : element-wise MAX all-reduce of the pass-1 DEPTH plane (f32)     (33 MB at 4K: every rank then culls against the
+                                                   GLOBAL Hi-Z, which keeps the per-triangle visible sets bit-exact; only the
+                                                   depth has to be global here -- the keys stay local until pass 2.  Multisampled
+                                                   targets exchange the keys instead: min-over-samples and max-over-ranks do not
+                                                   commute)
+  "pass2" : element-wise MAX of the 64-bit visibility keys, as a reduce-scatter to the row owners when the rows split
+            evenly (nobody needs the other ranks' rows any more)
 
 Screen rows are split across ranks for resolve + tonemap and the Rgba8 rows are all-gathered.
 """
@@ -84,6 +88,26 @@ def allgather_rows_(full, rank, world_size, group=None):
     return full
 
 
+def shadow_view_owner(view, world_size):
+    """Shadow views are sharded by view: view v belongs to rank v mod N (it draws every object there, nothing elsewhere)."""
+    return int(view) % int(world_size)
+
+
+def exchange_shadow_views_(atlas2d, shadows, rank, world_size, group=None, clock=None):
+    """atlas2d: (atlas_h, atlas_w) f32 tensor (a view of the atlas buffer); shadows: [{"offset": (x, y), "size": s}].
+    Every view's rectangle travels once: contiguous staging copy on the owner, broadcast, copy into the rectangle elsewhere."""
+    import torch.distributed as dist
+    for v, sh in enumerate(shadows):
+        x, y, size = int(sh["offset"][0]), int(sh["offset"][1]), int(sh["size"])
+        owner = shadow_view_owner(v, world_size)
+        rect = atlas2d[y:y + size, x:x + size]
+        stage = rect.contiguous() if rank == owner else rect.new_empty((size, size))
+        dist.broadcast(stage, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
+        if rank != owner:
+            rect.copy_(stage)
+    return atlas2d
+
+
 class _DevArray:
     """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
 
@@ -97,9 +121,10 @@ def device_tensor(ptr, count, dtype_str, device):
 
 
 class Exchange:
-    """The callable BaseRenderGraph.add_to_graph(exchange=...) expects, over torch.distributed."""
+    """The callable BaseRenderGraph.add_to_graph(exchange=...) expects, over torch.distributed.  `timings` (ms per call
+    site, HIP events on the context's stream) is filled when `timed` is set: bench.py --gpus N reports it."""
 
-    def __init__(self, renderer, device, group=None):
+    def __init__(self, renderer, device, group=None, timed=False):
         import ctypes
         import torch
         import torch.distributed as dist
@@ -109,6 +134,19 @@ class Exchange:
         self.stream = torch.cuda.ExternalStream(renderer.lib.r3n_stream(renderer.ctx), device=device)
         self._ct = ctypes
         self.rows_equal = False  # set by the caller when every rank resolves an equal, contiguous block of rows
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.timed = timed
+        self.events = []      # (what, start event, end event)
+        self.bytes = {}       # what -> bytes this rank hands to the collective per frame
+
+    def owns_shadow_view(self, view):
+        return shadow_view_owner(view, self.world) == self.rank
+
+    def assign_shadow_views(self, n_views):
+        """Shadow views by view: the ones this rank owns draw EVERY object slot, the others are not rendered here at all."""
+        for v in range(n_views):
+            if self.owns_shadow_view(v):
+                self.r.set_camera_object_range(v, 0, 0xFFFFFFFE)
 
     def _buffers(self):
         ct = self._ct
@@ -118,21 +156,41 @@ class Exchange:
                  "r3n_exchange_buffers")
         return vis.value, vis_n.value, atlas.value, atlas_n.value
 
-    def __call__(self, what, renderer):
+    def __call__(self, what, renderer, ev=None, samples=1):
         dist, torch = self.dist, self.torch
-        vis, vis_n, atlas, atlas_n = self._buffers()
         # the context's stream is made torch's current stream, so the collective is ordered after the kernels
         # already enqueued on it and the kernels enqueued next wait for the collective
         with torch.cuda.stream(self.stream):
+            t0 = t1 = None
+            if self.timed:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.stream)
             if what == "shadow":
-                if atlas_n:
-                    allreduce_max_(device_tensor(atlas, atlas_n, "<f4", self.device), self.group)
+                vis, vis_n, atlas, atlas_n = self._buffers()
+                if atlas_n and ev is not None and ev.shadows:
+                    aw, ah = ev.shadow_target_size
+                    a2 = device_tensor(atlas, atlas_n, "<f4", self.device).view(ah, aw)
+                    exchange_shadow_views_(a2, ev.shadows, self.rank, self.world, self.group)
+                    self.bytes[what] = sum(4 * int(sh["size"]) ** 2 for sh in ev.shadows)
+            elif what == "pass1" and samples == 1:
+                ct = self._ct
+                plane, n = ct.c_void_p(), ct.c_uint64()
+                r = self.r
+                r._check(r.lib.r3n_exchange_depth(r.ctx, ct.byref(plane), ct.byref(n)), "r3n_exchange_depth")
+                allreduce_max_(device_tensor(plane.value, n.value, "<f4", self.device), self.group)  # depth >= 0: float MAX
+                self.bytes[what] = 4 * n.value
             elif what == "pass2" and self.rows_equal:
                 # only the rows this rank resolves have to be complete from here on
-                world = dist.get_world_size(self.group)
-                reduce_scatter_max_rows_(device_tensor(vis, vis_n, "<i8", self.device), dist.get_rank(self.group), world, self.group)
+                vis, vis_n, atlas, atlas_n = self._buffers()
+                reduce_scatter_max_rows_(device_tensor(vis, vis_n, "<i8", self.device), self.rank, self.world, self.group)
+                self.bytes[what] = 8 * vis_n
             else:
+                vis, vis_n, atlas, atlas_n = self._buffers()
                 allreduce_max_(device_tensor(vis, vis_n, "<i8", self.device), self.group)
+                self.bytes[what] = 8 * vis_n
+            if self.timed:
+                t1.record(self.stream)
+                self.events.append((what, t0, t1))
 
     def gather_rows(self, width, height, world_size):
         """All-gather the Rgba8 rows each rank tonemapped (equal row counts required)."""
@@ -143,5 +201,22 @@ class Exchange:
         r = self.r
         r._check(r.lib.r3n_output_buffer(r.ctx, ctypes.byref(out), ctypes.byref(nbytes)), "r3n_output_buffer")
         with torch.cuda.stream(self.stream):
+            t0 = t1 = None
+            if self.timed:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.stream)
             full = device_tensor(out.value, nbytes.value, "|u1", self.device)
             allgather_rows_(full, dist.get_rank(self.group), world_size, self.group)
+            self.bytes["rows"] = nbytes.value
+            if self.timed:
+                t1.record(self.stream)
+                self.events.append(("rows", t0, t1))
+
+    def drain_timings(self):
+        """ms per exchange site summed over the recorded calls (synchronises the device), and the number of frames' worth."""
+        self.torch.cuda.synchronize(self.device)
+        out = {}
+        for what, t0, t1 in self.events:
+            out[what] = out.get(what, 0.0) + t0.elapsed_time(t1)
+        self.events = []
+        return out

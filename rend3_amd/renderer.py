@@ -542,6 +542,10 @@ class Renderer:
         """Multi-GPU sharding (not in the reference): this rank culls/draws object slots [begin, end)."""
         self._check(self.lib.r3n_set_object_range(self.ctx, begin, end), "r3n_set_object_range")
 
+    def set_camera_object_range(self, camera, begin, end):
+        """This camera's own object range (a shadow view owned whole by one rank draws every slot there)."""
+        self._check(self.lib.r3n_set_camera_object_range(self.ctx, camera, begin, end), "r3n_set_camera_object_range")
+
     # ------------------------------------------------------------------ per-frame evaluation
     def evaluate_instructions(self):
         self._flush_textures()
@@ -588,9 +592,12 @@ class Renderer:
         graph.execute(self, eval_output)
         if not readback:
             return None
-        return self.readback_frame(eval_output, width, height, samples)
+        owned = None
+        if exchange is not None and hasattr(exchange, "owns_shadow_view"):
+            owned = {si for si in range(len(eval_output.shadows)) if exchange.owns_shadow_view(si)}
+        return self.readback_frame(eval_output, width, height, samples, owned)
 
-    def readback_frame(self, eval_output, width, height, samples=1):
+    def readback_frame(self, eval_output, width, height, samples=1, owned_views=None):
         lib, ctx = self.lib, self.ctx
         cap = self.capacity
         out = {"capacity": cap, "shadows": []}
@@ -610,7 +617,8 @@ class Renderer:
 
         if cap and self.object_meta:
             for si in range(len(eval_output.shadows)):
-                out["shadows"].append(cam_sets(si))
+                # (multi-GPU: a shadow view this rank does not own was never culled here)
+                out["shadows"].append(cam_sets(si) if owned_views is None or si in owned_views else None)
             out.update(cam_sets(_ffi.CAMERA_VIEWPORT))
         vis = np.zeros((height, width) if samples == 1 else (height, width, samples), dtype=np.uint64)
         self._check(lib.r3n_readback_visibility(ctx, _ffi.ptr(vis)), "readback_visibility")
@@ -840,18 +848,21 @@ class BaseRenderGraph:
 
         graph.add_node("Skinning", skin)
         def shadow_nodes():
+            # multi-GPU: shadow views are sharded by view -- a rank renders the views it owns (whole) and receives the others
+            mine = [si for si in range(len(ev.shadows)) if exchange is None or not hasattr(exchange, "owns_shadow_view") or exchange.owns_shadow_view(si)]
             # shadow_object_uniform_upload (base.rs:148)
-            for si, sh in enumerate(ev.shadows):
+            for si in mine:
+                sh = ev.shadows[si]
                 self.gpu_culler.add_object_uniform_upload_to_graph(graph, si, (sh["size"], sh["size"]), 1, f"Shadow Culling S{si}")
             # pbr_shadow_culling (base.rs:150)
-            for si in range(len(ev.shadows)):
+            for si in mine:
                 self.gpu_culler.add_culling_to_graph(graph, si, f"Shadow Culling S{si}")
             # pbr_shadow_rendering (base.rs:153,366-396)
-            for si in range(len(ev.shadows)):
+            for si in mine:
                 for routine in (pbr.opaque_depth, pbr.cutout_depth):
                     routine.add_forward_to_graph(graph, f"pbr shadow renderering S{si}", si, _ffi.SOURCE_RESIDUAL)
             if exchange is not None and len(ev.shadows):
-                graph.add_node("exchange shadow atlas", lambda r, _ev: exchange("shadow", r))
+                graph.add_node("exchange shadow atlas", lambda r, _ev: exchange("shadow", r, ev=ev, samples=inputs.samples))
 
         def viewport_pass1_nodes():
             # object_uniform_upload (base.rs:156)
@@ -869,7 +880,7 @@ class BaseRenderGraph:
             shadow_nodes()
             viewport_pass1_nodes()
         if exchange is not None:
-            graph.add_node("exchange pass-1 depth", lambda r, _ev: exchange("pass1", r))
+            graph.add_node("exchange pass-1 depth", lambda r, _ev: exchange("pass1", r, ev=ev, samples=inputs.samples))
         # hi_z (base.rs:162)
         pbr.hi_z.add_hi_z_to_graph(graph)
         # pbr_culling (base.rs:169)
@@ -878,7 +889,7 @@ class BaseRenderGraph:
         for routine in (pbr.opaque_routine, pbr.cutout_routine):
             routine.add_forward_to_graph(graph, "PBR Forward Pass 2", VP, _ffi.SOURCE_RESIDUAL)
         if exchange is not None:
-            graph.add_node("exchange pass-2 keys", lambda r, _ev: exchange("pass2", r))
+            graph.add_node("exchange pass-2 keys", lambda r, _ev: exchange("pass2", r, ev=ev, samples=inputs.samples))
         # the deferred evaluation of the opaque passes' fragments (this design's stand-in for their fragment shaders)
         graph.add_node("Resolve Opaque", lambda r, _ev: r._check(r.lib.r3n_resolve_opaque(r.ctx), "r3n_resolve_opaque"))
         # skybox (base.rs:175): out of scope.  pbr_forward_rendering_transparent (base.rs:181)

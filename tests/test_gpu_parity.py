@@ -982,3 +982,121 @@ def test_shade_mode_fast_within_tolerance(r3):
         fp = p.render(w, h, ambient=amb, clear_color=clear)
         compare_frames(fo, fp, f"back to exact, {name}")
     assert worst <= 1e-3
+
+
+# ------------------------------------------------------------------ multi-GPU sharding on the HIP path, two contexts on one device
+def test_sharded_two_contexts_multi_frame(r3):
+    """The sharded product path over several frames with camera motion, without a second GPU: two contexts on this device
+    play rank 0 and rank 1 of rend3_amd/parallel.py's scheme -- viewport objects split by slot range, shadow views split by
+    view -- and their frames advance in lockstep, node by node; at every exchange point a local stand-in for the collectives
+    merges their buffers with torch (shadow rectangles copied from their owner, MAX of the pass-1 depth planes through
+    r3n_exchange_depth, MAX of the pass-2 keys).  Every frame: keys, atlas and image of BOTH contexts equal the unsharded
+    context's, each rank's L1 / L2 sets are the unsharded sets restricted to its range and their union is the whole set --
+    which only holds from frame 1 on if the Hi-Z each rank culls against is the global one."""
+    import ctypes
+    import torch
+    from rend3_amd import parallel
+    from rend3_amd.renderer import BaseRenderGraph, BaseRenderGraphInputs, BaseRenderGraphSettings, RenderGraph
+    w, h, frames = 640, 360, 4
+    ref, a, b = (r3.Renderer(oh.LEFT, f32(w) / f32(h)) for _ in range(3))
+    for r in (ref, a, b):
+        scenes.build_textured_scene(r, oh, r3.material_record, 300, 0x5AAD, lights=2)
+    counts = np.zeros(ref.capacity, dtype=np.int64)
+    for hd, m in ref.object_meta.items():
+        counts[hd] = ref.meshes[m["mesh"]].index_count // 3
+    ranges = parallel.partition_objects(counts, 2)
+    dev = torch.device("cuda", 0)
+
+    class Rank:
+        def __init__(self, r, rank):
+            self.r, self.rank, self.pending = r, rank, None
+            r.set_object_range(*ranges[rank])
+            for v in range(2):
+                if parallel.shadow_view_owner(v, 2) == rank:
+                    r.set_camera_object_range(v, 0, 0xFFFFFFFE)
+
+        def owns_shadow_view(self, v):
+            return parallel.shadow_view_owner(v, 2) == self.rank
+
+        def __call__(self, what, r, ev=None, samples=1):
+            self.pending = (what, ev)
+
+        def buffers(self):
+            vis, vis_n, atlas, atlas_n = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p(), ctypes.c_uint64()
+            self.r._check(self.r.lib.r3n_exchange_buffers(self.r.ctx, ctypes.byref(vis), ctypes.byref(vis_n), ctypes.byref(atlas), ctypes.byref(atlas_n)), "exchange_buffers")
+            return (parallel.device_tensor(vis.value, vis_n.value, "<i8", dev), parallel.device_tensor(atlas.value, atlas_n.value, "<f4", dev))
+
+        def depth_plane(self):
+            p, n = ctypes.c_void_p(), ctypes.c_uint64()
+            self.r._check(self.r.lib.r3n_exchange_depth(self.r.ctx, ctypes.byref(p), ctypes.byref(n)), "exchange_depth")
+            return parallel.device_tensor(p.value, n.value, "<f4", dev)
+
+    ranks = [Rank(a, 0), Rank(b, 1)]
+
+    def merge(what, ev):
+        if what == "pass1":
+            planes = [rk.depth_plane() for rk in ranks]
+        else:
+            bufs = [rk.buffers() for rk in ranks]
+        for rk in ranks:
+            rk.r.sync()
+        if what == "shadow":
+            aw, ah = ev.shadow_target_size
+            for v, sh in enumerate(ev.shadows):
+                x, y, s = sh["offset"][0], sh["offset"][1], sh["size"]
+                own = parallel.shadow_view_owner(v, 2)
+                src = bufs[own][1].view(ah, aw)[y:y + s, x:x + s]
+                bufs[1 - own][1].view(ah, aw)[y:y + s, x:x + s].copy_(src)
+        elif what == "pass1":
+            m = torch.maximum(planes[0], planes[1])
+            planes[0].copy_(m); planes[1].copy_(m)
+        else:
+            m = torch.maximum(bufs[0][0], bufs[1][0])
+            bufs[0][0].copy_(m); bufs[1][0].copy_(m)
+        torch.cuda.synchronize()
+
+    amb, clear = (0.1, 0.1, 0.1, 1.0), (0.02, 0.03, 0.05, 1.0)
+    for f in range(frames):
+        eye = (-14.0 + 3.0 * f, 3.0 + 0.5 * f, -14.0 + 2.0 * f)
+        for r in (ref, a, b):
+            r.set_camera_data(oh.look_at_lh(eye, (0.0, 0.0, 0.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fr = ref.render(w, h, ambient=amb, clear_color=clear)
+        graphs, evs = [], []
+        for rk in ranks:
+            ev = rk.r.evaluate_instructions()
+            base = BaseRenderGraph(rk.r)
+            g = RenderGraph()
+            base.add_to_graph(g, BaseRenderGraphInputs(ev, base.default_routines(), (w, h), 1), BaseRenderGraphSettings(amb, clear), exchange=rk)
+            graphs.append(g)
+            evs.append(ev)
+        assert len(graphs[0].nodes) == len(graphs[1].nodes)
+        for (na, body_a), (nb, body_b) in zip(graphs[0].nodes, graphs[1].nodes):
+            assert na.split(" S")[0] == nb.split(" S")[0]
+            body_a(a, evs[0])
+            body_b(b, evs[1])
+            if ranks[0].pending is not None:
+                assert ranks[1].pending is not None and ranks[1].pending[0] == ranks[0].pending[0]
+                merge(*ranks[0].pending)
+                ranks[0].pending = ranks[1].pending = None
+        outs = [rk.r.readback_frame(evs[k], w, h, 1, {v for v in range(2) if rk.owns_shadow_view(v)}) for k, rk in enumerate(ranks)]
+        tri_obj = np.searchsorted(np.concatenate([[0], np.cumsum(counts)])[:-1], np.arange(len(fr["pass"])), side="right") - 1
+        for k, fo in enumerate(outs):
+            tag = f"frame {f} rank {k}"
+            assert np.array_equal(fo["vis"], fr["vis"]), tag + " keys"
+            assert np.array_equal(fo["atlas"].view(np.uint32), fr["atlas"].view(np.uint32)), tag + " atlas"
+            assert np.array_equal(fo["hdr16"], fr["hdr16"]) and np.array_equal(fo["rgba8"], fr["rgba8"]), tag + " image"
+            lo, hi = ranges[k]
+            own = np.zeros(len(fr["visible"]), dtype=bool)
+            own[lo:hi] = True
+            assert np.array_equal(fo["visible"].astype(bool), fr["visible"].astype(bool) & own), tag + " L1"
+            town = own[tri_obj]
+            n = len(fr["pass"])
+            assert np.array_equal(fo["pass"][:n].astype(bool), fr["pass"].astype(bool) & town), tag + " L2 pass"
+            assert np.array_equal(fo["residual"][:n].astype(bool), fr["residual"].astype(bool) & town), tag + " L2 residual"
+            v = k  # the view this rank owns
+            assert np.array_equal(fo["shadows"][v]["visible"], fr["shadows"][v]["visible"]) and np.array_equal(fo["shadows"][v]["pass"], fr["shadows"][v]["pass"]), tag + " shadow sets"
+        n = len(fr["pass"])
+        assert np.array_equal((outs[0]["pass"][:n] | outs[1]["pass"][:n]), fr["pass"]), f"frame {f} union"
+    assert fr["residual"].sum() > 0 and fr["pass"].sum() > 1000
+    for r in (ref, a, b):
+        r.close()

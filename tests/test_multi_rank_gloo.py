@@ -1,5 +1,6 @@
-"""CPU, world_size 2, gloo: the multi-GPU algorithm of DESIGN.md section 6 (object-range sharding + MAX all-reduce of
-the shadow atlas and of the visibility keys + row-split resolve with all-gather) is exact: two ranks, each running the
+"""CPU, world_size 2, gloo: the multi-GPU algorithm of DESIGN.md section 6 (object-range sharding of the viewport, shadow
+views sharded by view and broadcast from their owners, MAX all-reduce of the pass-1 depth plane and of the pass-2 visibility
+keys, row-split resolve with all-gather) is exact: two ranks, each running the
 ORACLE over its own object range and exchanging through rend3_amd.parallel's collectives, end up with the same
 per-triangle sets (union), visibility keys and image as one unsharded oracle, bit for bit, over several frames."""
 import os
@@ -53,14 +54,18 @@ def _worker(rank, world, port, q):
         ranges = parallel.partition_objects(counts, world)
         assert ranges[0][0] == 0 and ranges[-1][1] == len(counts) and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
         shard.object_range = ranges[rank]
+        # shadow views by view: view v is rendered whole by rank v mod N
+        shard.shadow_views_owned = {v for v in range(len(shard.dir_lights)) if parallel.shadow_view_owner(v, world) == rank}
+        assert shard.shadow_views_owned and len(shard.shadow_views_owned) < len(shard.dir_lights)
         rows = parallel.row_ranges(H, world)
 
-        def exchange(what, arr):
+        def exchange(what, arr, shadows=None):
             if what == "shadow":
-                t = torch.from_numpy(arr)
+                parallel.exchange_shadow_views_(torch.from_numpy(arr), shadows, rank, world)
+            elif what == "pass1_depth":
+                parallel.allreduce_max_(torch.from_numpy(arr))  # f32 depth plane, depth >= 0
             else:
-                t = torch.from_numpy(arr.view(np.int64))
-            parallel.allreduce_max_(t)
+                parallel.allreduce_max_(torch.from_numpy(arr.view(np.int64)))
 
         for f in range(FRAMES):
             _camera(full, oh, math, f)
