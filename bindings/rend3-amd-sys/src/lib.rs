@@ -1,0 +1,292 @@
+// rend3-amd-sys: raw bindings of librend3_amd.so -- GENERATED from include/r3n.h by tools/gen_rust_sys.py, do not edit.
+// One item per #define, struct and function of the header; the documentation lives there (each entry point cites the
+// rend3 interface it replaces).  Source only in this repository: the build image has no Rust toolchain, so this crate is
+// kept honest by tests/test_rust_bindings.py (symbol-for-symbol diff against the header and the built library).
+#![allow(non_camel_case_types, non_upper_case_globals, clippy::too_many_arguments)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const R3N_OK: i32 = 0;
+pub const R3N_ERR_INVALID_ARG: i32 = -1;
+pub const R3N_ERR_HIP: i32 = -2;
+pub const R3N_ERR_NO_DEVICE: i32 = -3;
+pub const R3N_ERR_STATE: i32 = -4;
+pub const R3N_ERR_UNSUPPORTED: i32 = -5;
+pub const R3N_ERR_CAPACITY: i32 = -6;
+pub const R3N_CAMERA_VIEWPORT: u32 = 0xFFFFFFFF;
+pub const R3N_MAX_SHADOW_VIEWS: u32 = 64;
+pub const R3N_PASS_DEPTH: u32 = 0;
+pub const R3N_PASS_FORWARD: u32 = 1;
+pub const R3N_SOURCE_PREDICTED: u32 = 0;
+pub const R3N_SOURCE_RESIDUAL: u32 = 1;
+pub const R3N_KEY_OPAQUE: u32 = 0;
+pub const R3N_KEY_CUTOUT: u32 = 1;
+pub const R3N_KEY_BLEND: u32 = 2;
+pub const R3N_TEXTURE_RGBA8_UNORM: u32 = 0;
+pub const R3N_TEXTURE_RGBA8_UNORM_SRGB: u32 = 1;
+pub const R3N_TEXTURE_R8_UNORM: u32 = 2;
+pub const R3N_TEXTURE_RG8_UNORM: u32 = 3;
+pub const R3N_TEXTURE_BGRA8_UNORM: u32 = 4;
+pub const R3N_TEXTURE_BGRA8_UNORM_SRGB: u32 = 5;
+pub const R3N_TEXTURE_BC1_RGBA_UNORM: u32 = 6;
+pub const R3N_TEXTURE_BC1_RGBA_UNORM_SRGB: u32 = 7;
+pub const R3N_TEXTURE_BC2_RGBA_UNORM: u32 = 8;
+pub const R3N_TEXTURE_BC2_RGBA_UNORM_SRGB: u32 = 9;
+pub const R3N_TEXTURE_BC3_RGBA_UNORM: u32 = 10;
+pub const R3N_TEXTURE_BC3_RGBA_UNORM_SRGB: u32 = 11;
+pub const R3N_TEXTURE_BC4_R_UNORM: u32 = 12;
+pub const R3N_TEXTURE_BC5_RG_UNORM: u32 = 13;
+pub const R3N_TEXTURE_BC7_RGBA_UNORM: u32 = 14;
+pub const R3N_TEXTURE_BC7_RGBA_UNORM_SRGB: u32 = 15;
+pub const R3N_TEXTURE_FORMAT_COUNT: u32 = 16;
+pub const R3N_SHADE_EXACT: u32 = 0;
+pub const R3N_SHADE_FAST: u32 = 1;
+pub const R3N_OUTPUT_RGBA8_UNORM_SRGB: u32 = 0;
+pub const R3N_OUTPUT_BGRA8_UNORM_SRGB: u32 = 1;
+pub const R3N_OUTPUT_RGBA8_UNORM: u32 = 2;
+pub const R3N_OUTPUT_BGRA8_UNORM: u32 = 3;
+pub const R3N_STAGE_BAKE: i32 = 0;
+pub const R3N_STAGE_OBJECT_CULL: i32 = 1;
+pub const R3N_STAGE_TRIANGLE_CULL: i32 = 2;
+pub const R3N_STAGE_HIZ: i32 = 3;
+pub const R3N_STAGE_RASTER: i32 = 4;
+pub const R3N_STAGE_SHADE: i32 = 5;
+pub const R3N_STAGE_TONEMAP: i32 = 6;
+pub const R3N_STAGE_CLEAR: i32 = 7;
+pub const R3N_STAGE_RASTER_BIG: i32 = 8;
+pub const R3N_STAGE_SHADOW_RASTER: i32 = 9;
+pub const R3N_STAGE_SHADOW_RASTER_BIG: i32 = 10;
+pub const R3N_STAGE_SKINNING: i32 = 11;
+pub const R3N_STAGE_VERTEX: i32 = 12;
+pub const R3N_STAGE_POSE: i32 = 13;
+pub const R3N_STAGE_COUNT: i32 = 14;
+
+#[repr(C)]
+pub struct r3n_ctx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_object128 {
+    pub transform: [f32; 16],
+    pub bounding_sphere_center: [f32; 3],
+    pub bounding_sphere_radius: f32,
+    pub first_index: u32,
+    pub index_count: u32,
+    pub material_index: u32,
+    pub vertex_attribute_start_offsets: [u32; 6],
+    pub enabled: u32,
+    pub _pad: [u32; 2],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_material208 {
+    pub textures: [u32; 10],
+    pub _pad: [u32; 2],
+    pub uv_transform0: [f32; 12],
+    pub uv_transform1: [f32; 12],
+    pub albedo: [f32; 4],
+    pub emissive: [f32; 3],
+    pub roughness: f32,
+    pub metallic: f32,
+    pub reflectance: f32,
+    pub clear_coat: f32,
+    pub clear_coat_roughness: f32,
+    pub anisotropy: f32,
+    pub ambient_occlusion: f32,
+    pub alpha_cutout: f32,
+    pub flags: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_texture_desc32 {
+    pub offset: u32,
+    pub width: u32,
+    pub height: u32,
+    pub mips: u32,
+    pub format: u32,
+    pub stored_mips: u32,
+    pub _pad: [u32; 2],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_camera_header240 {
+    pub view: [f32; 16],
+    pub view_proj: [f32; 16],
+    pub shadow_index: u32,
+    pub _pad: [u32; 3],
+    pub frustum: [f32; 20],
+    pub resolution: [f32; 2],
+    pub flags: u32,
+    pub object_count: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_frame_uniforms496 {
+    pub view: [f32; 16],
+    pub view_proj: [f32; 16],
+    pub origin_view_proj: [f32; 16],
+    pub inv_view: [f32; 16],
+    pub inv_view_proj: [f32; 16],
+    pub inv_origin_view_proj: [f32; 16],
+    pub frustum: [f32; 20],
+    pub ambient: [f32; 4],
+    pub resolution: [u32; 2],
+    pub _pad: [u32; 2],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_indirect_call {
+    pub vertex_count: u32,
+    pub instance_count: u32,
+    pub base_index: u32,
+    pub vertex_offset: i32,
+    pub base_instance: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_skinning_input40 {
+    pub base_position_offset: u32,
+    pub base_normal_offset: u32,
+    pub base_tangent_offset: u32,
+    pub joint_indices_offset: u32,
+    pub joint_weight_offset: u32,
+    pub updated_position_offset: u32,
+    pub updated_normal_offset: u32,
+    pub updated_tangent_offset: u32,
+    pub joint_matrix_base_offset: u32,
+    pub vertex_count: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_anim_rig16 {
+    pub first_joint: u32,
+    pub n_joints: u32,
+    pub max_depth: u32,
+    pub _pad: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_anim_joint80 {
+    pub parent: i32,
+    pub depth: u32,
+    pub _pad: [u32; 2],
+    pub inverse_bind: [f32; 16],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_anim_clip16 {
+    pub rig: u32,
+    pub first_track: u32,
+    pub duration: f32,
+    pub _pad: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_anim_track80 {
+    pub animated: u32,
+    pub key_first: [u32; 3],
+    pub key_count: [u32; 3],
+    pub value_first: [u32; 3],
+    pub bind_t: [f32; 3],
+    pub bind_r: [f32; 4],
+    pub bind_s: [f32; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_pose_request16 {
+    pub clip: u32,
+    pub time: f32,
+    pub matrix_base: u32,
+    pub _pad: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_config {
+    pub struct_size: u32,
+    pub max_big_items: u32,
+    pub shade_mode: u32,
+    pub _pad: u32,
+    pub reserved: [u64; 2],
+}
+
+#[link(name = "rend3_amd")]
+extern "C" {
+    pub fn r3n_create(hip_device: c_int, config: *const r3n_config) -> *mut r3n_ctx;
+    pub fn r3n_destroy(ctx: *mut r3n_ctx);
+    pub fn r3n_last_error(ctx: *const r3n_ctx) -> *const c_char;
+    pub fn r3n_create_error() -> *const c_char;
+    pub fn r3n_sync(ctx: *mut r3n_ctx) -> c_int;
+    pub fn r3n_stream(ctx: *mut r3n_ctx) -> *mut c_void;
+    pub fn r3n_mesh_buffer_write(ctx: *mut r3n_ctx, byte_offset: u64, data: *const c_void, bytes: u64) -> c_int;
+    pub fn r3n_objects_write(ctx: *mut r3n_ctx, slots: *const u32, records: *const r3n_object128, n: u32, capacity: u32) -> c_int;
+    pub fn r3n_materials_write(ctx: *mut r3n_ctx, slots: *const u32, records: *const r3n_material208, keys: *const u8, n: u32) -> c_int;
+    pub fn r3n_textures_write(ctx: *mut r3n_ctx, descs: *const r3n_texture_desc32, n_textures: u32, texels: *const u32, n_texels: u64) -> c_int;
+    pub fn r3n_textures_write_encoded(ctx: *mut r3n_ctx, descs: *const r3n_texture_desc32, n_textures: u32, payload: *const c_void, payload_bytes: u64) -> c_int;
+    pub fn r3n_blend_order_write(ctx: *mut r3n_ctx, objects_back_to_front: *const u32, n: u32) -> c_int;
+    pub fn r3n_lights_write(ctx: *mut r3n_ctx, directional_buffer: *const c_void, directional_bytes: u64, point_buffer: *const c_void, point_bytes: u64) -> c_int;
+    pub fn r3n_set_output_format(ctx: *mut r3n_ctx, format: u32) -> c_int;
+    pub fn r3n_set_shade_mode(ctx: *mut r3n_ctx, mode: u32) -> c_int;
+    pub fn r3n_frame_begin(ctx: *mut r3n_ctx, uniforms: *const r3n_frame_uniforms496, width: u32, height: u32, samples: u32, clear_color: *const f32, shadow_atlas_width: u32, shadow_atlas_height: u32) -> c_int;
+    pub fn r3n_skinning(ctx: *mut r3n_ctx, inputs: *const r3n_skinning_input40, n_skeletons: u32, joint_matrices: *const f32, n_joint_matrices: u32) -> c_int;
+    pub fn r3n_animation_write(ctx: *mut r3n_ctx, rigs: *const r3n_anim_rig16, n_rigs: u32, joints: *const r3n_anim_joint80, n_joints: u32, clips: *const r3n_anim_clip16, n_clips: u32, tracks: *const r3n_anim_track80, n_tracks: u32, times: *const f32, n_times: u32, values: *const f32, n_values: u32) -> c_int;
+    pub fn r3n_pose_skeletons(ctx: *mut r3n_ctx, requests: *const r3n_pose_request16, n: u32) -> c_int;
+    pub fn r3n_uniform_bake(ctx: *mut r3n_ctx, camera: u32, header: *const r3n_camera_header240) -> c_int;
+    pub fn r3n_cull(ctx: *mut r3n_ctx, camera: u32) -> c_int;
+    pub fn r3n_hi_z(ctx: *mut r3n_ctx) -> c_int;
+    pub fn r3n_shadow_viewport(ctx: *mut r3n_ctx, shadow_camera: u32, x: u32, y: u32, size: u32) -> c_int;
+    pub fn r3n_forward(ctx: *mut r3n_ctx, camera: u32, pass: u32, source: u32, material_key: u32) -> c_int;
+    pub fn r3n_resolve_opaque(ctx: *mut r3n_ctx) -> c_int;
+    pub fn r3n_tonemap(ctx: *mut r3n_ctx, host_rgba8: *mut c_void, pitch_bytes: u64) -> c_int;
+    pub fn r3n_hdr_write(ctx: *mut r3n_ctx, rgba16f: *const u16, first_pixel: u64, n_pixels: u64) -> c_int;
+    pub fn r3n_frame_end(ctx: *mut r3n_ctx) -> c_int;
+    pub fn r3n_set_object_range(ctx: *mut r3n_ctx, begin: u32, end: u32) -> c_int;
+    pub fn r3n_set_camera_object_range(ctx: *mut r3n_ctx, camera: u32, begin: u32, end: u32) -> c_int;
+    pub fn r3n_exchange_depth(ctx: *mut r3n_ctx, depth_f32: *mut *mut c_void, count: *mut u64) -> c_int;
+    pub fn r3n_exchange_buffers(ctx: *mut r3n_ctx, visibility_keys: *mut *mut c_void, visibility_count: *mut u64, shadow_atlas: *mut *mut c_void, shadow_atlas_count: *mut u64) -> c_int;
+    pub fn r3n_set_row_range(ctx: *mut r3n_ctx, row_begin: u32, row_end: u32) -> c_int;
+    pub fn r3n_output_buffer(ctx: *mut r3n_ctx, rgba8: *mut *mut c_void, bytes: *mut u64) -> c_int;
+    pub fn r3n_readback_visible_objects(ctx: *mut r3n_ctx, camera: u32, flags: *mut u8, capacity: u32) -> c_int;
+    pub fn r3n_readback_triangle_sets(ctx: *mut r3n_ctx, camera: u32, pass: *mut u8, residual: *mut u8, n: u64) -> c_int;
+    pub fn r3n_readback_draw_calls(ctx: *mut r3n_ctx, camera: u32, calls: *mut r3n_indirect_call) -> c_int;
+    pub fn r3n_readback_raster_stats(ctx: *mut r3n_ctx, big_items: *mut u32) -> c_int;
+    pub fn r3n_readback_shadow_tile_counts(ctx: *mut r3n_ctx, shadow_view: u32, counts: *mut u32, n: u32, tiles_x: *mut u32) -> c_int;
+    pub fn r3n_readback_baked(ctx: *mut r3n_ctx, camera: u32, model_view_and_mvp: *mut f32, capacity: u32) -> c_int;
+    pub fn r3n_readback_mesh(ctx: *mut r3n_ctx, byte_offset: u64, dst: *mut c_void, bytes: u64) -> c_int;
+    pub fn r3n_readback_joint_matrices(ctx: *mut r3n_ctx, first_matrix: u32, dst: *mut f32, n_matrices: u32) -> c_int;
+    pub fn r3n_readback_texels(ctx: *mut r3n_ctx, first_texel: u64, rgba8: *mut u32, n_texels: u64) -> c_int;
+    pub fn r3n_readback_visibility(ctx: *mut r3n_ctx, keys: *mut u64) -> c_int;
+    pub fn r3n_readback_depth(ctx: *mut r3n_ctx, depth: *mut f32) -> c_int;
+    pub fn r3n_readback_hiz(ctx: *mut r3n_ctx, pyramid: *mut f32, count: u64) -> c_int;
+    pub fn r3n_readback_shadow_atlas(ctx: *mut r3n_ctx, atlas: *mut f32) -> c_int;
+    pub fn r3n_readback_hdr(ctx: *mut r3n_ctx, rgba16f: *mut u16) -> c_int;
+    pub fn r3n_readback_output(ctx: *mut r3n_ctx, rgba8: *mut u8, rgba_f32: *mut f32) -> c_int;
+    pub fn r3n_timing_enable(ctx: *mut r3n_ctx, enable: c_int) -> c_int;
+    pub fn r3n_set_multi_stream(ctx: *mut r3n_ctx, enable: c_int) -> c_int;
+    pub fn r3n_stage_times(ctx: *mut r3n_ctx, ms: *mut f64, launches: *mut u64, reset: c_int) -> c_int;
+    pub fn r3n_hbm_copy_rate(ctx: *mut r3n_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;
+    pub fn r3n_host_mat4_mul(a: *const f32, b: *const f32, out: *mut f32);
+    pub fn r3n_host_mat4_inverse(m: *const f32, out: *mut f32);
+    pub fn r3n_host_look_at(eye: *const f32, center: *const f32, up: *const f32, rh: c_int, out: *mut f32);
+    pub fn r3n_host_projection(kind: c_int, params: *const f32, rh: c_int, aspect_ratio: f32, out: *mut f32);
+    pub fn r3n_host_frustum_from_matrix(m: *const f32, planes20: *mut f32);
+    pub fn r3n_host_frustum_contains_sphere(planes20: *const f32, center: *const f32, radius: f32) -> c_int;
+    pub fn r3n_host_bounding_sphere_from_mesh(positions: *const f32, vertex_count: u64, out_center: *mut f32, out_radius: *mut f32);
+    pub fn r3n_host_bounding_sphere_apply_transform(center: *const f32, radius: f32, m: *const f32, out_center: *mut f32, out_radius: *mut f32);
+    pub fn r3n_host_build_object_records(n: u32, transforms: *const f32, mesh_desc: *const f32, mesh_u32: *const u32, material_index: *const u32, out_records: *mut r3n_object128);
+    pub fn r3n_host_calculate_normals(positions: *const f32, vertex_count: u64, indices: *const u32, index_count: u64, left_handed: c_int, normals: *mut f32);
+    pub fn r3n_host_shadow_camera(direction: *const f32, distance: f32, resolution: u32, camera_location: *const f32, rh: c_int, out_view: *mut f32, out_proj: *mut f32);
+    pub fn r3n_host_allocate_shadow_atlas(handles: *const u32, resolutions: *const u16, n: u32, max_dimension: u32, out_dimensions: *mut u32, out_maps: *mut u32) -> u32;
+}

@@ -1,0 +1,19 @@
+//! Node bodies of rend3-routine's hot path over the C ABI of `librend3_amd.so`.
+//!
+//! Every public item keeps the name and signature of the rend3-routine item it replaces (file:line cited on each); only the
+//! closures registered with the render graph differ: where the reference records wgpu passes, these call `r3n_*`.  The graph
+//! machinery, the managers and the user-facing `Renderer` API stay rend3's.  Source only in this repository (no Rust toolchain
+//! in the build image): the same call sequence runs from Python in `rend3_amd/renderer.py`, which the GPU tests drive.
+//!
+//! rend3 has no FFI of its own; the C ABI (`include/r3n.h`) is the boundary its node bodies call instead of wgpu.
+pub mod amd;
+pub mod base;
+pub mod culler;
+pub mod forward;
+pub mod hi_z;
+pub mod skinning;
+pub mod tonemapping;
+pub mod uniforms;
+pub mod upload;
+
+pub use amd::AmdContext;

@@ -1,0 +1,58 @@
+//! rend3-routine/src/skinning.rs:54-226: `build_gpu_skinning_input_buffers` + `add_skinning_to_graph`.
+use crate::amd::AmdContext;
+use rend3::graph::RenderGraph;
+use rend3_amd_sys as sys;
+
+pub struct GpuSkinner<'a> {
+    pub amd: &'a AmdContext,
+}
+
+impl<'a> GpuSkinner<'a> {
+    /// skinning.rs:211-226: nothing to do without skeletons (:216-218); otherwise the 40-byte `GpuSkinningInput` records and
+    /// the joint matrices exactly as skinning.rs:54-139 collects them -- ONE launch covers every skeleton (the reference
+    /// dispatches per skeleton with a dynamic offset, :181-198).
+    pub fn add_skinning_to_graph<'node>(&'node self, graph: &mut RenderGraph<'node>) {
+        let mut node = graph.add_node("skinning");
+        node.add_side_effect();
+        node.build(move |ctx| {
+            let (inputs, matrices) = collect_skinning_inputs(&ctx.data_core.skeleton_manager, &ctx.data_core.mesh_manager);
+            if inputs.is_empty() {
+                return;
+            }
+            self.amd.check(
+                unsafe { sys::r3n_skinning(self.amd.ctx, inputs.as_ptr(), inputs.len() as u32, matrices.as_ptr().cast(), (matrices.len() / 16) as u32) },
+                "r3n_skinning",
+            );
+        });
+    }
+}
+
+/// skinning.rs:54-139 without the buffer creation: per skeleton the attribute ranges of its mesh, its private output ranges
+/// and the base index of its joint matrices in the flat matrix array.
+fn collect_skinning_inputs(
+    skeletons: &rend3::managers::SkeletonManager,
+    meshes: &rend3::managers::MeshManager,
+) -> (Vec<sys::r3n_skinning_input40>, Vec<f32>) {
+    let mut inputs = Vec::new();
+    let mut matrices = Vec::new();
+    for skeleton in skeletons.skeletons() {
+        let mesh = meshes.internal_data(skeleton.mesh_handle.get_raw());
+        let off = |range: Option<&std::ops::Range<u64>>| range.map_or(u32::MAX, |r| r.start as u32);
+        inputs.push(sys::r3n_skinning_input40 {
+            base_position_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_POSITION)),
+            base_normal_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_NORMAL)),
+            base_tangent_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_TANGENT)),
+            joint_indices_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_JOINT_INDICES)),
+            joint_weight_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_JOINT_WEIGHTS)),
+            updated_position_offset: off(skeleton.overridden_attribute_ranges.get(0)),
+            updated_normal_offset: off(skeleton.overridden_attribute_ranges.get(1)),
+            updated_tangent_offset: off(skeleton.overridden_attribute_ranges.get(2)),
+            joint_matrix_base_offset: (matrices.len() / 16) as u32,
+            vertex_count: mesh.vertex_count as u32,
+        });
+        for m in &skeleton.joint_matrices {
+            matrices.extend_from_slice(&m.to_cols_array());
+        }
+    }
+    (inputs, matrices)
+}

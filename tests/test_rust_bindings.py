@@ -1,0 +1,57 @@
+"""The Rust side of the boundary exists as source files (bindings/): the raw FFI crate is generated from include/r3n.h and
+must match it symbol for symbol -- and match what the built library exports; the adaptor crate must call only symbols the
+sys crate declares and must cover every node of the reference's frame (base.rs:135-185)."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _sys_rs():
+    return open(os.path.join(ROOT, "bindings", "rend3-amd-sys", "src", "lib.rs")).read()
+
+
+def test_sys_crate_is_generated_from_the_header():
+    import gen_rust_sys
+    assert gen_rust_sys.generate() == _sys_rs(), "bindings/rend3-amd-sys/src/lib.rs is stale: run python tools/gen_rust_sys.py"
+
+
+def test_extern_block_matches_header_and_library():
+    from rend3_amd import _ffi, build
+    rs = _sys_rs()
+    block = rs[rs.index('extern "C" {'):]
+    declared = set(re.findall(r"pub fn (r3n_\w+)\(", block))
+    assert declared == set(_ffi.SIGNATURES), (sorted(declared ^ set(_ffi.SIGNATURES)))
+    # the header, parsed independently of the generator: every `r3n_*(` that is followed by a parameter list and a semicolon
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "r3n.h")).read(), flags=re.S)
+    in_header = set(re.findall(r"\b(r3n_\w+)\s*\([^;{}]*\)\s*;", hdr))
+    assert declared == in_header, sorted(declared ^ in_header)
+    so = build.build()
+    exported = set(re.findall(r"\bT (r3n_\w+)", subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout))
+    assert declared <= exported, sorted(declared - exported)
+    # argument counts agree with the ctypes signatures the tests actually call through
+    for name, params in re.findall(r"pub fn (r3n_\w+)\(([^)]*)\)", block):
+        n = len([p for p in params.split(",") if p.strip()])
+        assert n == len(_ffi.SIGNATURES[name][1]), name
+
+
+def test_adaptor_crate_calls_only_declared_symbols_and_covers_the_frame():
+    declared = set(re.findall(r"pub fn (r3n_\w+)\(", _sys_rs()))
+    src_dir = os.path.join(ROOT, "bindings", "rend3-routine-amd", "src")
+    used = set()
+    for f in sorted(os.listdir(src_dir)):
+        used |= set(re.findall(r"sys::(r3n_\w+)\(", open(os.path.join(src_dir, f)).read()))
+    assert used <= declared, sorted(used - declared)
+    frame = {"r3n_frame_begin", "r3n_shadow_viewport", "r3n_skinning", "r3n_uniform_bake", "r3n_cull", "r3n_forward", "r3n_hi_z",
+             "r3n_resolve_opaque", "r3n_tonemap", "r3n_frame_end", "r3n_set_output_format", "r3n_mesh_buffer_write", "r3n_objects_write",
+             "r3n_materials_write", "r3n_lights_write", "r3n_textures_write_encoded", "r3n_blend_order_write", "r3n_create", "r3n_destroy"}
+    assert frame <= used, sorted(frame - used)
+    base = open(os.path.join(src_dir, "base.rs")).read()
+    base = base[base.index("let amd = self.amd;"):]  # the body of add_to_graph
+    order = ["uniforms::add_to_graph", "add_skinning_to_graph", "Shadow Culling S", "pbr shadow renderering", "Uniform Bake", "PBR Forward Pass 1",
+             "add_hi_z_to_graph", "Primary Culling", "PBR Forward Pass 2", "Resolve Opaque", "PBR Forward Transparent", "tonemapping.add_to_graph", "Frame End"]
+    pos = [base.index(k) for k in order]
+    assert pos == sorted(pos), "node order differs from base.rs:135-185"
