@@ -44,6 +44,8 @@ pub const R3N_OUTPUT_RGBA8_UNORM_SRGB: u32 = 0;
 pub const R3N_OUTPUT_BGRA8_UNORM_SRGB: u32 = 1;
 pub const R3N_OUTPUT_RGBA8_UNORM: u32 = 2;
 pub const R3N_OUTPUT_BGRA8_UNORM: u32 = 3;
+pub const R3N_SKIN_EXACT: u32 = 0;
+pub const R3N_SKIN_MFMA: u32 = 1;
 pub const R3N_STAGE_BAKE: i32 = 0;
 pub const R3N_STAGE_OBJECT_CULL: i32 = 1;
 pub const R3N_STAGE_TRIANGLE_CULL: i32 = 2;
@@ -238,6 +240,7 @@ extern "C" {
     pub fn r3n_blend_order_write(ctx: *mut r3n_ctx, objects_back_to_front: *const u32, n: u32) -> c_int;
     pub fn r3n_lights_write(ctx: *mut r3n_ctx, directional_buffer: *const c_void, directional_bytes: u64, point_buffer: *const c_void, point_bytes: u64) -> c_int;
     pub fn r3n_set_output_format(ctx: *mut r3n_ctx, format: u32) -> c_int;
+    pub fn r3n_set_skinning_mode(ctx: *mut r3n_ctx, mode: u32) -> c_int;
     pub fn r3n_set_shade_mode(ctx: *mut r3n_ctx, mode: u32) -> c_int;
     pub fn r3n_frame_begin(ctx: *mut r3n_ctx, uniforms: *const r3n_frame_uniforms496, width: u32, height: u32, samples: u32, clear_color: *const f32, shadow_atlas_width: u32, shadow_atlas_height: u32) -> c_int;
     pub fn r3n_skinning(ctx: *mut r3n_ctx, inputs: *const r3n_skinning_input40, n_skeletons: u32, joint_matrices: *const f32, n_joint_matrices: u32) -> c_int;

@@ -268,6 +268,14 @@ int r3n_lights_write(r3n_ctx *ctx, const void *directional_buffer, uint64_t dire
 #define R3N_OUTPUT_RGBA8_UNORM 2u
 #define R3N_OUTPUT_BGRA8_UNORM 3u
 int r3n_set_output_format(r3n_ctx *ctx, uint32_t format);
+/* Skinning kernel (r3n_skinning).  EXACT (default): vector ALU, every operation rounded once -- bit-identical to the oracle's
+ * restatement of skinning.wgsl:37-94.  MFMA (opt-in): the joint-matrix x vertex-block contraction on the matrix cores
+ * (v_mfma_f32_16x16x4_f32: four joint matrices x 16 vertices per instruction), for rigs of at most FOUR joints
+ * (R3N_ERR_UNSUPPORTED otherwise); its f32 results follow the fused-multiply-add order of the instruction, bit-identical to
+ * oracle/r3o.c::r3o_skinning_mfma_order, within 1e-6 relative of EXACT. */
+#define R3N_SKIN_EXACT 0u
+#define R3N_SKIN_MFMA 1u
+int r3n_set_skinning_mode(r3n_ctx *ctx, uint32_t mode);
 /* switches the fragment-stage arithmetic (R3N_SHADE_*) for the resolves enqueued from now on */
 int r3n_set_shade_mode(r3n_ctx *ctx, uint32_t mode);
 

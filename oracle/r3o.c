@@ -1475,3 +1475,56 @@ void r3o_skinning(uint32_t *mesh, const r3o_skinning_input *inputs, uint32_t n_s
         }
     }
 }
+
+/* The same skinning in the operation order of the matrix-core variant (rend3_amd/csrc/skin_mfma.hip, R3N_SKIN_MFMA): the f32
+ * MFMA is a fused-multiply-add chain over k = 0..3, the blend weights are applied per JOINT SLOT j < 4 of the rig (not per
+ * influence) and the four slots are summed in slot order.  njoints[s] <= 4.  Not the arithmetic contract of r3o_skinning: a
+ * second, equally explicit order that the opt-in kernel is bit-identical to. */
+void r3o_skinning_mfma_order(uint32_t *mesh, const r3o_skinning_input *inputs, uint32_t n_skeletons, const float *joint_matrices,
+                             const uint32_t *njoints) {
+    for (uint32_t s = 0; s < n_skeletons; ++s) {
+        const r3o_skinning_input *in = &inputs[s];
+        for (uint32_t idx = 0; idx < in->vertex_count; ++idx) {
+            uint32_t j0 = mesh[in->joint_indices_offset / 4u + idx * 2u], j1 = mesh[in->joint_indices_offset / 4u + idx * 2u + 1u];
+            uint32_t ji[4] = {j0 & 0xFFFFu, (j0 >> 16) & 0xFFFFu, j1 & 0xFFFFu, (j1 >> 16) & 0xFFFFu};
+            float jw[4];
+            memcpy(jw, mesh + in->joint_weight_offset / 4u + idx * 4u, 16);
+            float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tan[3] = {0, 0, 0};
+            if (in->base_position_offset != R3O_INVALID) fetch_vec3(mesh, in->base_position_offset, idx, pos);
+            if (in->base_normal_offset != R3O_INVALID) fetch_vec3(mesh, in->base_normal_offset, idx, nrm);
+            if (in->base_tangent_offset != R3O_INVALID) fetch_vec3(mesh, in->base_tangent_offset, idx, tan);
+            float tp[4][3], tn[4][3], tt[4][3];
+            for (uint32_t j = 0; j < 4u; ++j) {
+                float W = 0.0f;
+                for (int i = 0; i < 4; ++i) W += (ji[i] == j && jw[i] > 0.0f) ? jw[i] : 0.0f;
+                for (int r = 0; r < 3; ++r) {
+                    float qp = 0.0f, qn = 0.0f, qt = 0.0f;
+                    if (j < njoints[s]) {
+                        const float *jm = joint_matrices + 16 * (size_t)(in->joint_matrix_base_offset + j);
+                        const float bp[4] = {pos[0], pos[1], pos[2], 1.0f};
+                        for (int k = 0; k < 4; ++k) qp = fmaf(jm[4 * k + r], bp[k], qp);
+                        for (int k = 0; k < 3; ++k) {
+                            const float a = jm[4 * k + r] * (1.0f / dot3(jm + 4 * k, jm + 4 * k));
+                            qn = fmaf(a, nrm[k], qn);
+                            qt = fmaf(a, tan[k], qt);
+                        }
+                        qn = fmaf(0.0f, 0.0f, qn);  /* k = 3 of the instruction: a = 0, b = 0 */
+                        qt = fmaf(0.0f, 0.0f, qt);
+                    }
+                    tp[j][r] = qp * W; tn[j][r] = qn * W; tt[j][r] = qt * W;
+                }
+            }
+            float pa[3], na[3], ta[3];
+            for (int r = 0; r < 3; ++r) {
+                pa[r] = ((tp[0][r] + tp[1][r]) + tp[2][r]) + tp[3][r];
+                na[r] = ((tn[0][r] + tn[1][r]) + tn[2][r]) + tn[3][r];
+                ta[r] = ((tt[0][r] + tt[1][r]) + tt[2][r]) + tt[3][r];
+            }
+            normalize3(na);
+            normalize3(ta);
+            if (in->updated_position_offset != R3O_INVALID) memcpy(mesh + in->updated_position_offset / 4u + idx * 3u, pa, 12);
+            if (in->updated_normal_offset != R3O_INVALID) memcpy(mesh + in->updated_normal_offset / 4u + idx * 3u, na, 12);
+            if (in->updated_tangent_offset != R3O_INVALID) memcpy(mesh + in->updated_tangent_offset / 4u + idx * 3u, ta, 12);
+        }
+    }
+}

@@ -37,6 +37,7 @@ SIGNATURES = {
     "r3n_pose_skeletons": (cint, [vp, vp, u32]),
     "r3n_set_output_format": (cint, [vp, u32]),
     "r3n_set_shade_mode": (cint, [vp, u32]),
+    "r3n_set_skinning_mode": (cint, [vp, u32]),
     "r3n_blend_order_write": (cint, [vp, vp, u32]),
     "r3n_lights_write": (cint, [vp, vp, u64, vp, u64]),
     "r3n_frame_begin": (cint, [vp, vp, u32, u32, u32, vp, u32, u32]),

@@ -28,6 +28,7 @@ UNITS = {
     "blend_sort.hip": [],
     "texture_decode.hip": ["bc7_tables.h"],
     "anim.hip": [],
+    "skin_mfma.hip": [],
     "host.cpp": [],
 }
 SOURCES = list(UNITS)

@@ -92,7 +92,8 @@ struct r3n_ctx {
     bool tri_base_dirty = true;
     DevBuf tri_base, slot_table;
     // skinning (row S1): cached skeleton records + the wave -> skeleton map derived from them
-    DevBuf skin_inputs, skin_matrices, skin_wave_skeleton, skin_wave_first;
+    DevBuf skin_inputs, skin_matrices, skin_wave_skeleton, skin_wave_first, skin_joint_counts;
+    uint32_t skinning_mode = R3N_SKIN_EXACT, skin_max_joints = 0;
     std::vector<r3n_skinning_input40> h_skin_inputs;
     uint32_t skin_total_waves = 0;
     uint32_t slot_table_size = 0;
@@ -523,7 +524,7 @@ void r3n_destroy(r3n_ctx *c) {
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
+                      &c->skin_wave_first, &c->skin_joint_counts, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
                       &c->frag_count, &c->sort_temp, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
                       &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
@@ -698,6 +699,8 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
 extern "C" int r3n_internal_pose_skeletons(const void *requests, uint32_t n, const void *rigs, const void *joints, const void *clips,
                                            const void *tracks, const float *times, const float *values, float *out, uint32_t max_joints,
                                            hipStream_t stream);
+extern "C" int r3n_internal_skinning_mfma(uint32_t *mesh, const void *inputs, const float *joint_matrices, const uint32_t *wave_skeleton,
+                                          const uint32_t *wave_first, const uint32_t *skeleton_joints, uint32_t total_waves, hipStream_t stream);
 extern "C" int r3n_internal_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const uint32_t *src,
                                          uint32_t *dst, const float *decode, const float *thr, hipStream_t stream);
 extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h);
@@ -896,6 +899,19 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         }
         wave_first[n] = w;
         c->skin_total_waves = w;
+        // joints per skeleton: the distance to the next larger matrix base (skinning.rs:96-118 lays the matrices out skeleton by skeleton)
+        std::vector<uint32_t> bases(n), counts(n);
+        for (uint32_t i = 0; i < n; ++i) bases[i] = inputs[i].joint_matrix_base_offset;
+        std::vector<uint32_t> sorted_bases(bases);
+        std::sort(sorted_bases.begin(), sorted_bases.end());
+        c->skin_max_joints = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            auto it = std::upper_bound(sorted_bases.begin(), sorted_bases.end(), bases[i]);
+            counts[i] = (it == sorted_bases.end() ? n_joints : *it) - bases[i];
+            c->skin_max_joints = std::max(c->skin_max_joints, counts[i]);
+        }
+        TRY(ensure(c, c->skin_joint_counts, (size_t)n * 4, false, -1));
+        HIP_TRY(c, hipMemcpyAsync(c->skin_joint_counts.p, counts.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         TRY(ensure(c, c->skin_inputs, (size_t)n * sizeof *inputs, false, -1));
         TRY(ensure(c, c->skin_wave_first, (size_t)(n + 1) * 4, false, -1));
         TRY(ensure(c, c->skin_wave_skeleton, std::max<size_t>(w, 1) * 4, false, -1));
@@ -920,6 +936,12 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
     }
     if (c->skin_total_waves == 0) return R3N_OK;
     Timed t(c, R3N_STAGE_SKINNING);
+    if (c->skinning_mode == R3N_SKIN_MFMA) {
+        if (c->skin_max_joints > 4u) return fail(c, R3N_ERR_UNSUPPORTED, "skinning: R3N_SKIN_MFMA handles rigs of at most four joints (one 16 x 16 x 4 tile holds four joint matrices)");
+        HIP_TRY(c, (hipError_t)r3n_internal_skinning_mfma(c->mesh.as<uint32_t>(), c->skin_inputs.p, c->skin_matrices.as<float>(), c->skin_wave_skeleton.as<uint32_t>(),
+                                                          c->skin_wave_first.as<uint32_t>(), c->skin_joint_counts.as<uint32_t>(), c->skin_total_waves, c->stream));
+        return R3N_OK;
+    }
     hipLaunchKernelGGL(k_skinning, dim3((c->skin_total_waves + 3u) / 4u), dim3(256), 0, c->stream, c->mesh.as<uint32_t>(),
                        c->skin_inputs.as<r3n_skinning_input40>(), c->skin_matrices.as<float>(),
                        c->skin_wave_skeleton.as<uint32_t>(), c->skin_wave_first.as<uint32_t>(), c->skin_total_waves);
@@ -1698,6 +1720,12 @@ int r3n_set_output_format(r3n_ctx *c, uint32_t format) {
         }
     }
     c->output_format = format;
+    return R3N_OK;
+}
+
+int r3n_set_skinning_mode(r3n_ctx *c, uint32_t mode) {
+    if (!c || mode > R3N_SKIN_MFMA) return fail(c, R3N_ERR_INVALID_ARG, "set_skinning_mode: unknown mode");
+    c->skinning_mode = mode;
     return R3N_OK;
 }
 

@@ -643,6 +643,10 @@ class Renderer:
         self._check(self.lib.r3n_set_output_format(self.ctx, int(fmt)), "r3n_set_output_format")
         self.output_format = int(fmt)
 
+    def set_skinning_mode(self, mode):
+        """0 = R3N_SKIN_EXACT (vector ALU, default), 1 = R3N_SKIN_MFMA (matrix cores; rigs of at most four joints)."""
+        self._check(self.lib.r3n_set_skinning_mode(self.ctx, int(mode)), "r3n_set_skinning_mode")
+
     def set_shade_mode(self, mode):
         """0 = R3N_SHADE_EXACT (default, bit-identical to the oracle), 1 = R3N_SHADE_FAST (fused / approximate shading arithmetic,
         framebuffer within 1e-3 after tonemap)."""

@@ -111,7 +111,7 @@ def test_gpu_config5_shape_many_instances():
     n = 5000
     p = r3.Renderer(oh.LEFT, f32(16 / 9))
     pos, idx, nrm, tang, ji, jw = skinned_cylinder(2)
-    assert len(pos) == 160 + 32 - 32 or len(pos) > 100
+    assert len(pos) > 100
     mesh = p.add_mesh(pos, idx, normals=nrm, tangents=tang, joint_indices=ji, joint_weights=jw)
     mat = p.add_material(r3.material_record(albedo=(0.7, 0.7, 0.7, 1), albedo_mode="value", roughness=0.6), 0)
     poses = [_pose(2, 7 + i) for i in range(n)]
@@ -132,4 +132,61 @@ def test_gpu_config5_shape_many_instances():
         o.lib.r3o_skinning(o.lib.ptr(o.mesh_words), o.lib.ptr(sk_in), len(sk_in), o.lib.ptr(sk_m))
         for a, b in zip(_skinned_runs(o, osk), _skinned_runs(p, sks[i])):
             assert np.array_equal(a, b), i
+    p.close()
+
+
+def test_oracle_mfma_order_is_close_to_the_contract():
+    """The FMA-ordered restatement (what the matrix-core kernel computes) against the contract's order on posed rigs: same
+    values to rounding -- a handful of ulps -- so choosing the kernel is a performance decision, not a visual one."""
+    for joints in (2, 4):
+        o = OracleRenderer(oh.LEFT)
+        _mesh, _mat, sks, _pos, _nrm = _rig(o, joints, omk, n_skeletons=2)
+        for i, sk in enumerate(sks):
+            o.set_skeleton_joint_matrices(sk, _pose(joints, 40 + i))
+        sk_in, sk_m = o.skinning_buffers()
+        o.lib.r3o_skinning(o.lib.ptr(o.mesh_words), o.lib.ptr(sk_in), len(sk_in), o.lib.ptr(sk_m))
+        exact = [a.view(f32).copy() for sk in sks for a in _skinned_runs(o, sk)]
+        nj = np.full(len(sk_in), joints, dtype=np.uint32)
+        o.lib.r3o_skinning_mfma_order(o.lib.ptr(o.mesh_words), o.lib.ptr(sk_in), len(sk_in), o.lib.ptr(sk_m), o.lib.ptr(nj))
+        fused = [a.view(f32).copy() for sk in sks for a in _skinned_runs(o, sk)]
+        for a, b in zip(exact, fused):
+            assert np.allclose(a, b, rtol=2e-6, atol=2e-6)
+        assert any((a != b).any() for a, b in zip(exact, fused)), "the two operation orders never differ: is the fused path wired up?"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("joints", [2, 4])
+def test_gpu_skinning_mfma_matches_its_oracle_order(joints):
+    """R3N_SKIN_MFMA (v_mfma_f32_16x16x4_f32: four joint matrices x 16 vertices per instruction) is bit-identical to the
+    FMA-ordered oracle restatement on rigs of up to four joints -- several skeletons, ragged last wave, the zero-weight and
+    four-influence vertices of the test rig -- and refuses larger rigs loudly."""
+    import torch
+    assert torch.cuda.is_available()
+    import rend3_amd as r3
+    o, p = OracleRenderer(oh.LEFT, f32(1.5)), r3.Renderer(oh.LEFT, f32(1.5))
+    rigs = []
+    for r, mk in ((o, omk), (p, r3.material_record)):
+        _mesh, mat, sks, _pos, _nrm = _rig(r, joints, mk, n_skeletons=5)
+        for i, sk in enumerate(sks):
+            r.add_object(None, mat, oh.translation((-2.4 + 1.2 * i, 0.0, 0.0)), skeleton=sk)
+            r.set_skeleton_joint_matrices(sk, _pose(joints, 900 + i))
+        r.set_camera_data(oh.look_at_lh((0, 1.2, -4), (0, 1, 0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        rigs.append(sks)
+    p.set_skinning_mode(1)
+    p.render(96, 64, readback=False)
+    sk_in, sk_m = o.skinning_buffers()
+    nj = np.full(len(sk_in), joints, dtype=np.uint32)
+    o.lib.r3o_skinning_mfma_order(o.lib.ptr(o.mesh_words), o.lib.ptr(sk_in), len(sk_in), o.lib.ptr(sk_m), o.lib.ptr(nj))
+    for i in range(5):
+        for a, b in zip(_skinned_runs(o, rigs[0][i]), _skinned_runs(p, rigs[1][i])):
+            bad = np.nonzero(a != b)[0]
+            assert len(bad) == 0, (i, len(bad), a.view(f32)[bad[:4]], b.view(f32)[bad[:4]])
+    # a rig with more than four joints is refused in this mode
+    q = r3.Renderer(oh.LEFT, f32(1.5))
+    _mesh, mat, (sk,), _pos, _nrm = _rig(q, 7, r3.material_record)
+    q.add_object(None, mat, oh.identity(), skeleton=sk)
+    q.set_skinning_mode(1)
+    with pytest.raises(Exception, match="four joints"):
+        q.render(64, 64, readback=False)
+    q.close()
     p.close()

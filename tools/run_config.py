@@ -31,10 +31,13 @@ def run(name, build, w, h, rh, steps=20):
                       "stage_ms": {k: round(v[0] / 10, 4) for k, v in st.items()}, "scene_build_s": round(build_s, 1)}))
     r.close()
 
-def run_cfg5(n=50000, steps=20):
-    """BASELINE.json configs[4]: 50 000 instances of a 160-ish vertex / 2-joint rig (RiggedSimple.glb shape), skinning only."""
+def run_cfg5(n=50000, steps=20, mfma=False):
+    """BASELINE.json configs[4]: 50 000 instances of a 160-ish vertex / 2-joint rig (RiggedSimple.glb shape), skinning only.
+    mfma: the matrix-core variant (R3N_SKIN_MFMA) instead of the vector kernel -- the A/B BASELINE.json's config names."""
     from rend3_amd.scenes import skinned_cylinder
     r = r3.Renderer(r3.host.LEFT, np.float32(16 / 9))
+    if mfma:
+        r.set_skinning_mode(1)
     pos, idx, nrm, tang, ji, jw = skinned_cylinder(2)
     mesh = r.add_mesh(pos, idx, normals=nrm, tangents=tang, joint_indices=ji, joint_weights=jw)
     rng = np.random.Generator(np.random.PCG64(0x5141))
@@ -58,7 +61,7 @@ def run_cfg5(n=50000, steps=20):
     st = r.stage_times(reset=True)
     kern_ms = st["skinning"][0] / steps
     bytes_v = 60 + 36 + 24  # p,n,t 36 + joints 8 + weights 16 read; p,n,t 36 written (60 B + 36 B) -- tangent run included
-    print(json.dumps({"config": "configs[4] skinning", "skeletons": n, "vertices": verts, "joints_per_skeleton": 2,
+    print(json.dumps({"config": "configs[4] skinning" + (" (R3N_SKIN_MFMA: v_mfma_f32_16x16x4_f32)" if mfma else " (vector kernel)"), "skeletons": n, "vertices": verts, "joints_per_skeleton": 2,
                       "kernel_ms": round(kern_ms, 4), "wall_ms_incl_matrix_upload": round(1e3 * wall, 3),
                       "vertices_per_s": round(verts / (kern_ms * 1e-3)),
                       "algorithmic_GBps": round(verts * 96 / (kern_ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000,
@@ -161,6 +164,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg2", "cfg4", "cfg5"]
     if "cfg5" in which:
         run_cfg5()
+    if "cfg5mfma" in which:
+        run_cfg5(mfma=True)
     if "cfg5anim" in which:
         run_cfg5_anim()
     if "cfg5asset" in which:
