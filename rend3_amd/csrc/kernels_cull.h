@@ -236,6 +236,100 @@ __global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header2
     object_scatter_body(hdr, objects, vis_flags, block_off, vis_list, slot_base, tri_base);
 }
 
+// The three passes above in ONE single-block launch, for worlds of up to R3N_FUSED_OBJECT_PASS_MAX object slots: the block
+// walks the slots 1024 at a time -- frustum test, block-wide exclusive scan (wave scans + LDS) with a running carry, scatter
+// -- and finishes with the totals.  Same outputs, bit for bit (the layout is slot order either way).  Measured on the bench
+// scene (4096 slots, four rounds of dependent record loads in one block): 23 us per camera against 14 us for the three
+// launches, so the limit is one round; the small scenes of the tests and examples run through it.
+#define R3N_FUSED_OBJECT_PASS_MAX 1024u
+R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
+                                    const uint8_t *__restrict__ material_keys, uint32_t n_materials, uint32_t range_begin,
+                                    uint32_t range_end, uint8_t *__restrict__ vis_flags, r3n_cull_counts *__restrict__ counts,
+                                    r3n_vis_entry *__restrict__ vis_list, r3n_sub_counts *__restrict__ sub_counts,
+                                    uint32_t *__restrict__ slot_base, uint32_t *__restrict__ tri_base) {
+    __shared__ uint32_t wtot[16][3];
+    __shared__ uint32_t carry[3];
+    __shared__ uint32_t ktot[3];
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+    const uint32_t cap = hdr->object_count;
+    if (t < 3u) { carry[t] = 0u; ktot[t] = 0u; }
+    if (t < 2u * 3u * R3N_SUBQ) (&sub_counts->n[0][0][0])[t] = 0u;
+    __syncthreads();
+    uint32_t kacc[3] = {0, 0, 0};
+    for (uint32_t base = 0; base < cap; base += 1024u) {
+        const uint32_t i = base + t;
+        uint32_t flag = 0, ntri = 0, nw = 0;
+        if (i < cap) {
+            const r3n_object128 *o = &objects[i];
+            ntri = o->enabled ? o->index_count / 3u : 0u;
+            const uint32_t mi0 = o->material_index;
+            uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
+            if (key0 > 2u) key0 = 2u;
+            if (ntri > 0u && ((i >= range_begin && i < range_end) || key0 == 2u)) {  // (see object_count_body)
+                const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
+                const float c[3] = {sph.x, sph.y, sph.z};
+                const float neg_radius = -sph.w;
+                bool inside = true;
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
+                    inside = inside && (d >= neg_radius);
+                }
+                flag = inside ? 1u : 0u;
+            }
+            if (flag) {
+                nw = (ntri + 63u) / 64u;
+                kacc[key0] += ntri;
+            }
+            vis_flags[i] = (uint8_t)flag;
+        }
+        const uint32_t s0 = wave_inclusive_scan(flag, lane), s1 = wave_inclusive_scan(nw, lane), s2 = wave_inclusive_scan(ntri, lane);
+        if (lane == 63u) { wtot[wave][0] = s0; wtot[wave][1] = s1; wtot[wave][2] = s2; }
+        __syncthreads();
+        uint32_t p0 = carry[0], p1 = carry[1], p2 = carry[2];
+        for (uint32_t w = 0; w < wave; ++w) { p0 += wtot[w][0]; p1 += wtot[w][1]; p2 += wtot[w][2]; }
+        if (i < cap) {
+            const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
+            if (flag) {
+                vis_list[e].object = i;
+                vis_list[e].wave_start = ws;
+            }
+            slot_base[i] = flag ? ws * 64u : R3N_INVALID;
+            if (tri_base != nullptr) tri_base[i] = p2 + s2 - ntri;
+        }
+        __syncthreads();  // everyone has read carry / wtot
+        if (t == 1023u) { carry[0] = p0 + s0; carry[1] = p1 + s1; carry[2] = p2 + s2; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (kacc[k]) atomicAdd(&ktot[k], kacc[k]);
+    __syncthreads();
+    if (t == 0u) {
+        counts->visible_objects = carry[0];
+        counts->total_waves = carry[1];
+        counts->total_triangles = carry[2];
+        uint32_t rb = 0;
+        for (int k = 0; k < 3; ++k) {
+            counts->key_triangles[k] = ktot[k];
+            counts->region_base[k] = rb;
+            rb += ktot[k];
+        }
+        vis_list[carry[0]].object = R3N_INVALID;  // sentinel
+        vis_list[carry[0]].wave_start = carry[1];
+    }
+}
+__global__ __launch_bounds__(1024) void k_object_pass_fused(const r3n_camera_header240 *__restrict__ hdr,
+                                                            const r3n_object128 *__restrict__ objects,
+                                                            const uint8_t *__restrict__ material_keys, uint32_t n_materials,
+                                                            uint32_t range_begin, uint32_t range_end, uint8_t *__restrict__ vis_flags,
+                                                            r3n_cull_counts *__restrict__ counts, r3n_vis_entry *__restrict__ vis_list,
+                                                            r3n_sub_counts *__restrict__ sub_counts, uint32_t *__restrict__ slot_base,
+                                                            uint32_t *__restrict__ tri_base) {
+    object_pass_fused_body(hdr, objects, material_keys, n_materials, range_begin, range_end, vis_flags, counts, vis_list, sub_counts,
+                           slot_base, tri_base);
+}
+
 // ------------------------------------------------------------------------------------------------ K8 skinning
 // skinning.wgsl:37-94.  One launch for all skeletons: wave slot w (64 vertices) belongs to skeleton wave_skeleton[w]
 // and covers its vertices [64 * (w - wave_first[skeleton]), +64): the skeleton record and its matrix base are

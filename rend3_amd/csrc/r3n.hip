@@ -337,6 +337,13 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
     TRY(ensure(c, s.sub_counts[idx], sizeof(r3n_sub_counts), false, 0));
     TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
     Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
+    if (cap <= R3N_FUSED_OBJECT_PASS_MAX) {  // small worlds: the three passes in one single-block launch
+        hipLaunchKernelGGL(k_object_pass_fused, dim3(1), dim3(1024), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
+                           c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin, range_end,
+                           s.vis_flags.as<uint8_t>(), s.counts[idx].as<r3n_cull_counts>(), s.vis_list.as<r3n_vis_entry>(),
+                           s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(), tri_base);
+        return check_launch(c, "object pass (fused)");
+    }
     hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
                        c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin,
                        range_end, s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
