@@ -46,6 +46,15 @@ R3N_DEV uint32_t wave_reduce_add(uint32_t v) {
     return v;
 }
 
+R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o, 64);
+        if (lane >= (uint32_t)o) v += n;
+    }
+    return v;
+}
+
 // Pass A: frustum test (batching.rs:146, frustum.rs:148-161) + per-block totals.
 R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
                                 const uint8_t *__restrict__ material_keys, uint32_t n_materials, uint32_t range_begin,
@@ -122,6 +131,43 @@ R3N_DEV void object_scan_body(const ObjBlockSums *__restrict__ block_sums, uint3
     __shared__ uint32_t carry[3];
     __shared__ uint32_t ktot[3];
     const uint32_t t = threadIdx.x;
+    if (blockDim.x == 64u) {
+        // up to 64 block totals (16 384 object slots): ONE wavefront, scans by lane shuffles, no LDS and no barrier.  A
+        // 1024-thread workgroup needs half a CU's wave slots at once and waits for them while the resolve of the previous
+        // frame fills the chip (5 us alone, 20+ us in flight); one wavefront starts anywhere.
+        for (uint32_t k = t; k < 2u * 3u * R3N_SUBQ; k += 64u) (&sub_counts->n[0][0][0])[k] = 0u;
+        uint32_t v[3] = {0, 0, 0}, key[3] = {0, 0, 0};
+        if (t < nblocks) {
+            v[0] = block_sums[t].visible; v[1] = block_sums[t].waves; v[2] = block_sums[t].tris_all;
+            key[0] = block_sums[t].key_tris[0]; key[1] = block_sums[t].key_tris[1]; key[2] = block_sums[t].key_tris[2];
+        }
+        uint32_t inc[3], tot[3], ktotal[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            inc[k] = wave_inclusive_scan(v[k], t);
+            tot[k] = __shfl(inc[k], 63, 64);
+            ktotal[k] = __shfl(wave_inclusive_scan(key[k], t), 63, 64);
+        }
+        if (t < nblocks) {
+            block_off[t].visible = inc[0] - v[0];
+            block_off[t].waves = inc[1] - v[1];
+            block_off[t].tris_all = inc[2] - v[2];
+        }
+        if (t == 0u) {
+            counts->visible_objects = tot[0];
+            counts->total_waves = tot[1];
+            counts->total_triangles = tot[2];
+            uint32_t base = 0;
+            for (int k = 0; k < 3; ++k) {
+                counts->key_triangles[k] = ktotal[k];
+                counts->region_base[k] = base;
+                base += ktotal[k];
+            }
+            vis_list[tot[0]].object = R3N_INVALID;  // sentinel
+            vis_list[tot[0]].wave_start = tot[1];
+        }
+        return;
+    }
     if (t < 3) { carry[t] = 0; ktot[t] = 0; }
     if (t < 2u * 3u * R3N_SUBQ) (&sub_counts->n[0][0][0])[t] = 0u;
     __syncthreads();
@@ -183,14 +229,6 @@ __global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__rest
     object_scan_body(block_sums, nblocks, block_off, counts, vis_list, sub_counts);
 }
 
-R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t n = __shfl_up(v, o, 64);
-        if (lane >= (uint32_t)o) v += n;
-    }
-    return v;
-}
 
 // Pass C: scatter visible objects into the work list (object-slot order => deterministic layout).
 // slot_base[i] = first triangle slot of object i in this frame's result bitmask, or INVALID when the object

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(1024) void k_shadow_object_scan(ShadowBatchArgs a, 
     object_scan_body(V.block_sums, nblocks, V.block_off, V.counts, V.vis_list, V.sub_counts);
     // the view's other append counters start the frame at zero too
     const uint32_t ntiles = V.tiles_x * V.tiles_x;
-    for (uint32_t i = threadIdx.x; i < ntiles; i += 1024u) V.tile_count[i] = 0u;
-    if (threadIdx.x < 3u * R3N_SUBQ) V.fb_counts[threadIdx.x] = 0u;
+    for (uint32_t i = threadIdx.x; i < ntiles; i += blockDim.x) V.tile_count[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < 3u * R3N_SUBQ; i += blockDim.x) V.fb_counts[i] = 0u;
 }
 __global__ __launch_bounds__(256) void k_shadow_object_scatter(ShadowBatchArgs a) {
     const ShadowView &V = a.views[blockIdx.y];

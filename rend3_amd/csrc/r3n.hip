@@ -347,7 +347,7 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
     hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
                        c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin,
                        range_end, s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
-    hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(1024), 0, stream, s.block_sums.as<ObjBlockSums>(), nblocks,
+    hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, s.block_sums.as<ObjBlockSums>(), nblocks,
                        s.block_off.as<ObjBlockOffsets>(), s.counts[idx].as<r3n_cull_counts>(),
                        s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>());
     hipLaunchKernelGGL(k_object_scatter, dim3(nblocks), dim3(256), 0, stream,
@@ -1180,7 +1180,7 @@ static int flush_shadows(r3n_ctx *c) {
         {
             Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
             hipLaunchKernelGGL(k_shadow_object_count, dim3(nblocks, nv), dim3(256), 0, stream, a);
-            hipLaunchKernelGGL(k_shadow_object_scan, dim3(1, nv), dim3(1024), 0, stream, a, nblocks);
+            hipLaunchKernelGGL(k_shadow_object_scan, dim3(1, nv), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, a, nblocks);
             hipLaunchKernelGGL(k_shadow_object_scatter, dim3(nblocks, nv), dim3(256), 0, stream, a);
         }
         {
