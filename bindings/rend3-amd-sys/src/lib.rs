@@ -37,7 +37,25 @@ pub const R3N_TEXTURE_BC4_R_UNORM: u32 = 12;
 pub const R3N_TEXTURE_BC5_RG_UNORM: u32 = 13;
 pub const R3N_TEXTURE_BC7_RGBA_UNORM: u32 = 14;
 pub const R3N_TEXTURE_BC7_RGBA_UNORM_SRGB: u32 = 15;
-pub const R3N_TEXTURE_FORMAT_COUNT: u32 = 16;
+pub const R3N_TEXTURE_R8_SNORM: u32 = 16;
+pub const R3N_TEXTURE_RG8_SNORM: u32 = 17;
+pub const R3N_TEXTURE_RGBA8_SNORM: u32 = 18;
+pub const R3N_TEXTURE_R16_FLOAT: u32 = 19;
+pub const R3N_TEXTURE_RG16_FLOAT: u32 = 20;
+pub const R3N_TEXTURE_RGBA16_FLOAT: u32 = 21;
+pub const R3N_TEXTURE_R32_FLOAT: u32 = 22;
+pub const R3N_TEXTURE_RG32_FLOAT: u32 = 23;
+pub const R3N_TEXTURE_RGBA32_FLOAT: u32 = 24;
+pub const R3N_TEXTURE_RGBA16_UNORM: u32 = 25;
+pub const R3N_TEXTURE_RGBA16_SNORM: u32 = 26;
+pub const R3N_TEXTURE_RGB10A2_UNORM: u32 = 27;
+pub const R3N_TEXTURE_RG11B10_FLOAT: u32 = 28;
+pub const R3N_TEXTURE_RGB9E5_UFLOAT: u32 = 29;
+pub const R3N_TEXTURE_BC4_R_SNORM: u32 = 30;
+pub const R3N_TEXTURE_BC5_RG_SNORM: u32 = 31;
+pub const R3N_TEXTURE_BC6H_RGB_UFLOAT: u32 = 32;
+pub const R3N_TEXTURE_BC6H_RGB_FLOAT: u32 = 33;
+pub const R3N_TEXTURE_FORMAT_COUNT: u32 = 34;
 pub const R3N_SHADE_EXACT: u32 = 0;
 pub const R3N_SHADE_FAST: u32 = 1;
 pub const R3N_OUTPUT_RGBA8_UNORM_SRGB: u32 = 0;

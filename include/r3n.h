@@ -120,7 +120,28 @@ typedef struct r3n_texture_desc32 {
 #define R3N_TEXTURE_BC5_RG_UNORM 13u
 #define R3N_TEXTURE_BC7_RGBA_UNORM 14u
 #define R3N_TEXTURE_BC7_RGBA_UNORM_SRGB 15u
-#define R3N_TEXTURE_FORMAT_COUNT 16u
+/* formats whose values are not 8-bit unorm: decoded into four f32 per texel (16 B per texel in the pool instead of 4).
+ * Missing channels read (0, 0, 1).  All levels must be in the payload (stored_mips 0): the blit chain runs in the RGBA8
+ * pool only.  rend3-gltf/src/lib.rs:1204-1330 (KTX2), :1480-1485 (D3D), :1499-1597 (DXGI) produce them. */
+#define R3N_TEXTURE_R8_SNORM 16u
+#define R3N_TEXTURE_RG8_SNORM 17u
+#define R3N_TEXTURE_RGBA8_SNORM 18u
+#define R3N_TEXTURE_R16_FLOAT 19u
+#define R3N_TEXTURE_RG16_FLOAT 20u
+#define R3N_TEXTURE_RGBA16_FLOAT 21u
+#define R3N_TEXTURE_R32_FLOAT 22u
+#define R3N_TEXTURE_RG32_FLOAT 23u
+#define R3N_TEXTURE_RGBA32_FLOAT 24u
+#define R3N_TEXTURE_RGBA16_UNORM 25u
+#define R3N_TEXTURE_RGBA16_SNORM 26u
+#define R3N_TEXTURE_RGB10A2_UNORM 27u
+#define R3N_TEXTURE_RG11B10_FLOAT 28u
+#define R3N_TEXTURE_RGB9E5_UFLOAT 29u
+#define R3N_TEXTURE_BC4_R_SNORM 30u
+#define R3N_TEXTURE_BC5_RG_SNORM 31u
+#define R3N_TEXTURE_BC6H_RGB_UFLOAT 32u
+#define R3N_TEXTURE_BC6H_RGB_FLOAT 33u
+#define R3N_TEXTURE_FORMAT_COUNT 34u
 
 /* PerCameraUniform header, 240 B (rend3-routine/src/culling/culler.rs:158-175) */
 typedef struct r3n_camera_header240 {

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libr3o.so")
 _SRC = os.path.join(_HERE, "r3o.c")
 _SRCS = [_SRC, os.path.join(_HERE, "bcn.c")]
-_DEPS = _SRCS + [os.path.join(_HERE, "bc7_tables.h")]
+_DEPS = _SRCS + [os.path.join(_HERE, "bc7_tables.h"), os.path.join(_HERE, "bc6h_tables.h")]
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 vp = ctypes.c_void_p
@@ -47,6 +47,12 @@ class OracleLib:
         c.r3o_texture_level_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         c.r3o_texture_decode_level.restype = ctypes.c_int
         c.r3o_texture_decode_level.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+        c.r3o_texture_is_float.restype = ctypes.c_int
+        c.r3o_texture_is_float.argtypes = [ctypes.c_uint32]
+        c.r3o_texture_decode_level_f32.restype = ctypes.c_int
+        c.r3o_texture_decode_level_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+        c.r3o_bc6h_decode_level_half.restype = ctypes.c_int
+        c.r3o_bc6h_decode_level_half.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         c.r3o_f32_to_f16.restype = ctypes.c_uint16
         c.r3o_f32_to_f16.argtypes = [ctypes.c_float]
         c.r3o_f16_to_f32.restype = ctypes.c_float

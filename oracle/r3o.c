@@ -545,9 +545,9 @@ static void fetch_triangle(const r3o_object *ob, const uint32_t *mesh, uint32_t 
  *     nearest: the level nearest to the LOD (ties up).
  */
 typedef struct {
-    uint32_t offset;  /* first texel of mip 0 in the pool (u32 RGBA8 texels, mips contiguous) */
+    uint32_t offset;  /* first word of mip 0 in the pool (u32 words: one per RGBA8 texel, four per float texel; mips contiguous) */
     uint32_t width, height, mips;
-    uint32_t format;  /* 0 = Rgba8Unorm, 1 = Rgba8UnormSrgb */
+    uint32_t format;  /* 0 = Rgba8Unorm, 1 = Rgba8UnormSrgb, 2 = four f32 per texel (the float-decoded formats, bcn.c) */
     uint32_t _pad[3];
 } r3o_texture_desc;
 
@@ -579,9 +579,14 @@ static inline uint32_t wrap_texel_i(float f, uint32_t n) { /* f = floor(coordina
     return (uint32_t)(((i % w) + w) % w);
 }
 static void tex_fetch(const r3o_textures *tt, const r3o_texture_desc *d, uint32_t mip, uint32_t x, uint32_t y, float o[4]) {
-    uint64_t off = d->offset;
+    uint64_t off = 0;
     for (uint32_t k = 0; k < mip; ++k) off += (uint64_t)tex_mip_dim(d->width, k) * tex_mip_dim(d->height, k);
-    uint32_t t = tt->texels[off + (uint64_t)y * tex_mip_dim(d->width, mip) + x];
+    off += (uint64_t)y * tex_mip_dim(d->width, mip) + x;
+    if (d->format == 2u) { /* float-decoded formats (bcn.c r3o_texture_decode_level_f32): four f32 per texel, used as they are */
+        memcpy(o, tt->texels + d->offset + 4u * off, 16);
+        return;
+    }
+    uint32_t t = tt->texels[d->offset + off];
     for (int c = 0; c < 4; ++c) {
         uint32_t b = (t >> (8 * c)) & 0xFFu;
         o[c] = (d->format == 1u && c < 3) ? g_srgb8_to_linear[b] : (float)b / 255.0f;

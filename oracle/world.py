@@ -226,8 +226,10 @@ class OracleRenderer:
         data, w, h, mips = host_mod.prepare_texture(self.lib, rgba8, srgb, mip_count, mip_source)
         return self._append_texels(data, w, h, mips, srgb)
 
-    def _append_texels(self, data, w, h, mips, srgb):
-        desc = np.array([[self.tex_used, w, h, mips, 1 if srgb else 0, 0, 0, 0]], dtype=np.uint32)
+    def _append_texels(self, data, w, h, mips, srgb, pool_float=False):
+        """data: pool words -- one per RGBA8 texel, or (pool_float) four f32 bit patterns per texel (r3o.c tex_fetch)."""
+        self.tex_used = (self.tex_used + 3) & ~3 if pool_float else self.tex_used
+        desc = np.array([[self.tex_used, w, h, mips, 2 if pool_float else (1 if srgb else 0), 0, 0, 0]], dtype=np.uint32)
         if self.tex_used + len(data) > len(self.tex_pool):
             grown = np.zeros(max(2 * len(self.tex_pool), self.tex_used + len(data)), dtype=np.uint32)
             grown[: self.tex_used] = self.tex_pool[: self.tex_used]
@@ -241,6 +243,17 @@ class OracleRenderer:
         """Mirror of the product's add_texture_2d_encoded: every level is decoded to RGBA8 by the oracle's decoders
         (oracle/bcn.c); generate_mips expands level 0 and runs the RGBA8 blit chain."""
         c = self.lib.c
+        if c.r3o_texture_is_float(fmt):
+            assert not generate_mips, "the blit chain runs on RGBA8 texels only"
+            words = []
+            for k, lv in enumerate(levels):
+                w, h = max(1, width >> k), max(1, height >> k)
+                src = np.frombuffer(lv, dtype=np.uint8)
+                assert len(src) == c.r3o_texture_level_bytes(fmt, w, h), "level byte count"
+                out = np.zeros((h, w, 4), dtype=np.float32)
+                assert c.r3o_texture_decode_level_f32(fmt, w, h, src.ctypes.data, out.ctypes.data) == 0
+                words.append(out.reshape(-1).view(np.uint32))
+            return self._append_texels(np.concatenate(words), width, height, len(levels), False, pool_float=True)
         decoded = []
         for k, lv in enumerate(levels):
             w, h = max(1, width >> k), max(1, height >> k)

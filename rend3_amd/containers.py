@@ -4,8 +4,8 @@
 
 The loader decides sRGB-ness from the texture's USE (albedo / emissive -> srgb, everything else linear), not from the
 file: every map takes the `srgb` flag and ignores the _SRGB suffix of the stored format.  Formats the maps turn into
-TextureFormats this library does not sample (snorm / integer / 16-bit / float, BC6H, ETC2, ASTC, depth) raise
-TextureUnsupported; formats the maps reject raise the reference's own error kinds.
+TextureFormats a float-sampled texture binding cannot hold or this library has no decoder for (integer, depth, ETC2 /
+EAC, ASTC) raise TextureUnsupported; formats the maps reject raise the reference's own error kinds.
 
 Host-side parsing only; decoding happens on the GPU (r3n_textures_write_encoded, csrc/texture_decode.hip).
 """
@@ -14,12 +14,22 @@ import struct
 # R3N_TEXTURE_* (include/r3n.h)
 RGBA8, RGBA8_SRGB, R8, RG8, BGRA8, BGRA8_SRGB = 0, 1, 2, 3, 4, 5
 BC1, BC1_SRGB, BC2, BC2_SRGB, BC3, BC3_SRGB, BC4, BC5, BC7, BC7_SRGB = 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+# decoded to float texels (snorm, 16-bit, float, packed float, BC4 / BC5 snorm, BC6H)
+R8_SNORM, RG8_SNORM, RGBA8_SNORM, R16F, RG16F, RGBA16F, R32F, RG32F, RGBA32F = 16, 17, 18, 19, 20, 21, 22, 23, 24
+RGBA16_UNORM, RGBA16_SNORM, RGB10A2, RG11B10F, RGB9E5, BC4_SNORM, BC5_SNORM, BC6H_UF, BC6H_SF = 25, 26, 27, 28, 29, 30, 31, 32, 33
+FORMAT_COUNT = 34
 FORMAT_NAMES = {RGBA8: "Rgba8Unorm", RGBA8_SRGB: "Rgba8UnormSrgb", R8: "R8Unorm", RG8: "Rg8Unorm", BGRA8: "Bgra8Unorm",
                 BGRA8_SRGB: "Bgra8UnormSrgb", BC1: "Bc1RgbaUnorm", BC1_SRGB: "Bc1RgbaUnormSrgb", BC2: "Bc2RgbaUnorm",
                 BC2_SRGB: "Bc2RgbaUnormSrgb", BC3: "Bc3RgbaUnorm", BC3_SRGB: "Bc3RgbaUnormSrgb", BC4: "Bc4RUnorm",
-                BC5: "Bc5RgUnorm", BC7: "Bc7RgbaUnorm", BC7_SRGB: "Bc7RgbaUnormSrgb"}
-BLOCK_BYTES = {BC1: 8, BC1_SRGB: 8, BC4: 8, BC2: 16, BC2_SRGB: 16, BC3: 16, BC3_SRGB: 16, BC5: 16, BC7: 16, BC7_SRGB: 16}
-TEXEL_BYTES = {RGBA8: 4, RGBA8_SRGB: 4, BGRA8: 4, BGRA8_SRGB: 4, R8: 1, RG8: 2}
+                BC5: "Bc5RgUnorm", BC7: "Bc7RgbaUnorm", BC7_SRGB: "Bc7RgbaUnormSrgb", R8_SNORM: "R8Snorm", RG8_SNORM: "Rg8Snorm",
+                RGBA8_SNORM: "Rgba8Snorm", R16F: "R16Float", RG16F: "Rg16Float", RGBA16F: "Rgba16Float", R32F: "R32Float",
+                RG32F: "Rg32Float", RGBA32F: "Rgba32Float", RGBA16_UNORM: "Rgba16Unorm", RGBA16_SNORM: "Rgba16Snorm",
+                RGB10A2: "Rgb10a2Unorm", RG11B10F: "Rg11b10Float", RGB9E5: "Rgb9e5Ufloat", BC4_SNORM: "Bc4RSnorm",
+                BC5_SNORM: "Bc5RgSnorm", BC6H_UF: "Bc6hRgbUfloat", BC6H_SF: "Bc6hRgbFloat"}
+BLOCK_BYTES = {BC1: 8, BC1_SRGB: 8, BC4: 8, BC2: 16, BC2_SRGB: 16, BC3: 16, BC3_SRGB: 16, BC5: 16, BC7: 16, BC7_SRGB: 16,
+               BC4_SNORM: 8, BC5_SNORM: 16, BC6H_UF: 16, BC6H_SF: 16}
+TEXEL_BYTES = {RGBA8: 4, RGBA8_SRGB: 4, BGRA8: 4, BGRA8_SRGB: 4, R8: 1, RG8: 2, R8_SNORM: 1, RG8_SNORM: 2, RGBA8_SNORM: 4, R16F: 2,
+               RG16F: 4, RGBA16F: 8, R32F: 4, RG32F: 8, RGBA32F: 16, RGBA16_UNORM: 8, RGBA16_SNORM: 8, RGB10A2: 4, RG11B10F: 4, RGB9E5: 4}
 
 
 class TextureLoadError(ValueError):
@@ -47,6 +57,11 @@ def is_block_format(fmt):
     return fmt in BLOCK_BYTES
 
 
+def is_float_format(fmt):
+    """Decoded into float texels (four f32 per texel in the pool) instead of RGBA8."""
+    return R8_SNORM <= fmt < FORMAT_COUNT
+
+
 def _pick(srgb, linear_fmt, srgb_fmt):
     return srgb_fmt if srgb else linear_fmt
 
@@ -54,14 +69,13 @@ def _pick(srgb, linear_fmt, srgb_fmt):
 # ---------------------------------------------------------------------------------------------- KTX2
 KTX2_MAGIC = bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x32, 0x30, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A])
 # VkFormat values (vulkan_core.h)
-_VK_UNSUPPORTED = {  # mapped by the reference, not sampled here
-    10: "R8Snorm", 13: "R8Uint", 14: "R8Sint", 17: "Rg8Snorm", 20: "Rg8Uint", 21: "Rg8Sint", 38: "Rgba8Snorm",
-    41: "Rgba8Uint", 42: "Rgba8Sint", 64: "Rgb10a2Unorm", 74: "R16Uint", 75: "R16Sint", 76: "R16Float", 81: "Rg16Uint",
-    82: "Rg16Sint", 83: "Rg16Float", 91: "Rgba16Unorm", 92: "Rgba16Snorm", 95: "Rgba16Uint", 96: "Rgba16Sint",
-    97: "Rgba16Float", 98: "R32Uint", 99: "R32Sint", 100: "R32Float", 101: "Rg32Uint", 102: "Rg32Sint", 103: "Rg32Float",
-    107: "Rgba32Uint", 108: "Rgba32Sint", 109: "Rgba32Float", 122: "Rg11b10Float", 123: "Rgb9e5Ufloat",
-    125: "Depth24Plus", 126: "Depth32Float", 129: "Depth24PlusStencil8", 140: "Bc4RSnorm", 142: "Bc5RgSnorm",
-    143: "Bc6hRgbUfloat", 144: "Bc6hRgbFloat"}
+_VK_FLOAT = {10: R8_SNORM, 17: RG8_SNORM, 38: RGBA8_SNORM, 64: RGB10A2, 76: R16F, 83: RG16F, 91: RGBA16_UNORM, 92: RGBA16_SNORM,
+             97: RGBA16F, 100: R32F, 103: RG32F, 109: RGBA32F, 122: RG11B10F, 123: RGB9E5, 140: BC4_SNORM, 142: BC5_SNORM,
+             143: BC6H_UF, 144: BC6H_SF}
+_VK_UNSUPPORTED = {  # mapped by the reference to formats a float-sampled binding cannot hold
+    13: "R8Uint", 14: "R8Sint", 20: "Rg8Uint", 21: "Rg8Sint", 41: "Rgba8Uint", 42: "Rgba8Sint", 74: "R16Uint", 75: "R16Sint",
+    81: "Rg16Uint", 82: "Rg16Sint", 95: "Rgba16Uint", 96: "Rgba16Sint", 98: "R32Uint", 99: "R32Sint", 101: "Rg32Uint",
+    102: "Rg32Sint", 107: "Rgba32Uint", 108: "Rgba32Sint", 125: "Depth24Plus", 126: "Depth32Float", 129: "Depth24PlusStencil8"}
 
 
 def map_ktx2_format(vk, srgb):
@@ -86,6 +100,8 @@ def map_ktx2_format(vk, srgb):
         return BC5
     if vk in (145, 146):
         return _pick(srgb, BC7, BC7_SRGB)
+    if vk in _VK_FLOAT:
+        return _VK_FLOAT[vk]
     if vk in _VK_UNSUPPORTED or 147 <= vk <= 184:  # ETC2 / EAC / ASTC blocks
         raise TextureUnsupported(f"KTX2 vkFormat {vk} ({_VK_UNSUPPORTED.get(vk, 'ETC2 / EAC / ASTC')})")
     return None
@@ -128,12 +144,13 @@ _DXGI = {  # map_dxgi_format; typeless members of a family behave like its unorm
     70: ("bc1",), 71: ("bc1",), 72: ("bc1",), 73: ("bc2",), 74: ("bc2",), 75: ("bc2",), 76: ("bc3",), 77: ("bc3",), 78: ("bc3",),
     79: ("bc4",), 80: ("bc4",), 82: ("bc5",), 83: ("bc5",), 87: ("bgra",), 90: ("bgra",), 91: ("bgra",),
     97: ("bc7",), 98: ("bc7",), 99: ("bc7",)}
-_DXGI_UNSUPPORTED = {2: "Rgba32Float", 3: "Rgba32Uint", 4: "Rgba32Sint", 10: "Rgba16Float", 12: "Rgba16Uint", 14: "Rgba16Sint",
-                     16: "Rg32Float", 17: "Rg32Uint", 18: "Rg32Sint", 24: "Rgb10a2Unorm", 26: "Rg11b10Float", 30: "Rgba8Uint",
-                     31: "Rgba8Snorm", 32: "Rgba8Sint", 34: "Rg16Float", 36: "Rg16Uint", 38: "Rg16Sint", 40: "Depth32Float",
-                     41: "R32Float", 42: "R32Uint", 43: "R32Sint", 50: "Rg8Uint", 51: "Rg8Snorm", 52: "Rg8Sint", 54: "R16Float",
-                     57: "R16Uint", 59: "R16Sint", 62: "R8Uint", 63: "R8Snorm", 64: "R8Sint", 67: "Rgb9e5Ufloat",
-                     81: "Bc4RSnorm", 84: "Bc5RgSnorm", 94: "Bc6hRgbUfloat", 95: "Bc6hRgbUfloat", 96: "Bc6hRgbFloat"}
+_DXGI_FLOAT = {1: RGBA32F, 2: RGBA32F, 9: RGBA16F, 10: RGBA16F, 15: RG32F, 16: RG32F, 26: RG11B10F, 31: RGBA8_SNORM, 33: RG16F,
+               34: RG16F, 39: R32F, 41: R32F, 51: RG8_SNORM, 53: R16F, 54: R16F, 63: R8_SNORM, 67: RGB9E5, 81: BC4_SNORM,
+               84: BC5_SNORM, 94: BC6H_UF, 95: BC6H_UF, 96: BC6H_SF}
+_DXGI_UNSUPPORTED = {3: "Rgba32Uint", 4: "Rgba32Sint", 12: "Rgba16Uint", 14: "Rgba16Sint", 17: "Rg32Uint", 18: "Rg32Sint",
+                     30: "Rgba8Uint", 32: "Rgba8Sint", 36: "Rg16Uint", 38: "Rg16Sint", 40: "Depth32Float", 42: "R32Uint",
+                     43: "R32Sint", 44: "Depth24PlusStencil8", 45: "Depth24PlusStencil8", 46: "Depth24Plus", 50: "Rg8Uint",
+                     52: "Rg8Sint", 57: "R16Uint", 59: "R16Sint", 62: "R8Uint", 64: "R8Sint"}
 _FAMILY = {"rgba": (RGBA8, RGBA8_SRGB), "bgra": (BGRA8, BGRA8_SRGB), "bc1": (BC1, BC1_SRGB), "bc2": (BC2, BC2_SRGB),
            "bc3": (BC3, BC3_SRGB), "bc7": (BC7, BC7_SRGB), "r": (R8, R8), "rg": (RG8, RG8), "bc4": (BC4, BC4), "bc5": (BC5, BC5)}
 
@@ -142,6 +159,8 @@ def map_dxgi_format(dxgi, srgb):
     if dxgi in _DXGI:
         lin, s = _FAMILY[_DXGI[dxgi][0]]
         return _pick(srgb, lin, s)
+    if dxgi in _DXGI_FLOAT:
+        return _DXGI_FLOAT[dxgi]
     if dxgi in _DXGI_UNSUPPORTED:
         raise TextureUnsupported(f"DXGI format {dxgi} ({_DXGI_UNSUPPORTED[dxgi]})")
     return None
@@ -149,7 +168,10 @@ def map_dxgi_format(dxgi, srgb):
 
 def _d3d_format(flags, fourcc, bits, rm, gm, bm, am):
     """ddsfile::D3DFormat::try_from_pixel_format for the members map_d3d_format accepts.  Returns a name or None."""
-    if flags & 0x4:  # DDPF_FOURCC
+    if flags & 0x4:  # DDPF_FOURCC: a four-character code, or a D3DFORMAT number for the float formats
+        code = int.from_bytes(fourcc, "little")
+        if code in (111, 112, 113, 114, 115, 116):
+            return {111: "R16F", 112: "G16R16F", 113: "A16B16G16R16F", 114: "R32F", 115: "G32R32F", 116: "A32B32G32R32F"}[code]
         return {b"DXT1": "DXT1", b"DXT2": "DXT2", b"DXT3": "DXT3", b"DXT4": "DXT4", b"DXT5": "DXT5"}.get(fourcc)
     if flags & 0x40 and bits == 32 and flags & 0x1:  # DDPF_RGB | DDPF_ALPHAPIXELS
         if (rm, gm, bm, am) == (0xFF, 0xFF00, 0xFF0000, 0xFF000000):
@@ -162,6 +184,8 @@ def _d3d_format(flags, fourcc, bits, rm, gm, bm, am):
 
 
 def map_d3d_format(name, srgb):
+    if name in ("R16F", "G16R16F", "A16B16G16R16F", "R32F", "G32R32F", "A32B32G32R32F"):
+        return {"R16F": R16F, "G16R16F": RG16F, "A16B16G16R16F": RGBA16F, "R32F": R32F, "G32R32F": RG32F, "A32B32G32R32F": RGBA32F}[name]
     fam = {"A8B8G8R8": "rgba", "A8R8G8B8": "bgra", "A8": "r", "DXT1": "bc1", "DXT2": "bc2", "DXT3": "bc2", "DXT4": "bc3",
            "DXT5": "bc3"}.get(name)
     if fam is None:
@@ -219,5 +243,6 @@ def parse_dds(data, srgb):
 
 def generate_mips_allowed(fmt):
     """load_image generates a chain for single-level files only when the format is filterable AND a render attachment
-    (the blit chain of util/mipmap.rs renders into it): true for the uncompressed 8-bit formats, false for BCn."""
-    return not is_block_format(fmt)
+    (the blit chain of util/mipmap.rs renders into it): true for the uncompressed 8-bit unorm formats; false for BCn, and
+    for the float-decoded formats (this library generates chains in the RGBA8 pool only)."""
+    return not is_block_format(fmt) and not is_float_format(fmt)

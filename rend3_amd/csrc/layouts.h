@@ -138,6 +138,9 @@ struct r3n_sub_counts {
 
 #define R3N_MAX_HIZ_MIPS 16
 #define R3N_TEX_LEVELS 16  // extents <= 65535: at most 16 levels per texture (level-offset table of the sampler)
+// device-side r3n_texture_desc32.format: 0 / 1 = RGBA8 texels (unorm / sRGB), one pool word each; R3N_POOL_FLOAT = four f32 per
+// texel (r3n_textures_write_encoded puts every non-8-bit-unorm format there); `offset` counts pool words either way
+#define R3N_POOL_FLOAT 2u
 struct r3n_hiz_desc {
     uint32_t width, height, mips, _pad;
     uint32_t offset[R3N_MAX_HIZ_MIPS];  // element offset of each mip

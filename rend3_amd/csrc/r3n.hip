@@ -658,15 +658,16 @@ static TextureArgs texture_args(r3n_ctx *c) {
     return t;
 }
 
-// First texel (pool index) of every level of every texture: R3N_TEX_LEVELS entries per texture, so that the sampler does not
-// walk the chain.  `descs` = the descriptors as the device holds them (offsets in texels).
+// First word (pool index) of every level of every texture: R3N_TEX_LEVELS entries per texture, so that the sampler does not
+// walk the chain.  `descs` = the descriptors as the device holds them (offsets in pool words; a texel is one word, or four
+// for R3N_POOL_FLOAT textures).
 static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, uint64_t n_texels) {
     std::vector<uint32_t> off((size_t)std::max(n, 1u) * R3N_TEX_LEVELS, 0u);
     for (uint32_t i = 0; i < n; ++i) {
         uint64_t at = descs[i].offset;
         for (uint32_t k = 0; k < R3N_TEX_LEVELS; ++k) {
             off[(size_t)i * R3N_TEX_LEVELS + k] = (uint32_t)at;
-            if (k < descs[i].mips) at += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k);
+            if (k < descs[i].mips) at += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k) * (descs[i].format == R3N_POOL_FLOAT ? 4u : 1u);
         }
     }
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
@@ -712,6 +713,9 @@ extern "C" int r3n_internal_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh
                                          uint32_t *dst, const float *decode, const float *thr, hipStream_t stream);
 extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32_t h);
 extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h, const void *src, uint32_t *dst, hipStream_t stream);
+extern "C" int r3n_internal_decode_level_f32(uint32_t format, uint32_t w, uint32_t h, const void *src, float *dst, hipStream_t stream);
+extern "C" int r3n_internal_format_is_float(uint32_t format);
+extern "C" uint32_t r3n_internal_format_align(uint32_t format);
 
 int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, const void *payload, uint64_t payload_bytes) {
     if (!c || (n && (!descs || !payload))) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): null");
@@ -719,7 +723,8 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
     uint64_t n_texels = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const r3n_texture_desc32 &d = descs[i];
-        if (d.format >= R3N_TEXTURE_FORMAT_COUNT) return fail(c, R3N_ERR_UNSUPPORTED, "textures write (encoded): format not built (8-bit colour, BC1-5, BC7 only)");
+        if (d.format >= R3N_TEXTURE_FORMAT_COUNT) return fail(c, R3N_ERR_UNSUPPORTED, "textures write (encoded): unknown format id");
+        const bool is_float = r3n_internal_format_is_float(d.format) != 0;
         if (!d.width || !d.height || !d.mips || d.width > 65535u || d.height > 65535u) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): bad extent");
         uint32_t max_mips = 0;
         for (uint32_t m = std::max(d.width, d.height); m; m >>= 1) ++max_mips;
@@ -727,12 +732,13 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         if (d.stored_mips > d.mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): more stored levels than mips");
         const uint32_t stored = d.stored_mips ? d.stored_mips : d.mips;
         if (stored < d.mips && d.format >= R3N_TEXTURE_BC1_RGBA_UNORM)
-            return fail(c, R3N_ERR_UNSUPPORTED, "textures write (encoded): mips are generated for uncompressed formats only (block formats are not render targets)");
+            return fail(c, R3N_ERR_UNSUPPORTED, is_float ? "textures write (encoded): mips are generated in the RGBA8 pool only; float-decoded formats must carry their levels"
+                                                         : "textures write (encoded): mips are generated for uncompressed formats only (block formats are not render targets)");
         uint64_t end = d.offset, texels = 0;
         for (uint32_t k = 0; k < d.mips; ++k) {
             const uint32_t w = std::max(1u, d.width >> k), h = std::max(1u, d.height >> k);
             if (k < stored) end += r3n_internal_level_bytes(d.format, w, h);
-            texels += (uint64_t)w * h;
+            texels += (uint64_t)w * h * (is_float ? 4u : 1u);  // pool words
         }
         if (end > payload_bytes) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): levels outside the payload");
         if ((d.offset & 3u) != 0u) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): level 0 must start on a 4-byte boundary");
@@ -744,7 +750,7 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         internal[i] = d;
         internal[i].stored_mips = 0;
         internal[i].offset = (uint32_t)n_texels;
-        internal[i].format = srgb ? R3N_TEXTURE_RGBA8_UNORM_SRGB : R3N_TEXTURE_RGBA8_UNORM;
+        internal[i].format = is_float ? R3N_POOL_FLOAT : (srgb ? R3N_TEXTURE_RGBA8_UNORM_SRGB : R3N_TEXTURE_RGBA8_UNORM);
         n_texels += texels;
     }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -761,7 +767,13 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
             const uint32_t stored = descs[i].stored_mips ? descs[i].stored_mips : descs[i].mips;
             for (uint32_t k = 0; k < descs[i].mips && e == hipSuccess; ++k) {
                 const uint32_t w = std::max(1u, descs[i].width >> k), h = std::max(1u, descs[i].height >> k);
-                if (k < stored) {
+                if (internal[i].format == R3N_POOL_FLOAT) {
+                    // sources are read through their own width (format_align): every level of those formats is a multiple of it
+                    e = (hipError_t)r3n_internal_decode_level_f32(descs[i].format, w, h, static_cast<const char *>(staged) + src,
+                                                                  reinterpret_cast<float *>(c->tex_texels.as<uint32_t>() + dst), c->stream);
+                    src += r3n_internal_level_bytes(descs[i].format, w, h);
+                    dst += (uint64_t)w * h * 3u;  // + w * h below: four words per texel
+                } else if (k < stored) {
                     // block-compressed and 32-bit sources are read as dwords: every level of those formats is a multiple of 4 B
                     e = (hipError_t)r3n_internal_decode_level(descs[i].format, w, h, static_cast<const char *>(staged) + src,
                                                               c->tex_texels.as<uint32_t>() + dst, c->stream);

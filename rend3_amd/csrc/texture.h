@@ -8,7 +8,8 @@
 //   depth.wgsl:108-118                       the shadow / depth cutout test (its quirks are reproduced by the caller)
 //
 // Contract (identical in oracle/r3o.c): RGBA8 texels, c / 255, sRGB decoded per texel BEFORE filtering through a
-// 256-entry table of the exact formula; bilinear footprint u * w - 0.5 / floor / Repeat; level of detail from
+// 256-entry table of the exact formula (textures of the float-decoded formats, R3N_POOL_FLOAT: four f32 per texel, used as
+// they are); bilinear footprint u * w - 0.5 / floor / Repeat; level of detail from
 // rho = max(|ddx * size|, |ddy * size|) = m * 2^e as e + (m - 1) -- exponent exact, mantissa as the fraction, no
 // transcendental call, so CPU and GPU agree bit for bit; rho <= 1 or NaN -> level 0; linear mixes two levels,
 // nearest takes the level nearest to the LOD (ties up).
@@ -18,7 +19,7 @@
 struct TextureArgs {
     const r3n_texture_desc32 *descs;
     uint32_t count;
-    const uint32_t *texels;       // RGBA8, every texture's mips contiguous
+    const uint32_t *texels;       // the pool: every texture's mips contiguous; one word per RGBA8 texel, four per float texel
     const float *decode;          // 512 entries: [0, 256) = c / 255 (unorm), [256, 512) = sRGB8 -> linear, built on the
                                   // host with libm like the oracle's.  Both hold exactly what the per-texel expressions
                                   // give.  The resolve stages them in LDS: a texel decode is then 4 LDS reads instead of
@@ -107,9 +108,13 @@ struct Texel4 {
 };
 // NEED_A = false: the caller reads r, g, b only (AO / roughness / metallic, emissive ...): alpha is neither decoded nor filtered
 template <bool NEED_A>
-R3N_DEV Texel4 tex_texel(const TextureArgs &t, bool srgb, const uint32_t *__restrict__ lvl, uint32_t i) {
+R3N_DEV Texel4 tex_texel(const TextureArgs &t, uint32_t fmt, const uint32_t *__restrict__ lvl, uint32_t i) {
+    if (fmt == R3N_POOL_FLOAT) {  // 16-byte aligned: textures start on 4-word boundaries, levels are whole float4s
+        const float4 v = reinterpret_cast<const float4 *>(lvl)[i];
+        return Texel4{(f2){v.x, v.y}, (f2){v.z, NEED_A ? v.w : 0.0f}};
+    }
     const uint32_t v = lvl[i];
-    const float *rgb = t.decode + (srgb ? 256 : 0);
+    const float *rgb = t.decode + (fmt == 1u ? 256 : 0);
     Texel4 o;
     o.rg = (f2){rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu]};
     o.ba = (f2){rgb[(v >> 16) & 0xFFu], NEED_A ? t.decode[v >> 24] : 0.0f};
@@ -119,10 +124,10 @@ template <class M> R3N_DEV f2 mix2(f2 a, f2 b, float t, float one_minus_t) {  //
     return M::mad(b, splat2(t), a * splat2(one_minus_t));
 }
 template <class M, bool NEED_A>
-R3N_DEV Texel4 tex_bilinear(const TextureArgs &t, bool srgb, size_t lvl_off, const TexFootprint::Lvl &l) {
+R3N_DEV Texel4 tex_bilinear(const TextureArgs &t, uint32_t fmt, size_t lvl_off, const TexFootprint::Lvl &l) {
     const uint32_t *lvl = t.texels + lvl_off;
-    const Texel4 c00 = tex_texel<NEED_A>(t, srgb, lvl, l.i00), c10 = tex_texel<NEED_A>(t, srgb, lvl, l.i10);
-    const Texel4 c01 = tex_texel<NEED_A>(t, srgb, lvl, l.i01), c11 = tex_texel<NEED_A>(t, srgb, lvl, l.i11);
+    const Texel4 c00 = tex_texel<NEED_A>(t, fmt, lvl, l.i00), c10 = tex_texel<NEED_A>(t, fmt, lvl, l.i10);
+    const Texel4 c01 = tex_texel<NEED_A>(t, fmt, lvl, l.i01), c11 = tex_texel<NEED_A>(t, fmt, lvl, l.i11);
     const float omx = 1.0f - l.fx, omy = 1.0f - l.fy;
     Texel4 o;
     o.rg = mix2<M>(mix2<M>(c00.rg, c10.rg, l.fx, omx), mix2<M>(c01.rg, c11.rg, l.fx, omx), l.fy, omy);
@@ -136,12 +141,12 @@ R3N_DEV Texel4 tex_bilinear(const TextureArgs &t, bool srgb, size_t lvl_off, con
 }
 template <class M, bool NEED_A>
 R3N_DEV Texel4 tex_apply(const TextureArgs &t, const r3n_texture_desc32 &d, const TexFootprint &f) {
-    const size_t lvl = (size_t)d.offset + f.level_off;
-    const bool srgb = d.format == 1u;
-    if (f.nearest) return tex_texel<NEED_A>(t, srgb, t.texels + lvl, f.l[0].i00);
-    Texel4 o = tex_bilinear<M, NEED_A>(t, srgb, lvl, f.l[0]);
+    const uint32_t fmt = d.format, words = fmt == R3N_POOL_FLOAT ? 4u : 1u;  // pool words per texel
+    const size_t lvl = (size_t)d.offset + (size_t)f.level_off * words;
+    if (f.nearest) return tex_texel<NEED_A>(t, fmt, t.texels + lvl, f.l[0].i00);
+    Texel4 o = tex_bilinear<M, NEED_A>(t, fmt, lvl, f.l[0]);
     if (f.frac > 0.0f) {
-        const Texel4 hi = tex_bilinear<M, NEED_A>(t, srgb, lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level), f.l[1]);
+        const Texel4 hi = tex_bilinear<M, NEED_A>(t, fmt, lvl + (size_t)f.l[0].w * tex_mip_dim(d.height, f.level) * words, f.l[1]);
         const float omf = 1.0f - f.frac;
         o.rg = mix2<M>(o.rg, hi.rg, f.frac, omf);
         if (NEED_A) o.ba = mix2<M>(o.ba, hi.ba, f.frac, omf);
@@ -194,7 +199,8 @@ R3N_DEV Texel4 tex_bilinear_fast(const TextureArgs &t, const float *__restrict__
 // textureSampleGrad(textures[id - 1], nearest ? nearest_sampler : primary_sampler, (u, v), ddx, ddy).
 // The level of detail and the footprint are the same exact arithmetic under both policies (a fused operation must not move a
 // sample to another mip level or texel); M only governs the blends.
-// Short path (what scanned material sets hit): linear sampler, power-of-two extents, tame coordinates, pool below 4 GiB.  Same
+// Short path (what scanned material sets hit): linear sampler, RGBA8 texels, power-of-two extents, tame coordinates, pool below
+// 4 GiB.  Same
 // values as the general path -- masks instead of remainders, the level's first texel from a table instead of a walk over
 // the chain, 32-bit byte offsets from the uniform pool pointer -- with one branch per sample instead of one per texel.
 // (Sharing one footprint between the maps of a material that have the same extent was measured: slower -- the cached
@@ -205,7 +211,7 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
     if (id == 0u || id > t.count) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const r3n_texture_desc32 d = t.descs[id - 1u];
     const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
-    if (!nearest && pow2 && t.small_pool != 0u) {
+    if (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT) {
         // level of detail exactly as tex_footprint derives it
         const float W = (float)d.width, H = (float)d.height;
         const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;

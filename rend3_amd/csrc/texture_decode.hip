@@ -1,9 +1,10 @@
 // texture_decode.hip -- row N2, texture formats: everything rend3-gltf's loader hands to Renderer::add_texture_2d that
 // the PBR path samples (rend3-gltf/src/lib.rs:1013-1130; util::map_ktx2_format / map_dxgi_format / map_d3d_format) is
-// converted ON THE GPU into the library's RGBA8 texel pool when the texture array is written: R8 / RG8 / BGRA8
+// converted ON THE GPU into the library's texel pool when the texture array is written: R8 / RG8 / BGRA8
 // expansion and BC1 / BC2 / BC3 / BC4 / BC5 / BC7 block decoding (Khronos Data Format Specification 1.3: S3TC, RGTC,
-// BPTC).  The reference leaves the decoding to the texture unit; a compute rasteriser has none, and decoding once at
-// load keeps the per-pixel sampler (texture.h) a plain RGBA8 fetch.
+// BPTC) into RGBA8 texels; the formats whose values are not 8-bit unorm -- snorm, 16-bit, float, packed float, BC4 / BC5
+// snorm, BC6H -- into four f32 per texel (second half of this file).  The reference leaves the decoding to the texture
+// unit; a compute rasteriser has none, and decoding once at load keeps the per-pixel sampler (texture.h) a plain fetch.
 //
 // One thread per 4x4 block: 8 / 16 B in, 64 B out -- a streaming, HBM-bound kernel (80 B per block); BC7 adds ~250
 // integer instructions per block.  Rounding conventions (bit-replicated 5:6:5, truncating thirds / sevenths / fifths)
@@ -14,6 +15,8 @@
 
 #define BC7_TABLE static __device__ const
 #include "bc7_tables.h"
+#define BC6H_TABLE static __device__ const
+#include "bc6h_tables.h"
 
 namespace {
 
@@ -309,6 +312,203 @@ __global__ __launch_bounds__(256) void k_generate_mip(uint32_t srgb, uint32_t sw
     dst[g] = out;
 }
 
+
+// ---- formats decoded to float texels.  Value definitions and rounding: oracle/bcn.c (r3o_texture_decode_level_f32), which
+// cites the specifications; the two agree bit for bit (every conversion below is exact or one correctly rounded division).
+__device__ inline float pow2f(int k) { return __uint_as_float((uint32_t)(k + 127) << 23); }  // -126 <= k <= 127
+__device__ inline float half_to_float(uint32_t h) {
+    const uint32_t s = (h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    if (e == 0u) return __uint_as_float(s | __float_as_uint((float)m * pow2f(-24)));
+    if (e == 31u) return __uint_as_float(s | 0x7F800000u | (m << 13));
+    return __uint_as_float(s | ((e + 112u) << 23) | (m << 13));
+}
+__device__ inline float ufloat_to_float(uint32_t v, uint32_t mb) {  // 5 exponent bits, mb mantissa bits, no sign
+    const uint32_t e = v >> mb, m = v & ((1u << mb) - 1u);
+    if (e == 0u) return (float)m * pow2f(-14 - (int)mb);
+    if (e == 31u) return __uint_as_float(0x7F800000u | (m << (23u - mb)));
+    return (float)((1u << mb) | m) * pow2f((int)e - 15 - (int)mb);
+}
+__device__ inline float snorm8(uint32_t c) { return fmaxf((float)(int)(int8_t)c / 127.0f, -1.0f); }
+__device__ inline float snorm16(uint32_t c) { return fmaxf((float)(int)(int16_t)c / 32767.0f, -1.0f); }
+
+// one thread per texel; `src` is read through the narrowest aligned type of the format
+__global__ __launch_bounds__(256) void k_expand_texels_f32(uint32_t format, uint64_t n, const uint8_t *__restrict__ src, float4 *__restrict__ dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint16_t *s16 = reinterpret_cast<const uint16_t *>(src);
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    switch (format) {
+    case R3N_TEXTURE_R8_SNORM: o.x = snorm8(src[i]); break;
+    case R3N_TEXTURE_RG8_SNORM: { const uint32_t v = s16[i]; o.x = snorm8(v & 0xFFu); o.y = snorm8(v >> 8); break; }
+    case R3N_TEXTURE_RGBA8_SNORM: { const uint32_t v = s32[i]; o = make_float4(snorm8(v & 0xFFu), snorm8((v >> 8) & 0xFFu), snorm8((v >> 16) & 0xFFu), snorm8(v >> 24)); break; }
+    case R3N_TEXTURE_R16_FLOAT: o.x = half_to_float(s16[i]); break;
+    case R3N_TEXTURE_RG16_FLOAT: { const uint32_t v = s32[i]; o.x = half_to_float(v & 0xFFFFu); o.y = half_to_float(v >> 16); break; }
+    case R3N_TEXTURE_RGBA16_FLOAT: { const uint32_t a = s32[2 * i], b = s32[2 * i + 1]; o = make_float4(half_to_float(a & 0xFFFFu), half_to_float(a >> 16), half_to_float(b & 0xFFFFu), half_to_float(b >> 16)); break; }
+    case R3N_TEXTURE_R32_FLOAT: o.x = __uint_as_float(s32[i]); break;
+    case R3N_TEXTURE_RG32_FLOAT: o.x = __uint_as_float(s32[2 * i]); o.y = __uint_as_float(s32[2 * i + 1]); break;
+    case R3N_TEXTURE_RGBA32_FLOAT: o = make_float4(__uint_as_float(s32[4 * i]), __uint_as_float(s32[4 * i + 1]), __uint_as_float(s32[4 * i + 2]), __uint_as_float(s32[4 * i + 3])); break;
+    case R3N_TEXTURE_RGBA16_UNORM: { const uint32_t a = s32[2 * i], b = s32[2 * i + 1]; o = make_float4((float)(a & 0xFFFFu) / 65535.0f, (float)(a >> 16) / 65535.0f, (float)(b & 0xFFFFu) / 65535.0f, (float)(b >> 16) / 65535.0f); break; }
+    case R3N_TEXTURE_RGBA16_SNORM: { const uint32_t a = s32[2 * i], b = s32[2 * i + 1]; o = make_float4(snorm16(a & 0xFFFFu), snorm16(a >> 16), snorm16(b & 0xFFFFu), snorm16(b >> 16)); break; }
+    case R3N_TEXTURE_RGB10A2_UNORM: { const uint32_t v = s32[i]; o = make_float4((float)(v & 1023u) / 1023.0f, (float)((v >> 10) & 1023u) / 1023.0f, (float)((v >> 20) & 1023u) / 1023.0f, (float)(v >> 30) / 3.0f); break; }
+    case R3N_TEXTURE_RG11B10_FLOAT: { const uint32_t v = s32[i]; o.x = ufloat_to_float(v & 2047u, 6u); o.y = ufloat_to_float((v >> 11) & 2047u, 6u); o.z = ufloat_to_float(v >> 22, 5u); break; }
+    default: {  // R3N_TEXTURE_RGB9E5_UFLOAT
+        const uint32_t v = s32[i];
+        const float sc = pow2f((int)(v >> 27) - 24);
+        o.x = (float)(v & 511u) * sc; o.y = (float)((v >> 9) & 511u) * sc; o.z = (float)((v >> 18) & 511u) * sc;
+        break;
+    }
+    }
+    dst[i] = o;
+}
+
+// RGTC signed block -> 16 floats (snorm8 endpoints, integer ordering, palette interpolated in f32)
+__device__ void decode_snorm_block(uint64_t blk, float out[16]) {
+    const int a0 = (int)(int8_t)(blk & 0xFFu), a1 = (int)(int8_t)((blk >> 8) & 0xFFu);
+    const float f0 = fmaxf((float)a0 / 127.0f, -1.0f), f1 = fmaxf((float)a1 / 127.0f, -1.0f);
+    const uint64_t sel = blk >> 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t k = (uint32_t)(sel >> (3 * i)) & 7u;
+        float v;
+        if (k == 0u) v = f0;
+        else if (k == 1u) v = f1;
+        else if (a0 > a1) v = ((float)(8u - k) * f0 + (float)(k - 1u) * f1) / 7.0f;
+        else if (k < 6u) v = ((float)(6u - k) * f0 + (float)(k - 1u) * f1) / 5.0f;
+        else v = k == 6u ? -1.0f : 1.0f;
+        out[i] = v;
+    }
+}
+
+// ---- BC6H (BPTC float): bit layouts from bc6h_tables.h, integer pipeline of the specification
+__device__ inline uint32_t bits128(uint64_t lo, uint64_t hi, uint32_t pos, uint32_t n) {  // 1 <= n <= 16
+    uint64_t v;
+    if (pos >= 64u) v = hi >> (pos - 64u);
+    else v = pos == 0u ? lo : ((lo >> pos) | (hi << (64u - pos)));
+    return (uint32_t)v & ((1u << n) - 1u);
+}
+__device__ inline int sign_extend(int v, uint32_t bits) { return (v & (1 << (bits - 1u))) ? v - (1 << bits) : v; }
+__device__ inline int bc6h_unquantize(int x, uint32_t epb, bool is_signed) {
+    if (!is_signed) {
+        if (epb >= 15u) return x;
+        if (x == 0) return 0;
+        if (x == (1 << epb) - 1) return 0xFFFF;
+        return ((x << 16) + 0x8000) >> epb;
+    }
+    if (epb >= 16u) return x;
+    const bool neg = x < 0;
+    if (neg) x = -x;
+    int u;
+    if (x == 0) u = 0;
+    else if (x >= (1 << (epb - 1u)) - 1) u = 0x7FFF;
+    else u = ((x << 15) + 0x4000) >> (epb - 1u);
+    return neg ? -u : u;
+}
+__device__ inline uint32_t bc6h_finalize(int v, bool is_signed) {
+    if (!is_signed) return (uint32_t)((v * 31) >> 6);
+    if (v < 0) return 0x8000u | (uint32_t)(((-v) * 31) >> 5);
+    return (uint32_t)((v * 31) >> 5);
+}
+__device__ void decode_bc6h_block(uint64_t lo, uint64_t hi, bool is_signed, float4 out[16]) {
+    const uint32_t first = (uint32_t)lo & 31u;
+    int mode = -1;
+    if ((first & 3u) < 2u) mode = (int)(first & 3u);
+    else
+        for (int k = 2; k < 14; ++k)
+            if ((BC6H_MODE[k] & 31u) == first) mode = k;
+    if (mode < 0) {  // reserved: zeros
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        return;
+    }
+    const uint32_t info = BC6H_MODE[mode];
+    const uint32_t epb = (info >> 8) & 31u, regions = ((info >> 29) & 1u) + 1u;
+    const bool transformed = ((info >> 28) & 1u) != 0u;
+    int f[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) f[k] = 0;
+    uint32_t pos = (info >> 5) & 7u;
+    for (int k = 0; k < BC6H_MAX_ENTRIES; ++k) {
+        const uint32_t e = BC6H_LAYOUT[mode][k];
+        if (e == 0xFFFFu) break;
+        const uint32_t fld = e & 15u, lsb = (e >> 4) & 15u, n = ((e >> 8) & 15u) + 1u;
+        uint32_t v = bits128(lo, hi, pos, n);
+        if ((e >> 12) & 1u) v = __brev(v) >> (32u - n);
+        // f[] is indexed dynamically: kept in scratch; a load-time kernel
+        f[fld] |= (int)(v << lsb);
+        pos += n;
+    }
+    int ep[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t dbits = (info >> (13 + 5 * c)) & 31u;
+        int base = f[c];
+        if (is_signed) base = sign_extend(base, epb);
+        ep[0][c] = base;
+#pragma unroll
+        for (uint32_t e = 1; e < 4u; ++e) {
+            int v = f[3 * e + c];
+            if (transformed) {
+                v = sign_extend(v, dbits);
+                v = (base + v) & ((1 << epb) - 1);
+                if (is_signed) v = sign_extend(v, epb);
+            } else if (is_signed) {
+                v = sign_extend(v, dbits);
+            }
+            ep[e][c] = v;
+        }
+#pragma unroll
+        for (uint32_t e = 0; e < 4u; ++e) ep[e][c] = bc6h_unquantize(ep[e][c], epb, is_signed);
+    }
+    const uint32_t part = (uint32_t)f[12] & 31u;
+    const uint32_t ib = regions == 2u ? 3u : 4u;
+    const uint32_t anchor = regions == 2u ? BC7_A2[part] : 0u;
+    pos = regions == 2u ? 82u : 65u;
+    for (uint32_t i = 0; i < 16u; ++i) {
+        const uint32_t sub = regions == 2u ? BC7_P2[part][i] : 0u;
+        const uint32_t n = (i == 0u || (regions == 2u && i == anchor)) ? ib - 1u : ib;
+        const uint32_t idx = bits128(lo, hi, pos, n);
+        pos += n;
+        const int w = (int)bc7_weight(ib, idx);
+        float ch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int e0 = sub ? ep[2][c] : ep[0][c], e1 = sub ? ep[3][c] : ep[1][c];
+            ch[c] = half_to_float(bc6h_finalize((e0 * (64 - w) + e1 * w + 32) >> 6, is_signed));
+        }
+        out[i] = make_float4(ch[0], ch[1], ch[2], 1.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_decode_blocks_f32(uint32_t format, uint32_t w, uint32_t h, const uint32_t *__restrict__ src,
+                                                           float4 *__restrict__ dst) {
+    const uint32_t bw = (w + 3u) / 4u, bh = (h + 3u) / 4u;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= bw * bh) return;
+    const uint32_t bx = g % bw, by = g / bw;
+    const bool small = format == R3N_TEXTURE_BC4_R_SNORM;
+    const uint32_t *s = src + (size_t)g * (small ? 2u : 4u);
+    const uint64_t lo = (uint64_t)s[0] | ((uint64_t)s[1] << 32), hi = small ? 0ull : ((uint64_t)s[2] | ((uint64_t)s[3] << 32));
+    float4 px[16];
+    if (format == R3N_TEXTURE_BC4_R_SNORM || format == R3N_TEXTURE_BC5_RG_SNORM) {
+        float r[16], gch[16];
+        decode_snorm_block(lo, r);
+        if (!small) decode_snorm_block(hi, gch);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) px[i] = make_float4(r[i], small ? 0.0f : gch[i], 0.0f, 1.0f);
+    } else {
+        decode_bc6h_block(lo, hi, format == R3N_TEXTURE_BC6H_RGB_FLOAT, px);
+    }
+#pragma unroll
+    for (uint32_t y = 0; y < 4u; ++y) {
+        const uint32_t ty = by * 4u + y;
+        if (ty >= h) break;
+#pragma unroll
+        for (uint32_t x = 0; x < 4u; ++x)
+            if (bx * 4u + x < w) dst[(size_t)ty * w + bx * 4u + x] = px[y * 4u + x];
+    }
+}
+
 }  // namespace
 
 extern "C" int r3n_internal_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const uint32_t *src,
@@ -328,9 +528,29 @@ extern "C" uint64_t r3n_internal_level_bytes(uint32_t format, uint32_t w, uint32
         return (uint64_t)((w + 3u) / 4u) * ((h + 3u) / 4u) * 8u;
     case R3N_TEXTURE_BC2_RGBA_UNORM: case R3N_TEXTURE_BC2_RGBA_UNORM_SRGB: case R3N_TEXTURE_BC3_RGBA_UNORM:
     case R3N_TEXTURE_BC3_RGBA_UNORM_SRGB: case R3N_TEXTURE_BC5_RG_UNORM: case R3N_TEXTURE_BC7_RGBA_UNORM:
-    case R3N_TEXTURE_BC7_RGBA_UNORM_SRGB:
+    case R3N_TEXTURE_BC7_RGBA_UNORM_SRGB: case R3N_TEXTURE_BC5_RG_SNORM: case R3N_TEXTURE_BC6H_RGB_UFLOAT: case R3N_TEXTURE_BC6H_RGB_FLOAT:
         return (uint64_t)((w + 3u) / 4u) * ((h + 3u) / 4u) * 16u;
+    case R3N_TEXTURE_BC4_R_SNORM: return (uint64_t)((w + 3u) / 4u) * ((h + 3u) / 4u) * 8u;
+    case R3N_TEXTURE_R8_SNORM: return (uint64_t)w * h;
+    case R3N_TEXTURE_RG8_SNORM: case R3N_TEXTURE_R16_FLOAT: return (uint64_t)w * h * 2u;
+    case R3N_TEXTURE_RGBA8_SNORM: case R3N_TEXTURE_RG16_FLOAT: case R3N_TEXTURE_R32_FLOAT: case R3N_TEXTURE_RGB10A2_UNORM:
+    case R3N_TEXTURE_RG11B10_FLOAT: case R3N_TEXTURE_RGB9E5_UFLOAT:
+        return (uint64_t)w * h * 4u;
+    case R3N_TEXTURE_RGBA16_FLOAT: case R3N_TEXTURE_RG32_FLOAT: case R3N_TEXTURE_RGBA16_UNORM: case R3N_TEXTURE_RGBA16_SNORM:
+        return (uint64_t)w * h * 8u;
+    case R3N_TEXTURE_RGBA32_FLOAT: return (uint64_t)w * h * 16u;
     default: return 0;
+    }
+}
+
+// 1: the format decodes to four f32 per texel (r3n_internal_decode_level_f32), 0: to RGBA8
+extern "C" int r3n_internal_format_is_float(uint32_t format) { return format >= R3N_TEXTURE_R8_SNORM && format < R3N_TEXTURE_FORMAT_COUNT; }
+// required alignment of a level's first byte in the payload (the decoders read it through that type)
+extern "C" uint32_t r3n_internal_format_align(uint32_t format) {
+    switch (format) {
+    case R3N_TEXTURE_R8_UNORM: case R3N_TEXTURE_RG8_UNORM: case R3N_TEXTURE_R8_SNORM: return 1u;
+    case R3N_TEXTURE_RG8_SNORM: case R3N_TEXTURE_R16_FLOAT: return 2u;
+    default: return 4u;
     }
 }
 
@@ -344,6 +564,20 @@ extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h
         const uint64_t n = (uint64_t)w * h;
         hipLaunchKernelGGL(k_expand_texels, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, stream, format, n,
                            static_cast<const uint8_t *>(src), dst);
+    }
+    return (int)hipGetLastError();
+}
+
+// one level: device source (its own format) -> w * h float texels at `dst` (device, 16-byte aligned)
+extern "C" int r3n_internal_decode_level_f32(uint32_t format, uint32_t w, uint32_t h, const void *src, float *dst, hipStream_t stream) {
+    if (format >= R3N_TEXTURE_BC4_R_SNORM) {
+        const uint32_t blocks = ((w + 3u) / 4u) * ((h + 3u) / 4u);
+        hipLaunchKernelGGL(k_decode_blocks_f32, dim3((blocks + 255u) / 256u), dim3(256), 0, stream, format, w, h,
+                           static_cast<const uint32_t *>(src), reinterpret_cast<float4 *>(dst));
+    } else {
+        const uint64_t n = (uint64_t)w * h;
+        hipLaunchKernelGGL(k_expand_texels_f32, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, stream, format, n,
+                           static_cast<const uint8_t *>(src), reinterpret_cast<float4 *>(dst));
     }
     return (int)hipGetLastError();
 }

@@ -374,8 +374,8 @@ class Renderer:
         chain would.  Block-compressed data goes to the GPU as stored and is decoded there."""
         from . import containers
         if generate_mips:
-            if containers.is_block_format(fmt) or len(levels) != 1:
-                raise ValueError("mips are generated for single-level uncompressed textures only")
+            if not containers.generate_mips_allowed(fmt) or len(levels) != 1:
+                raise ValueError("mips are generated for single-level 8-bit uncompressed textures only")
             mips = int(max(width, height)).bit_length()
             return self._append_texture(np.frombuffer(levels[0], dtype=np.uint8), width, height, mips, fmt, 1 if mips > 1 else 0)
         for k, lv in enumerate(levels):
@@ -660,11 +660,16 @@ class Renderer:
             self._check(self.lib.r3n_readback_joint_matrices(self.ctx, 0, _ffi.ptr(out), n), "r3n_readback_joint_matrices")
         return out[:n]
 
-    def readback_texels(self):
-        """The decoded RGBA8 texels of every texture (levels back to back, array order) as (n, 4) u8.  In the library's
-        pool every texture starts on a 4-texel boundary (r3n_textures_write_encoded); the gaps are dropped here."""
+    def readback_texels(self, per_texture=False):
+        """The decoded texels of every texture (levels back to back, array order): RGBA8 textures as (n, 4) u8, textures
+        of the float-decoded formats as (n, 4) f32.  per_texture=False concatenates them into one (n, 4) u8 array (a float
+        texel is then four rows).  In the library's pool every texture starts on a 4-word boundary
+        (r3n_textures_write_encoded); the gaps are dropped here."""
+        from . import containers
         self._flush_textures()
-        sizes = [sum(max(1, int(d[1]) >> k) * max(1, int(d[2]) >> k) for k in range(int(d[3]))) for d in self.tex_descs]
+        is_float = [containers.is_float_format(int(d[4])) for d in self.tex_descs]
+        sizes = [sum(max(1, int(d[1]) >> k) * max(1, int(d[2]) >> k) for k in range(int(d[3]))) * (4 if fl else 1)
+                 for d, fl in zip(self.tex_descs, is_float)]
         starts, cur = [], 0
         for n in sizes:
             cur = (cur + 3) & ~3
@@ -674,6 +679,8 @@ class Renderer:
         if cur:
             self._check(self.lib.r3n_readback_texels(self.ctx, 0, _ffi.ptr(pool), cur), "r3n_readback_texels")
         parts = [pool[s0:s0 + n] for s0, n in zip(starts, sizes)]
+        if per_texture:
+            return [p.view(np.float32).reshape(-1, 4) if fl else p.view(np.uint8).reshape(-1, 4) for p, fl in zip(parts, is_float)]
         return (np.concatenate(parts) if parts else pool[:0]).view(np.uint8).reshape(-1, 4)
 
     def readback_hiz(self, width, height):

@@ -9,6 +9,7 @@ The scenes restate the reference's own tests:
   examples/src/cube/mod.rs.
 """
 import math
+import os
 
 import numpy as np
 
@@ -113,7 +114,9 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
     uv transform, unlit, and cutout materials whose alpha comes from the texture (forward and shadow passes).
     encoded: the same materials over textures in the loader's other formats -- BC7 / BC1 / BC3 / BC5 blocks with stored
     mip chains (random block data: every BC7 mode, punch-through BC1 blocks, both BC3 / BC5 endpoint orders), BGRA8,
-    and RG8 / R8 with generated chains (add_texture_2d_encoded)."""
+    and RG8 / R8 with generated chains (add_texture_2d_encoded).  encoded="float": the float-decoded formats in the same
+    slots -- Rgba16Float / Rgba16Unorm / Rg16Float with stored chains, Rgb10a2Unorm, Rgba32Float, Rgb9e5Ufloat, BC5 snorm
+    blocks as the normal map and BC6H blocks (the committed unsaturated vectors) as the emissive map."""
     rng = Pcg32(seed)
     nrng = np.random.default_rng(seed)
     meshes = []
@@ -145,7 +148,28 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
               for i in range(levels)]
         return r.add_texture_2d_encoded(fmt_id, w, h, lv)
 
-    if encoded:
+    def chain(img, levels):
+        """Point-sampled levels of an (H, W, C) array (any values do: both sides decode the same bytes)."""
+        h, w = img.shape[:2]
+        out = []
+        for k in range(levels):
+            lh, lw = max(1, h >> k), max(1, w >> k)
+            out.append(np.ascontiguousarray(img[(np.arange(lh) * h) // lh][:, (np.arange(lw) * w) // lw]))
+        return out
+
+    if encoded == "float":
+        nf = noise.astype(np.float32) / np.float32(255.0)
+        nf[..., :3] *= np.float32(1.5)  # values above 1 too
+        t_noise = r.add_texture_2d_encoded(21, 64, 64, [lv.astype(np.float16).tobytes() for lv in chain(nf, 4)])       # Rgba16Float
+        c10 = checker.astype(np.uint32)
+        packed = (c10[..., 0] * 4 + 1) | ((c10[..., 1] * 4 + 2) << 10) | ((c10[..., 2] * 4 + 3) << 20) | ((c10[..., 3] // 64) << 30)
+        t_check = r.add_texture_2d_encoded(27, 128, 32, [packed.astype(np.uint32).tobytes()])                          # Rgb10a2Unorm
+        o16 = odd.astype(np.uint16) * np.uint16(257) ^ np.uint16(0x00A5)
+        t_odd = r.add_texture_2d_encoded(25, 37, 19, [lv.tobytes() for lv in chain(o16, 3)])                            # Rgba16Unorm
+        t_one = r.add_texture_2d_encoded(24, 1, 1, [np.array([0.6, 0.2, 0.03, 1.0], dtype=np.float32).tobytes()])      # Rgba32Float
+        e5 = nrng.integers(0, 1 << 27, (64, 64), dtype=np.uint32) | (nrng.integers(8, 16, (64, 64), dtype=np.uint32) << 27)
+        t_flat = r.add_texture_2d_encoded(29, 64, 64, [e5.tobytes()])                                                  # Rgb9e5Ufloat
+    elif encoded:
         t_noise = blocks(15, 16, 64, 64, 4, 0)       # Bc7RgbaUnormSrgb, 4 stored levels
         t_check = blocks(6, 8, 128, 32, 1, 1)        # Bc1RgbaUnorm, single level
         t_odd = blocks(11, 16, 37, 19, 3, 2)         # Bc3RgbaUnormSrgb, extent not a multiple of the block
@@ -183,7 +207,13 @@ def build_textured_scene(r, hm, mk, n_objects, seed, extent=(20.0, 6.0, 20.0), h
     emis[::4, :, 0] = 255
     emis[:, ::4, 2] = 200
     emis[..., 3] = 255
-    if encoded:
+    if encoded == "float":
+        t_nmap = blocks(31, 16, 64, 64, 7, 3)        # Bc5RgSnorm, full stored chain
+        am = aomr_tex[..., :2].astype(np.float32) / np.float32(255.0)
+        t_aomr = r.add_texture_2d_encoded(20, 32, 32, [lv.astype(np.float16).tobytes() for lv in chain(am, 6)])        # Rg16Float
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bcn_float_blocks.npz"))
+        t_emis = r.add_texture_2d_encoded(32, 16, 16, [gold["bc6h_uf_data"][:16 * 16].tobytes()])                     # Bc6hRgbUfloat
+    elif encoded:
         t_nmap = blocks(13, 16, 64, 64, 7, 3)        # Bc5RgUnorm, full stored chain
         t_aomr = r.add_texture_2d_encoded(3, 32, 32, [np.ascontiguousarray(aomr_tex[..., :2]).tobytes()], generate_mips=True)  # Rg8Unorm
         t_emis = r.add_texture_2d_encoded(2, 16, 16, [np.ascontiguousarray(emis[..., 0]).tobytes()], generate_mips=True)       # R8Unorm

@@ -481,8 +481,11 @@ def test_abi_error_behaviour(r3):
     assert lib.r3n_objects_write(ctx, None, None, 0, 1) == -1
     # encoded textures: formats outside the built set, levels outside the payload, misaligned level 0
     payload = np.zeros(256, dtype=np.uint8)
-    desc = np.array([[0, 8, 8, 1, 16, 0, 0, 0]], dtype=np.uint32)
+    desc = np.array([[0, 8, 8, 1, 34, 0, 0, 0]], dtype=np.uint32)
     assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -5 and b"format" in lib.r3n_last_error(ctx)
+    desc[0, 3:6] = (4, 21, 1)   # Rgba16Float with a generated chain: chains are generated in the RGBA8 pool only
+    assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -5 and b"float" in lib.r3n_last_error(ctx)
+    desc[0, 3:6] = (1, 34, 0)
     desc[0, 4] = 14
     assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 32) == -1   # 4 BC7 blocks need 64 B
     desc[0, 0] = 2
@@ -701,6 +704,65 @@ def test_texture_decode_matches_oracle(r3):
     bad = (got != want).any(axis=1)
     assert not bad.any(), f"{bad.sum()} of {len(bad)} texels differ, first at {np.nonzero(bad)[0][:4]}"
     del o
+
+
+def test_float_texture_decode_matches_oracle(r3):
+    """Row N2, the formats whose texels are not 8-bit unorm (snorm, 16-bit, float, packed float, BC4 / BC5 snorm, BC6H):
+    decoded on the GPU into four f32 per texel against the oracle's decoders (oracle/bcn.c r3o_texture_decode_level_f32,
+    pinned on numpy restatements and an independent block decoder): the committed BC6H / BC5-snorm vectors (every BC6H mode),
+    random data with the special encodings planted, extents that are not block multiples, stored chains down to 1 x 1, mixed
+    with RGBA8 textures in the same array.  Bit patterns must agree, NaN payloads and signed zeros included."""
+    import test_texture_formats as T
+    o, p = both(r3)
+    rng = np.random.default_rng(0xF10A7)
+    expect = []
+    for name in ("bc6h_uf", "bc6h_sf", "bc5s"):
+        fmt, w, h = (int(v) for v in T.FLOAT_GOLD[name + "_meta"])
+        data = T.FLOAT_GOLD[name + "_data"].tobytes()
+        p.add_texture_2d_encoded(fmt, w, h, [data])
+        expect.append(T.oracle_decode_f32(fmt, w, h, data).reshape(-1, 4))
+    rgba = rng.integers(0, 256, (5, 9, 4), dtype=np.uint8)
+    p.add_texture_2d(rgba, srgb=True)  # an RGBA8 texture between the float ones: both kinds share the pool
+    expect.append(rgba.reshape(-1, 4))
+    for fmt in range(16, 34):
+        w, h = (37, 21) if fmt >= 30 else (37, 23)
+        levels = []
+        for k in range(int(max(w, h)).bit_length()):
+            lw, lh = max(1, w >> k), max(1, h >> k)
+            data = T.float_format_level(fmt, lw, lh, rng) if fmt < 30 and k == 0 else rng.integers(0, 256, T.C.level_bytes(fmt, lw, lh), dtype=np.uint8).tobytes()
+            levels.append(data)
+            expect.append(T.oracle_decode_f32(fmt, lw, lh, data).reshape(-1, 4))
+        p.add_texture_2d_encoded(fmt, w, h, levels)
+    got = p.readback_texels(per_texture=True)
+    assert len(got) == 4 + 18
+    at = 0
+    for t, g in enumerate(got):
+        want = np.concatenate(expect[at:at + (1 if t < 4 else int(37).bit_length())])
+        at += 1 if t < 4 else int(37).bit_length()
+        assert g.shape == want.shape and g.dtype == want.dtype, (t, g.shape, want.shape)
+        gb, wb = (g.view(np.uint32), want.view(np.uint32)) if g.dtype == np.float32 else (g, want)
+        bad = (gb != wb).any(axis=1)
+        assert not bad.any(), f"texture {t}: {bad.sum()} of {len(bad)} texels differ, first at {np.nonzero(bad)[0][:4]}: {g[bad][:2].tolist()} vs {want[bad][:2].tolist()}"
+    with pytest.raises(ValueError):
+        p.add_texture_2d_encoded(21, 8, 8, [bytes(8 * 8 * 8)], generate_mips=True)  # chains are generated in the RGBA8 pool only
+    del o
+
+
+@pytest.mark.parametrize("samples", [1, 4])
+def test_float_textures_in_a_scene(r3, samples):
+    """The textured multi-frame scene over float-decoded textures in every material slot (HDR albedo above 1, snorm normal
+    map, BC6H emissive, cutout alpha from an Rgba16Float texture): the sampler's float-texel path against the oracle's --
+    visible sets, keys, atlas and HDR bit-identical."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    scenes.build_textured_scene(o, oh, omk, 200, 0xF16, lights=2, encoded="float")
+    scenes.build_textured_scene(p, oh, r3.material_record, 200, 0xF16, lights=2, encoded="float")
+    for f in range(2):
+        eye = (-14.0 + 4.0 * f, 3.0 + f, -14.0 + 3.0 * f)
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh(eye, (0.0, 0.0, 0.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, 192, samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"float textures frame {f}")
 
 
 @pytest.mark.parametrize("samples", [1, 4])

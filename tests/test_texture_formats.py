@@ -125,8 +125,8 @@ def test_ktx2_reader_and_format_map():
         assert got["format"] == fmt and (got["width"], got["height"]) == (20, 12) and got["levels"] == levels, vk
     assert C.parse_ktx2(b"not a ktx2 file" * 10, False) is None
     for vk, srgb, kind in ((9, True, "TextureBadKxt2Format"), (16, True, "TextureBadKxt2Format"), (23, False, "TextureBadKxt2Format"),
-                           (70, False, "TextureBadKxt2Format"), (143, False, "TextureUnsupported"), (97, False, "TextureUnsupported"),
-                           (157, True, "TextureUnsupported"), (140, False, "TextureUnsupported")):
+                           (70, False, "TextureBadKxt2Format"), (95, False, "TextureUnsupported"), (126, False, "TextureUnsupported"),
+                           (157, True, "TextureUnsupported"), (99, False, "TextureUnsupported")):
         with pytest.raises(C.TextureLoadError) as e:
             C.parse_ktx2(write_ktx2(vk, 8, 8, [bytes(64)]), srgb)
         assert e.value.kind == kind, (vk, e.value.kind)
@@ -154,7 +154,8 @@ def test_dds_reader_and_format_maps():
     one = C.parse_dds(write_dds(8, 8, [bytes(64)], dxgi=98), False)
     assert len(one["levels"]) == 1
     assert C.parse_dds(b"DDSx" + bytes(200), False) is None
-    for kw, kind in ((dict(dxgi=95), "TextureUnsupported"), (dict(dxgi=88), "TextureBadDxgiFormat"), (dict(dxgi=10), "TextureUnsupported"),
+    for kw, kind in ((dict(dxgi=12), "TextureUnsupported"), (dict(dxgi=88), "TextureBadDxgiFormat"), (dict(dxgi=40), "TextureUnsupported"),
+                     (dict(dxgi=24), "TextureBadDxgiFormat"), (dict(dxgi=11), "TextureBadDxgiFormat"), (dict(dxgi=56), "TextureBadDxgiFormat"),
                      (dict(fourcc=b"ATI2"), "TextureBadD3DFormat"), (dict(masks=(0x40, 24, 0xFF0000, 0xFF00, 0xFF, 0)), "TextureBadD3DFormat")):
         with pytest.raises(C.TextureLoadError) as e:
             C.parse_dds(write_dds(8, 8, [bytes(256)], **kw), False)
@@ -185,3 +186,244 @@ def test_dds_files_agree_with_independent_reader():
             assert np.array_equal(mine[..., :2], theirs[..., :2])
         else:
             assert np.array_equal(mine, theirs)
+
+
+# ------------------------------------------------------------------------------------------------ float-decoded formats
+FLOAT_GOLD = np.load(os.path.join(HERE, "golden", "bcn_float_blocks.npz"))
+
+
+def oracle_decode_f32(fmt, w, h, data):
+    c = olib.get().c
+    src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))
+    assert c.r3o_texture_is_float(fmt) == 1
+    assert c.r3o_texture_level_bytes(fmt, w, h) == len(src) == C.level_bytes(fmt, w, h)
+    out = np.zeros((h, w, 4), dtype=np.float32)
+    assert c.r3o_texture_decode_level_f32(fmt, w, h, src.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def small_ufloat(v, mant_bits):
+    """Unsigned small float (5 exponent bits, bias 15) -> f64, from the format's definition."""
+    v = v.astype(np.int64)
+    e, m = v >> mant_bits, v & ((1 << mant_bits) - 1)
+    normal = (1.0 + m / float(1 << mant_bits)) * np.exp2((e - 15).astype(np.float64))
+    denorm = m / float(1 << mant_bits) * 2.0 ** -14
+    out = np.where(e == 0, denorm, normal)
+    out = np.where((e == 31) & (m == 0), np.inf, out)
+    return np.where((e == 31) & (m != 0), np.nan, out)
+
+
+def numpy_decode_f32(fmt, w, h, data):
+    """An independent restatement on numpy: IEEE conversions by numpy's float16, integer ratios evaluated in f64 and rounded
+    once to f32 (a correctly rounded f32 division of two exactly representable integers gives the same value)."""
+    raw = np.frombuffer(data, dtype=np.uint8)
+    n = w * h
+    out = np.zeros((n, 4), dtype=np.float64)
+    out[:, 3] = 1.0
+    if fmt in (C.R8_SNORM, C.RG8_SNORM, C.RGBA8_SNORM):
+        ch = {C.R8_SNORM: 1, C.RG8_SNORM: 2, C.RGBA8_SNORM: 4}[fmt]
+        out[:, :ch] = np.maximum(raw.view(np.int8).reshape(n, ch).astype(np.float64) / 127.0, -1.0)
+    elif fmt in (C.R16F, C.RG16F, C.RGBA16F):
+        ch = {C.R16F: 1, C.RG16F: 2, C.RGBA16F: 4}[fmt]
+        res = np.zeros((n, 4), dtype=np.float32)
+        res[:, 3] = 1.0
+        res[:, :ch] = raw.view(np.float16).reshape(n, ch).astype(np.float32)
+        return res.reshape(h, w, 4)
+    elif fmt in (C.R32F, C.RG32F, C.RGBA32F):
+        ch = {C.R32F: 1, C.RG32F: 2, C.RGBA32F: 4}[fmt]
+        res = np.zeros((n, 4), dtype=np.float32)
+        res[:, 3] = 1.0
+        res[:, :ch] = raw.view(np.float32).reshape(n, ch)
+        return res.reshape(h, w, 4)
+    elif fmt == C.RGBA16_UNORM:
+        out[:] = raw.view(np.uint16).reshape(n, 4).astype(np.float64) / 65535.0
+    elif fmt == C.RGBA16_SNORM:
+        out[:] = np.maximum(raw.view(np.int16).reshape(n, 4).astype(np.float64) / 32767.0, -1.0)
+    elif fmt == C.RGB10A2:
+        v = raw.view(np.uint32).astype(np.int64)
+        out[:, 0], out[:, 1], out[:, 2], out[:, 3] = (v & 1023) / 1023.0, ((v >> 10) & 1023) / 1023.0, ((v >> 20) & 1023) / 1023.0, (v >> 30) / 3.0
+    elif fmt == C.RG11B10F:
+        v = raw.view(np.uint32)
+        out[:, 0], out[:, 1], out[:, 2] = small_ufloat(v & 2047, 6), small_ufloat((v >> 11) & 2047, 6), small_ufloat(v >> 22, 5)
+    elif fmt == C.RGB9E5:
+        v = raw.view(np.uint32).astype(np.int64)
+        sc = np.exp2(((v >> 27) - 24).astype(np.float64))
+        out[:, 0], out[:, 1], out[:, 2] = (v & 511) * sc, ((v >> 9) & 511) * sc, ((v >> 18) & 511) * sc
+    else:
+        raise AssertionError(fmt)
+    return out.astype(np.float32).reshape(h, w, 4)
+
+
+UNCOMPRESSED_FLOAT = [C.R8_SNORM, C.RG8_SNORM, C.RGBA8_SNORM, C.R16F, C.RG16F, C.RGBA16F, C.R32F, C.RG32F, C.RGBA32F, C.RGBA16_UNORM,
+                      C.RGBA16_SNORM, C.RGB10A2, C.RG11B10F, C.RGB9E5]
+
+
+def float_format_level(fmt, w, h, rng):
+    """Random bytes, with the special encodings planted: every 8-bit / 16-bit code of the narrow formats, -128 / -32768,
+    infinities, NaNs, subnormals, zero exponents."""
+    data = rng.integers(0, 256, C.level_bytes(fmt, w, h), dtype=np.uint8)
+    if fmt in (C.R8_SNORM, C.RG8_SNORM, C.RGBA8_SNORM):
+        data[:256] = np.arange(256, dtype=np.uint8)
+    elif fmt in (C.R16F, C.RG16F, C.RGBA16F, C.RGBA16_UNORM, C.RGBA16_SNORM):
+        sp = np.array([0, 0x8000, 1, 0x8001, 0x03FF, 0x0400, 0x7BFF, 0x7C00, 0xFC00, 0x7C01, 0x7E00, 0xFFFF, 0x7FFF, 0x8001, 0x3C00, 0xBC00], dtype=np.uint16)
+        data[:32] = sp.view(np.uint8)
+    elif fmt in (C.RG11B10F, C.RGB9E5, C.RGB10A2):
+        sp = np.array([0, 0xFFFFFFFF, 0x7C0 | (0x7C1 << 11) | (0x3E0 << 22), 0x7FF, 1 | (1 << 11) | (1 << 22), 0x3F | (0x40 << 11) | (0x1F << 22),
+                       31 << 27, 0xF8000000 | 0x1FF, 0x07FFFFFF, 1 << 27], dtype=np.uint32)
+        data[:40] = sp.view(np.uint8)
+    return data.tobytes()
+
+
+@pytest.mark.parametrize("fmt", UNCOMPRESSED_FLOAT)
+def test_oracle_float_formats_match_numpy_restatement(fmt):
+    rng = np.random.default_rng(100 + fmt)
+    w, h = 37, 23
+    data = float_format_level(fmt, w, h, rng)
+    got, want = oracle_decode_f32(fmt, w, h, data), numpy_decode_f32(fmt, w, h, data)
+    # bit patterns: signed zeros, subnormals and (where numpy carries them: binary16 / binary32) NaN payloads included
+    if fmt == C.RG11B10F:  # the f64 restatement only says "NaN"
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+        got, want = np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0)
+    assert np.array_equal(bits(got), bits(want)), f"{C.FORMAT_NAMES[fmt]}: {(bits(got) != bits(want)).sum()} values differ"
+
+
+def bc6h_half_levels(signed, variant, w, h, data):
+    c = olib.get().c
+    src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8))
+    out = np.zeros((h, w, 3), dtype=np.uint16)
+    assert c.r3o_bc6h_decode_level_half(signed, variant, w, h, src.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+@pytest.mark.parametrize("name", ["bc6h_uf", "bc6h_sf"])
+def test_bc6h_decoder_matches_independent_decoder(name):
+    """Every texel of every mode (96 blocks per mode, chosen for unsaturated 8-bit values) under the independent decoder's
+    two arithmetic deviations (oracle/bcn.c r3o_bc6h_decode_level_half); the specification variant is what the f32 decode
+    returns, differs from it only through those two expressions, and decodes reserved modes to zeros."""
+    fmt, w, h = (int(v) for v in FLOAT_GOLD[name + "_meta"])
+    data = FLOAT_GOLD[name + "_data"].tobytes()
+    signed = 1 if name == "bc6h_sf" else 0
+    half = bc6h_half_levels(signed, 1, w, h, data)
+    value = half.view(np.float16).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        as8 = (np.clip(np.nan_to_num(value, nan=0.0), 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)  # the decoder's 8-bit image
+    want = FLOAT_GOLD[name + "_rgb8"]
+    assert ((want > 0) & (want < 255)).mean() > 0.6  # the vectors do exercise the value range an 8-bit image resolves
+    assert np.array_equal(as8, want), f"{(as8 != want).any(axis=2).sum()} texels differ"
+    # the specification's variant, through the public decode
+    spec = bc6h_half_levels(signed, 0, w, h, data)
+    f32 = oracle_decode_f32(fmt, w, h, data)
+    assert np.array_equal(bits(f32[..., :3]), bits(spec.view(np.float16).astype(np.float32)))
+    assert (f32[..., 3] == 1.0).all()
+    blocks = np.frombuffer(data, dtype=np.uint8).reshape(-1, 16)
+    reserved = np.nonzero(np.isin(blocks[:, 0] & 31, [19, 23, 27, 31]))[0]
+    assert len(reserved) == 4
+    for b in reserved:
+        by, bx = divmod(int(b), w // 4)
+        assert (f32[4 * by:4 * by + 4, 4 * bx:4 * bx + 4, :3] == 0).all()
+    if not signed:
+        # rounding term only: the two variants are at most one binary16 step apart, and differ somewhere
+        d = spec.astype(np.int32) - half.astype(np.int32)
+        assert d.min() >= 0 and d.max() == 1
+
+
+def test_bc6h_mode_coverage_of_the_vectors():
+    blocks = FLOAT_GOLD["bc6h_uf_data"].reshape(-1, 16)
+    two = blocks[:, 0] & 3
+    five = blocks[:, 0] & 31
+    for m in (0, 1):
+        assert (two == m).sum() >= 96
+    for m in (2, 6, 10, 14, 18, 22, 26, 30, 3, 7, 11, 15):
+        assert (five == m).sum() >= 96, m
+    # two-region modes: all 32 partitions occur (bits 77..81)
+    v = np.array([int.from_bytes(b.tobytes(), "little") for b in blocks], dtype=object)
+    parts = {int((x >> 77) & 31) for x, t in zip(v, two) if t < 2}
+    assert parts == set(range(32))
+
+
+def rgtc_signed_numpy(block8):
+    """(n, 8) u8 RGTC signed blocks -> the palette index of each texel, endpoints, ordering: the format's definition on numpy."""
+    a0, a1 = block8[:, 0].view(np.int8).astype(np.int64), block8[:, 1].view(np.int8).astype(np.int64)
+    sel = np.zeros(len(block8), dtype=np.uint64)
+    for i in range(6):
+        sel |= block8[:, 2 + i].astype(np.uint64) << np.uint64(8 * i)
+    k = np.stack([(sel >> np.uint64(3 * i)) & np.uint64(7) for i in range(16)], axis=1).astype(np.int64)
+    return a0, a1, k
+
+
+def test_bc5_snorm_decoder():
+    fmt, w, h = (int(v) for v in FLOAT_GOLD["bc5s_meta"])
+    data = FLOAT_GOLD["bc5s_data"]
+    got = oracle_decode_f32(fmt, w, h, data.tobytes())
+    pil = FLOAT_GOLD["bc5s_rgb8"].astype(np.int64) - 128
+    blocks = data.reshape(-1, 16)
+    for ch in range(2):
+        a0, a1, k = rgtc_signed_numpy(np.ascontiguousarray(blocks[:, 8 * ch:8 * ch + 8]))
+        f0 = np.maximum(a0.astype(np.float32) / np.float32(127.0), np.float32(-1.0))[:, None]
+        f1 = np.maximum(a1.astype(np.float32) / np.float32(127.0), np.float32(-1.0))[:, None]
+        kf = k.astype(np.float32)
+        six = ((np.float32(8.0) - kf) * f0 + (kf - np.float32(1.0)) * f1) / np.float32(7.0)
+        four = ((np.float32(6.0) - kf) * f0 + (kf - np.float32(1.0)) * f1) / np.float32(5.0)
+        four = np.where(k == 6, np.float32(-1.0), np.where(k == 7, np.float32(1.0), four))
+        want = np.where(k == 0, f0, np.where(k == 1, f1, np.where((a0 > a1)[:, None], six, four))).astype(np.float32)
+        # the independent decoder's integer palette (flooring division), same selectors and ordering
+        i6 = np.floor(((8 - k) * a0[:, None] + (k - 1) * a1[:, None]) / 7.0)
+        i4 = np.floor(((6 - k) * a0[:, None] + (k - 1) * a1[:, None]) / 5.0)
+        i4 = np.where(k == 6, -128, np.where(k == 7, 127, i4))
+        theirs = np.where(k == 0, a0[:, None], np.where(k == 1, a1[:, None], np.where((a0 > a1)[:, None], i6, i4)))
+        img_want = np.zeros((h, w), np.float32)
+        img_theirs = np.zeros((h, w), np.int64)
+        for b in range(len(blocks)):
+            by, bx = divmod(b, w // 4)
+            img_want[4 * by:4 * by + 4, 4 * bx:4 * bx + 4] = want[b].reshape(4, 4)
+            img_theirs[4 * by:4 * by + 4, 4 * bx:4 * bx + 4] = theirs[b].reshape(4, 4)
+        assert np.array_equal(img_theirs, pil[..., ch])           # the restatement reads the blocks like the independent decoder
+        assert np.array_equal(bits(got[..., ch]), bits(img_want))  # and the oracle is the restatement with the f32 palette
+        assert np.abs(got[..., ch] * 127.0 - pil[..., ch]).max() < 2.0
+    assert (got[..., 2] == 0).all() and (got[..., 3] == 1).all()
+    # BC4 snorm = the red half alone
+    red = np.ascontiguousarray(blocks[:, :8]).tobytes()
+    r = oracle_decode_f32(C.BC4_SNORM, w, h, red)
+    assert np.array_equal(bits(r[..., 0]), bits(got[..., 0])) and (r[..., 1:3] == 0).all() and (r[..., 3] == 1).all()
+
+
+def test_float_format_container_maps():
+    rng = np.random.default_rng(21)
+    for vk, fmt in ((10, C.R8_SNORM), (17, C.RG8_SNORM), (38, C.RGBA8_SNORM), (64, C.RGB10A2), (76, C.R16F), (83, C.RG16F), (91, C.RGBA16_UNORM),
+                    (92, C.RGBA16_SNORM), (97, C.RGBA16F), (100, C.R32F), (103, C.RG32F), (109, C.RGBA32F), (122, C.RG11B10F), (123, C.RGB9E5),
+                    (140, C.BC4_SNORM), (142, C.BC5_SNORM), (143, C.BC6H_UF), (144, C.BC6H_SF)):
+        for srgb in (False, True):  # no sRGB variants: the flag is ignored (rend3-gltf/src/lib.rs:1204-1330)
+            levels = chain(fmt, 12, 20, 3, rng)
+            got = C.parse_ktx2(write_ktx2(vk, 12, 20, levels), srgb)
+            assert got["format"] == fmt and got["levels"] == levels, vk
+        assert C.is_float_format(fmt) and not C.generate_mips_allowed(fmt)
+    for kw, fmt in ((dict(dxgi=2), C.RGBA32F), (dict(dxgi=10), C.RGBA16F), (dict(dxgi=16), C.RG32F), (dict(dxgi=26), C.RG11B10F),
+                    (dict(dxgi=31), C.RGBA8_SNORM), (dict(dxgi=34), C.RG16F), (dict(dxgi=41), C.R32F), (dict(dxgi=51), C.RG8_SNORM),
+                    (dict(dxgi=54), C.R16F), (dict(dxgi=63), C.R8_SNORM), (dict(dxgi=67), C.RGB9E5), (dict(dxgi=81), C.BC4_SNORM),
+                    (dict(dxgi=84), C.BC5_SNORM), (dict(dxgi=94), C.BC6H_UF), (dict(dxgi=95), C.BC6H_UF), (dict(dxgi=96), C.BC6H_SF),
+                    (dict(fourcc=struct.pack("<I", 111)), C.R16F), (dict(fourcc=struct.pack("<I", 113)), C.RGBA16F),
+                    (dict(fourcc=struct.pack("<I", 114)), C.R32F), (dict(fourcc=struct.pack("<I", 116)), C.RGBA32F)):
+        levels = chain(fmt, 16, 8, 2, rng)
+        got = C.parse_dds(write_dds(16, 8, levels, **kw), True)
+        assert got["format"] == fmt and got["levels"] == levels, kw
+    assert not C.is_float_format(C.BC7) and C.generate_mips_allowed(C.RG8)
+
+
+def test_bc6h_dds_file_agrees_with_independent_reader():
+    """A BC6H DDS file through this reader + the oracle, and through Pillow's plugin, on the committed unsaturated blocks."""
+    PIL = pytest.importorskip("PIL.Image")
+    fmt, w, h = (int(v) for v in FLOAT_GOLD["bc6h_uf_meta"])
+    data = FLOAT_GOLD["bc6h_uf_data"].tobytes()
+    blob = write_dds(w, h, [data], dxgi=95)
+    parsed = C.parse_dds(blob, False)
+    assert parsed["format"] == C.BC6H_UF
+    mine = oracle_decode_f32(parsed["format"], w, h, parsed["levels"][0])
+    im = PIL.open(io.BytesIO(blob))
+    im.load()
+    theirs = np.asarray(im).astype(np.float32) / 255.0
+    # the specification's rounding term moves a value by at most one binary16 step: below one 8-bit step here
+    assert np.abs(np.clip(mine[..., :3], 0, 1) - theirs).max() < 1.5 / 255.0
