@@ -48,3 +48,48 @@ impl AmdContext {
         self.check(unsafe { sys::r3n_blend_order_write(self.ctx, objects_back_to_front.as_ptr(), objects_back_to_front.len() as u32) }, "r3n_blend_order_write");
     }
 }
+
+/// `Texture::format` -> the library's format id for `r3n_texture_desc32::format` (`include/r3n.h` R3N_TEXTURE_*): every format
+/// rend3-gltf's maps produce (rend3-gltf/src/lib.rs:1157-1610) that a `texture_2d<f32>` binding can hold.  `None`: integer, depth,
+/// ETC2 / EAC and ASTC formats -- `add_texture_2d` reports them instead of uploading.
+pub fn texture_format_id(format: rend3::types::TextureFormat) -> Option<u32> {
+    use rend3::types::TextureFormat as F;
+    Some(match format {
+        F::Rgba8Unorm => sys::R3N_TEXTURE_RGBA8_UNORM,
+        F::Rgba8UnormSrgb => sys::R3N_TEXTURE_RGBA8_UNORM_SRGB,
+        F::R8Unorm => sys::R3N_TEXTURE_R8_UNORM,
+        F::Rg8Unorm => sys::R3N_TEXTURE_RG8_UNORM,
+        F::Bgra8Unorm => sys::R3N_TEXTURE_BGRA8_UNORM,
+        F::Bgra8UnormSrgb => sys::R3N_TEXTURE_BGRA8_UNORM_SRGB,
+        F::Bc1RgbaUnorm => sys::R3N_TEXTURE_BC1_RGBA_UNORM,
+        F::Bc1RgbaUnormSrgb => sys::R3N_TEXTURE_BC1_RGBA_UNORM_SRGB,
+        F::Bc2RgbaUnorm => sys::R3N_TEXTURE_BC2_RGBA_UNORM,
+        F::Bc2RgbaUnormSrgb => sys::R3N_TEXTURE_BC2_RGBA_UNORM_SRGB,
+        F::Bc3RgbaUnorm => sys::R3N_TEXTURE_BC3_RGBA_UNORM,
+        F::Bc3RgbaUnormSrgb => sys::R3N_TEXTURE_BC3_RGBA_UNORM_SRGB,
+        F::Bc4RUnorm => sys::R3N_TEXTURE_BC4_R_UNORM,
+        F::Bc5RgUnorm => sys::R3N_TEXTURE_BC5_RG_UNORM,
+        F::Bc7RgbaUnorm => sys::R3N_TEXTURE_BC7_RGBA_UNORM,
+        F::Bc7RgbaUnormSrgb => sys::R3N_TEXTURE_BC7_RGBA_UNORM_SRGB,
+        // decoded to four f32 per texel
+        F::R8Snorm => sys::R3N_TEXTURE_R8_SNORM,
+        F::Rg8Snorm => sys::R3N_TEXTURE_RG8_SNORM,
+        F::Rgba8Snorm => sys::R3N_TEXTURE_RGBA8_SNORM,
+        F::R16Float => sys::R3N_TEXTURE_R16_FLOAT,
+        F::Rg16Float => sys::R3N_TEXTURE_RG16_FLOAT,
+        F::Rgba16Float => sys::R3N_TEXTURE_RGBA16_FLOAT,
+        F::R32Float => sys::R3N_TEXTURE_R32_FLOAT,
+        F::Rg32Float => sys::R3N_TEXTURE_RG32_FLOAT,
+        F::Rgba32Float => sys::R3N_TEXTURE_RGBA32_FLOAT,
+        F::Rgba16Unorm => sys::R3N_TEXTURE_RGBA16_UNORM,
+        F::Rgba16Snorm => sys::R3N_TEXTURE_RGBA16_SNORM,
+        F::Rgb10a2Unorm => sys::R3N_TEXTURE_RGB10A2_UNORM,
+        F::Rg11b10Float => sys::R3N_TEXTURE_RG11B10_FLOAT,
+        F::Rgb9e5Ufloat => sys::R3N_TEXTURE_RGB9E5_UFLOAT,
+        F::Bc4RSnorm => sys::R3N_TEXTURE_BC4_R_SNORM,
+        F::Bc5RgSnorm => sys::R3N_TEXTURE_BC5_RG_SNORM,
+        F::Bc6hRgbUfloat => sys::R3N_TEXTURE_BC6H_RGB_UFLOAT,
+        F::Bc6hRgbFloat => sys::R3N_TEXTURE_BC6H_RGB_FLOAT,
+        _ => return None,
+    })
+}

@@ -49,6 +49,14 @@ def test_adaptor_crate_calls_only_declared_symbols_and_covers_the_frame():
              "r3n_resolve_opaque", "r3n_tonemap", "r3n_frame_end", "r3n_set_output_format", "r3n_mesh_buffer_write", "r3n_objects_write",
              "r3n_materials_write", "r3n_lights_write", "r3n_textures_write_encoded", "r3n_blend_order_write", "r3n_create", "r3n_destroy"}
     assert frame <= used, sorted(frame - used)
+    # constants too, and the texture-format map covers every format id of the header
+    consts = set(re.findall(r"pub const (R3N_\w+):", _sys_rs()))
+    used_consts = set()
+    for f in sorted(os.listdir(src_dir)):
+        used_consts |= set(re.findall(r"sys::(R3N_\w+)", open(os.path.join(src_dir, f)).read()))
+    assert used_consts <= consts, sorted(used_consts - consts)
+    formats = {c for c in consts if c.startswith("R3N_TEXTURE_") and c != "R3N_TEXTURE_FORMAT_COUNT"}
+    assert len(formats) == 34 and formats <= used_consts, sorted(formats - used_consts)
     base = open(os.path.join(src_dir, "base.rs")).read()
     base = base[base.index("let amd = self.amd;"):]  # the body of add_to_graph
     order = ["uniforms::add_to_graph", "add_skinning_to_graph", "Shadow Culling S", "pbr shadow renderering", "Uniform Bake", "PBR Forward Pass 1",
