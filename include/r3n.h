@@ -98,7 +98,7 @@ typedef struct r3n_texture_desc32 {
     uint32_t stored_mips; /* r3n_textures_write_encoded only: 0 = all `mips` levels are in the payload (MipmapSource::Uploaded);
                              k < mips = the first k levels are, the others are GENERATED on the GPU (MipmapSource::Generated,
                              rend3/src/util/mipmap.rs + mipmap.wgsl: Linear / ClampToEdge blit per level in the texture's
-                             format); uncompressed formats only */
+                             format); uncompressed 8-bit formats, 16-bit float formats and RGB10A2 only */
     uint32_t _pad[2];
 } r3n_texture_desc32;
 #define R3N_TEXTURE_RGBA8_UNORM 0u
@@ -121,8 +121,10 @@ typedef struct r3n_texture_desc32 {
 #define R3N_TEXTURE_BC7_RGBA_UNORM 14u
 #define R3N_TEXTURE_BC7_RGBA_UNORM_SRGB 15u
 /* formats whose values are not 8-bit unorm: decoded into four f32 per texel (16 B per texel in the pool instead of 4).
- * Missing channels read (0, 0, 1).  All levels must be in the payload (stored_mips 0): the blit chain runs in the RGBA8
- * pool only.  rend3-gltf/src/lib.rs:1204-1330 (KTX2), :1480-1485 (D3D), :1499-1597 (DXGI) produce them. */
+ * Missing channels read (0, 0, 1).  stored_mips < mips (generated levels) is accepted for R16 / RG16 / RGBA16_FLOAT and
+ * RGB10A2_UNORM -- the ones rend3-gltf generates chains for (filterable render targets; the level is rounded to the format:
+ * binary16 to nearest even); the others must carry every level.  rend3-gltf/src/lib.rs:1204-1330 (KTX2), :1480-1485 (D3D),
+ * :1499-1597 (DXGI) produce them. */
 #define R3N_TEXTURE_R8_SNORM 16u
 #define R3N_TEXTURE_RG8_SNORM 17u
 #define R3N_TEXTURE_RGBA8_SNORM 18u

@@ -51,6 +51,12 @@ class OracleLib:
         c.r3o_texture_is_float.argtypes = [ctypes.c_uint32]
         c.r3o_texture_decode_level_f32.restype = ctypes.c_int
         c.r3o_texture_decode_level_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
+        c.r3o_float_to_half.restype = ctypes.c_uint16
+        c.r3o_float_to_half.argtypes = [ctypes.c_float]
+        c.r3o_texture_generates_mips_f32.restype = ctypes.c_int
+        c.r3o_texture_generates_mips_f32.argtypes = [ctypes.c_uint32]
+        c.r3o_generate_mips_f32.restype = ctypes.c_int
+        c.r3o_generate_mips_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp]
         c.r3o_bc6h_decode_level_half.restype = ctypes.c_int
         c.r3o_bc6h_decode_level_half.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         c.r3o_f32_to_f16.restype = ctypes.c_uint16

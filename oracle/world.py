@@ -243,8 +243,16 @@ class OracleRenderer:
         """Mirror of the product's add_texture_2d_encoded: every level is decoded to RGBA8 by the oracle's decoders
         (oracle/bcn.c); generate_mips expands level 0 and runs the RGBA8 blit chain."""
         c = self.lib.c
+        if c.r3o_texture_is_float(fmt) and generate_mips:
+            assert len(levels) == 1 and c.r3o_texture_generates_mips_f32(fmt), "chains are generated for R16Float / Rg16Float / Rgba16Float / Rgb10a2Unorm"
+            mips = int(max(width, height)).bit_length()
+            chain = np.zeros((host.mip_chain_texels(width, height, mips), 4), dtype=np.float32)
+            src = np.frombuffer(levels[0], dtype=np.uint8)
+            assert len(src) == c.r3o_texture_level_bytes(fmt, width, height), "level byte count"
+            assert c.r3o_texture_decode_level_f32(fmt, width, height, src.ctypes.data, chain.ctypes.data) == 0
+            assert c.r3o_generate_mips_f32(fmt, width, height, mips, chain.ctypes.data) == 0
+            return self._append_texels(chain.reshape(-1).view(np.uint32), width, height, mips, False, pool_float=True)
         if c.r3o_texture_is_float(fmt):
-            assert not generate_mips, "the blit chain runs on RGBA8 texels only"
             words = []
             for k, lv in enumerate(levels):
                 w, h = max(1, width >> k), max(1, height >> k)

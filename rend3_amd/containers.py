@@ -243,6 +243,7 @@ def parse_dds(data, srgb):
 
 def generate_mips_allowed(fmt):
     """load_image generates a chain for single-level files only when the format is filterable AND a render attachment
-    (the blit chain of util/mipmap.rs renders into it): true for the uncompressed 8-bit unorm formats; false for BCn, and
-    for the float-decoded formats (this library generates chains in the RGBA8 pool only)."""
-    return not is_block_format(fmt) and not is_float_format(fmt)
+    (the blit chain of util/mipmap.rs renders into it) under the default device features: the uncompressed 8-bit unorm
+    formats, R16Float / Rg16Float / Rgba16Float and Rgb10a2Unorm; not BCn, snorm, 32-bit float (not filterable), 16-bit norm,
+    Rg11b10Float or Rgb9e5Ufloat (not render attachments)."""
+    return (not is_block_format(fmt) and not is_float_format(fmt)) or fmt in (R16F, RG16F, RGBA16F, RGB10A2)

@@ -716,6 +716,9 @@ extern "C" int r3n_internal_decode_level(uint32_t format, uint32_t w, uint32_t h
 extern "C" int r3n_internal_decode_level_f32(uint32_t format, uint32_t w, uint32_t h, const void *src, float *dst, hipStream_t stream);
 extern "C" int r3n_internal_format_is_float(uint32_t format);
 extern "C" uint32_t r3n_internal_format_align(uint32_t format);
+extern "C" int r3n_internal_format_generates_mips_f32(uint32_t format);
+extern "C" int r3n_internal_generate_mip_f32(uint32_t format, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const float *src, float *dst,
+                                             hipStream_t stream);
 
 int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, const void *payload, uint64_t payload_bytes) {
     if (!c || (n && (!descs || !payload))) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): null");
@@ -731,8 +734,8 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
         if (d.mips > max_mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): more mips than the extent has");
         if (d.stored_mips > d.mips) return fail(c, R3N_ERR_INVALID_ARG, "textures write (encoded): more stored levels than mips");
         const uint32_t stored = d.stored_mips ? d.stored_mips : d.mips;
-        if (stored < d.mips && d.format >= R3N_TEXTURE_BC1_RGBA_UNORM)
-            return fail(c, R3N_ERR_UNSUPPORTED, is_float ? "textures write (encoded): mips are generated in the RGBA8 pool only; float-decoded formats must carry their levels"
+        if (stored < d.mips && d.format >= R3N_TEXTURE_BC1_RGBA_UNORM && !r3n_internal_format_generates_mips_f32(d.format))
+            return fail(c, R3N_ERR_UNSUPPORTED, is_float ? "textures write (encoded): among the float-decoded formats mips are generated for R16Float / Rg16Float / Rgba16Float / Rgb10a2Unorm only (filterable render targets); the others must carry their levels"
                                                          : "textures write (encoded): mips are generated for uncompressed formats only (block formats are not render targets)");
         uint64_t end = d.offset, texels = 0;
         for (uint32_t k = 0; k < d.mips; ++k) {
@@ -768,10 +771,15 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
             for (uint32_t k = 0; k < descs[i].mips && e == hipSuccess; ++k) {
                 const uint32_t w = std::max(1u, descs[i].width >> k), h = std::max(1u, descs[i].height >> k);
                 if (internal[i].format == R3N_POOL_FLOAT) {
-                    // sources are read through their own width (format_align): every level of those formats is a multiple of it
-                    e = (hipError_t)r3n_internal_decode_level_f32(descs[i].format, w, h, static_cast<const char *>(staged) + src,
-                                                                  reinterpret_cast<float *>(c->tex_texels.as<uint32_t>() + dst), c->stream);
-                    src += r3n_internal_level_bytes(descs[i].format, w, h);
+                    float *level = reinterpret_cast<float *>(c->tex_texels.as<uint32_t>() + dst);
+                    if (k < stored) {
+                        // sources are read through their own width (format_align): every level of those formats is a multiple of it
+                        e = (hipError_t)r3n_internal_decode_level_f32(descs[i].format, w, h, static_cast<const char *>(staged) + src, level, c->stream);
+                        src += r3n_internal_level_bytes(descs[i].format, w, h);
+                    } else {  // MipmapSource::Generated: blit of the level above, written in the texture's format
+                        const uint32_t sw = std::max(1u, descs[i].width >> (k - 1u)), sh = std::max(1u, descs[i].height >> (k - 1u));
+                        e = (hipError_t)r3n_internal_generate_mip_f32(descs[i].format, sw, sh, w, h, level - (uint64_t)sw * sh * 4u, level, c->stream);
+                    }
                     dst += (uint64_t)w * h * 3u;  // + w * h below: four words per texel
                 } else if (k < stored) {
                     // block-compressed and 32-bit sources are read as dwords: every level of those formats is a multiple of 4 B

@@ -509,6 +509,62 @@ __global__ __launch_bounds__(256) void k_decode_blocks_f32(uint32_t format, uint
     }
 }
 
+
+// MipmapSource::Generated for the float-decoded formats the loader generates chains for (single-level R16Float / Rg16Float /
+// Rgba16Float / Rgb10a2Unorm files): the blit of k_generate_mip on float texels, then the render-target write of the format --
+// f32 -> binary16 round to nearest even, done in integers so that every bit pattern (NaN payloads too) is the oracle's
+// (oracle/bcn.c float_to_half_rne); unorm: clamp, x * (2^n - 1) + 0.5 truncated.  Channels the format does not store keep (0, 0, 1).
+__device__ inline uint32_t float_to_half_rne(float f) {
+    const uint32_t x = __float_as_uint(f);
+    const uint32_t sign = (x >> 16) & 0x8000u, mag = x & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return sign | 0x7C00u | (mag > 0x7F800000u ? (0x200u | ((mag >> 13) & 0x3FFu)) : 0u);
+    if (mag >= 0x477FF000u) return sign | 0x7C00u;
+    if (mag < 0x33000001u) return sign;
+    const int e = (int)(mag >> 23) - 127;
+    const uint32_t m = (mag & 0x7FFFFFu) | 0x800000u;
+    const int shift = e >= -14 ? 13 : 13 + (-14 - e);
+    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
+    uint32_t q = m >> shift;
+    if (rest > half || (rest == half && (q & 1u))) ++q;
+    return sign | (e >= -14 ? ((uint32_t)(e + 14) << 10) + q : q);
+}
+__device__ inline float quantize_channel(uint32_t format, int c, float r) {
+    if (format == R3N_TEXTURE_RGB10A2_UNORM) {
+        const float e = fminf(fmaxf(r, 0.0f), 1.0f);
+        return c < 3 ? (float)(uint32_t)(e * 1023.0f + 0.5f) / 1023.0f : (float)(uint32_t)(e * 3.0f + 0.5f) / 3.0f;
+    }
+    return half_to_float(float_to_half_rne(r));
+}
+__global__ __launch_bounds__(256) void k_generate_mip_f32(uint32_t format, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
+                                                          const float4 *__restrict__ src, float4 *__restrict__ dst) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= dw * dh) return;
+    const uint32_t x = g % dw, y = g / dw;
+    const float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+    const float tx = u * (float)sw - 0.5f, ty = v * (float)sh - 0.5f;
+    const float fx0 = floorf(tx), fy0 = floorf(ty);
+    const float fx = tx - fx0, fy = ty - fy0;
+    const int ix = (int)fx0, iy = (int)fy0;
+    auto clampi = [](int a, int hi) { return a < 0 ? 0 : (a > hi ? hi : a); };
+    const uint32_t x0 = (uint32_t)clampi(ix, (int)sw - 1), x1 = (uint32_t)clampi(ix + 1, (int)sw - 1);
+    const uint32_t y0 = (uint32_t)clampi(iy, (int)sh - 1), y1 = (uint32_t)clampi(iy + 1, (int)sh - 1);
+    const float4 t4[4] = {src[(size_t)y0 * sw + x0], src[(size_t)y0 * sw + x1], src[(size_t)y1 * sw + x0], src[(size_t)y1 * sw + x1]};
+    const int stored = format == R3N_TEXTURE_R16_FLOAT ? 1 : (format == R3N_TEXTURE_RG16_FLOAT ? 2 : 4);
+    float o[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= stored) continue;
+        const float q0 = c == 0 ? t4[0].x : (c == 1 ? t4[0].y : (c == 2 ? t4[0].z : t4[0].w));
+        const float q1 = c == 0 ? t4[1].x : (c == 1 ? t4[1].y : (c == 2 ? t4[1].z : t4[1].w));
+        const float q2 = c == 0 ? t4[2].x : (c == 1 ? t4[2].y : (c == 2 ? t4[2].z : t4[2].w));
+        const float q3 = c == 0 ? t4[3].x : (c == 1 ? t4[3].y : (c == 2 ? t4[3].z : t4[3].w));
+        const float top = q0 * (1.0f - fx) + q1 * fx;
+        const float bot = q2 * (1.0f - fx) + q3 * fx;
+        o[c] = quantize_channel(format, c, top * (1.0f - fy) + bot * fy);
+    }
+    dst[g] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace
 
 extern "C" int r3n_internal_generate_mip(uint32_t srgb, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const uint32_t *src,
@@ -579,5 +635,16 @@ extern "C" int r3n_internal_decode_level_f32(uint32_t format, uint32_t w, uint32
         hipLaunchKernelGGL(k_expand_texels_f32, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, stream, format, n,
                            static_cast<const uint8_t *>(src), reinterpret_cast<float4 *>(dst));
     }
+    return (int)hipGetLastError();
+}
+
+// 1: MipmapSource::Generated is available for this float-decoded format (the loader generates chains for single-level files of it)
+extern "C" int r3n_internal_format_generates_mips_f32(uint32_t format) {
+    return format == R3N_TEXTURE_R16_FLOAT || format == R3N_TEXTURE_RG16_FLOAT || format == R3N_TEXTURE_RGBA16_FLOAT || format == R3N_TEXTURE_RGB10A2_UNORM;
+}
+extern "C" int r3n_internal_generate_mip_f32(uint32_t format, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh, const float *src, float *dst,
+                                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_generate_mip_f32, dim3((dw * dh + 255u) / 256u), dim3(256), 0, stream, format, sw, sh, dw, dh,
+                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst));
     return (int)hipGetLastError();
 }

@@ -483,7 +483,7 @@ def test_abi_error_behaviour(r3):
     payload = np.zeros(256, dtype=np.uint8)
     desc = np.array([[0, 8, 8, 1, 34, 0, 0, 0]], dtype=np.uint32)
     assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -5 and b"format" in lib.r3n_last_error(ctx)
-    desc[0, 3:6] = (4, 21, 1)   # Rgba16Float with a generated chain: chains are generated in the RGBA8 pool only
+    desc[0, 3:6] = (4, 24, 1)   # Rgba32Float with a generated chain: not a filterable format, the loader never asks for it
     assert lib.r3n_textures_write_encoded(ctx, _ffi.ptr(desc), 1, _ffi.ptr(payload), 256) == -5 and b"float" in lib.r3n_last_error(ctx)
     desc[0, 3:6] = (1, 34, 0)
     desc[0, 4] = 14
@@ -744,8 +744,46 @@ def test_float_texture_decode_matches_oracle(r3):
         bad = (gb != wb).any(axis=1)
         assert not bad.any(), f"texture {t}: {bad.sum()} of {len(bad)} texels differ, first at {np.nonzero(bad)[0][:4]}: {g[bad][:2].tolist()} vs {want[bad][:2].tolist()}"
     with pytest.raises(ValueError):
-        p.add_texture_2d_encoded(21, 8, 8, [bytes(8 * 8 * 8)], generate_mips=True)  # chains are generated in the RGBA8 pool only
+        p.add_texture_2d_encoded(24, 8, 8, [bytes(8 * 8 * 16)], generate_mips=True)  # Rgba32Float is not filterable: no generated chains
     del o
+
+
+def test_generated_float_mip_chains_match_oracle(r3):
+    """MipmapSource::Generated for the float-decoded formats the loader generates chains for (single-level R16Float / Rg16Float /
+    Rgba16Float / Rgb10a2Unorm files): level 0 decoded and every further level blitted and rounded to the format on the GPU,
+    against the oracle's chain (oracle/bcn.c r3o_generate_mips_f32; binary16 rounding pinned on numpy), bit patterns equal (NaNs:
+    as NaNs) -- power-of-two, odd and 1-wide extents, values with infinities / NaNs / subnormals in level 0."""
+    import test_texture_formats as T
+    o, p = both(r3)
+    rng = np.random.default_rng(0x3170)
+    handles = []
+    for fmt in (T.C.R16F, T.C.RG16F, T.C.RGBA16F, T.C.RGB10A2):
+        for (w, h) in ((64, 32), (37, 19), (1, 9), (5, 1)):
+            data = T.float_format_level(fmt, w, h, rng) if w * h >= 64 else rng.integers(0, 256, T.C.level_bytes(fmt, w, h), dtype=np.uint8).tobytes()
+            if fmt != T.C.RGB10A2 and (w, h) == (64, 32):
+                # mostly finite mid-range values so that the rounding of sums is exercised, the special encodings stay in front
+                a = np.frombuffer(data, dtype=np.uint16).copy()
+                a[64:] = (rng.random(len(a) - 64) * 4.0 - 2.0).astype(np.float16).view(np.uint16)
+                data = a.tobytes()
+            hp = p.add_texture_2d_encoded(fmt, w, h, [data], generate_mips=True)
+            ho = o.add_texture_2d_encoded(fmt, w, h, [data], generate_mips=True)
+            assert hp == ho
+            handles.append((fmt, w, h))
+    got = p.readback_texels(per_texture=True)
+    assert len(got) == len(handles)
+    for t, (fmt, w, h) in enumerate(handles):
+        d = o.tex_descs[t]
+        mips = int(max(w, h)).bit_length()
+        assert int(d[3]) == mips and int(d[4]) == 2
+        n = sum(max(1, w >> k) * max(1, h >> k) for k in range(mips))
+        want = o.tex_pool[int(d[0]): int(d[0]) + 4 * n].reshape(-1, 4)
+        g = got[t].view(np.uint32)
+        assert g.shape == want.shape, (t, g.shape, want.shape)
+        # a NaN produced by the blit's arithmetic (inf * 0, inf - inf) has no defined sign / payload: x86 and the GPU differ there;
+        # NaN-ness itself must agree
+        both_nan = np.isnan(g.view(np.float32)) & np.isnan(want.view(np.float32))
+        bad = ((g != want) & ~both_nan).any(axis=1)
+        assert not bad.any(), f"{T.C.FORMAT_NAMES[fmt]} {w}x{h}: {bad.sum()} of {len(bad)} texels differ, first at {np.nonzero(bad)[0][:4]}"
 
 
 @pytest.mark.parametrize("samples", [1, 4])

@@ -400,7 +400,8 @@ def test_float_format_container_maps():
             levels = chain(fmt, 12, 20, 3, rng)
             got = C.parse_ktx2(write_ktx2(vk, 12, 20, levels), srgb)
             assert got["format"] == fmt and got["levels"] == levels, vk
-        assert C.is_float_format(fmt) and not C.generate_mips_allowed(fmt)
+        # chains are generated for the filterable render-target formats only (rend3-gltf/src/lib.rs:1031-1036)
+        assert C.is_float_format(fmt) and C.generate_mips_allowed(fmt) == (fmt in (C.R16F, C.RG16F, C.RGBA16F, C.RGB10A2))
     for kw, fmt in ((dict(dxgi=2), C.RGBA32F), (dict(dxgi=10), C.RGBA16F), (dict(dxgi=16), C.RG32F), (dict(dxgi=26), C.RG11B10F),
                     (dict(dxgi=31), C.RGBA8_SNORM), (dict(dxgi=34), C.RG16F), (dict(dxgi=41), C.R32F), (dict(dxgi=51), C.RG8_SNORM),
                     (dict(dxgi=54), C.R16F), (dict(dxgi=63), C.R8_SNORM), (dict(dxgi=67), C.RGB9E5), (dict(dxgi=81), C.BC4_SNORM),
@@ -427,3 +428,57 @@ def test_bc6h_dds_file_agrees_with_independent_reader():
     theirs = np.asarray(im).astype(np.float32) / 255.0
     # the specification's rounding term moves a value by at most one binary16 step: below one 8-bit step here
     assert np.abs(np.clip(mine[..., :3], 0, 1) - theirs).max() < 1.5 / 255.0
+
+
+def test_half_rounding_matches_numpy():
+    """f32 -> binary16, round to nearest even (the render-target write of a generated level): every exponent range, ties,
+    the subnormal and overflow boundaries, both signs -- against numpy's conversion."""
+    c = olib.get().c
+    rng = np.random.default_rng(3)
+    special = np.array([0, 0x80000000, 0x33000000, 0x33000001, 0x337FFFFF, 0x33800000, 0x38800000, 0x387FFFFF, 0x387FE000, 0x387FF000,
+                        0x477FE000, 0x477FEFFF, 0x477FF000, 0x47800000, 0x7F800000, 0xFF800000, 0x3F800000, 0x3F801000, 0x3F803000,
+                        0x3F802FFF, 0x3F801001, 0x38000000, 0x37FFFFFF], dtype=np.uint32)
+    sub = rng.integers(0x33000000, 0x38800000, 20000, dtype=np.uint64).astype(np.uint32)
+    ties = ((rng.integers(0x38800000 >> 13, 0x47800000 >> 13, 20000, dtype=np.uint64) << 13) | 0x1000).astype(np.uint32)
+    bits32 = np.concatenate([rng.integers(0, 2 ** 32, 60000, dtype=np.uint64).astype(np.uint32), special, sub, sub | np.uint32(0x80000000), ties])
+    f = bits32.view(np.float32)
+    keep = ~np.isnan(f)
+    with np.errstate(over="ignore"):
+        want = f[keep].astype(np.float16).view(np.uint16)
+    got = np.array([c.r3o_float_to_half(float(x)) for x in f[keep]], dtype=np.uint16)
+    assert np.array_equal(got, want), f"{(got != want).sum()} differ"
+
+
+def test_generated_float_chain_is_the_box_average_rounded_to_the_format():
+    """Power-of-two extents: the Linear / ClampToEdge blit at texel centres is ((a + b) / 2 + (c + d) / 2) / 2 in the blit's
+    operation order; each level is rounded to the format before the next one reads it."""
+    c = olib.get().c
+    rng = np.random.default_rng(4)
+    w, h = 16, 8
+    lvl0 = (rng.random((h, w, 4)) * 8.0 - 4.0).astype(np.float16)
+    mips = 5
+    chain = np.zeros((sum(max(1, w >> k) * max(1, h >> k) for k in range(mips)), 4), dtype=np.float32)
+    chain[: w * h] = lvl0.astype(np.float32).reshape(-1, 4)
+    assert c.r3o_generate_mips_f32(C.RGBA16F, w, h, mips, chain.ctypes.data) == 0
+    src, at = lvl0.astype(np.float32), w * h
+    half = np.float32(0.5)
+    for k in range(1, mips):
+        sh, sw = src.shape[:2]
+        dh, dw = max(1, sh // 2), max(1, sw // 2)
+        if sh >= 2 and sw >= 2:
+            top = src[0::2, 0::2] * half + src[0::2, 1::2] * half
+            bot = src[1::2, 0::2] * half + src[1::2, 1::2] * half
+            dst = top * half + bot * half
+        else:  # one texel high: both rows clamp to it (weights 0.5 / 0.5 of the same value)
+            row = src[0:1, 0::2] * half + src[0:1, 1::2] * half
+            dst = row * half + row * half
+        dst = dst.astype(np.float32).astype(np.float16).astype(np.float32)
+        got = chain[at: at + dw * dh].reshape(dh, dw, 4)
+        assert np.array_equal(got.view(np.uint32), dst.view(np.uint32)), k
+        src, at = dst, at + dw * dh
+    # Rgb10a2Unorm: codes survive a 1 x 1 -> chain of length 1, and a generated level holds exact n / 1023 (n / 3) values
+    one = np.zeros((5, 4), dtype=np.float32)
+    one[:4] = np.array([[0.1, 0.5, 0.9, 1.0], [0.3, 0.25, 0.0, 0.0], [0.7, 0.125, 1.0, 1.0], [0.2, 0.75, 0.5, 0.34]], dtype=np.float32)
+    assert c.r3o_generate_mips_f32(C.RGB10A2, 2, 2, 2, one.ctypes.data) == 0
+    rgb = one[4, :3].astype(np.float64) * 1023.0
+    assert np.abs(rgb - np.rint(rgb)).max() < 1e-3 and abs(one[4, 3] * 3.0 - round(float(one[4, 3]) * 3.0)) < 1e-6
