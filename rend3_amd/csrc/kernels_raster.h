@@ -168,6 +168,10 @@ R3N_DEV void global_max_u32(uint32_t *p, uint32_t v) {
     typedef __attribute__((address_space(1))) uint32_t *gp_t;
     (void)__hip_atomic_fetch_max((gp_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+R3N_DEV uint32_t global_add_u32(uint32_t *p, uint32_t v) {  // returning; global address space whatever the pointer's provenance
+    typedef __attribute__((address_space(1))) uint32_t *gp_t;
+    return __hip_atomic_fetch_add((gp_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 R3N_DEV void global_max_u64(unsigned long long *p, unsigned long long v) {
     typedef __attribute__((address_space(1))) unsigned long long *gp_t;
     (void)__hip_atomic_fetch_max((gp_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,7 +313,7 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
         } else {
             const uint32_t tx = (uint32_t)(bw + (R3N_TILE - 1)) / R3N_TILE, ty = (uint32_t)(bh + (R3N_TILE - 1)) / R3N_TILE;
             const uint32_t cnt = tx * ty;
-            const uint32_t start = atomicAdd(&a.big_count[bq], cnt);
+            const uint32_t start = global_add_u32(&a.big_count[bq], cnt);
             r3n_big_item *big = a.big_items + (size_t)bq * a.big_capacity;
             for (uint32_t t = 0; t < cnt; ++t) {
                 const uint32_t ix = t % tx, iy = t / tx;
@@ -353,9 +357,23 @@ __global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs 
 }
 // The same over several targets at once: blockIdx.y picks the view's argument block (kernels_shadow.h: the shadow views'
 // fallback lists, one launch for all views).
+// A pointer read from memory is a FLAT pointer as far as the compiler can prove (a kernel argument is known to be global): the
+// work-queue append became a flat_atomic_add, measured 10x slower for the launch.  The append goes through global_add_u32
+// (explicit address space); readfirstlane keeps the pointers in scalar registers like kernel arguments.
+template <class T> R3N_DEV T *uniform_global(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
 __global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small_views(const RasterArgs *__restrict__ views) {
-    const RasterArgs a = views[blockIdx.y];
+    RasterArgs a = views[blockIdx.y];
+    a.big_count = uniform_global(a.big_count);
+    a.big_items = uniform_global(a.big_items);
+    a.big_uv = uniform_global(a.big_uv);
+    a.depth = uniform_global(a.depth);
+    a.list = uniform_global(a.list);
+    a.sub_counts = uniform_global(a.sub_counts);
     raster_small_body<DEPTH_ONLY, S, TEX>(a);
 }
 

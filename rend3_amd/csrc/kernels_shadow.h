@@ -73,6 +73,8 @@ struct ShadowBatchArgs {
     uint32_t n_materials;
     uint32_t *atlas;                   // f32 bits
     uint32_t atlas_pitch;
+    uint32_t bin_tiles;                // 1: opaque triangles are set up and binned for k_shadow_tiles; 0: every passing triangle goes
+                                       //    to the per-view lists of the general rasteriser (batched per-view path, no tile pass)
 };
 
 // ------------------------------------------------------------------------------------------------ bake + object pass, batched
@@ -164,7 +166,9 @@ __global__ __launch_bounds__(256) void k_shadow_cull_bin(ShadowBatchArgs a) {
                         mul_point(V.baked[obj].model_view_proj, v[k], p[k]);
                     }
                     pass = execute_culling_clip(p, flags, true, res_x, res_y, no_hiz);
-                    if (pass && key == R3N_KEY_OPAQUE) {
+                    if (pass && key == R3N_KEY_OPAQUE && a.bin_tiles == 0u) {
+                        fb = true;
+                    } else if (pass && key == R3N_KEY_OPAQUE) {
                         // what prepare_triangle<DEPTH_ONLY> (kernels_raster.h) derives from the same clip positions
                         setup_triangle(p, half, half, positive_visible, ts);
                         if (ts.valid && tri_bounds(p, half, half, (int)V.vp_size, (int)V.vp_size, x0, y0, x1, y1)) {

@@ -136,6 +136,7 @@ struct r3n_ctx {
     DevBuf shadow_views[3], shadow_rargs[2];  // device arrays of the batched shadow stages: ShadowView per stage, RasterArgs per key
     bool shadow_pending = false;
     bool shadow_tiles = false;  // R3N_SHADOW_TILES=1: the batched tile-owned shadow path (kernels_shadow.h) instead of the per-view one
+    bool shadow_bin = true;     // R3N_SHADOW_TILES=2: the batched path WITHOUT the tile pass (every view in one launch per stage, general rasteriser)
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
     // pinned staging ring for small per-frame uploads (headers, uniforms, light buffers): the caller owns its
@@ -451,7 +452,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
-    if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) c->shadow_tiles = e4[0] == '1';
+    if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) { c->shadow_tiles = e4[0] == '1' || e4[0] == '2'; c->shadow_bin = e4[0] != '2'; }
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
@@ -1189,6 +1190,7 @@ static int flush_shadows(r3n_ctx *c) {
     a.n_materials = c->n_materials;
     a.atlas = c->atlas.as<uint32_t>();
     a.atlas_pitch = c->atlas_w;
+    a.bin_tiles = c->shadow_bin ? 1u : 0u;
     if (!hv[0].empty()) {
         a.views = c->shadow_views[0].as<ShadowView>();
         Timed t(c, R3N_STAGE_BAKE, stream);
@@ -1208,7 +1210,7 @@ static int flush_shadows(r3n_ctx *c) {
             hipLaunchKernelGGL(k_shadow_cull_bin, dim3(std::max(1u, std::min(chunks, 4096u)), nv), dim3(256), 0, stream, a);
         }
     }
-    if (!hv[2].empty()) {
+    if (!hv[2].empty() && c->shadow_bin) {
         a.views = c->shadow_views[2].as<ShadowView>();
         Timed t(c, R3N_STAGE_SHADOW_RASTER, stream);
         hipLaunchKernelGGL(k_shadow_tiles, dim3(max_tiles, (unsigned)hv[2].size()), dim3(R3N_STILE_THREADS), 0, stream, a);
@@ -1222,12 +1224,13 @@ static int flush_shadows(r3n_ctx *c) {
             const RasterArgs *views = c->shadow_rargs[key].as<RasterArgs>() + first;
             for (unsigned k = 0; k < nv; ++k) HIP_TRY(c, hipMemsetAsync(hr[key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
             Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream);
+            const unsigned gs = c->shadow_bin ? R3N_FB_SMALL_GRID : R3N_SMALL_GRID, gb = c->shadow_bin ? R3N_FB_BIG_GRID : R3N_BIG_GRID;
             if (tex) {
-                hipLaunchKernelGGL((k_raster_small_views<true, 1, true>), dim3(R3N_FB_SMALL_GRID, nv), dim3(256), 0, stream, views);
-                hipLaunchKernelGGL((k_raster_big_views<true, 1, true>), dim3(R3N_FB_BIG_GRID, nv), dim3(256), 0, stream, views);
+                hipLaunchKernelGGL((k_raster_small_views<true, 1, true>), dim3(gs, nv), dim3(256), 0, stream, views);
+                hipLaunchKernelGGL((k_raster_big_views<true, 1, true>), dim3(gb, nv), dim3(256), 0, stream, views);
             } else {
-                hipLaunchKernelGGL((k_raster_small_views<true, 1, false>), dim3(R3N_FB_SMALL_GRID, nv), dim3(256), 0, stream, views);
-                hipLaunchKernelGGL((k_raster_big_views<true, 1, false>), dim3(R3N_FB_BIG_GRID, nv), dim3(256), 0, stream, views);
+                hipLaunchKernelGGL((k_raster_small_views<true, 1, false>), dim3(gs, nv), dim3(256), 0, stream, views);
+                hipLaunchKernelGGL((k_raster_big_views<true, 1, false>), dim3(gb, nv), dim3(256), 0, stream, views);
             }
         }
     }
