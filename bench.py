@@ -119,18 +119,19 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_exchange
-    if distributed:
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     import rend3_amd as r3
     import rend3_amd.scenes  # noqa: F401
     from rend3_amd import parallel
 
     # ---------------------------------------------------------------- scene: replicated on every rank
+    # the context comes FIRST: its streams must take their hardware queues before the communication library creates its own
+    # (rend3_amd/csrc/r3n.hip r3n_create; 1.19 vs 1.65 ms per frame at N = 1 with the exchange forced, profiles/r02_summary.md)
     r = r3.Renderer(r3.host.RIGHT, np.float32(WIDTH) / np.float32(HEIGHT), device=local_rank)
+    if distributed:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=args.objects, target_tris=args.tris,
                                  textured=not args.untextured, unique=not args.instanced)
     view0 = info["camera"][0]

@@ -279,6 +279,8 @@ extern "C" {
     pub fn r3n_exchange_buffers(ctx: *mut r3n_ctx, visibility_keys: *mut *mut c_void, visibility_count: *mut u64, shadow_atlas: *mut *mut c_void, shadow_atlas_count: *mut u64) -> c_int;
     pub fn r3n_set_row_range(ctx: *mut r3n_ctx, row_begin: u32, row_end: u32) -> c_int;
     pub fn r3n_output_buffer(ctx: *mut r3n_ctx, rgba8: *mut *mut c_void, bytes: *mut u64) -> c_int;
+    pub fn r3n_output_buffer_async(ctx: *mut r3n_ctx, rgba8: *mut *mut c_void, bytes: *mut u64, stream: *mut *mut c_void) -> c_int;
+    pub fn r3n_output_work_enqueued(ctx: *mut r3n_ctx) -> c_int;
     pub fn r3n_readback_visible_objects(ctx: *mut r3n_ctx, camera: u32, flags: *mut u8, capacity: u32) -> c_int;
     pub fn r3n_readback_triangle_sets(ctx: *mut r3n_ctx, camera: u32, pass: *mut u8, residual: *mut u8, n: u64) -> c_int;
     pub fn r3n_readback_draw_calls(ctx: *mut r3n_ctx, camera: u32, calls: *mut r3n_indirect_call) -> c_int;

@@ -374,6 +374,13 @@ int r3n_exchange_buffers(r3n_ctx *ctx, void **visibility_keys, uint64_t *visibil
  * rank resolves/tonemaps when screen-space work is split after the exchange. */
 int r3n_set_row_range(r3n_ctx *ctx, uint32_t row_begin, uint32_t row_end);
 int r3n_output_buffer(r3n_ctx *ctx, void **rgba8, uint64_t *bytes);
+/* The same buffer WITHOUT ordering the main stream behind the resolve, for work that only has to follow the resolve (the row
+ * all-gather): *stream = the HIP stream this frame's resolve was enqueued on (its own stream while frames are in flight, else
+ * the main stream).  Work enqueued there is announced with r3n_output_work_enqueued, so that whatever later waits for the resolve
+ * (read-backs, the frame that reuses these targets) waits for that work too.  The next frame's culling and rasterisation then
+ * overlap with the resolve AND the gather, as they do without an exchange. */
+int r3n_output_buffer_async(r3n_ctx *ctx, void **rgba8, uint64_t *bytes, void **stream);
+int r3n_output_work_enqueued(r3n_ctx *ctx);
 
 /* ---- parity / debug taps (not in the reference; synchronise) */
 /* L1 set: flags[i] = 1 iff object slot i survived the frustum test of `camera`'s last r3n_cull */

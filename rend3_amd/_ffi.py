@@ -57,6 +57,8 @@ SIGNATURES = {
     "r3n_exchange_depth": (cint, [vp, vp, vp]),
     "r3n_set_row_range": (cint, [vp, u32, u32]),
     "r3n_output_buffer": (cint, [vp, vp, vp]),
+    "r3n_output_buffer_async": (cint, [vp, vp, vp, vp]),
+    "r3n_output_work_enqueued": (cint, [vp]),
     "r3n_readback_visible_objects": (cint, [vp, u32, vp, u32]),
     "r3n_readback_triangle_sets": (cint, [vp, u32, vp, vp, u64]),
     "r3n_readback_draw_calls": (cint, [vp, u32, vp]),

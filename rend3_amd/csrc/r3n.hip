@@ -48,7 +48,9 @@ std::string g_create_error;
 
 }  // namespace
 
-#define R3N_AUX_STREAMS 4
+#ifndef R3N_AUX_STREAMS
+#define R3N_AUX_STREAMS 2  // main + shade + these = the four hardware queues the runtime uses by default; 3 / 4 streams measured no faster (profiles/r02_summary.md section 9)
+#endif
 
 struct r3n_ctx {
     int device = 0;
@@ -57,8 +59,8 @@ struct r3n_ctx {
     // resolve reads the atlas, and their kernels are latency-bound rather than throughput-bound: each shadow camera
     // runs on its own auxiliary stream (forked after the frame's clears, joined before the resolve) so the five
     // chains overlap and the launch gaps of one hide behind the work of the others.
-    hipStream_t aux[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[R3N_AUX_STREAMS] = {};
+    hipEvent_t fork_ev[R3N_AUX_STREAMS] = {};
     // Frames in flight.  The resolve is VALU-bound and everything before it (culls, rasterisers, Hi-Z) is latency- and
     // atomic-bound, so frame N's resolve runs on its own stream while the main stream and the lanes already work on frame
     // N + 1.  Everything the resolve reads that the next frame rewrites exists twice; the two sets swap at frame_begin:
@@ -76,8 +78,8 @@ struct r3n_ctx {
     DevBuf alt_vis, alt_atlas, alt_fu, alt_dir, alt_point, alt_vp_baked, alt_vp_hdr;
     std::vector<uint8_t> h_dir, h_point;   // the light buffers as last written (uploaded into the frame's slot at frame_begin)
     uint64_t lights_version = 1, slot_lights_version[2] = {0, 0};
-    hipEvent_t join_ev[R3N_AUX_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
-    bool aux_used[R3N_AUX_STREAMS] = {false, false, false, false};
+    hipEvent_t join_ev[R3N_AUX_STREAMS] = {};
+    bool aux_used[R3N_AUX_STREAMS] = {};
     bool multi_stream = true;
     std::string err;
     // world data
@@ -129,7 +131,7 @@ struct r3n_ctx {
     uint32_t output_format = R3N_OUTPUT_RGBA8_UNORM_SRGB;
     uint32_t shade_mode = R3N_SHADE_EXACT;
     DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
-    uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {0, 0, 0, 0, 0};
+    uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {};
     uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (80 B) per work sub-queue (R3N_BIGQ of them)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
@@ -470,6 +472,22 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
             r3n_destroy(c);
             return nullptr;
         }
+    // Bind every stream to its hardware queue NOW, in this order: the runtime hands queues out at a stream's first submission, and
+    // the frame is tuned for main / shade / two pairs of lanes on the four queues the runtime uses by default (measured: with a
+    // communication library initialised first its streams take queues ahead of these and the same frame takes 1.65 ms instead of
+    // 1.19 -- so create the context BEFORE torch.distributed / RCCL is initialised, bench.py does).
+    {
+        hipStream_t order[2 + R3N_AUX_STREAMS] = {c->stream, c->shade};
+        for (int k = 0; k < R3N_AUX_STREAMS; ++k) order[2 + k] = c->aux[k];
+        void *probe = nullptr;
+        if (hipMalloc(&probe, 256) == hipSuccess) {
+            for (hipStream_t st : order) {
+                (void)hipMemsetAsync(probe, 0, 256, st);
+                (void)hipStreamSynchronize(st);
+            }
+            (void)hipFree(probe);
+        }
+    }
     // empty light buffers: count = 0
     bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->srgb8_decode, 512 * 4, false, -1) == R3N_OK &&
               ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->tex_level_off, 64, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
@@ -1853,6 +1871,19 @@ int r3n_output_buffer(r3n_ctx *c, void **rgba8, uint64_t *bytes) {
     TRY(join_shade(c));  // whoever reads the buffer orders itself on the main stream (r3n_stream)
     if (rgba8) *rgba8 = c->out8.p;
     if (bytes) *bytes = (uint64_t)c->width * c->height * 4;
+    return R3N_OK;
+}
+int r3n_output_buffer_async(r3n_ctx *c, void **rgba8, uint64_t *bytes, void **stream) {
+    if (!c || !c->out8.p) return fail(c, R3N_ERR_STATE, "output_buffer: no frame targets yet");
+    if (rgba8) *rgba8 = c->out8.p;
+    if (bytes) *bytes = (uint64_t)c->width * c->height * 4;
+    if (stream) *stream = c->shade_unjoined ? (void *)c->shade : (void *)c->stream;
+    return R3N_OK;
+}
+int r3n_output_work_enqueued(r3n_ctx *c) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    // the event later waits go through (join_shade, r3n_frame_begin's reuse of this frame slot) now also covers that work
+    if (c->shade_unjoined) HIP_TRY(c, hipEventRecord(c->shade_done[c->shade_last], c->shade));
     return R3N_OK;
 }
 

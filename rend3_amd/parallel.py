@@ -135,6 +135,11 @@ class Exchange:
         self._ct = ctypes
         self.rows_equal = False  # set by the caller when every rank resolves an equal, contiguous block of rows
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # the row all-gather follows the resolve on the resolve's stream and has its own communicator: on the frame's main
+        # communicator it would queue in front of the NEXT frame's pass-1 exchange and hold that frame's culling back until this
+        # frame's resolve is done (collectives of one communicator run in issue order)
+        self.group_rows = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group))
+        self._streams = {}
         self.timed = timed
         self.events = []      # (what, start event, end event)
         self.bytes = {}       # what -> bytes this rank hands to the collective per frame
@@ -193,24 +198,28 @@ class Exchange:
                 self.events.append((what, t0, t1))
 
     def gather_rows(self, width, height, world_size):
-        """All-gather the Rgba8 rows each rank tonemapped (equal row counts required)."""
+        """All-gather the Rgba8 rows each rank tonemapped (equal row counts required), on the stream the resolve ran on."""
         import ctypes
         dist, torch = self.dist, self.torch
         assert height % world_size == 0
-        out, nbytes = ctypes.c_void_p(), ctypes.c_uint64()
+        out, nbytes, sp = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p()
         r = self.r
-        r._check(r.lib.r3n_output_buffer(r.ctx, ctypes.byref(out), ctypes.byref(nbytes)), "r3n_output_buffer")
-        with torch.cuda.stream(self.stream):
+        r._check(r.lib.r3n_output_buffer_async(r.ctx, ctypes.byref(out), ctypes.byref(nbytes), ctypes.byref(sp)), "r3n_output_buffer_async")
+        stream = self._streams.get(sp.value)
+        if stream is None:
+            stream = self._streams[sp.value] = torch.cuda.ExternalStream(sp.value, device=self.device)
+        with torch.cuda.stream(stream):
             t0 = t1 = None
             if self.timed:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record(self.stream)
+                t0.record(stream)
             full = device_tensor(out.value, nbytes.value, "|u1", self.device)
-            allgather_rows_(full, dist.get_rank(self.group), world_size, self.group)
+            allgather_rows_(full, dist.get_rank(self.group_rows), world_size, self.group_rows)
             self.bytes["rows"] = nbytes.value
             if self.timed:
-                t1.record(self.stream)
+                t1.record(stream)
                 self.events.append(("rows", t0, t1))
+        r._check(r.lib.r3n_output_work_enqueued(r.ctx), "r3n_output_work_enqueued")
 
     def drain_timings(self):
         """ms per exchange site summed over the recorded calls (synchronises the device), and the number of frames' worth."""
