@@ -9,7 +9,6 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 B="python $root/bench.py"
-$B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"
 $B --steps 100 --warmup 10 --no-cpu-baseline --shade-mode fast > "$out/bench_fast.json" 2>/dev/null
 $B --steps 100 --warmup 10 --no-cpu-baseline --instanced > "$out/bench_instanced.json" 2>/dev/null
 $B --steps 100 --warmup 10 --no-cpu-baseline --untextured > "$out/bench_untextured.json" 2>/dev/null
@@ -22,6 +21,9 @@ R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kts
 cd "$root"
 bash tools/gpu_pmc.sh "$tag/pmc" > "$out/pmc_table.txt" 2>&1
 bash tools/gpu_pmc.sh "$tag/pmc_fast" --shade-mode fast > "$out/pmc_fast_table.txt" 2>&1
+# the headline line LAST, quoting the counter traffic of THIS build (bench.py refuses traffic.json of other kernel sources)
+[ -f "$out/pmc/traffic.json" ] && cp "$out/pmc/traffic.json" "$root/profiles/traffic.json"
+$B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"
 find "$out" -name "*_kernel_trace.csv" -size +8M -delete
 find "$out" -name "*counter_collection.csv" -size +8M -delete
 ls "$out"
