@@ -48,6 +48,7 @@ std::string g_create_error;
 
 }  // namespace
 
+#define R3N_QLANES 4  // shadow views drawn concurrently at most (batched path: two per lane)
 #ifndef R3N_AUX_STREAMS
 #define R3N_AUX_STREAMS 2  // main + shade + these = the four hardware queues the runtime uses by default; 3 / 4 streams measured no faster (profiles/r02_summary.md section 9)
 #endif
@@ -125,13 +126,13 @@ struct r3n_ctx {
     std::vector<r3n_anim_rig16> h_anim_rigs;
     std::vector<r3n_anim_clip16> h_anim_clips;
     uint32_t n_pose_requests = 0, pose_matrix_end = 0, anim_max_joints = 1;
-    DevBuf big_uv[1 + R3N_AUX_STREAMS];
+    DevBuf big_uv[1 + R3N_QLANES];
     DevBuf srgb_thr;  // 255 floats: smallest linear value whose Rgba8UnormSrgb code is >= c (GPU mip generation)
     DevBuf srgb_lut;  // 8-bit output code of every half in [0, 1): kernels_raster.h k_build_srgb_lut (or r3n_set_output_format)
     uint32_t output_format = R3N_OUTPUT_RGBA8_UNORM_SRGB;
     uint32_t shade_mode = R3N_SHADE_EXACT;
-    DevBuf big_items[1 + R3N_AUX_STREAMS], big_count[1 + R3N_AUX_STREAMS];  // per stream lane
-    uint32_t forward_index_lane[1 + R3N_AUX_STREAMS] = {};
+    DevBuf big_items[1 + R3N_QLANES], big_count[1 + R3N_QLANES];  // work queues: [0] the viewport's, 1.. one per concurrently drawn shadow view
+    uint32_t forward_index_lane[1 + R3N_QLANES] = {};
     uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (80 B) per work sub-queue (R3N_BIGQ of them)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
@@ -492,7 +493,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->srgb8_decode, 512 * 4, false, -1) == R3N_OK &&
               ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->tex_level_off, 64, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
               ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
-    for (int lane = 0; ok && lane < 1 + R3N_AUX_STREAMS; ++lane)
+    for (int lane = 0; ok && lane < 1 + R3N_QLANES; ++lane)
         ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
              ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK &&
              ensure(c, c->big_uv[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_uv), false, -1) == R3N_OK;
@@ -545,7 +546,7 @@ void r3n_destroy(r3n_ctx *c) {
     if (c->shade) (void)hipStreamSynchronize(c->shade);
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
         if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
-    for (int lane = 0; lane < 1 + R3N_AUX_STREAMS; ++lane)
+    for (int lane = 0; lane < 1 + R3N_QLANES; ++lane)
         for (DevBuf *b : {&c->big_items[lane], &c->big_uv[lane], &c->big_count[lane]})
             if (b->p) (void)hipFree(b->p);
     DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
@@ -1108,20 +1109,24 @@ static int flush_shadows(r3n_ctx *c) {
         for (auto &b : batch) b.second->pend_bake = b.second->pend_cull = b.second->pend_draw[0] = b.second->pend_draw[1] = false;
         return R3N_OK;
     }
-    const int lane = c->multi_stream ? 1 : 0;
-    hipStream_t stream = lane_stream(c, lane);
     const uint32_t cap = c->capacity, nblocks = (cap + 255u) / 256u;
     const uint32_t mw = max_waves(c);
     const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
     const uint32_t subcap = ((chunks + R3N_SUBQ - 1u) / R3N_SUBQ) * (R3N_CHUNK_WAVES * 64u);
     const size_t list_bytes = (size_t)3 * R3N_SUBQ * subcap * sizeof(r3n_tri_ref);
+    // Groups: the tile pass needs every view in one launch (one group, lane 1).  Without it (R3N_SHADOW_TILES=2) the views are
+    // split over the lanes -- view v in group v mod lanes -- and each lane issues ONE launch per stage for its views, concurrently
+    // with the other lane.  A view drawn concurrently with others has a work queue of its own (queues 1 .. R3N_QLANES).
+    const int ngroups = (!c->shadow_bin && c->multi_stream) ? R3N_AUX_STREAMS : 1;
+    const uint32_t per_launch = (uint32_t)std::max(1, R3N_QLANES / ngroups);  // views per raster launch of a group
     // ---- sizes first (allocations run on the main stream), then the descriptors
-    std::vector<ShadowView> hv[3];  // [bake | cull | draw]
-    std::vector<RasterArgs> hr[2];  // fallback / cutout draws per key
+    std::vector<ShadowView> hv[R3N_AUX_STREAMS][3];  // per group: [bake | cull | draw]
+    std::vector<RasterArgs> hr[R3N_AUX_STREAMS][2];  // per group: general-rasteriser draws per key
     uint32_t max_tiles = 1;
     for (auto &b : batch) {
         CamState &s = *b.second;
         const int cur = s.cur;
+        const int g = ngroups > 1 ? (int)(b.first % (uint32_t)ngroups) : 0;
         TRY(ensure(c, s.vis_flags, cap, false, -1));
         TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
         TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
@@ -1131,10 +1136,10 @@ static int flush_shadows(r3n_ctx *c) {
         TRY(ensure(c, s.counts[cur], sizeof(r3n_cull_counts), false, 0));
         TRY(ensure(c, s.mask[cur], (size_t)mw * 8u, false, -1));
         TRY(ensure(c, s.predicted[cur], list_bytes, false, -1));
-        TRY(ensure(c, s.recs, (size_t)mw * 64u * sizeof(r3n_shadow_tri), false, -1));
         const uint32_t tiles_x = std::max(1u, (s.vp_size + R3N_STILE - 1u) / R3N_STILE);
+        if (c->shadow_bin) TRY(ensure(c, s.recs, (size_t)mw * 64u * sizeof(r3n_shadow_tri), false, -1));
         TRY(ensure(c, s.tile_count, (size_t)tiles_x * tiles_x * 4u, false, 0));
-        TRY(ensure(c, s.tile_list, (size_t)tiles_x * tiles_x * R3N_STILE_CAP * 4u, false, -1));
+        if (c->shadow_bin) TRY(ensure(c, s.tile_list, (size_t)tiles_x * tiles_x * R3N_STILE_CAP * 4u, false, -1));
         TRY(ensure(c, s.fb_counts, 3u * R3N_SUBQ * 4u, false, 0));
         s.subcap[cur] = subcap;
         max_tiles = std::max(max_tiles, tiles_x * tiles_x);
@@ -1158,13 +1163,14 @@ static int flush_shadows(r3n_ctx *c) {
         v.vp_x = s.vp_x; v.vp_y = s.vp_y; v.vp_size = s.vp_size; v.tiles_x = tiles_x;
         v.range_begin = s.range_set ? s.range_begin : c->range_begin;
         v.range_end = s.range_set ? s.range_end : c->range_end;
-        if (s.pend_bake) hv[0].push_back(v);
-        if (s.pend_cull) hv[1].push_back(v);
-        if (s.pend_draw[0]) hv[2].push_back(v);
+        if (s.pend_bake) hv[g][0].push_back(v);
+        if (s.pend_cull) hv[g][1].push_back(v);
+        if (s.pend_draw[0]) hv[g][2].push_back(v);
         for (uint32_t key = 0; key < 2u; ++key) {
             if (!s.pend_draw[key]) continue;
-            const uint32_t slot = (uint32_t)hr[key].size();  // its own work queue: at most R3N_AUX_STREAMS views per raster launch
-            const int qlane = 1 + (int)(slot % R3N_AUX_STREAMS);
+            // its own work queue among the views drawn at the same time: `per_launch` views per raster launch of the group
+            const uint32_t slot = (uint32_t)hr[g][key].size();
+            const int qlane = 1 + g * (int)per_launch + (int)(slot % per_launch);
             RasterArgs a{};
             a.hdr = v.hdr;
             a.objects = c->objects.as<r3n_object128>();
@@ -1186,69 +1192,83 @@ static int flush_shadows(r3n_ctx *c) {
             a.tex = texture_args(c);
             a.vp_x = s.vp_x; a.vp_y = s.vp_y; a.vp_w = s.vp_size; a.vp_h = s.vp_size; a.target_pitch = c->atlas_w;
             a.depth = c->atlas.as<uint32_t>();
-            hr[key].push_back(a);
+            hr[g][key].push_back(a);
         }
         s.pend_bake = s.pend_cull = s.pend_draw[0] = s.pend_draw[1] = false;
     }
+    // the descriptor arrays of all groups go up in one piece per kind (main stream); a group's launches index its own range
     auto upload = [&](DevBuf &dst, const void *src, size_t bytes) -> int {
         TRY(ensure(c, dst, std::max<size_t>(bytes, 256), false, -1));
         for (size_t off = 0; off < bytes; off += r3n_ctx::kStageSlotBytes)
             TRY(upload_small(c, static_cast<char *>(dst.p) + off, static_cast<const char *>(src) + off, std::min<size_t>(r3n_ctx::kStageSlotBytes, bytes - off)));
         return R3N_OK;
     };
-    for (int st = 0; st < 3; ++st)
-        if (!hv[st].empty()) TRY(upload(c->shadow_views[st], hv[st].data(), hv[st].size() * sizeof(ShadowView)));
-    for (int key = 0; key < 2; ++key)
-        if (!hr[key].empty()) TRY(upload(c->shadow_rargs[key], hr[key].data(), hr[key].size() * sizeof(RasterArgs)));
-    TRY(fork_lane(c, lane));  // after the header / descriptor uploads and the frame's clears (main stream)
-    ShadowBatchArgs a{};
-    a.objects = c->objects.as<r3n_object128>();
-    a.mesh = c->mesh.as<uint32_t>();
-    a.material_keys = c->material_keys.as<uint8_t>();
-    a.n_materials = c->n_materials;
-    a.atlas = c->atlas.as<uint32_t>();
-    a.atlas_pitch = c->atlas_w;
-    a.bin_tiles = c->shadow_bin ? 1u : 0u;
-    if (!hv[0].empty()) {
-        a.views = c->shadow_views[0].as<ShadowView>();
-        Timed t(c, R3N_STAGE_BAKE, stream);
-        hipLaunchKernelGGL(k_shadow_bake, dim3((cap * 4u + 255u) / 256u, (unsigned)hv[0].size()), dim3(256), 0, stream, a);
+    size_t v_first[R3N_AUX_STREAMS][3] = {}, r_first[R3N_AUX_STREAMS][2] = {};
+    for (int st = 0; st < 3; ++st) {
+        std::vector<ShadowView> all;
+        for (int g = 0; g < ngroups; ++g) { v_first[g][st] = all.size(); all.insert(all.end(), hv[g][st].begin(), hv[g][st].end()); }
+        if (!all.empty()) TRY(upload(c->shadow_views[st], all.data(), all.size() * sizeof(ShadowView)));
     }
-    if (!hv[1].empty()) {
-        a.views = c->shadow_views[1].as<ShadowView>();
-        const unsigned nv = (unsigned)hv[1].size();
-        {
-            Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
-            hipLaunchKernelGGL(k_shadow_object_count, dim3(nblocks, nv), dim3(256), 0, stream, a);
-            hipLaunchKernelGGL(k_shadow_object_scan, dim3(1, nv), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, a, nblocks);
-            hipLaunchKernelGGL(k_shadow_object_scatter, dim3(nblocks, nv), dim3(256), 0, stream, a);
+    for (int key = 0; key < 2; ++key) {
+        std::vector<RasterArgs> all;
+        for (int g = 0; g < ngroups; ++g) { r_first[g][key] = all.size(); all.insert(all.end(), hr[g][key].begin(), hr[g][key].end()); }
+        if (!all.empty()) TRY(upload(c->shadow_rargs[key], all.data(), all.size() * sizeof(RasterArgs)));
+    }
+    for (int g = 0; g < ngroups; ++g) {
+        if (hv[g][0].empty() && hv[g][1].empty() && hv[g][2].empty() && hr[g][0].empty() && hr[g][1].empty()) continue;
+        const int lane = c->multi_stream ? 1 + g : 0;
+        hipStream_t stream = lane_stream(c, lane);
+        TRY(fork_lane(c, lane));  // after the header / descriptor uploads and the frame's clears (main stream)
+        ShadowBatchArgs a{};
+        a.objects = c->objects.as<r3n_object128>();
+        a.mesh = c->mesh.as<uint32_t>();
+        a.material_keys = c->material_keys.as<uint8_t>();
+        a.n_materials = c->n_materials;
+        a.atlas = c->atlas.as<uint32_t>();
+        a.atlas_pitch = c->atlas_w;
+        a.bin_tiles = c->shadow_bin ? 1u : 0u;
+        if (!hv[g][0].empty()) {
+            a.views = c->shadow_views[0].as<ShadowView>() + v_first[g][0];
+            Timed t(c, R3N_STAGE_BAKE, stream);
+            hipLaunchKernelGGL(k_shadow_bake, dim3((cap * 4u + 255u) / 256u, (unsigned)hv[g][0].size()), dim3(256), 0, stream, a);
         }
-        {
-            Timed t(c, R3N_STAGE_TRIANGLE_CULL, stream);
-            hipLaunchKernelGGL(k_shadow_cull_bin, dim3(std::max(1u, std::min(chunks, 4096u)), nv), dim3(256), 0, stream, a);
+        if (!hv[g][1].empty()) {
+            a.views = c->shadow_views[1].as<ShadowView>() + v_first[g][1];
+            const unsigned nv = (unsigned)hv[g][1].size();
+            {
+                Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
+                hipLaunchKernelGGL(k_shadow_object_count, dim3(nblocks, nv), dim3(256), 0, stream, a);
+                hipLaunchKernelGGL(k_shadow_object_scan, dim3(1, nv), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, a, nblocks);
+                hipLaunchKernelGGL(k_shadow_object_scatter, dim3(nblocks, nv), dim3(256), 0, stream, a);
+            }
+            {
+                Timed t(c, R3N_STAGE_TRIANGLE_CULL, stream);
+                hipLaunchKernelGGL(k_shadow_cull_bin, dim3(std::max(1u, std::min(chunks, 4096u)), nv), dim3(256), 0, stream, a);
+            }
         }
-    }
-    if (!hv[2].empty() && c->shadow_bin) {
-        a.views = c->shadow_views[2].as<ShadowView>();
-        Timed t(c, R3N_STAGE_SHADOW_RASTER, stream);
-        hipLaunchKernelGGL(k_shadow_tiles, dim3(max_tiles, (unsigned)hv[2].size()), dim3(R3N_STILE_THREADS), 0, stream, a);
-    }
-    TRY(check_launch(c, "shadow batch"));
-    // what the tiles declined (opaque key) and the cutout key: general rasteriser over the fallback lists, AFTER the tile stores
-    for (uint32_t key = 0; key < 2u; ++key) {
-        const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
-        for (size_t first = 0; first < hr[key].size(); first += R3N_AUX_STREAMS) {
-            const unsigned nv = (unsigned)std::min<size_t>(R3N_AUX_STREAMS, hr[key].size() - first);
-            const RasterArgs *views = c->shadow_rargs[key].as<RasterArgs>() + first;
-            for (unsigned k = 0; k < nv; ++k) HIP_TRY(c, hipMemsetAsync(hr[key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
-            Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream);
-            const unsigned gs = c->shadow_bin ? R3N_FB_SMALL_GRID : R3N_SMALL_GRID, gb = c->shadow_bin ? R3N_FB_BIG_GRID : R3N_BIG_GRID;
-            if (tex) {
-                hipLaunchKernelGGL((k_raster_small_views<true, 1, true>), dim3(gs, nv), dim3(256), 0, stream, views);
-                hipLaunchKernelGGL((k_raster_big_views<true, 1, true>), dim3(gb, nv), dim3(256), 0, stream, views);
-            } else {
-                hipLaunchKernelGGL((k_raster_small_views<true, 1, false>), dim3(gs, nv), dim3(256), 0, stream, views);
-                hipLaunchKernelGGL((k_raster_big_views<true, 1, false>), dim3(gb, nv), dim3(256), 0, stream, views);
+        if (!hv[g][2].empty() && c->shadow_bin) {
+            a.views = c->shadow_views[2].as<ShadowView>() + v_first[g][2];
+            Timed t(c, R3N_STAGE_SHADOW_RASTER, stream);
+            hipLaunchKernelGGL(k_shadow_tiles, dim3(max_tiles, (unsigned)hv[g][2].size()), dim3(R3N_STILE_THREADS), 0, stream, a);
+        }
+        TRY(check_launch(c, "shadow batch"));
+        // what the tiles declined (opaque key) and the cutout key -- or, without the tile pass, everything: the general rasteriser
+        // over the per-view lists, AFTER the tile stores
+        for (uint32_t key = 0; key < 2u; ++key) {
+            const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
+            for (size_t first = 0; first < hr[g][key].size(); first += per_launch) {
+                const unsigned nv = (unsigned)std::min<size_t>(per_launch, hr[g][key].size() - first);
+                const RasterArgs *views = c->shadow_rargs[key].as<RasterArgs>() + r_first[g][key] + first;
+                for (unsigned k = 0; k < nv; ++k) HIP_TRY(c, hipMemsetAsync(hr[g][key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
+                Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream);
+                const unsigned gs = c->shadow_bin ? R3N_FB_SMALL_GRID : R3N_SMALL_GRID, gb = c->shadow_bin ? R3N_FB_BIG_GRID : R3N_BIG_GRID;
+                if (tex) {
+                    hipLaunchKernelGGL((k_raster_small_views<true, 1, true>), dim3(gs, nv), dim3(256), 0, stream, views);
+                    hipLaunchKernelGGL((k_raster_big_views<true, 1, true>), dim3(gb, nv), dim3(256), 0, stream, views);
+                } else {
+                    hipLaunchKernelGGL((k_raster_small_views<true, 1, false>), dim3(gs, nv), dim3(256), 0, stream, views);
+                    hipLaunchKernelGGL((k_raster_big_views<true, 1, false>), dim3(gb, nv), dim3(256), 0, stream, views);
+                }
             }
         }
     }
@@ -1966,10 +1986,10 @@ int r3n_readback_triangle_sets(r3n_ctx *c, r3n_camera cam, uint8_t *pass, uint8_
 
 int r3n_readback_raster_stats(r3n_ctx *c, uint32_t big_items[64]) {
     if (!c || !big_items) return R3N_ERR_INVALID_ARG;
-    // entries [0..16): main-stream lane (viewport) calls; [16 + 12*k ..): auxiliary lane k (shadow views)
+    // entries [0..16): the viewport's work queue; [16 + 12*k ..): shadow work queue k
     std::vector<uint32_t> raw(64 * R3N_BIGQ);
     for (int f = 0; f < 64; ++f) big_items[f] = 0;
-    for (int lane = 0; lane < 1 + R3N_AUX_STREAMS; ++lane) {
+    for (int lane = 0; lane < 1 + R3N_QLANES; ++lane) {
         TRY(d2h(c, raw.data(), c->big_count[lane].p, raw.size() * 4));
         const int base = lane == 0 ? 0 : 16 + 12 * (lane - 1), n = lane == 0 ? 16 : 12;
         for (int f = 0; f < n; ++f)
