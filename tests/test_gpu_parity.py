@@ -602,6 +602,16 @@ def test_exchange_path_single_rank(r3):
             fp = p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0), exchange=ex)
             ex.gather_rows(320, 192, 1)
             compare_frames(fo, fp, f"exchange path frame {f}")
+        # frames in flight: nothing read back between the frames, the row gather enqueued on the resolve's stream
+        # (r3n_output_buffer_async / r3n_output_work_enqueued) while the next frame's culling is already being enqueued
+        for f in range(3, 6):
+            for r in (o, p):
+                r.set_camera_data(oh.look_at_lh((3.0 + f, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+            fo = o.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+            assert p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0), exchange=ex, readback=False) is None
+            ex.gather_rows(320, 192, 1)
+        fp = p.readback_frame(p.evaluate_instructions(), 320, 192)
+        compare_frames(fo, fp, "exchange path, frames in flight, last frame")
         p.close()
     finally:
         dist.destroy_process_group()
