@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Where does the host time of a frame go?  cProfile over 200 steady-state frames of the bench scene, by own time and by caller."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np, torch
+import rend3_amd as r3, rend3_amd.scenes as S
+import bench
+r = r3.Renderer(r3.host.RIGHT, np.float32(bench.WIDTH) / np.float32(bench.HEIGHT))
+info = S.bistro_like(r, r3.host, r3.material_record, textured=True)
+base = r3.BaseRenderGraph(r)
+def frame(k):
+    r.set_camera_data(bench.camera_path(r3.host, info["camera"][0], k), info["camera"][1])
+    r.render(bench.WIDTH, bench.HEIGHT, ambient=bench.AMBIENT, clear_color=bench.CLEAR, readback=False, base=base)
+for k in range(10): frame(k)
+torch.cuda.synchronize()
+K = 200
+t0 = time.perf_counter()
+for k in range(K): frame(10 + k)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"enqueue {1e3*(t1-t0)/K:.3f} ms/frame, until done {1e3*(t2-t0)/K:.3f} ms/frame")
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for k in range(K): frame(300 + k)
+pr.disable(); torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
