@@ -74,6 +74,34 @@ def reduce_scatter_max_rows_(tensor, rank, world_size, group=None):
     return tensor
 
 
+def direct_reduce_scatter_max_(tensor, rank, world_size, group=None):
+    """The reduce-scatter of reduce_scatter_max_rows_ as ONE all-to-all + a local MAX: rank r sends its partial chunk j straight to
+    rank j -- over the full xGMI mesh that is one point-to-point transfer per link, all seven links of a GPU busy at once, each
+    carrying 1/N of the buffer -- and reduces the N chunks it received on its own.  Same result as the collective (MAX is exact and
+    order-free).  Opt-in (R3N_EXCHANGE_DIRECT=1 / Exchange(direct=True)): not measured on a multi-GPU node yet."""
+    import torch
+    import torch.distributed as dist
+    assert tensor.numel() % world_size == 0
+    chunk = tensor.numel() // world_size
+    recv = torch.empty_like(tensor)
+    dist.all_to_all_single(recv, tensor, group=group)
+    tensor[rank * chunk:(rank + 1) * chunk].copy_(recv.view(world_size, chunk).amax(dim=0))
+    return tensor
+
+
+def direct_allreduce_max_(tensor, rank, world_size, group=None):
+    """MAX all-reduce as direct_reduce_scatter_max_ + an all-gather of the reduced chunks (buffers whose size divides by N)."""
+    import torch.distributed as dist
+    direct_reduce_scatter_max_(tensor, rank, world_size, group)
+    chunk = tensor.numel() // world_size
+    mine = tensor[rank * chunk:(rank + 1) * chunk].clone()
+    if hasattr(dist, "all_gather_into_tensor") and tensor.is_cuda:
+        dist.all_gather_into_tensor(tensor, mine, group=group)
+    else:
+        dist.all_gather([tensor[r * chunk:(r + 1) * chunk] for r in range(world_size)], mine, group=group)
+    return tensor
+
+
 def allgather_rows_(full, rank, world_size, group=None):
     """`full` is the whole flat image; rank r has valid data in its r-th equal chunk.  Gathers every chunk in place."""
     import torch.distributed as dist
@@ -124,8 +152,10 @@ class Exchange:
     """The callable BaseRenderGraph.add_to_graph(exchange=...) expects, over torch.distributed.  `timings` (ms per call
     site, HIP events on the context's stream) is filled when `timed` is set: bench.py --gpus N reports it."""
 
-    def __init__(self, renderer, device, group=None, timed=False):
+    def __init__(self, renderer, device, group=None, timed=False, direct=None):
         import ctypes
+        import os
+        self.direct = (os.environ.get("R3N_EXCHANGE_DIRECT", "0") == "1") if direct is None else bool(direct)
         import torch
         import torch.distributed as dist
         self.dist, self.torch, self.group = dist, torch, group
@@ -182,12 +212,20 @@ class Exchange:
                 plane, n = ct.c_void_p(), ct.c_uint64()
                 r = self.r
                 r._check(r.lib.r3n_exchange_depth(r.ctx, ct.byref(plane), ct.byref(n)), "r3n_exchange_depth")
-                allreduce_max_(device_tensor(plane.value, n.value, "<f4", self.device), self.group)  # depth >= 0: float MAX
+                t = device_tensor(plane.value, n.value, "<f4", self.device)  # depth >= 0: float MAX
+                if self.direct and n.value % self.world == 0:
+                    direct_allreduce_max_(t, self.rank, self.world, self.group)
+                else:
+                    allreduce_max_(t, self.group)
                 self.bytes[what] = 4 * n.value
             elif what == "pass2" and self.rows_equal:
                 # only the rows this rank resolves have to be complete from here on
                 vis, vis_n, atlas, atlas_n = self._buffers()
-                reduce_scatter_max_rows_(device_tensor(vis, vis_n, "<i8", self.device), self.rank, self.world, self.group)
+                t = device_tensor(vis, vis_n, "<i8", self.device)
+                if self.direct:
+                    direct_reduce_scatter_max_(t, self.rank, self.world, self.group)
+                else:
+                    reduce_scatter_max_rows_(t, self.rank, self.world, self.group)
                 self.bytes[what] = 8 * vis_n
             else:
                 vis, vis_n, atlas, atlas_n = self._buffers()

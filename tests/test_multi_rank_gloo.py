@@ -101,6 +101,15 @@ def _worker(rank, world, port, q):
             n = keys.numel() // world
             assert np.array_equal(keys.numpy()[rank * n:(rank + 1) * n].view(np.uint64), ref["vis"].reshape(-1)[rank * n:(rank + 1) * n])
             assert np.array_equal(img.numpy().reshape(H, W, 4), ref["rgba8"]), f"gather frame {f}"
+            # the direct (all-to-all + local MAX) forms of the two reductions give the collectives' results
+            part = torch.from_numpy(got["vis"].copy().reshape(-1).view(np.int64))
+            part[(1 - rank) * n:(2 - rank) * n] >>= 1  # this rank's partial values of the OTHER rank's rows: something smaller
+            parallel.direct_reduce_scatter_max_(part, rank, world)
+            assert np.array_equal(part.numpy()[rank * n:(rank + 1) * n].view(np.uint64), ref["vis"].reshape(-1)[rank * n:(rank + 1) * n])
+            plane = torch.from_numpy(np.where((np.arange(W * H) % world) == rank, got["atlas"].reshape(-1)[:W * H], np.float32(0.0)).astype(np.float32))
+            want = torch.from_numpy(got["atlas"].reshape(-1)[:W * H].copy())
+            parallel.direct_allreduce_max_(plane, rank, world)
+            assert np.array_equal(plane.numpy().view(np.uint32), want.numpy().view(np.uint32)), f"direct all-reduce frame {f}"
         q.put((rank, "ok"))
     except Exception as exc:  # noqa: BLE001
         import traceback
