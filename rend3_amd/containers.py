@@ -32,6 +32,11 @@ TEXEL_BYTES = {RGBA8: 4, RGBA8_SRGB: 4, BGRA8: 4, BGRA8_SRGB: 4, R8: 1, RG8: 2, 
                RG16F: 4, RGBA16F: 8, R32F: 4, RG32F: 8, RGBA32F: 16, RGBA16_UNORM: 8, RGBA16_SNORM: 8, RGB10A2: 4, RG11B10F: 4, RGB9E5: 4}
 
 
+# TextureFormat::describe().components where it is not 4 (the loader picks the normal / AO-M-R packing modes from it)
+COMPONENTS = {R8: 1, BC4: 1, R8_SNORM: 1, R16F: 1, R32F: 1, BC4_SNORM: 1, RG8: 2, BC5: 2, RG8_SNORM: 2, RG16F: 2, RG32F: 2, BC5_SNORM: 2,
+              RG11B10F: 3, RGB9E5: 3, BC6H_UF: 3, BC6H_SF: 3}
+
+
 class TextureLoadError(ValueError):
     """GltfLoadError's texture variants (rend3-gltf/src/lib.rs:286-310): kind is the variant name."""
 

@@ -169,7 +169,7 @@ def load_image(g, r, cache, image_index, srgb):
             fmt = parsed["format"]
             generate = len(parsed["levels"]) == 1 and containers.generate_mips_allowed(fmt)
             handle = r.add_texture_2d_encoded(fmt, parsed["width"], parsed["height"], parsed["levels"], generate_mips=generate)
-            comps = {containers.R8: 1, containers.BC4: 1, containers.RG8: 2, containers.BC5: 2}.get(fmt, 4)
+            comps = containers.COMPONENTS.get(fmt, 4)  # TextureFormat::describe().components
             cache[key] = (handle, comps)
         else:
             import io

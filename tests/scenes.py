@@ -290,10 +290,24 @@ def write_textured_gltf(path, containers=False):
         def blocks(bb, w, h, n):
             return [rng.integers(0, 256, ((max(1, w >> k) + 3) // 4) * ((max(1, h >> k) + 3) // 4) * bb, dtype=np.uint8).tobytes() for k in range(n)]
 
-        images[0] = uri(T.write_dds(32, 32, blocks(16, 32, 32, 3), dxgi=98))
-        images[1] = uri(T.write_ktx2(141, 16, 16, blocks(16, 16, 16, 5)))
-        images[2] = uri(T.write_dds(16, 16, blocks(8, 16, 16, 1), fourcc=b"DXT1"))
-        images[4] = uri(T.write_ktx2(9, 8, 8, [lum.tobytes()]))
+        if containers == "float":
+            # base colour: BC6H (unsaturated blocks of the committed vectors), 3 stored levels; normal map: BC5 snorm, 5 levels;
+            # occlusion / metallic-roughness: Rgb10a2Unorm DDS-less KTX2, one level -> generated chain; emissive: Rgba16Float KTX2,
+            # one level -> generated chain; luminance occlusion: R16Float KTX2 with its two levels stored
+            gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bcn_float_blocks.npz"))["bc6h_uf_data"].reshape(-1, 16)
+            images[0] = uri(T.write_dds(32, 32, [gold[:64].tobytes(), gold[64:80].tobytes(), gold[80:84].tobytes()], dxgi=95))
+            images[1] = uri(T.write_ktx2(142, 16, 16, blocks(16, 16, 16, 5)))
+            o10 = orm.astype(np.uint32) * 4 + 1
+            images[2] = uri(T.write_ktx2(64, 16, 16, [(o10[..., 0] | (o10[..., 1] << 10) | (o10[..., 2] << 20) | (3 << 30)).astype(np.uint32).tobytes()]))
+            e16 = np.concatenate([emi.astype(np.float32) / np.float32(64.0), np.ones((8, 8, 1), np.float32)], axis=2).astype(np.float16)
+            images[3] = uri(T.write_ktx2(97, 8, 8, [e16.tobytes()]))
+            l16 = (lum.astype(np.float32) / np.float32(255.0)).astype(np.float16)
+            images[4] = uri(T.write_ktx2(76, 8, 8, [l16.tobytes(), l16[::2, ::2].copy().tobytes()]))
+        else:
+            images[0] = uri(T.write_dds(32, 32, blocks(16, 32, 32, 3), dxgi=98))
+            images[1] = uri(T.write_ktx2(141, 16, 16, blocks(16, 16, 16, 5)))
+            images[2] = uri(T.write_dds(16, 16, blocks(8, 16, 16, 1), fourcc=b"DXT1"))
+            images[4] = uri(T.write_ktx2(9, 8, 8, [lum.tobytes()]))
 
     # one quad (two triangles) with normals, tangents, uvs
     pos = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
