@@ -364,6 +364,32 @@ def test_config2_scifi_full_size(r3):
     p.close()
 
 
+def test_config4_full_size(r3):
+    """BASELINE.json configs[3] at FULL size -- 1 048 576 objects / 55 M triangles, 3840x2160 -- against the oracle (its
+    cull and rasterisers are OpenMP loops: seconds per frame at this size): three frames with a turning camera, so the first
+    has no history, the second culls against the Hi-Z of the first's predicted set and the third draws a non-empty
+    residual.  Everything compare_frames checks is required: L1 set over the 2^20 slots, L2 pass / residual sets over all
+    triangles, IndirectCall counts, baked matrices, visibility keys, HDR, framebuffer (culler.rs:531-659, cull.wgsl)."""
+    import rend3_amd.scenes as S
+    w, h = 3840, 2160
+    o = OracleRenderer(oh.LEFT, f32(w) / f32(h))
+    p = r3.Renderer(oh.LEFT, f32(w) / f32(h))
+    io = S.emerald_like(o, oh, omk)
+    ip = S.emerald_like(p, r3.host, r3.material_record)
+    assert io["objects"] == ip["objects"] == 1 << 20 and io["triangles"] == ip["triangles"] > 50_000_000
+    view0, proj = io["camera"]
+    for f, yaw in enumerate((0.0, 0.03, 0.08)):
+        for r, hm in ((o, oh), (p, r3.host)):
+            r.set_camera_data(hm.mat4_mul(hm.rotation_y(yaw), view0), proj)
+        fo, fp = o.render(w, h, ambient=(0.1, 0.1, 0.1, 1)), p.render(w, h, ambient=(0.1, 0.1, 0.1, 1))
+        compare_frames(fo, fp, f"cfg4 full size, frame {f}")
+        assert fo["visible"].sum() > 100_000 and fo["pass"].sum() > 50_000
+        if f == 0:
+            assert fo["residual"].sum() == fo["pass"].sum()
+    assert 0 < fo["residual"].sum() < fo["pass"].sum()
+    p.close()
+
+
 def test_config4_million_objects_properties(r3):
     """BASELINE.json configs[3] shape: 1 048 576 objects (oracle too slow): properties only -- determinism across
     contexts, residual(frame 0) == pass(frame 0), call counts == popcounts, every nearest fragment from a drawn triangle,
@@ -1034,6 +1060,81 @@ def test_config3_4k_frame(r3):
         fp = p.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
         compare_frames(fo, fp, f"config 3 at 4K, frame {k}")
     assert fo["hiz"].size > w * h and fo["residual"].sum() > 0
+
+
+# ------------------------------------------------------------------ runtime switches: every shipped code path is in the suite
+_ORACLE_FRAMES = {}
+
+
+def _scenario_frames(r3, name, make_renderer):
+    """Three small multi-frame scenarios (cutout + two lights + world edits; textured right-handed; the benchmarked scene
+    generator with four shadow views).  The oracle's frames are rendered once per scenario and kept; `make_renderer(handedness,
+    aspect)` supplies the HIP renderer under test."""
+    if name == "random":
+        hand, w, h = oh.LEFT, 320, 192
+        build = lambda r, hm, mk: scenes.build_random_scene(r, oh, mk, 300, 0xC0FFEE, handedness=hand, lights=2, with_cutout=True)
+
+        def step(f, r, hm, handles):
+            ang = 0.35 * f
+            eye = (3.0 * math.sin(ang), 1.0 + 0.5 * f, -3.0 * math.cos(ang))
+            r.set_camera_data(oh.look_at_lh(eye, (10 * math.sin(ang + 0.3), 0, 10 * math.cos(ang + 0.3)), (0, 1, 0)), ("perspective", 60.0, 0.1))
+            if f == 2:
+                r.set_object_transform(handles[5], oh.mat4_mul(oh.translation((2.0, 0.5, 6.0)), oh.scale((2, 2, 2))))
+                r.remove_object(handles[7])
+        frames, kw = 4, dict(ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+    elif name == "textured":
+        hand, w, h = oh.RIGHT, 320, 192
+        build = lambda r, hm, mk: scenes.build_textured_scene(r, oh, mk, 200, 0xBEEF, handedness=hand, lights=2)
+
+        def step(f, r, hm, handles):
+            r.set_camera_data(oh.look_at_rh((-14.0 + 3.0 * f, 3.0 + f, -14.0 + 2.0 * f), (0.0, 0.0, 0.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        frames, kw = 3, dict(ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+    else:  # "bistro": bench.py's generator, four 512^2 shadow views, bench.py's camera dolly
+        import bench
+        import rend3_amd.scenes as S
+        hand, w, h = oh.RIGHT, 960, 540
+        build = lambda r, hm, mk: S.bistro_like(r, hm, mk, unique=True, n_objects=600, target_tris=120_000, textured=True, tex_size=128, shadow_res=512)
+
+        def step(f, r, hm, info):
+            r.set_camera_data(bench.camera_path(hm, info["camera"][0], f), info["camera"][1])
+        frames, kw = 3, dict(ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+    if name not in _ORACLE_FRAMES:
+        o = OracleRenderer(hand, f32(w) / f32(h))
+        ho = build(o, oh, omk)
+        out = []
+        for f in range(frames):
+            step(f, o, oh, ho)
+            out.append(o.render(w, h, **kw))
+        _ORACLE_FRAMES[name] = out
+    p = make_renderer(hand, f32(w) / f32(h))
+    hp = build(p, r3.host, r3.material_record)
+    for f, fo in enumerate(_ORACLE_FRAMES[name]):
+        step(f, p, r3.host, hp)
+        yield f, fo, p.render(w, h, **kw)
+    p.close()
+
+
+RUNTIME_SWITCHES = [
+    {},                              # the defaults (reference for the others: same scenarios, same oracle frames)
+    {"R3N_SHADOW_TILES": "1"},       # batched shadow views with the tile-owned LDS rasteriser (kernels_shadow.h)
+    {"R3N_SHADOW_TILES": "2"},       # batched shadow views, general rasteriser (k_raster_*_views)
+    {"R3N_PIPELINE": "0"},           # no frames in flight: the resolve on the main stream
+    {"R3N_SINGLE_STREAM": "1"},      # every camera on the main stream
+    {"R3N_FRAME_NODES": "1"},        # the host mirror issues the frame node by node (one C call per reference node) instead of r3n_render_frame
+]
+
+
+@pytest.mark.parametrize("scenario", ["random", "textured", "bistro"])
+@pytest.mark.parametrize("env", RUNTIME_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
+def test_runtime_switches(r3, monkeypatch, env, scenario):
+    """Every opt-in path the library ships (r3n_create reads the environment, r3n.hip) renders the same frames as the default
+    path: all of compare_frames -- sets of every camera, keys, shadow atlas, HDR bit-identical to the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for f, fo, fp in _scenario_frames(r3, scenario, lambda hand, aspect: r3.Renderer(hand, aspect)):
+        compare_frames(fo, fp, f"{scenario} {env} frame {f}")
+    if scenario == "bistro":
+        assert len(fo["shadows"]) == 4 and all(s["pass"].sum() > 200 for s in fo["shadows"]) and (fo["atlas"] != 0).mean() > 0.05
 
 
 def compare_frames_fast(o, p, tag=""):

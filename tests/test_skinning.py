@@ -135,6 +135,63 @@ def test_gpu_config5_shape_many_instances():
     p.close()
 
 
+@pytest.mark.gpu
+def test_gpu_config5_full_size():
+    """BASELINE.json configs[4] at FULL size on the asset it names: the reference's examples/src/skinning/RiggedSimple.glb
+    (160 vertices, 2 joints; tests/golden/skinning-RiggedSimple.glb, read by the product's GLB reader) x 50 000 skeleton
+    instances, every instance with its own pair of joint matrices (rotation + translation + non-uniform scale), skinned by
+    ONE launch (skinning.rs:142-199 issues 50 000 dispatches).  EVERY skinned position / normal run of EVERY instance --
+    8 000 000 vertices -- is compared bit for bit with the oracle's restatement of skinning.wgsl:37-94 over the same
+    GpuSkinningInput records (skinning.rs:23-46) and matrices."""
+    import os
+    import torch
+    assert torch.cuda.is_available()
+    import rend3_amd as r3
+    from rend3_amd.gltf import Gltf
+    n = 50_000
+    g = Gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "skinning-RiggedSimple.glb"))
+    prim = g.primitive(0, 0)
+    assert len(prim["positions"]) == 160 and int(prim["joints"].max()) == 1
+    idx = prim["indices"].reshape(-1, 3)[:, ::-1].reshape(-1)  # left-handed renderer: load_meshes flips the winding (rend3-gltf/src/lib.rs:628-634)
+    kw = dict(normals=prim.get("normals"), tangents=prim.get("tangents"), joint_indices=prim["joints"], joint_weights=prim["weights"])
+    p = r3.Renderer(oh.LEFT, f32(16 / 9))
+    o = OracleRenderer(oh.LEFT, f32(16 / 9))
+    pm, om = p.add_mesh(prim["positions"], idx, **kw), o.add_mesh(prim["positions"], idx, **kw)
+    assert p.meshes[pm].attr_off == o.meshes[om].attr_off and p.meshes[pm].joint_off == o.meshes[om].joint_off
+    rng = np.random.Generator(np.random.PCG64(0x5141))
+    ang = rng.uniform(-1.2, 1.2, (n, 2, 3)).astype(f32)
+    poses = np.tile(oh.identity(), (n, 2, 1)).astype(f32)
+    cx, sx, cz, sz = np.cos(ang[..., 0]), np.sin(ang[..., 0]), np.cos(ang[..., 2]), np.sin(ang[..., 2])
+    sc = rng.uniform(0.5, 2.0, (n, 2, 3)).astype(f32)
+    # Rz(a2) * Rx(a0) * S, column-major, plus a translation
+    poses[..., 0], poses[..., 1], poses[..., 2] = cz * sc[..., 0], sz * sc[..., 0], 0.0
+    poses[..., 4], poses[..., 5], poses[..., 6] = -sz * cx * sc[..., 1], cz * cx * sc[..., 1], sx * sc[..., 1]
+    poses[..., 8], poses[..., 9], poses[..., 10] = sz * sx * sc[..., 2], -cz * sx * sc[..., 2], cx * sc[..., 2]
+    poses[..., 12:15] = rng.uniform(-0.5, 0.5, (n, 2, 3)).astype(f32)
+    base_words = p.mesh_cursor
+    assert base_words == len(o.mesh_words)
+    sks = p.add_skeletons_bulk(pm, list(poses))
+    sk_in, sk_m = p.skinning_buffers()
+    assert len(sk_in) == n and int(sk_in[:, 9].sum()) == 8_000_000 and np.array_equal(sk_m.reshape(n, 2, 16), poses)
+    p._check(p.lib.r3n_skinning(p.ctx, r3._ffi.ptr(sk_in), n, r3._ffi.ptr(sk_m), len(sk_m)), "r3n_skinning")
+    tail = p.mesh_cursor - base_words
+    got = p.readback_mesh_words(4 * base_words, tail)
+    # the oracle over the same records: its mesh buffer = the same base mesh + a zeroed tail of the same size
+    words = np.concatenate([o.mesh_words, np.zeros(tail, dtype=np.uint32)])
+    o.lib.r3o_skinning(o.lib.ptr(words), o.lib.ptr(sk_in), n, o.lib.ptr(sk_m))
+    want = words[base_words:]
+    assert want.any() and np.array_equal(got, want), f"{int((got != want).sum())} of {tail} skinned words differ"
+    # and drawn: a few instances as objects through the whole frame
+    mat = p.add_material(r3.material_record(albedo=(0.7, 0.7, 0.7, 1), albedo_mode="value", roughness=0.6), 0)
+    for i in range(0, n, 5000):
+        p.add_object(None, mat, oh.translation((-9.0 + 0.0004 * i, 0.0, 0.0)), skeleton=sks[i])
+    p.set_camera_data(oh.mat4_mul(oh.from_euler_xyz(0.0, 0.0, 0.0), oh.translation((0.0, 0.0, 12.0))), ("perspective", 60.0, 0.1))
+    out = p.render(640, 360)
+    assert out["pass"].sum() > 0 and (out["vis"] != 0).sum() > 100
+    assert np.array_equal(p.readback_mesh_words(4 * base_words, tail), want)  # the frame's own skinning pass: same result
+    p.close()
+
+
 def test_oracle_mfma_order_is_close_to_the_contract():
     """The FMA-ordered restatement (what the matrix-core kernel computes) against the contract's order on posed rigs: same
     values to rounding -- a handful of ulps -- so choosing the kernel is a performance decision, not a visual one."""
