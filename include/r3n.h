@@ -356,6 +356,57 @@ int r3n_hdr_write(r3n_ctx *ctx, const uint16_t *rgba16f, uint64_t first_pixel, u
 /* Marks the end of the frame: swaps the temporal state (InputOutputBuffer::swap, culling/suballoc.rs:164-214). */
 int r3n_frame_end(r3n_ctx *ctx);
 
+/* ---- the whole frame in ONE call.  r3n_render_frame issues every node of BaseRenderGraph::add_to_graph
+ * (rend3-routine/src/base.rs:129-185, executed by RenderGraph::execute, rend3/src/graph/graph.rs:265-518) in the reference's
+ * order -- exactly the sequence of the per-node entry points above: r3n_frame_begin, r3n_shadow_viewport, r3n_skinning, per shadow
+ * view r3n_uniform_bake / r3n_cull / r3n_forward(DEPTH, RESIDUAL, OPAQUE | CUTOUT), the viewport's r3n_uniform_bake,
+ * r3n_forward(FORWARD, PREDICTED, ..), r3n_hi_z, r3n_cull, r3n_forward(FORWARD, RESIDUAL, ..), r3n_resolve_opaque, the transparent
+ * r3n_forward, r3n_tonemap, r3n_frame_end.  The per-node entry points stay (a Rust integration calls them from its node closures);
+ * this one is for hosts that do not need a graph between the nodes: one FFI crossing per frame instead of ~45.
+ * `desc` carries what Renderer::evaluate_instructions + the node closures compute on the CPU in the reference: the FrameUniforms
+ * (uniforms.rs:28-48), the viewport's PerCameraUniform header (culler.rs:485-502), one header + atlas viewport per shadow map
+ * (directional.rs:99-157, base.rs:366-396), the light buffers, optionally this frame's skinning inputs. */
+typedef struct r3n_shadow_view272 {
+    r3n_camera_header240 header;   /* header.shadow_index == the view's index in the array */
+    uint32_t x, y, size;           /* ShadowMap offset / size in the atlas (base.rs:369) */
+    uint32_t _pad[5];
+} r3n_shadow_view272;
+/* multi-GPU hook (not in the reference): called on the calling thread at the points where ranks merge -- after the shadow
+ * nodes, after pass 1 (before r3n_hi_z), after pass 2 (before r3n_resolve_opaque); the callee enqueues its collectives on
+ * r3n_stream() (r3n_exchange_depth / r3n_exchange_buffers give the buffers).  Non-zero return aborts the frame (R3N_ERR_STATE). */
+#define R3N_EXCHANGE_SHADOW 0u
+#define R3N_EXCHANGE_PASS1 1u
+#define R3N_EXCHANGE_PASS2 2u
+typedef int (*r3n_exchange_fn)(void *user, uint32_t site);
+#define R3N_FRAME_VIEWPORT_FIRST 1u  /* hand the GPU the viewport's bake + pass 1 before the shadow nodes (same results) */
+#define R3N_FRAME_SHADOW_MASK 2u     /* shadow_view_mask is valid: bit v set = this rank renders view v, WHOLE (every object slot,
+                                        whatever r3n_set_object_range says); the others are not rendered here (their atlas
+                                        rectangles arrive through the exchange) */
+typedef struct r3n_frame_desc {
+    uint32_t struct_size;            /* sizeof(r3n_frame_desc) */
+    uint32_t flags;                  /* R3N_FRAME_* */
+    uint32_t width, height, samples; /* as r3n_frame_begin */
+    uint32_t shadow_atlas_width, shadow_atlas_height;
+    uint32_t n_shadow_views;
+    float clear_color[4];
+    const r3n_frame_uniforms496 *uniforms;
+    const r3n_camera_header240 *viewport_header;
+    const r3n_shadow_view272 *shadow_views;  /* n_shadow_views entries */
+    uint64_t shadow_view_mask;
+    /* light buffers as r3n_lights_write takes them; NULL directional_buffer = keep what the context has */
+    const void *directional_buffer;
+    uint64_t directional_bytes;
+    const void *point_buffer;
+    uint64_t point_bytes;
+    /* skinning (base.rs:145) as r3n_skinning takes it; n_skeletons == 0 = no skinning node this frame */
+    const r3n_skinning_input40 *skin_inputs;
+    uint32_t n_skeletons, n_joint_matrices;
+    const float *joint_matrices;
+    r3n_exchange_fn exchange;        /* NULL = single GPU */
+    void *exchange_user;
+} r3n_frame_desc;
+int r3n_render_frame(r3n_ctx *ctx, const r3n_frame_desc *desc);
+
 /* ---- multi-GPU support: object-range sharding (not in the reference).
  * Only objects with slot in [begin, end) are culled/drawn by this context; buffers stay replicated. */
 int r3n_set_object_range(r3n_ctx *ctx, uint32_t begin, uint32_t end);
@@ -476,6 +527,43 @@ void r3n_host_shadow_camera(const float direction[3], float distance, uint32_t r
 uint32_t r3n_host_allocate_shadow_atlas(const uint32_t *handles, const uint16_t *resolutions, uint32_t n,
                                         uint32_t max_dimension, uint32_t out_dimensions[2],
                                         uint32_t *out_maps /* 4*n */);
+
+/* Everything the CPU computes per frame on the path, in one call: CameraState::new (camera.rs:23-85) for the viewport,
+ * DirectionalLightManager::evaluate (directional.rs:99-157: shadow atlas allocation, one shadow camera per light, the light
+ * buffer), FrameUniforms::new (uniforms.rs:28-48) and the PerCameraUniform headers of the viewport and of every shadow view
+ * (culler.rs:477-502).  `lights[i].resolution == 0` marks a free slot of the light manager (skipped; handles keep their index). */
+typedef struct r3n_host_camera144 {
+    float view[16];
+    uint32_t projection_kind;      /* 0 Orthographic{size}, 1 Perspective{vfov, near}, 2 Raw(mat4) (camera.rs:88-107) */
+    uint32_t handedness;           /* 0 left, 1 right */
+    float aspect_ratio;            /* Option<f32>: <= 0 = None (1.0) */
+    uint32_t _pad;
+    float projection_params[16];   /* size.xyz | vfov degrees, near | the matrix */
+} r3n_host_camera144;
+typedef struct r3n_host_directional_light48 {
+    float color[3];
+    float intensity;
+    float direction[3];
+    float distance;
+    uint32_t resolution;
+    uint32_t _pad[3];
+} r3n_host_directional_light48;
+typedef struct r3n_host_frame {
+    r3n_frame_uniforms496 uniforms;
+    r3n_camera_header240 viewport_header;
+    uint32_t shadow_atlas_width, shadow_atlas_height, n_shadow_views, _pad0;
+    float camera_location[3];
+    float _pad1;
+    float view_proj[16];
+    r3n_shadow_view272 shadow_views[R3N_MAX_SHADOW_VIEWS];
+    uint32_t shadow_handles[R3N_MAX_SHADOW_VIEWS];  /* light handle of view i */
+    uint64_t directional_bytes;                     /* 16 + 128 * n_shadow_views */
+    uint8_t directional_buffer[8208];              /* 16 + 128 * R3N_MAX_SHADOW_VIEWS */
+} r3n_host_frame;
+/* returns 0, or -1 when more than R3N_MAX_SHADOW_VIEWS lights cast shadows */
+int r3n_host_evaluate_frame(const r3n_host_camera144 *camera, const r3n_host_directional_light48 *lights, uint32_t n_lights,
+                            uint32_t max_atlas_dimension, const float ambient[4], uint32_t width, uint32_t height, uint32_t samples,
+                            uint32_t object_capacity, r3n_host_frame *out);
 
 #ifdef __cplusplus
 }

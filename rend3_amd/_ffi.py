@@ -51,6 +51,7 @@ SIGNATURES = {
     "r3n_tonemap": (cint, [vp, vp, u64]),
     "r3n_hdr_write": (cint, [vp, vp, u64, u64]),
     "r3n_frame_end": (cint, [vp]),
+    "r3n_render_frame": (cint, [vp, vp]),
     "r3n_set_object_range": (cint, [vp, u32, u32]),
     "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
     "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
@@ -90,7 +91,48 @@ SIGNATURES = {
     "r3n_host_calculate_normals": (None, [vp, u64, vp, u64, cint, vp]),
     "r3n_host_shadow_camera": (None, [vp, cfloat, u32, vp, cint, vp, vp]),
     "r3n_host_allocate_shadow_atlas": (u32, [vp, vp, u32, u32, vp, vp]),
+    "r3n_host_evaluate_frame": (cint, [vp, vp, u32, u32, vp, u32, u32, u32, u32, vp]),
 }
+
+MAX_SHADOW_VIEWS = 64
+EXCHANGE_SITES = ("shadow", "pass1", "pass2")  # R3N_EXCHANGE_*
+FRAME_VIEWPORT_FIRST, FRAME_SHADOW_MASK = 1, 2
+EXCHANGE_FN = ctypes.CFUNCTYPE(cint, vp, u32)  # r3n_exchange_fn
+
+
+class ShadowView272(ctypes.Structure):
+    """r3n_shadow_view272"""
+    _fields_ = [("header", ctypes.c_uint8 * 240), ("x", u32), ("y", u32), ("size", u32), ("_pad", u32 * 5)]
+
+
+class HostCamera144(ctypes.Structure):
+    """r3n_host_camera144"""
+    _fields_ = [("view", cfloat * 16), ("projection_kind", u32), ("handedness", u32), ("aspect_ratio", cfloat), ("_pad", u32),
+                ("projection_params", cfloat * 16)]
+
+
+class HostFrame(ctypes.Structure):
+    """r3n_host_frame"""
+    _fields_ = [("uniforms", ctypes.c_uint8 * 496), ("viewport_header", ctypes.c_uint8 * 240),
+                ("shadow_atlas_width", u32), ("shadow_atlas_height", u32), ("n_shadow_views", u32), ("_pad0", u32),
+                ("camera_location", cfloat * 3), ("_pad1", cfloat), ("view_proj", cfloat * 16),
+                ("shadow_views", ShadowView272 * MAX_SHADOW_VIEWS), ("shadow_handles", u32 * MAX_SHADOW_VIEWS),
+                ("directional_bytes", u64), ("directional_buffer", ctypes.c_uint8 * (16 + 128 * MAX_SHADOW_VIEWS))]
+
+
+class FrameDesc(ctypes.Structure):
+    """r3n_frame_desc"""
+    _fields_ = [("struct_size", u32), ("flags", u32), ("width", u32), ("height", u32), ("samples", u32),
+                ("shadow_atlas_width", u32), ("shadow_atlas_height", u32), ("n_shadow_views", u32), ("clear_color", cfloat * 4),
+                ("uniforms", vp), ("viewport_header", vp), ("shadow_views", vp), ("shadow_view_mask", u64),
+                ("directional_buffer", vp), ("directional_bytes", u64), ("point_buffer", vp), ("point_bytes", u64),
+                ("skin_inputs", vp), ("n_skeletons", u32), ("n_joint_matrices", u32), ("joint_matrices", vp),
+                ("exchange", EXCHANGE_FN), ("exchange_user", vp)]
+
+
+# sizes the C side pins with static_asserts (rend3_amd/csrc/layouts.h)
+assert ctypes.sizeof(ShadowView272) == 272 and ctypes.sizeof(HostCamera144) == 144 and ctypes.sizeof(FrameDesc) == 152
+assert ctypes.sizeof(HostFrame) == 26712
 
 _LIB = None
 

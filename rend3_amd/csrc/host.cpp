@@ -349,4 +349,101 @@ uint32_t r3n_host_allocate_shadow_atlas(const uint32_t *handles, const uint16_t 
     return written;
 }
 
+// CameraState::new (camera.rs:23-85): proj, view_proj = proj * view, origin_view_proj (view without its translation), location
+static void camera_state(const float *view, const float *proj, float *view_proj, float *origin_view_proj, float *location) {
+    float orig[16];
+    std::memcpy(orig, view, sizeof orig);
+    orig[12] = 0.0f; orig[13] = 0.0f; orig[14] = 0.0f; orig[15] = 1.0f;
+    r3n_host_mat4_mul(proj, view, view_proj);
+    if (origin_view_proj) r3n_host_mat4_mul(proj, orig, origin_view_proj);
+    if (location) {
+        float inv[16];
+        r3n_host_mat4_inverse(view, inv);
+        location[0] = inv[12]; location[1] = inv[13]; location[2] = inv[14];
+    }
+}
+
+// PerCameraUniform header (culler.rs:477-502)
+static void camera_header(const float *view, const float *view_proj, uint32_t shadow_index, float res_x, float res_y, int rh, uint32_t samples,
+                          uint32_t object_count, r3n_camera_header240 *h) {
+    std::memset(h, 0, sizeof *h);
+    std::memcpy(h->view, view, 64);
+    std::memcpy(h->view_proj, view_proj, 64);
+    h->shadow_index = shadow_index;
+    r3n_host_frustum_from_matrix(view_proj, h->frustum);
+    h->resolution[0] = res_x; h->resolution[1] = res_y;
+    const bool shadow = shadow_index != 0xFFFFFFFFu;
+    // culler.rs:133-141,477-480 with winding = handedness.into() (rend3-types/src/lib.rs:1190-1197)
+    const bool positive_area_visible = rh ? !shadow : shadow;
+    h->flags = (positive_area_visible ? 1u : 0u) | (samples != 1u ? 2u : 0u);
+    h->object_count = object_count;
+}
+
+int r3n_host_evaluate_frame(const r3n_host_camera144 *cam, const r3n_host_directional_light48 *lights, uint32_t n_lights,
+                            uint32_t max_atlas_dimension, const float ambient[4], uint32_t width, uint32_t height, uint32_t samples,
+                            uint32_t object_capacity, r3n_host_frame *out) {
+    const int rh = cam->handedness != 0u;
+    float proj[16];
+    if (cam->projection_kind == 2u) std::memcpy(proj, cam->projection_params, 64);
+    else r3n_host_projection((int)cam->projection_kind, cam->projection_params, rh, cam->aspect_ratio > 0.0f ? cam->aspect_ratio : 1.0f, proj);
+    float origin_view_proj[16];
+    camera_state(cam->view, proj, out->view_proj, origin_view_proj, out->camera_location);
+    // FrameUniforms::new (uniforms.rs:28-48)
+    r3n_frame_uniforms496 &u = out->uniforms;
+    std::memset(&u, 0, sizeof u);
+    std::memcpy(u.view, cam->view, 64);
+    std::memcpy(u.view_proj, out->view_proj, 64);
+    std::memcpy(u.origin_view_proj, origin_view_proj, 64);
+    r3n_host_mat4_inverse(cam->view, u.inv_view);
+    r3n_host_mat4_inverse(out->view_proj, u.inv_view_proj);
+    r3n_host_mat4_inverse(origin_view_proj, u.inv_origin_view_proj);
+    r3n_host_frustum_from_matrix(proj, u.frustum);
+    std::memcpy(u.ambient, ambient, 16);
+    u.resolution[0] = width; u.resolution[1] = height;
+    camera_header(cam->view, out->view_proj, 0xFFFFFFFFu, (float)width, (float)height, rh, samples, object_capacity, &out->viewport_header);
+    // DirectionalLightManager::evaluate (directional.rs:99-157)
+    uint32_t handles[R3N_MAX_SHADOW_VIEWS];
+    uint16_t res[R3N_MAX_SHADOW_VIEWS];
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < n_lights; ++i) {
+        if (lights[i].resolution == 0u) continue;
+        if (n == R3N_MAX_SHADOW_VIEWS) return -1;
+        handles[n] = i;
+        res[n] = (uint16_t)lights[i].resolution;
+        ++n;
+    }
+    uint32_t dims[2] = {0, 0}, maps[4 * R3N_MAX_SHADOW_VIEWS];
+    const uint32_t placed = r3n_host_allocate_shadow_atlas(handles, res, n, max_atlas_dimension, dims, maps);
+    const uint32_t kMin = 32u;  // MINIMUM_SHADOW_MAP_SIZE (directional.rs:24)
+    out->shadow_atlas_width = std::max(dims[0], kMin);
+    out->shadow_atlas_height = std::max(dims[1], kMin);
+    out->n_shadow_views = placed;
+    std::memset(out->directional_buffer, 0, 16);
+    std::memcpy(out->directional_buffer, &placed, 4);
+    out->directional_bytes = 16u + 128u * (uint64_t)placed;
+    const float sizef[2] = {(float)out->shadow_atlas_width, (float)out->shadow_atlas_height};
+    for (uint32_t k = 0; k < placed; ++k) {
+        const uint32_t ox = maps[4 * k], oy = maps[4 * k + 1], sz = maps[4 * k + 2], handle = maps[4 * k + 3];
+        const r3n_host_directional_light48 &l = lights[handle];
+        float sview[16], sproj[16], svp[16];
+        r3n_host_shadow_camera(l.direction, l.distance, l.resolution, out->camera_location, rh, sview, sproj);
+        camera_state(sview, sproj, svp, nullptr, nullptr);
+        r3n_shadow_view272 &v = out->shadow_views[k];
+        std::memset(&v, 0, sizeof v);
+        camera_header(sview, svp, k, (float)sz, (float)sz, rh, 1u, object_capacity, &v.header);
+        v.x = ox; v.y = oy; v.size = sz;
+        out->shadow_handles[k] = handle;
+        float rec[32];
+        std::memset(rec, 0, sizeof rec);
+        std::memcpy(rec, svp, 64);
+        for (int c = 0; c < 3; ++c) rec[16 + c] = l.color[c] * l.intensity;
+        for (int c = 0; c < 3; ++c) rec[20 + c] = l.direction[c];
+        rec[24] = 1.0f / sizef[0]; rec[25] = 1.0f / sizef[1];
+        rec[26] = (float)ox / sizef[0]; rec[27] = (float)oy / sizef[1];
+        rec[28] = (float)sz / sizef[0]; rec[29] = (float)sz / sizef[1];
+        std::memcpy(out->directional_buffer + 16 + 128 * (size_t)k, rec, 128);
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -22,6 +22,12 @@ static_assert(offsetof(r3n_camera_header240, frustum) == 144, "frustum @144");
 static_assert(offsetof(r3n_camera_header240, flags) == 232, "flags @232");
 static_assert(sizeof(r3n_frame_uniforms496) == 496, "FrameUniforms must be 496 B");
 static_assert(sizeof(r3n_indirect_call) == 20, "IndirectCall must be 20 B");
+// the one-call frame boundary (r3n_render_frame / r3n_host_evaluate_frame): sizes the ctypes / Rust mirrors repeat
+static_assert(sizeof(r3n_shadow_view272) == 272, "shadow view = 240-byte header + viewport");
+static_assert(sizeof(r3n_frame_desc) == 152 && offsetof(r3n_frame_desc, uniforms) == 48 && offsetof(r3n_frame_desc, exchange) == 136, "r3n_frame_desc layout");
+static_assert(sizeof(r3n_host_camera144) == 144, "host camera inputs");
+static_assert(sizeof(r3n_host_directional_light48) == 48, "host directional light");
+static_assert(sizeof(r3n_host_frame) == 26712 && offsetof(r3n_host_frame, shadow_views) == 832 && offsetof(r3n_host_frame, directional_buffer) == 18504, "r3n_host_frame layout");
 
 #define R3N_INVALID 0xFFFFFFFFu
 

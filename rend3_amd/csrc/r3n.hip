@@ -155,6 +155,7 @@ struct r3n_ctx {
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     double stage_ms[R3N_STAGE_COUNT] = {0};
+    int hbm_best_variant = -1;
     uint64_t stage_launches[R3N_STAGE_COUNT] = {0};
 };
 
@@ -1837,6 +1838,72 @@ int r3n_frame_end(r3n_ctx *c) {
     return R3N_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the frame in one call
+// BaseRenderGraph::add_to_graph's node list (base.rs:135-185) issued from here: the per-node entry points above, in the reference's
+// order, without a host-language graph (or ~45 FFI crossings) between them.
+int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
+    if (!c || !d || d->struct_size < sizeof(r3n_frame_desc)) return fail(c, R3N_ERR_INVALID_ARG, "render_frame: bad descriptor");
+    if (!d->uniforms || !d->viewport_header || (d->n_shadow_views && !d->shadow_views) || d->n_shadow_views > R3N_MAX_SHADOW_VIEWS)
+        return fail(c, R3N_ERR_INVALID_ARG, "render_frame: null uniforms / headers, or too many shadow views");
+    if (c->in_frame) return fail(c, R3N_ERR_STATE, "render_frame: a frame is already open");
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v)
+        if (d->shadow_views[v].header.shadow_index != v) return fail(c, R3N_ERR_INVALID_ARG, "render_frame: shadow view i must carry shadow_index i");
+    if (d->directional_buffer) TRY(r3n_lights_write(c, d->directional_buffer, d->directional_bytes, d->point_buffer, d->point_bytes));
+    // clear_shadow_buffers + create_frame_uniforms (base.rs:139,142)
+    TRY(r3n_frame_begin(c, d->uniforms, d->width, d->height, d->samples, d->clear_color, d->shadow_atlas_width, d->shadow_atlas_height));
+    struct Closer {  // an error in the middle must not leave the frame open
+        r3n_ctx *c; bool armed = true;
+        ~Closer() { if (armed && c->in_frame) { const std::string keep = c->err; (void)r3n_frame_end(c); c->err = keep; } }
+    } closer{c};
+    const bool masked = (d->flags & R3N_FRAME_SHADOW_MASK) != 0u;
+    auto mine = [&](uint32_t v) { return !masked || ((d->shadow_view_mask >> v) & 1ull) != 0ull; };
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v) {
+        const r3n_shadow_view272 &sv = d->shadow_views[v];
+        TRY(r3n_shadow_viewport(c, v, sv.x, sv.y, sv.size));
+        // multi-GPU: a view this rank owns is drawn WHOLE here, whatever the viewport's object range is -- set every frame, so the
+        // ownership test and the range cannot disagree (a view that changed owner returns to the global range)
+        if (masked) TRY(r3n_set_camera_object_range(c, v, mine(v) ? 0u : 0xFFFFFFFFu, mine(v) ? 0xFFFFFFFEu : 0xFFFFFFFFu));
+    }
+    // skinning (base.rs:145)
+    if (d->n_skeletons) TRY(r3n_skinning(c, d->skin_inputs, d->n_skeletons, d->joint_matrices, d->n_joint_matrices));
+    auto shadow_nodes = [&]() -> int {
+        for (uint32_t v = 0; v < d->n_shadow_views; ++v)  // shadow_object_uniform_upload (base.rs:148)
+            if (mine(v)) TRY(r3n_uniform_bake(c, v, &d->shadow_views[v].header));
+        for (uint32_t v = 0; v < d->n_shadow_views; ++v)  // pbr_shadow_culling (base.rs:150)
+            if (mine(v)) TRY(r3n_cull(c, v));
+        for (uint32_t v = 0; v < d->n_shadow_views; ++v)  // pbr_shadow_rendering (base.rs:153,366-396)
+            if (mine(v)) {
+                TRY(r3n_forward(c, v, R3N_PASS_DEPTH, R3N_SOURCE_RESIDUAL, R3N_KEY_OPAQUE));
+                TRY(r3n_forward(c, v, R3N_PASS_DEPTH, R3N_SOURCE_RESIDUAL, R3N_KEY_CUTOUT));
+            }
+        if (d->exchange && d->n_shadow_views && d->exchange(d->exchange_user, R3N_EXCHANGE_SHADOW) != 0)
+            return fail(c, R3N_ERR_STATE, "render_frame: the shadow exchange callback failed");
+        return R3N_OK;
+    };
+    auto viewport_pass1 = [&]() -> int {
+        TRY(r3n_uniform_bake(c, R3N_CAMERA_VIEWPORT, d->viewport_header));  // object_uniform_upload (base.rs:156)
+        // pbr_render_opaque_predicted_triangles (base.rs:159)
+        TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_PREDICTED, R3N_KEY_OPAQUE));
+        TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_PREDICTED, R3N_KEY_CUTOUT));
+        return R3N_OK;
+    };
+    if (d->flags & R3N_FRAME_VIEWPORT_FIRST) { TRY(viewport_pass1()); TRY(shadow_nodes()); }
+    else { TRY(shadow_nodes()); TRY(viewport_pass1()); }
+    if (d->exchange && d->exchange(d->exchange_user, R3N_EXCHANGE_PASS1) != 0) return fail(c, R3N_ERR_STATE, "render_frame: the pass-1 exchange callback failed");
+    TRY(r3n_hi_z(c));                         // hi_z (base.rs:162)
+    TRY(r3n_cull(c, R3N_CAMERA_VIEWPORT));    // pbr_culling (base.rs:169)
+    // pbr_render_opaque_residual_triangles (base.rs:172)
+    TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_OPAQUE));
+    TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_CUTOUT));
+    if (d->exchange && d->exchange(d->exchange_user, R3N_EXCHANGE_PASS2) != 0) return fail(c, R3N_ERR_STATE, "render_frame: the pass-2 exchange callback failed");
+    TRY(r3n_resolve_opaque(c));               // the opaque passes' fragment stages, deferred
+    // pbr_forward_rendering_transparent (base.rs:181)
+    TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_BLEND));
+    TRY(r3n_tonemap(c, nullptr, 0));          // tonemapping (base.rs:184)
+    closer.armed = false;
+    return r3n_frame_end(c);
+}
+
 // ------------------------------------------------------------------------------------------------ multi-GPU
 int r3n_set_object_range(r3n_ctx *c, uint32_t begin, uint32_t end) {
     if (!c || begin > end) return fail(c, R3N_ERR_INVALID_ARG, "set_object_range: begin > end");
@@ -2110,16 +2177,48 @@ int r3n_set_multi_stream(r3n_ctx *c, int enable) {
     return R3N_OK;
 }
 
-// four independent 16-byte loads in flight per thread and iteration
-__global__ __launch_bounds__(256) static void k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n) {
+}  // extern "C"
+
+// HBM copy kernels for the measured roofline denominator.  Variants, best of all is reported: grid-stride with four / eight
+// independent 16-byte loads in flight per thread, plain or nontemporal (streaming: no reuse, keep L2 / Infinity Cache lines out
+// of the way of the opposite stream), and a block-contiguous walk (each workgroup streams its own contiguous span, which
+// keeps a DRAM page open per workgroup instead of striding the whole buffer).
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) static void k_copy_f4(const f4v *__restrict__ src, f4v *__restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * 256u;
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    for (; i + 3u * stride < n; i += 4u * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2u * stride], d = src[i + 3u * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2u * stride] = c; dst[i + 3u * stride] = d;
+    for (; i + (size_t)(UNROLL - 1) * stride < n; i += (size_t)UNROLL * stride) {
+        f4v v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) v[k] = NT ? __builtin_nontemporal_load(src + i + (size_t)k * stride) : src[i + (size_t)k * stride];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            if (NT) __builtin_nontemporal_store(v[k], dst + i + (size_t)k * stride);
+            else dst[i + (size_t)k * stride] = v[k];
+        }
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
+template <bool NT>
+__global__ __launch_bounds__(256) static void k_copy_f4_span(const f4v *__restrict__ src, f4v *__restrict__ dst, size_t n) {
+    const size_t per = (n + gridDim.x - 1u) / gridDim.x;  // float4s per workgroup, contiguous
+    const size_t b = (size_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    size_t i = b + threadIdx.x;
+    for (; i + 768u < e; i += 1024u) {
+        f4v v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = NT ? __builtin_nontemporal_load(src + i + 256u * k) : src[i + 256u * k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NT) __builtin_nontemporal_store(v[k], dst + i + 256u * k);
+            else dst[i + 256u * k] = v[k];
+        }
+    }
+    for (; i < e; i += 256u) dst[i] = src[i];
+}
+
+extern "C" {
 
 int r3n_hbm_copy_rate(r3n_ctx *c, uint64_t bytes, uint32_t repeats, double *gb_per_s) {
     if (!c || !gb_per_s || bytes < (64ull << 20) || repeats == 0) return fail(c, R3N_ERR_INVALID_ARG, "hbm_copy_rate: bytes >= 64 MiB, repeats >= 1");
@@ -2134,15 +2233,32 @@ int r3n_hbm_copy_rate(r3n_ctx *c, uint64_t bytes, uint32_t repeats, double *gb_p
         hipEventCreate(&e1) != hipSuccess || hipMemsetAsync(a, 1, n * 16, c->stream) != hipSuccess) {
         rc = fail(c, R3N_ERR_HIP, "hbm_copy_rate: scratch allocation failed");
     } else {
-        const unsigned grids[3] = {256u * 8u, 256u * 16u, 256u * 32u};  // the best of a few grid sizes and of the runtime's own copy counts
-        for (uint32_t r = 0; r <= 4u * repeats && rc == R3N_OK; ++r) {  // first pass untimed (page mapping, clocks)
+        const f4v *src = (const f4v *)a;
+        f4v *dst = (f4v *)b;
+        const unsigned grids[4] = {256u * 4u, 256u * 8u, 256u * 16u, 256u * 32u};
+        const int kVariants = 4 * 6 + 1;  // 6 kernels x 4 grids + the runtime's own copy
+        for (uint32_t r = 0; r <= (uint32_t)kVariants * repeats && rc == R3N_OK; ++r) {  // first pass untimed (page mapping, clocks)
+            const int v = (int)(r % (uint32_t)kVariants);
             (void)hipEventRecord(e0, c->stream);
-            if (r % 4u == 3u) (void)hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, c->stream);
-            else hipLaunchKernelGGL(k_copy_f4, dim3(grids[r % 4u]), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n);
+            if (v == kVariants - 1) (void)hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, c->stream);
+            else {
+                const dim3 g(grids[v % 4]), t(256);
+                switch (v / 4) {
+                    case 0: hipLaunchKernelGGL((k_copy_f4<4, false>), g, t, 0, c->stream, src, dst, n); break;
+                    case 1: hipLaunchKernelGGL((k_copy_f4<4, true>), g, t, 0, c->stream, src, dst, n); break;
+                    case 2: hipLaunchKernelGGL((k_copy_f4<8, false>), g, t, 0, c->stream, src, dst, n); break;
+                    case 3: hipLaunchKernelGGL((k_copy_f4<8, true>), g, t, 0, c->stream, src, dst, n); break;
+                    case 4: hipLaunchKernelGGL((k_copy_f4_span<false>), g, t, 0, c->stream, src, dst, n); break;
+                    default: hipLaunchKernelGGL((k_copy_f4_span<true>), g, t, 0, c->stream, src, dst, n); break;
+                }
+            }
             (void)hipEventRecord(e1, c->stream);
             float ms = 0.0f;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(c, R3N_ERR_HIP, "hbm_copy_rate: timing failed");
-            else if (r > 0 && (best == 0.0f || ms < best)) best = ms;
+            else if (r > 0 && (best == 0.0f || ms < best)) {
+                best = ms;
+                c->hbm_best_variant = v;
+            }
         }
     }
     if (e0) (void)hipEventDestroy(e0);
@@ -2150,6 +2266,7 @@ int r3n_hbm_copy_rate(r3n_ctx *c, uint64_t bytes, uint32_t repeats, double *gb_p
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     if (rc == R3N_OK) *gb_per_s = best > 0.0f ? 2.0 * (double)(n * 16) / ((double)best * 1e-3) / 1e9 : 0.0;
+    if (rc == R3N_OK && std::getenv("R3N_VERBOSE")) std::fprintf(stderr, "r3n_hbm_copy_rate: best variant %d (kernel %d, grid %u): %.1f GB/s\n", c->hbm_best_variant, c->hbm_best_variant / 4, c->hbm_best_variant < 24 ? 256u * (4u << (c->hbm_best_variant % 4)) : 0u, *gb_per_s);
     return rc;
 }
 

@@ -168,7 +168,7 @@ class EvalOutput:
     """What Renderer::evaluate_instructions hands the graph (rend3/src/renderer/eval.rs:157-187), path subset."""
 
     def __init__(self, shadows, shadow_target_size):
-        self.shadows = shadows
+        self.shadows = shadows  # [dict(offset=(x, y), size, handle[, camera])] in shadow-view order
         self.shadow_target_size = shadow_target_size
 
 
@@ -200,9 +200,17 @@ class Renderer:
         self.next_handle = 0
         self.dirty_objects = {}
         self.dir_lights, self.point_lights = [], []
-        self.camera = host.CameraState(host.identity(), ("raw", host.identity()), handedness, aspect_ratio)
+        self._camera_inputs = (host.identity(), ("raw", host.identity()))
+        self._camera = None
         self.object_range = None
         self.skeletons = []
+        # R3N_FRAME_NODES=1: render() issues the frame node by node through the graph mirror (one C call per reference node, what
+        # a Rust integration's node closures do); default: Renderer::evaluate's CPU work and the whole node list behind ONE C call
+        # each (r3n_host_evaluate_frame, r3n_render_frame)
+        self.frame_nodes = os.environ.get("R3N_FRAME_NODES", "0") == "1"
+        self._fc = None  # persistent ctypes blocks of the one-call path
+        self._lights_version = 0
+        self._capacity_sent = None
         self._write_objects([], force_capacity=True)
 
     def close(self):
@@ -428,9 +436,11 @@ class Renderer:
     def update_directional_light(self, handle, **changes):
         """Renderer::update_directional_light with a DirectionalLightChange (only the given fields change)."""
         self.dir_lights[handle].update(changes)
+        self._lights_version += 1
 
     def update_point_light(self, handle, **changes):
         self.point_lights[handle].update(changes)
+        self._lights_version += 1
 
     def _alloc_handle(self):
         if self.free_handles:
@@ -529,14 +539,25 @@ class Renderer:
                               resolution=2048):
         self.dir_lights.append(dict(color=color, intensity=intensity, direction=direction, distance=distance,
                                     resolution=resolution))
+        self._lights_version += 1
         return len(self.dir_lights) - 1
 
     def add_point_light(self, position, color=(1, 1, 1), intensity=1.0, radius=1.0):
         self.point_lights.append(dict(position=position, color=color, intensity=intensity, radius=radius))
+        self._lights_version += 1
         return len(self.point_lights) - 1
 
     def set_camera_data(self, view, projection):
-        self.camera = host.CameraState(view, projection, self.handedness, self.aspect_ratio)
+        """Renderer::set_camera_data: the CameraState (camera.rs:23-85) is derived when something asks for it -- in the one-call
+        frame path that is r3n_host_evaluate_frame, in C++."""
+        self._camera_inputs = (view, projection)
+        self._camera = None
+
+    @property
+    def camera(self):
+        if self._camera is None:
+            self._camera = host.CameraState(self._camera_inputs[0], self._camera_inputs[1], self.handedness, self.aspect_ratio)
+        return self._camera
 
     def set_object_range(self, begin, end):
         """Multi-GPU sharding (not in the reference): this rank culls/draws object slots [begin, end)."""
@@ -551,39 +572,57 @@ class Renderer:
         self._flush_textures()
         return self._evaluate_instructions()
 
-    def _evaluate_instructions(self):
-        """Renderer::evaluate_instructions (rend3/src/renderer/eval.rs:9-187), path subset: flush dirty objects,
-        evaluate lights -> shadow cameras + atlas + light buffers."""
+    def _flush_objects(self):
+        """ObjectManager::evaluate (object.rs:344-364): last frame's removals become real, dirty records are scattered."""
         for h in self.pending_free:
             self.dirty_objects[h] = np.zeros(32, dtype=np.uint32)  # unwrap_or_default(), object.rs:363
             self.object_meta.pop(h, None)
             self.free_handles.append(h)
         self.pending_free = self.deferred_removals
         self.deferred_removals = []
-        self._write_objects(sorted(self.dirty_objects.items()), force_capacity=True)
-        self.dirty_objects = {}
+        if self.dirty_objects or self._capacity_sent != self.capacity:
+            self._write_objects(sorted(self.dirty_objects.items()), force_capacity=True)
+            self.dirty_objects = {}
+            self._capacity_sent = self.capacity
+
+    def _evaluate_instructions(self):
+        """Renderer::evaluate_instructions (rend3/src/renderer/eval.rs:9-187), path subset: flush dirty objects,
+        evaluate lights -> shadow cameras + atlas + light buffers."""
+        self._flush_objects()
         size, shadows, dir_buf = host.evaluate_directional_lights(self.dir_lights, self.camera)
         point_buf = host.point_light_buffer(self.point_lights)
         self._check(self.lib.r3n_lights_write(self.ctx, _ffi.ptr(dir_buf), dir_buf.nbytes, _ffi.ptr(point_buf),
                                               point_buf.nbytes), "r3n_lights_write")
         self._dir_buf, self._point_buf = dir_buf, point_buf
+        self._write_blend_order(self.camera.location)
+        return EvalOutput(shadows, size)
+
+    def _write_blend_order(self, camera_location):
         # the CPU batcher's back-to-front order of the blend-key objects (batching.rs:146-176), every frame
         if self._blend_cache is None:  # rebuilt only after objects / materials changed
             self._blend_cache = [h for h, m in sorted(self.object_meta.items())
                                  if m["enabled"] and self.materials[m["material"]][1] == BLEND]
         blend = self._blend_cache
-        order = host.blend_draw_order(self.camera.location, blend, [self.object_meta[h]["location"] for h in blend]) if blend else []
+        order = host.blend_draw_order(camera_location, blend, [self.object_meta[h]["location"] for h in blend]) if blend else []
         if order or self._had_blend:
             arr = np.asarray(order, dtype=np.uint32)
             self._check(self.lib.r3n_blend_order_write(self.ctx, _ffi.ptr(arr) if len(arr) else None, len(arr)), "r3n_blend_order_write")
         self._had_blend = bool(order)
-        return EvalOutput(shadows, size)
 
     # ------------------------------------------------------------------ convenience: one whole frame
     def render(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0), readback=True,
                base=None, exchange=None):
         """The reference's per-frame driver (rend3-test/src/runner.rs:121-169): evaluate, build the graph with
         BaseRenderGraph::add_to_graph, execute.  `readback` additionally pulls the parity taps."""
+        if not self.frame_nodes:
+            eval_output = self.render_frame(width, height, samples, ambient, clear_color, exchange,
+                                            viewport_first=bool(base is not None and base.viewport_first))
+            if not readback:
+                return None
+            owned = None
+            if exchange is not None and hasattr(exchange, "owns_shadow_view"):
+                owned = {si for si in range(len(eval_output.shadows)) if exchange.owns_shadow_view(si)}
+            return self.readback_frame(eval_output, width, height, samples, owned)
         eval_output = self.evaluate_instructions()
         base = base or BaseRenderGraph(self)
         graph = RenderGraph()
@@ -596,6 +635,112 @@ class Renderer:
         if exchange is not None and hasattr(exchange, "owns_shadow_view"):
             owned = {si for si in range(len(eval_output.shadows)) if exchange.owns_shadow_view(si)}
         return self.readback_frame(eval_output, width, height, samples, owned)
+
+    # ------------------------------------------------------------------ the frame in two C calls
+    def render_frame(self, width, height, samples=1, ambient=(0, 0, 0, 0), clear_color=(0, 0, 0, 0), exchange=None,
+                     viewport_first=False):
+        """evaluate_instructions + BaseRenderGraph::add_to_graph + RenderGraph::execute with the host out of the loop: the CPU
+        half (camera state, shadow cameras + atlas, light buffer, frame uniforms, camera headers) is r3n_host_evaluate_frame, the
+        node list r3n_render_frame.  Same inputs, same results as the node-by-node path (R3N_FRAME_NODES=1); returns the
+        EvalOutput (shadow layout) the read-backs want."""
+        import ctypes as ct
+        lib = self.lib
+        fc = self._fc
+        if fc is None:
+            fc = self._fc = dict(cam=_ffi.HostCamera144(), frame=_ffi.HostFrame(), desc=_ffi.FrameDesc(), lights=None, lights_version=-1,
+                                 point=None, ambient=(ct.c_float * 4)(), cb=None, cb_for=None, error=None)
+            d = fc["desc"]
+            d.struct_size = ct.sizeof(_ffi.FrameDesc)
+            fr = fc["frame"]
+            base = ct.addressof(fr)
+            d.uniforms = base + _ffi.HostFrame.uniforms.offset
+            d.viewport_header = base + _ffi.HostFrame.viewport_header.offset
+            d.shadow_views = base + _ffi.HostFrame.shadow_views.offset
+            d.directional_buffer = base + _ffi.HostFrame.directional_buffer.offset
+        self._flush_textures()
+        self._flush_objects()
+        cam, fr, d = fc["cam"], fc["frame"], fc["desc"]
+        view, projection = self._camera_inputs
+        ct.memmove(cam.view, np.ascontiguousarray(view, dtype=f32).ctypes.data, 64)
+        kind = projection[0]
+        cam.handedness = 1 if self.handedness == host.RIGHT else 0
+        cam.aspect_ratio = 0.0 if self.aspect_ratio is None else float(self.aspect_ratio)
+        if kind == "perspective":
+            cam.projection_kind = 1
+            cam.projection_params[0], cam.projection_params[1] = projection[1], projection[2]
+        elif kind == "orthographic":
+            cam.projection_kind = 0
+            cam.projection_params[0], cam.projection_params[1], cam.projection_params[2] = projection[1]
+        elif kind == "raw":
+            cam.projection_kind = 2
+            ct.memmove(cam.projection_params, np.ascontiguousarray(projection[1], dtype=f32).ctypes.data, 64)
+        else:
+            raise ValueError(kind)
+        if fc["lights_version"] != self._lights_version:
+            la = np.zeros((max(len(self.dir_lights), 1), 12), dtype=f32)
+            for i, l in enumerate(self.dir_lights):
+                if l is None:
+                    continue
+                la[i, 0:3], la[i, 3] = l["color"], l["intensity"]
+                la[i, 4:7], la[i, 7] = l["direction"], l["distance"]
+                la[i, 8:9].view(np.uint32)[0] = l["resolution"]
+            fc["lights"] = la
+            fc["point"] = np.ascontiguousarray(host.point_light_buffer(self.point_lights))
+            fc["lights_version"] = self._lights_version
+        amb = fc["ambient"]
+        amb[0], amb[1], amb[2], amb[3] = ambient
+        if lib.r3n_host_evaluate_frame(ct.byref(cam), fc["lights"].ctypes.data, len(self.dir_lights), 16384, amb, width, height, samples,
+                                       self.capacity, ct.byref(fr)) != 0:
+            raise _ffi.R3nError("r3n_host_evaluate_frame: more shadow-casting lights than R3N_MAX_SHADOW_VIEWS")
+        n_views = fr.n_shadow_views
+        shadows = [dict(offset=(fr.shadow_views[k].x, fr.shadow_views[k].y), size=fr.shadow_views[k].size, handle=fr.shadow_handles[k])
+                   for k in range(n_views)]
+        ev = EvalOutput(shadows, (fr.shadow_atlas_width, fr.shadow_atlas_height))
+        if self._blend_cache is None or self._blend_cache or self._had_blend:
+            self._write_blend_order(np.array(fr.camera_location[:], dtype=f32))
+        d.flags = _ffi.FRAME_VIEWPORT_FIRST if viewport_first else 0
+        d.width, d.height, d.samples = width, height, samples
+        d.shadow_atlas_width, d.shadow_atlas_height, d.n_shadow_views = fr.shadow_atlas_width, fr.shadow_atlas_height, n_views
+        d.clear_color[0], d.clear_color[1], d.clear_color[2], d.clear_color[3] = clear_color
+        d.directional_bytes = fr.directional_bytes
+        d.point_buffer, d.point_bytes = fc["point"].ctypes.data, fc["point"].nbytes
+        d.shadow_view_mask = 0
+        if exchange is not None and hasattr(exchange, "owns_shadow_view"):
+            d.flags |= _ffi.FRAME_SHADOW_MASK
+            d.shadow_view_mask = sum(1 << v for v in range(n_views) if exchange.owns_shadow_view(v))
+        keep = None
+        if self.skeletons:  # skinning (base.rs:145, skinning.rs:211-226)
+            sk_in, sk_m = self.skinning_buffers()
+            poses = self._pose_requests()
+            if len(poses):
+                self._check(lib.r3n_pose_skeletons(self.ctx, _ffi.ptr(np.ascontiguousarray(poses)), len(poses)), "r3n_pose_skeletons")
+            keep = (sk_in, sk_m)
+            d.skin_inputs, d.n_skeletons, d.joint_matrices, d.n_joint_matrices = sk_in.ctypes.data, len(sk_in), sk_m.ctypes.data, len(sk_m)
+        else:
+            d.skin_inputs, d.n_skeletons, d.joint_matrices, d.n_joint_matrices = None, 0, None, 0
+        if exchange is not None:
+            state = dict(ev=ev, samples=samples)
+            fc["cb_state"] = state
+            if fc["cb_for"] is not exchange:
+                def callback(_user, site, _self=self, _fc=fc, _exchange=exchange):
+                    try:
+                        st = _fc["cb_state"]
+                        _exchange(_ffi.EXCHANGE_SITES[site], _self, ev=st["ev"], samples=st["samples"])
+                        return 0
+                    except BaseException as e:  # never unwind through the C frames
+                        _fc["error"] = e
+                        return -1
+                fc["cb"], fc["cb_for"] = _ffi.EXCHANGE_FN(callback), exchange
+            d.exchange = fc["cb"]
+        else:
+            d.exchange = _ffi.EXCHANGE_FN()
+        code = lib.r3n_render_frame(self.ctx, ct.byref(d))
+        del keep
+        if fc["error"] is not None:
+            err, fc["error"] = fc["error"], None
+            raise err
+        self._check(code, "r3n_render_frame")
+        return ev
 
     def readback_frame(self, eval_output, width, height, samples=1, owned_views=None):
         lib, ctx = self.lib, self.ctx
@@ -860,7 +1005,15 @@ class BaseRenderGraph:
         graph.add_node("Skinning", skin)
         def shadow_nodes():
             # multi-GPU: shadow views are sharded by view -- a rank renders the views it owns (whole) and receives the others
-            mine = [si for si in range(len(ev.shadows)) if exchange is None or not hasattr(exchange, "owns_shadow_view") or exchange.owns_shadow_view(si)]
+            sharded = exchange is not None and hasattr(exchange, "owns_shadow_view")
+            mine = [si for si in range(len(ev.shadows)) if not sharded or exchange.owns_shadow_view(si)]
+            if sharded:
+                # an owned view is drawn WHOLE here (every object slot), whatever the viewport's object range is; set every frame
+                # next to the ownership test so the two cannot disagree (r3n_render_frame does the same from its view mask)
+                def ranges(r, _ev):
+                    for si in range(len(ev.shadows)):
+                        r.set_camera_object_range(si, *((0, 0xFFFFFFFE) if si in mine else (0xFFFFFFFF, 0xFFFFFFFF)))
+                graph.add_node("shadow view ownership", ranges)
             # shadow_object_uniform_upload (base.rs:148)
             for si in mine:
                 sh = ev.shadows[si]

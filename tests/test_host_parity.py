@@ -166,3 +166,56 @@ def test_shadow_atlas_random_agree():
         a = oh.allocate_shadow_atlas(maps, 2048)
         b = ph.allocate_shadow_atlas(maps, 2048)
         assert a[0] == b[0] and a[1] == b[1]
+
+
+@pytest.mark.parametrize("hand", [oh.LEFT, oh.RIGHT])
+def test_evaluate_frame_matches_the_oracle_host_math(hand):
+    """r3n_host_evaluate_frame (host.cpp) -- the CPU half of a frame behind one C call -- against the oracle's numpy restatement
+    of the same reference code: CameraState (camera.rs:23-85), DirectionalLightManager::evaluate (directional.rs:99-157: atlas,
+    shadow cameras, light buffer), FrameUniforms::new (uniforms.rs:28-48), PerCameraUniform headers (culler.rs:477-502).
+    Every output byte is compared; ctypes struct layouts are the ones layouts.h pins."""
+    import ctypes as ct
+    lib = _ffi.lib()
+    ol = oracle_lib()
+    lights = [dict(color=(1.0, 0.9, 0.8), intensity=15.0, direction=(1.0, -5.0, -1.0), distance=100.0, resolution=2048),
+              None,
+              dict(color=(0.2, 0.4, 1.0), intensity=3.5, direction=(-0.3, -1.0, 0.2), distance=40.0, resolution=512),
+              dict(color=(1.0, 1.0, 1.0), intensity=1.0, direction=(0.1, -1.0, 0.0), distance=400.0, resolution=1024),
+              dict(color=(0.5, 0.5, 0.5), intensity=2.0, direction=(2.0, -1.0, 0.5), distance=25.0, resolution=2048)]
+    cases = [(("perspective", 60.0, 0.1), f32(16 / 9), 1), (("orthographic", (2.5, 2.5, 5.0)), None, 4),
+             (("raw", oh.orthographic_lh(0, 2, 16, 0, 0, 1)), f32(1.25), 1)]
+    for (proj, aspect, samples), view in zip(cases, rand_mats(3, 0x51DE)):
+        view = oh.mat4_inverse(view)
+        for use in (lights, lights[:1], []):
+            cam = _ffi.HostCamera144()
+            ct.memmove(cam.view, np.ascontiguousarray(view, dtype=f32).ctypes.data, 64)
+            cam.handedness = 1 if hand == oh.RIGHT else 0
+            cam.aspect_ratio = 0.0 if aspect is None else float(aspect)
+            cam.projection_kind = {"orthographic": 0, "perspective": 1, "raw": 2}[proj[0]]
+            params = np.zeros(16, dtype=f32)
+            if proj[0] == "perspective":
+                params[:2] = proj[1:]
+            elif proj[0] == "orthographic":
+                params[:3] = proj[1]
+            else:
+                params[:] = proj[1]
+            ct.memmove(cam.projection_params, params.ctypes.data, 64)
+            la = np.zeros((max(len(use), 1), 12), dtype=f32)
+            for i, l in enumerate(use):
+                if l is not None:
+                    la[i, 0:3], la[i, 3], la[i, 4:7], la[i, 7] = l["color"], l["intensity"], l["direction"], l["distance"]
+                    la[i, 8:9].view(np.uint32)[0] = l["resolution"]
+            amb = (ct.c_float * 4)(0.1, 0.2, 0.3, 1.0)
+            fr = _ffi.HostFrame()
+            assert lib.r3n_host_evaluate_frame(ct.byref(cam), la.ctypes.data, len(use), 16384, amb, 1920, 1080, samples, 4096, ct.byref(fr)) == 0
+            ocam = oh.CameraState(view, proj, hand, aspect)
+            size, shadows, dir_buf = oh.evaluate_directional_lights(use, ocam)
+            assert (fr.shadow_atlas_width, fr.shadow_atlas_height) == tuple(size) and fr.n_shadow_views == len(shadows)
+            assert bytes(fr.directional_buffer)[: fr.directional_bytes] == bytes(dir_buf) and fr.directional_bytes == len(bytes(dir_buf))
+            assert bytes(fr.uniforms) == oh.frame_uniforms(ocam, (0.1, 0.2, 0.3, 1.0), (1920, 1080), ol).tobytes()
+            assert bytes(fr.viewport_header) == oh.camera_header(ocam, None, (1920, 1080), samples, 4096, ol).tobytes()
+            assert eq(fr.camera_location[:], ocam.location)
+            for k, sh in enumerate(shadows):
+                v = fr.shadow_views[k]
+                assert (v.x, v.y, v.size, fr.shadow_handles[k]) == (sh["offset"][0], sh["offset"][1], sh["size"], sh["handle"])
+                assert bytes(v.header) == oh.camera_header(sh["camera"], k, (sh["size"], sh["size"]), 1, 4096, ol).tobytes()

@@ -53,19 +53,29 @@ def parse(text):
             decl = " ".join(decl.split())
             if not decl:
                 continue
-            ctype, names = decl.rsplit(" ", 1)[0], decl.rsplit(" ", 1)[1]
-            # 'uint32_t first_joint, n_joints' style lists
-            parts = [p.strip() for p in decl[len(decl.split(" ")[0]):].split(",")]
-            base = decl.split(" ")[0]
-            for p in parts:
-                am = re.match(r"(\w+)((?:\[\w+\])*)$", p)
-                name, dims = am.group(1), re.findall(r"\[(\w+)\]", am.group(2))
+            const = decl.startswith("const ")
+            if const:
+                decl = decl[6:]
+            base, rest = decl.split(" ", 1)
+            # 'uint32_t first_joint, n_joints' style lists; '*name' declarators are pointers
+            for p in [q.strip() for q in rest.split(",")]:
+                am = re.match(r"(\**)\s*(\w+)((?:\[\w+\])*)$", p)
+                stars, name, dims = len(am.group(1)), am.group(2), re.findall(r"\[(\w+)\]", am.group(3))
                 ty = SCALARS.get(base, base)
+                for k in range(stars):
+                    ty = ("*const " if (const and k == 0) else "*mut ") + ty
                 for d in reversed(dims):
                     ty = f"[{ty}; {d} as usize]" if not d.isdigit() else f"[{ty}; {d}]"
                 fields.append((name, ty))
         structs.append((m.group(3), fields))
     opaque = re.findall(r"typedef\s+struct\s+(\w+)\s+(\w+)\s*;", text)
+    fnptrs = []  # typedef int (*name)(args);
+    for m in re.finditer(r"typedef\s+(\w+)\s*\(\s*\*\s*(\w+)\s*\)\s*\(([^)]*)\)\s*;", text):
+        params = []
+        for a in m.group(3).split(","):
+            am = re.match(r"(.+?)(\w+)$", a.strip())
+            params.append((am.group(2), rust_type(am.group(1).strip())))
+        fnptrs.append((m.group(2), rust_type(m.group(1)), params))
     funcs = []
     body = text[text.index('extern "C" {'):]
     for m in re.finditer(r"(?:^|\n)\s*((?:const\s+)?[\w]+(?:\s*\*+\s*|\s+))(r3n_\w+)\s*\(([^;{}]*?)\)\s*;", body):
@@ -80,11 +90,11 @@ def parse(text):
                     ctype = ctype + " *"
                 params.append((pname if pname not in ("type", "fn", "ref", "box") else pname + "_", rust_type(ctype)))
         funcs.append((name, rust_type(ret) if ret != "void" else None, params))
-    return consts, structs, opaque, funcs
+    return consts, structs, opaque, funcs, fnptrs
 
 
 def generate():
-    consts, structs, opaque, funcs = parse(open(HEADER).read())
+    consts, structs, opaque, funcs, fnptrs = parse(open(HEADER).read())
     out = ["// rend3-amd-sys: raw bindings of librend3_amd.so -- GENERATED from include/r3n.h by tools/gen_rust_sys.py, do not edit.",
            "// One item per #define, struct and function of the header; the documentation lives there (each entry point cites the",
            "// rend3 interface it replaces).  Source only in this repository: the build image has no Rust toolchain, so this crate is",
@@ -96,6 +106,9 @@ def generate():
     out.append("")
     for _tag, name in opaque:
         out += [f"#[repr(C)]", f"pub struct {name} {{", "    _private: [u8; 0],", "}", ""]
+    for name, ret, params in fnptrs:
+        ps = ", ".join(f"{p}: {t}" for p, t in params)
+        out += [f'pub type {name} = Option<unsafe extern "C" fn({ps}) -> {ret}>;', ""]
     for name, fields in structs:
         out += ["#[repr(C)]", "#[derive(Clone, Copy)]", f"pub struct {name} {{"]
         out += [f"    pub {f}: {t}," for f, t in fields]
