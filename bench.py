@@ -83,6 +83,33 @@ def camera_path(hm, view0, step):
     return hm.mat4_mul(hm.mat4_mul(hm.rotation_y(yaw), hm.translation((0.0, 0.0, d))), view0)
 
 
+def build_workload(args, r, hm, mk):
+    """The benchmarked world on renderer `r` (the HIP renderer, or the oracle in the cpu_baseline leg): the synthetic stand-in of
+    the named config, or -- `--scene` -- a real asset through the scene-viewer harness.  Returns the generator's info plus
+    ambient / clear / workload description / data kind."""
+    import rend3_amd.scenes as S
+    if args.scene:
+        from rend3_amd import scene_viewer as sv
+        info = dict(sv.build(r, hm, mk, sv.settings_from(args)))
+        info["data"] = "asset"
+        info["workload"] = (f"scene viewer (examples/src/scene_viewer/mod.rs) on {info['file']}: {info['objects']} objects, {info['triangles']} triangles, "
+                            f"{WIDTH}x{HEIGHT}, " + ("MSAA x4, " if args.msaa == 4 else "") + f"{len([l for l in r.dir_lights if l is not None])} directional shadow view(s), "
+                            "camera dolly from the given camera")
+        return info
+    if args.config == 4:
+        info = dict(S.emerald_like(r, hm, mk, n_lights=4))
+        info.update(ambient=AMBIENT, clear=CLEAR, data="synthetic",
+                    workload="BASELINE.json configs[3] stand-in: emerald_like (seed 0xE5A0), 1 048 576 objects / 55 M triangles, 3840x2160, full PBR "
+                             "opaque + 4 directional shadow views (2048^2), factor-only materials, camera dolly" + (", MSAA x4" if args.samples == 4 else ""))
+        return info
+    info = dict(S.bistro_like(r, hm, mk, n_objects=args.objects, target_tris=args.tris, textured=not args.untextured, unique=not args.instanced))
+    info.update(ambient=AMBIENT, clear=CLEAR, data="synthetic",
+                workload="BASELINE.json configs[2] stand-in: bistro_like (seed 0xB157, " + ("11 instanced meshes" if args.instanced else "every object owns its geometry")
+                         + "), 3840x2160, full PBR opaque + 4 directional shadow views (2048^2), camera dolly, " + ("MSAA x4, " if args.samples == 4 else "")
+                         + ("factor-only materials" if args.untextured else "130 materials with base colour + normal + AO/roughness/metallic maps (RGBA8, mips, trilinear)"))
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +132,22 @@ def main():
     ap.add_argument("--instanced", action="store_true",
                     help="the round-1 stand-in: 3 000 objects instancing 11 shared meshes (1.5 MB of geometry, L2-resident) instead "
                          "of one mesh per object (~216 MB)")
-    args = ap.parse_args()
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4),
+                    help="3 (default): BASELINE.json configs[2] stand-in, the config the metric is quoted on; 4: configs[3] stand-in "
+                         "(emerald_like, 1 048 576 objects / 55 M triangles, 4 shadow views), the workload whose per-rank work is milliseconds")
+    ap.add_argument("--scene", default=None, metavar="FILE.glb|FILE.gltf",
+                    help="run the benchmark on a real glTF asset through the scene-viewer harness (rend3_amd/scene_viewer.py; its flags "
+                         "below; `data` becomes \"asset\"): hand it Bistro.glb with tools/scene_viewer.py's --bistro flags and the line is "
+                         "the reference's own configs[2]")
+    ap.add_argument("--resolution", default=None, help="WxH of the target (default 3840x2160, the metric's)")
+    from rend3_amd import scene_viewer as sv
+    sv.add_arguments(ap)
+    args = ap.parse_args(sv.normalize_argv(sys.argv[1:]))
+    if args.resolution:
+        global WIDTH, HEIGHT
+        WIDTH, HEIGHT = (int(v) for v in args.resolution.lower().split("x"))
+    if args.scene:
+        args.samples = args.msaa
 
     import numpy as np
     import torch
@@ -132,9 +174,9 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    info = r3.scenes.bistro_like(r, r3.host, r3.material_record, n_objects=args.objects, target_tris=args.tris,
-                                 textured=not args.untextured, unique=not args.instanced)
+    info = build_workload(args, r, r3.host, r3.material_record)
     view0 = info["camera"][0]
+    ambient, clear = info["ambient"], info["clear"]
     if args.shade_mode == "fast":
         r.set_shade_mode(1)
     hbm_measured = r.hbm_copy_rate(1 << 30, 5)
@@ -159,7 +201,7 @@ def main():
 
     def frame(k, readback=False):
         r.set_camera_data(views[k], info["camera"][1])
-        out = r.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR, readback=readback, base=base, exchange=exchange)
+        out = r.render(WIDTH, HEIGHT, samples=args.samples, ambient=ambient, clear_color=clear, readback=readback, base=base, exchange=exchange)
         if exchange is not None:
             exchange.gather_rows(WIDTH, HEIGHT, world)
         return out
@@ -218,7 +260,8 @@ def main():
     # + tools/make_traffic.py).  Quoted only when they were taken on these kernel sources and this workload variant.
     traffic, valu_busy, valu_insts, traffic_note = {}, {}, {}, "no PMC pass on record"
     variant = ("instanced" if args.instanced else "unique") + ("-untextured" if args.untextured else "-textured") + f"-s{args.samples}" + \
-              ("-fast" if args.shade_mode == "fast" else "")
+              ("-fast" if args.shade_mode == "fast" else "") + ("-cfg4" if args.config == 4 else "") + \
+              ("-scene:" + os.path.basename(args.scene) if args.scene else "") + ("" if (WIDTH, HEIGHT) == (3840, 2160) else f"-{WIDTH}x{HEIGHT}")
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             committed = json.load(fh)
@@ -236,7 +279,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         mpix = WIDTH * HEIGHT * args.steps / elapsed / 1e6
-        cameras = 1 + 4
+        cameras = 1 + len([l for l in r.dir_lights if l is not None])
         stage_ms = {s: (ms / n_inst) for s, (ms, _n) in stages.items()}
         launches = {s: n / n_inst for s, (_ms, n) in stages.items()}
         cull_ms = stage_ms["bake"] + stage_ms["object_cull"] + stage_ms["triangle_cull"]
@@ -295,7 +338,7 @@ def main():
         # section 5: ">= 16 B / shaded pixel") + 4 B for the Rgba8UnormSrgb blit fused into it.  VALU-bound, not HBM-bound, so its
         # fraction of the HBM roofline is small by construction; `valu` says how close it is to its own bound.
         roofline_of("k_resolve_opaque", "shade", 20.0 * WIDTH * HEIGHT / world, "k_resolve_opaque",
-                    "8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; VALU-bound: 4 lights x "
+                    f"8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; VALU-bound: {cameras - 1} lights x "
                     "(5-tap PCF + GGX)" + ("" if args.untextured else ", 3 trilinear maps, tangent frame"))
         dominant = max(rooflines, key=lambda st: stage_ms[st])
         roof = dict(rooflines[dominant], dominant_by="largest kernel time per frame in the HIP-event stage table")
@@ -303,12 +346,8 @@ def main():
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2] stand-in: bistro_like (seed 0xB157, "
-                                   + ("11 instanced meshes" if args.instanced else "every object owns its geometry") + "), 3840x2160, "
-                                   "full PBR opaque + 4 directional shadow views (2048^2), camera dolly, " + ("MSAA x4, " if args.samples == 4 else "")
-                                   + ("factor-only materials" if args.untextured else
-                                      "130 materials with base colour + normal + AO/roughness/metallic maps (RGBA8, mips, trilinear)"),
+            "dtype": "f32", "data": info["data"],
+            "config": {"workload": info["workload"],
                        "shade_mode": args.shade_mode,
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
                        "parallelism": "single GPU" if world == 1 else f"viewport objects by slot range x{world}, shadow views by view (broadcast), RCCL MAX all-reduce of "
@@ -352,9 +391,9 @@ def cpu_baseline(args, hip_frame1):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     o = OracleRenderer(oh.RIGHT, np.float32(WIDTH) / np.float32(HEIGHT))
-    info_o = r3.scenes.bistro_like(o, oh, omk, n_objects=args.objects, target_tris=args.tris, textured=not args.untextured,
-                                   unique=not args.instanced)
+    info_o = build_workload(args, o, oh, omk)
     view0 = info_o["camera"][0]
+    AMBIENT, CLEAR = info_o["ambient"], info_o["clear"]
     o.set_camera_data(camera_path(oh, view0, 0), info_o["camera"][1])
     o.render(WIDTH, HEIGHT, samples=args.samples, ambient=AMBIENT, clear_color=CLEAR)  # history frame (untimed)
     times, splits, parity = [], [], None

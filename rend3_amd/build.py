@@ -25,7 +25,6 @@ UNITS = {
     "shade.hip": ["texture.h", "kernels_shade.h"],
     "shade_ms.hip": ["texture.h", "kernels_shade.h"],
     "shade_blend.hip": ["texture.h", "kernels_shade.h"],
-    "blend_sort.hip": [],
     "texture_decode.hip": ["bc7_tables.h", "bc6h_tables.h"],
     "anim.hip": [],
     "skin_mfma.hip": [],

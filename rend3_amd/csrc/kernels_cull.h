@@ -368,6 +368,133 @@ __global__ __launch_bounds__(1024) void k_object_pass_fused(const r3n_camera_hea
                            slot_base, tri_base);
 }
 
+// Uniform bake + the three object passes in ONE multi-block launch (r3n_render_frame's path): a block bakes and counts its 256
+// object slots, PUBLISHES its six totals, reads the totals of every block in front of it (the exclusive prefix it needs;
+// agent-scope atomics: the L2 of another XCD is not coherent for plain loads) and scatters.  The last block also writes the
+// totals.  Same outputs bit for bit as k_object_count / k_object_scan / k_object_scatter (slot order either way).  Records carry
+// the launch's epoch as their tag, so nothing has to be cleared between launches.  A block waits only for blocks with LOWER
+// indices; the host uses this form up to R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS blocks (all resident at once) and the three
+// launches beyond.  Per camera and frame this is 1 launch instead of 4: the launches were 5-6 us each on the GPU, three of them on
+// the viewport's serial chain between Hi-Z and the triangle cull, and ~3 us each on the host.
+#define R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS 512u
+struct ObjChainRec {
+    uint32_t v[6];  // visible, waves, tris_all, key_tris[3]
+    uint32_t tag;   // epoch of the launch that wrote v
+    uint32_t _pad;
+};
+template <bool BAKE>
+__global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_header240 *__restrict__ hdr,
+                                                             const r3n_object128 *__restrict__ objects,
+                                                             const uint8_t *__restrict__ material_keys, uint32_t n_materials,
+                                                             uint32_t range_begin, uint32_t range_end, uint8_t *__restrict__ vis_flags,
+                                                             ObjChainRec *chain, uint32_t epoch, r3n_cull_counts *__restrict__ counts,
+                                                             r3n_vis_entry *__restrict__ vis_list, r3n_sub_counts *__restrict__ sub_counts,
+                                                             uint32_t *__restrict__ slot_base, r3n_baked128 *__restrict__ baked) {
+    __shared__ uint32_t red[4][6];
+    __shared__ uint32_t pre[6];
+    __shared__ uint32_t wtot[4][2];
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+    const uint32_t cap = hdr->object_count;
+    if (blockIdx.x == 0u && t < 2u * 3u * R3N_SUBQ) (&sub_counts->n[0][0][0])[t] = 0u;  // culler.rs:642 + cull.wgsl:47-61
+    if (BAKE) {  // uniform_prep.wgsl:9-27 for this block's 256 slots: thread (slot, column), four rounds of 64 slots
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; ++r) {
+            const uint32_t obj = blockIdx.x * 256u + r * 64u + (t >> 2), c = t & 3u;
+            if (obj < cap && objects[obj].enabled != 0u) {
+                const float4 col = reinterpret_cast<const float4 *>(objects[obj].transform)[c];
+                float mv[4], mvp[4];
+                mul_vec4(hdr->view, col.x, col.y, col.z, col.w, mv);
+                mul_vec4(hdr->view_proj, col.x, col.y, col.z, col.w, mvp);
+                reinterpret_cast<float4 *>(baked[obj].model_view)[c] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                reinterpret_cast<float4 *>(baked[obj].model_view_proj)[c] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+            }
+        }
+    }
+    // ---- count (object_count_body)
+    const uint32_t i = blockIdx.x * 256u + t;
+    uint32_t flag = 0, ntri = 0, nw = 0, key = 0;
+    if (i < cap) {
+        const r3n_object128 *o = &objects[i];
+        ntri = o->enabled ? o->index_count / 3u : 0u;
+        const uint32_t mi0 = o->material_index;
+        uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
+        if (key0 > 2u) key0 = 2u;
+        if (ntri > 0u && ((i >= range_begin && i < range_end) || key0 == 2u)) {
+            const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
+            const float c[3] = {sph.x, sph.y, sph.z};
+            const float neg_radius = -sph.w;
+            bool inside = true;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
+                inside = inside && (d >= neg_radius);
+            }
+            flag = inside ? 1u : 0u;
+        }
+        if (flag) { nw = (ntri + 63u) / 64u; key = key0; }
+        vis_flags[i] = (uint8_t)flag;
+    }
+    const uint32_t ntri_vis = flag ? ntri : 0u;
+    const uint32_t vals[6] = {flag, nw, ntri, key == 0u ? ntri_vis : 0u, key == 1u ? ntri_vis : 0u, key == 2u ? ntri_vis : 0u};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t sum = wave_reduce_add(vals[k]);
+        if (lane == 0u) red[wave][k] = sum;
+    }
+    __syncthreads();
+    uint32_t own = 0;
+    if (t < 6u) {
+        own = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        __hip_atomic_store(&chain[blockIdx.x].v[t], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // the six stores are issued ...
+    if (t == 0u) __hip_atomic_store(&chain[blockIdx.x].tag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... and published
+    // ---- exclusive prefix over the blocks in front (object_scan_body's result for this block)
+    uint32_t acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t j = t; j < blockIdx.x; j += 256u) {
+        while (__hip_atomic_load(&chain[j].tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += __hip_atomic_load(&chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // red is reused
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t sum = wave_reduce_add(acc[k]);
+        if (lane == 0u) red[wave][k] = sum;
+    }
+    __syncthreads();
+    if (t < 6u) pre[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    // ---- scatter (object_scatter_body)
+    const uint32_t s0 = wave_inclusive_scan(flag, lane), s1 = wave_inclusive_scan(nw, lane);
+    if (lane == 63u) { wtot[wave][0] = s0; wtot[wave][1] = s1; }
+    __syncthreads();
+    uint32_t p0 = pre[0], p1 = pre[1];
+    for (uint32_t w = 0; w < wave; ++w) { p0 += wtot[w][0]; p1 += wtot[w][1]; }
+    if (i < cap) {
+        const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
+        if (flag) {
+            vis_list[e].object = i;
+            vis_list[e].wave_start = ws;
+        }
+        slot_base[i] = flag ? ws * 64u : R3N_INVALID;
+    }
+    if (blockIdx.x == gridDim.x - 1u && t < 6u) red[0][t] = pre[t] + own;  // totals: everything in front + this block
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1u && t == 0u) {
+        counts->visible_objects = red[0][0];
+        counts->total_waves = red[0][1];
+        counts->total_triangles = red[0][2];
+        uint32_t rb = 0;
+        for (int k = 0; k < 3; ++k) {
+            counts->key_triangles[k] = red[0][3 + k];
+            counts->region_base[k] = rb;
+            rb += red[0][3 + k];
+        }
+        vis_list[red[0][0]].object = R3N_INVALID;  // sentinel
+        vis_list[red[0][0]].wave_start = red[0][1];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K8 skinning
 // skinning.wgsl:37-94.  One launch for all skeletons: wave slot w (64 vertices) belongs to skeleton wave_skeleton[w]
 // and covers its vertices [64 * (w - wave_first[skeleton]), +64): the skeleton record and its matrix base are

@@ -39,10 +39,13 @@ struct RasterArgs {
     r3n_big_uv *big_uv;                    // same indexing as big_items; textured cutout triangles only
     TextureArgs tex;
     // transparent pass (row N3): fragments that pass the depth test are appended here instead of written as keys
-    unsigned long long *frag_keys;         // (pixel * samples + sample) << 32 | draw order of the triangle
-    uint32_t *frag_vals;                   // canonical slot + 1
-    uint32_t *frag_count;
+    // ... as nodes of one linked list per pixel sample (no sort, no count on the host):
+    unsigned long long *frag_keys;         // node: next node of the sample's list (R3N_INVALID ends it) << 32 | draw order of the triangle
+    uint32_t *frag_vals;                   // node: canonical slot + 1
+    uint32_t *frag_count;                  // nodes allocated
     uint32_t frag_capacity;
+    uint32_t *frag_head;                   // per pixel sample: first node of its list, R3N_INVALID = none
+    uint32_t *status;                      // host-visible: bit 0 set when nodes / work items ran out (reported by a later call)
     uint32_t row_begin, row_end;           // rows this rank resolves
 };
 
@@ -196,8 +199,11 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             if (!(z >= dz)) continue;
             const uint32_t at = atomicAdd(a.frag_count, 1u);
             if (at < a.frag_capacity) {
-                a.frag_keys[at] = ((unsigned long long)ps << 32) | (unsigned long long)tw.material;
+                const uint32_t next = atomicExch(&a.frag_head[ps], at);  // push: the list's order is irrelevant (k_blend_apply orders by key)
+                a.frag_keys[at] = ((unsigned long long)next << 32) | (unsigned long long)tw.material;
                 a.frag_vals[at] = tw.slot1;
+            } else {
+                __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         return;
@@ -416,7 +422,8 @@ __global__ __launch_bounds__(256) void k_blend_setup(RasterArgs a, BlendSetupArg
         const uint32_t ix = t % tx, iy = t / tx;
         const int rx0 = tw.x0 + (int)ix * R3N_TILE, ry0 = tw.y0 + (int)iy * R3N_TILE;
         const int rx1 = min(rx0 + (R3N_TILE - 1), tw.x1), ry1 = min(ry0 + (R3N_TILE - 1), tw.y1);
-        if (start + t >= a.big_capacity) {  // the caller sees big_count > capacity and fails the frame
+        if (start + t >= a.big_capacity) {  // reported through the status word (a later call fails with R3N_ERR_CAPACITY)
+            __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             continue;
         }
         r3n_big_item it;
@@ -672,9 +679,9 @@ __global__ __launch_bounds__(256) void k_hiz_downsample(const float *__restrict_
 // pass -- registers for the first 2x2, LDS for the rest.  Only used for levels whose SOURCE dimensions are even (then
 // hi_z.wgsl's window is a plain 2x2 and tiles are independent); the host picks `levels` accordingly.
 // With multisampling mip 0 is the depth resolve of resolve_depth_min.wgsl:19-27 (nearest = 1.0, min over the samples).
-__global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__restrict__ vis, float *__restrict__ pyr,
-                                                  r3n_hiz_desc d, uint32_t levels, uint32_t samples) {
-    __shared__ float t[16][17];
+R3N_DEV void hiz_head_body(const unsigned long long *__restrict__ vis, float *__restrict__ pyr, const r3n_hiz_desc &d, uint32_t levels,
+                           uint32_t samples, float (*t)[17]) {
+
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t x0 = (blockIdx.x * 16u + tx) * 2u, y0 = (blockIdx.y * 16u + ty) * 2u;
     float q[2][2];
@@ -736,9 +743,8 @@ __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__re
 // pass-1 raster -> Hi-Z -> cull -> pass-2 raster -> resolve).
 #define R3N_HIZ_LDS_A 8192u
 #define R3N_HIZ_LDS_B 2304u
-__global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {
-    __shared__ float lds_a[R3N_HIZ_LDS_A];
-    __shared__ float lds_b[R3N_HIZ_LDS_B];
+R3N_DEV void hiz_tail_body(float *__restrict__ pyr, const r3n_hiz_desc &d, uint32_t first, uint32_t nthreads, float *lds_a, uint32_t cap_a,
+                           float *lds_b, uint32_t cap_b) {
     const float *src_lds = nullptr;  // previous level, when it was kept in LDS
     bool to_a = true;
     for (uint32_t l = first; l < d.mips; ++l) {
@@ -746,9 +752,9 @@ __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_
         const uint32_t dw = mip_dim(d.width, l), dh = mip_dim(d.height, l);
         const float *src = pyr + d.offset[l - 1u];
         float *dst = pyr + d.offset[l];
-        float *dst_lds = dw * dh <= (to_a ? R3N_HIZ_LDS_A : R3N_HIZ_LDS_B) ? (to_a ? lds_a : lds_b) : nullptr;
+        float *dst_lds = dw * dh <= (to_a ? cap_a : cap_b) ? (to_a ? lds_a : lds_b) : nullptr;
         const uint32_t nx = 2u + (sw & 1u), ny = 2u + (sh & 1u);
-        for (uint32_t i = threadIdx.x; i < dw * dh; i += 1024u) {
+        for (uint32_t i = threadIdx.x; i < dw * dh; i += nthreads) {
             const uint32_t x = i % dw, y = i / dw;
             float nearest = 1.0f;
             for (uint32_t ix = 0; ix < nx; ++ix)
@@ -765,4 +771,38 @@ __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_
         src_lds = dst_lds;
         to_a = !to_a;
     }
+}
+// `ticket` != nullptr: the tail of the pyramid (levels + 1 .. mips - 1) is built by the LAST block of this launch to finish instead
+// of a second launch: every block fences its stores and takes a ticket; the block that draws the last one sees the whole level
+// `levels` (agent-scope fence on both sides: other XCDs' L2 slices are not coherent for plain accesses) and walks the remaining
+// levels -- the first one from memory, the small ones through LDS.  One launch less on the frame's serial chain (pass 1 -> Hi-Z ->
+// cull), and no 1024-thread workgroup waiting for half a CU while the previous frame's resolve fills the chip.
+#define R3N_HIZ_FUSED_LDS_A 2304u
+#define R3N_HIZ_FUSED_LDS_B 640u
+__global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__restrict__ vis, float *__restrict__ pyr,
+                                                  r3n_hiz_desc d, uint32_t levels, uint32_t samples, uint32_t *ticket) {
+    __shared__ float t[16][17];
+    __shared__ float tail_a[R3N_HIZ_FUSED_LDS_A];
+    __shared__ float tail_b[R3N_HIZ_FUSED_LDS_B];
+    __shared__ uint32_t last_block;
+    hiz_head_body(vis, pyr, d, levels, samples, t);
+    if (ticket == nullptr) return;
+    __threadfence();  // this block's levels are visible device-wide before its ticket is
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t n = gridDim.x * gridDim.y;
+        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = mine == n - 1u ? 1u : 0u;
+        if (mine == n - 1u) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    if (last_block == 0u) return;
+    __threadfence();  // acquire: every other block's stores
+    hiz_tail_body(pyr, d, levels + 1u, 256u, tail_a, R3N_HIZ_FUSED_LDS_A, tail_b, R3N_HIZ_FUSED_LDS_B);
+}
+
+__global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {
+    __shared__ float lds_a[R3N_HIZ_LDS_A];
+    __shared__ float lds_b[R3N_HIZ_LDS_B];
+    hiz_tail_body(pyr, d, first, 1024u, lds_a, R3N_HIZ_LDS_A, lds_b, R3N_HIZ_LDS_B);
 }

@@ -80,9 +80,10 @@ static_assert(sizeof(TriRecord) == 256, "triangle record is 64 dwords");
 
 // Transparent pass, stage 3 (see k_blend_apply below).
 struct BlendApplyArgs {
-    const unsigned long long *keys;
-    const uint32_t *vals;
-    uint32_t n;
+    const unsigned long long *keys;   // nodes: next << 32 | draw order
+    const uint32_t *vals;             // nodes: canonical slot + 1
+    const uint32_t *head;             // per pixel sample: first node, R3N_INVALID = none
+    uint32_t first_sample, n_samples; // the samples of the rows this rank resolves
     ushort4 *samples;  // S == 1: the HDR target itself; S == 4: the per-sample colours
 };
 
@@ -970,15 +971,21 @@ static __global__ __launch_bounds__(256) void k_resolve_edge_pixels(ShadeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ transparent pass
-// Stage 3 (row N3): the collected fragments, sorted by (pixel sample, draw order).  The thread that owns the first
-// fragment of a sample walks that sample's run in order: evaluate the fragment (once per triangle and pixel centre,
-// like the forward pass), BlendState::ALPHA_BLENDING on the half-rounded destination -- rgb = src * a + dst * (1 - a),
-// alpha = src.a + dst.a * (1 - a) in f32, result rounded to half -- exactly the oracle's sequence.
+// Stage 3 (row N3): the collected fragments, one linked list per pixel sample.  The thread of a sample with a list applies its
+// fragments in DRAW ORDER -- the next one is the node with the smallest order above the last one applied (orders are unique
+// inside a sample: a triangle covers it once; lists are a few nodes long) -- evaluate the fragment (once per triangle and pixel
+// centre, like the forward pass), BlendState::ALPHA_BLENDING on the half-rounded destination -- rgb = src * a + dst * (1 - a),
+// alpha = src.a + dst.a * (1 - a) in f32, result rounded to half -- exactly the oracle's sequence.  Nothing here needs the
+// fragment count on the host: the launch covers the samples, workgroups without a fragment leave before staging anything.
 template <int S, bool TEX>
 __global__ __launch_bounds__(256) void k_blend_apply(ShadeArgs a, BlendApplyArgs b) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ps = b.first_sample + i;
+    const uint32_t head = i < b.n_samples ? b.head[ps] : R3N_INVALID;
+    if (!__syncthreads_or(head != R3N_INVALID)) return;
     if (TEX) {
         s_decode[threadIdx.x] = a.tex.decode[threadIdx.x];
         s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
@@ -986,18 +993,27 @@ __global__ __launch_bounds__(256) void k_blend_apply(ShadeArgs a, BlendApplyArgs
     }
     uint32_t n_dir, n_point;
     stage_lights(a, s_dir, s_point, n_dir, n_point);
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= b.n) return;
-    const uint32_t ps = (uint32_t)(b.keys[i] >> 32);
-    if (i > 0u && (uint32_t)(b.keys[i - 1u] >> 32) == ps) return;  // not the head of its run
+    if (head == R3N_INVALID) return;
     const uint32_t pix = ps / (uint32_t)S;
     const uint32_t x = pix % a.width, y = pix / a.width;
     const ushort4 d16 = b.samples[ps];
     float d[4] = {(float)__builtin_bit_cast(_Float16, d16.x), (float)__builtin_bit_cast(_Float16, d16.y),
                   (float)__builtin_bit_cast(_Float16, d16.z), (float)__builtin_bit_cast(_Float16, d16.w)};
-    for (uint32_t j = i; j < b.n && (uint32_t)(b.keys[j] >> 32) == ps; ++j) {
+    bool first = true;
+    uint32_t last = 0u;
+    for (;;) {
+        uint32_t best = R3N_INVALID, best_order = 0xFFFFFFFFu;
+        for (uint32_t n = head; n != R3N_INVALID;) {
+            const unsigned long long k = b.keys[n];
+            const uint32_t order = (uint32_t)k;
+            if ((first || order > last) && order <= best_order) { best = n; best_order = order; }
+            n = (uint32_t)(k >> 32);
+        }
+        if (best == R3N_INVALID) break;
+        first = false;
+        last = best_order;
         float src[4];
-        shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, b.vals[j], x, y, src);
+        shade_fragment<TEX>(a, s_dir, s_point, n_dir, n_point, b.vals[best], x, y, src);
         const float al = src[3];
         float r[4];
 #pragma unroll
@@ -1005,6 +1021,7 @@ __global__ __launch_bounds__(256) void k_blend_apply(ShadeArgs a, BlendApplyArgs
         r[3] = src[3] * 1.0f + d[3] * (1.0f - al);
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[c] = (float)(_Float16)r[c];
+        if (last == 0xFFFFFFFFu) break;
     }
     b.samples[ps] = pack_half4(d);
 }

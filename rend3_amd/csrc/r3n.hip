@@ -32,7 +32,13 @@ struct CamState {
     int cur = 0;                 // ping-pong index written by this frame's cull
     int last = -1;               // index holding the most recent cull results (for readbacks)
     uint32_t vp_x = 0, vp_y = 0, vp_size = 0;
-    DevBuf d_hdr, baked, vis_flags, vis_list, block_sums, block_off;
+    DevBuf d_hdr;                // NOT owned: points into the frame-constants block of the current frame slot (canon: into own_hdr)
+    DevBuf own_hdr;
+    uint64_t hdr_frame = ~0ull;  // frame whose constants block already carries this camera's header (r3n_render_frame)
+    DevBuf chain;                // k_object_pass_chained: one ObjChainRec per block, tagged with the launch's epoch
+    uint32_t chain_epoch = 0;
+    uint64_t object_pass_frame = ~0ull;  // frame whose object pass already ran, fused with the bake (r3n_render_frame)
+    DevBuf baked, vis_flags, vis_list, block_sums, block_off;
     DevBuf slot_base[2], mask[2], predicted[2], sub_counts[2], counts[2];
     uint32_t subcap[2] = {0, 0};  // list entries reserved per (material key, sub-list)
     DevBuf residual;
@@ -65,7 +71,7 @@ struct r3n_ctx {
     // Frames in flight.  The resolve is VALU-bound and everything before it (culls, rasterisers, Hi-Z) is latency- and
     // atomic-bound, so frame N's resolve runs on its own stream while the main stream and the lanes already work on frame
     // N + 1.  Everything the resolve reads that the next frame rewrites exists twice; the two sets swap at frame_begin:
-    //   vis, atlas, fu, dir_buf, point_buf, viewport.baked, viewport.d_hdr  <->  alt_*
+    //   vis, atlas, viewport.baked  <->  alt_*;  fu, dir_buf, point_buf, every camera's d_hdr: the frame-constants block of the slot
     // shade_done[slot] (recorded on the shade stream after the resolve of the frame that used `slot`) is what the main
     // stream waits for before it clears that slot's targets two frames later.  R3N_PIPELINE=0 disables the overlap.
     hipStream_t shade = nullptr;
@@ -76,7 +82,22 @@ struct r3n_ctx {
     int slot = 0;
     uint64_t frame_no = 0;
     bool overlap = true;
-    DevBuf alt_vis, alt_atlas, alt_fu, alt_dir, alt_point, alt_vp_baked, alt_vp_hdr;
+    bool fused_frame = false;  // inside r3n_render_frame: a camera's bake and object pass are ONE launch, issued at its r3n_uniform_bake
+    DevBuf alt_vis, alt_atlas, alt_vp_baked;
+    // Frame-constants block: FrameUniforms, the viewport's camera header, the directional-light buffer, every shadow view's camera
+    // header and the point-light buffer of one frame live in ONE device block per frame slot (fu / dir_buf / point_buf / d_hdr
+    // point into it), filled through one pinned host image per frame in flight: r3n_render_frame uploads a frame's constants
+    // with ONE copy; the per-node path uploads uniforms + lights at r3n_frame_begin and each header at its r3n_uniform_bake.
+    static constexpr size_t kFbUniforms = 0, kFbViewportHdr = 512, kFbDir = 768, kFbShadowHdr = 3072,
+                            kFbPoint = kFbShadowHdr + 256 * R3N_MAX_SHADOW_VIEWS, kFbBytes = kFbPoint + 8448;
+    static constexpr int kFbHost = 4;
+    DevBuf fb_dev[2];
+    uint8_t *fb_host[kFbHost] = {};
+    hipEvent_t fb_ev[kFbHost] = {};
+    bool fb_pending[kFbHost] = {};
+    // fork_lane is a no-op while nothing the lanes depend on has been enqueued on the main stream since their last fork
+    uint64_t main_epoch = 1, lane_epoch[R3N_AUX_STREAMS] = {};
+    DevBuf big_count_all;  // the work-queue counters of every lane: zeroed once per frame
     std::vector<uint8_t> h_dir, h_point;   // the light buffers as last written (uploaded into the frame's slot at frame_begin)
     uint64_t lights_version = 1, slot_lights_version[2] = {0, 0};
     hipEvent_t join_ev[R3N_AUX_STREAMS] = {};
@@ -109,13 +130,16 @@ struct r3n_ctx {
     bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
+    DevBuf hiz_ticket;             // k_hiz_head's last-block ticket (returns to 0 by itself)
+    bool hiz_fused = true;         // R3N_HIZ_FUSED=0: the pyramid's tail as its own launch
     bool hiz_plane_ready = false;  // mip 0 already holds the (merged) pass-1 depth: r3n_exchange_depth
     // transparent pass (row N3)
     DevBuf tri_rec, tri_seen;  // per-triangle vertex-stage records of the resolve (kernels_raster.h TriRecord)
-    DevBuf blend_order, blend_rank_base, frag_keys[2], frag_vals[2], frag_count, sort_temp, samples16;
+    DevBuf blend_order, blend_rank_base, frag_keys, frag_vals, frag_count, frag_head, samples16;
+    uint32_t *status_host = nullptr, *status_dev = nullptr;  // host-mapped word the kernels raise when a fixed-size buffer ran out
     std::vector<uint32_t> h_blend_order;
     uint32_t n_blend = 0, blend_tris = 0;
-    uint32_t frag_capacity = 32u << 20;  // fragments (24 B each incl. the sort's double buffers), allocated on first use
+    uint32_t frag_capacity = 32u << 20;  // fragment nodes (12 B each), allocated on first use
     DevBuf tex_descs, tex_texels, tex_level_off, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
     uint64_t n_texels = 0;
@@ -149,6 +173,10 @@ struct r3n_ctx {
     uint32_t stage_next = 0;
     hipEvent_t stage_half_done[2] = {nullptr, nullptr};
     bool stage_half_pending[2] = {false, false};
+    // pinned staging for LARGE per-frame uploads (joint matrices, pose requests): the caller owns its pointer only for the duration
+    // of the call and the frame path must not wait for the GPU; a buffer is reused once the copy issued from it has executed
+    struct Bulk { uint8_t *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; } bulk[4];
+    uint32_t bulk_next = 0;
     // timing taps
     bool timing = false;
     struct Span { hipEvent_t a, b; int stage; };
@@ -181,6 +209,7 @@ int join_lanes(r3n_ctx *c);
 int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
     if (bytes <= b.bytes && b.p) return R3N_OK;
     size_t want = std::max<size_t>(bytes, 256);
+    ++c->main_epoch;  // copies / fills below run on the main stream
     if (b.bytes) want = std::max(want, b.bytes + b.bytes / 2);  // amortised growth
     void *np = nullptr;
     HIP_TRY(c, hipMalloc(&np, want));
@@ -222,10 +251,46 @@ int upload_small(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     uint8_t *h = c->stage + (size_t)slot * r3n_ctx::kStageSlotBytes;
     std::memcpy(h, src, bytes);
     HIP_TRY(c, hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, c->stream));
+    ++c->main_epoch;
     c->stage_next = (slot + 1) % r3n_ctx::kStageSlots;
     if (c->stage_next % half_slots == 0) {
         HIP_TRY(c, hipEventRecord(c->stage_half_done[half], c->stream));
         c->stage_half_pending[half] = true;
+    }
+    return R3N_OK;
+}
+
+// Asynchronous upload of any size through the pinned bulk buffers (round robin).
+int upload_bulk(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes <= r3n_ctx::kStageSlotBytes) return upload_small(c, dst, src, bytes);
+    r3n_ctx::Bulk &b = c->bulk[c->bulk_next];
+    c->bulk_next = (c->bulk_next + 1u) % 4u;
+    if (b.pending) {
+        HIP_TRY(c, hipEventSynchronize(b.ev));
+        b.pending = false;
+    }
+    if (b.bytes < bytes) {
+        if (b.p) (void)hipHostFree(b.p);
+        b.p = nullptr; b.bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        HIP_TRY(c, hipHostMalloc((void **)&b.p, want, hipHostMallocDefault));
+        b.bytes = want;
+    }
+    if (!b.ev) HIP_TRY(c, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+    std::memcpy(b.p, src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(dst, b.p, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(b.ev, c->stream));
+    b.pending = true;
+    ++c->main_epoch;
+    return R3N_OK;
+}
+
+// A kernel of an EARLIER call ran out of a fixed-size buffer (transparent pass: fragment nodes / work items).  Nothing on the
+// frame path reads counts back, so the condition surfaces here: at the next frame, sync or read-back.
+int check_async_status(r3n_ctx *c) {
+    if (c->status_host && c->status_host[0] != 0u) {
+        c->status_host[0] = 0u;
+        return fail(c, R3N_ERR_CAPACITY, "an earlier transparent pass overflowed the fragment buffer or the raster work queue (r3n_config.max_big_items); that frame's image is incomplete");
     }
     return R3N_OK;
 }
@@ -271,9 +336,11 @@ hipStream_t lane_stream(const r3n_ctx *c, int lane) { return lane == 0 ? c->stre
 int fork_lane(r3n_ctx *c, int lane) {
     if (lane == 0) return R3N_OK;
     const int k = lane - 1;
+    c->aux_used[k] = true;
+    if (c->lane_epoch[k] == c->main_epoch) return R3N_OK;  // already ordered behind everything the main stream holds for it
     HIP_TRY(c, hipEventRecord(c->fork_ev[k], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->aux[k], c->fork_ev[k], 0));
-    c->aux_used[k] = true;
+    c->lane_epoch[k] = c->main_epoch;
     return R3N_OK;
 }
 // Order the main stream after everything enqueued on the auxiliary streams so far.
@@ -320,7 +387,7 @@ CamState *find_cam(r3n_ctx *c, r3n_camera cam, bool create) {
 }
 
 void free_cam(CamState &s) {
-    DevBuf *bufs[] = {&s.d_hdr, &s.baked, &s.vis_flags, &s.vis_list, &s.block_sums, &s.block_off, &s.slot_base[0],
+    DevBuf *bufs[] = {&s.own_hdr, &s.chain, &s.baked, &s.vis_flags, &s.vis_list, &s.block_sums, &s.block_off, &s.slot_base[0],
                       &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.sub_counts[0],
                       &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual, &s.recs, &s.tile_count, &s.tile_list, &s.fb_counts};
     for (DevBuf *b : bufs)
@@ -362,6 +429,30 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
     return check_launch(c, "object pass");
 }
 
+// Bake + object pass of one camera as ONE launch (k_object_pass_chained); false when the world is too large for the chained form.
+bool chained_pass_fits(const r3n_ctx *c) {
+    const uint32_t nblocks = (c->capacity + 255u) / 256u;
+    return nblocks >= 1u && nblocks <= R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS;
+}
+int run_bake_and_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint32_t range_end, hipStream_t stream) {
+    const uint32_t cap = c->capacity;
+    const uint32_t nblocks = (cap + 255u) / 256u;
+    TRY(ensure(c, s.vis_flags, cap, false, -1));
+    TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
+    TRY(ensure(c, s.slot_base[idx], (size_t)cap * 4u, true, 0xFF));
+    TRY(ensure(c, s.sub_counts[idx], sizeof(r3n_sub_counts), false, 0));
+    TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
+    TRY(ensure(c, s.chain, (size_t)nblocks * sizeof(ObjChainRec), false, 0));  // zero tags: no launch has epoch 0
+    if (++s.chain_epoch == 0u) ++s.chain_epoch;
+    Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
+    hipLaunchKernelGGL(k_object_pass_chained<true>, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
+                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin, range_end,
+                       s.vis_flags.as<uint8_t>(), s.chain.as<ObjChainRec>(), s.chain_epoch, s.counts[idx].as<r3n_cull_counts>(),
+                       s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(),
+                       s.baked.as<r3n_baked128>());
+    return check_launch(c, "k_object_pass_chained");
+}
+
 int refresh_tri_base(r3n_ctx *c) {
     if (!c->tri_base_dirty) return R3N_OK;
     if (c->capacity == 0) { c->tri_base_dirty = false; return R3N_OK; }
@@ -370,7 +461,9 @@ int refresh_tri_base(r3n_ctx *c) {
     r3n_camera_header240 h{};
     h.object_count = c->capacity;
     h.shadow_index = 0;
-    TRY(ensure(c, c->canon.d_hdr, sizeof h, false, -1));
+    TRY(ensure(c, c->canon.own_hdr, sizeof h, false, -1));
+    c->canon.d_hdr = c->canon.own_hdr;
+    ++c->main_epoch;  // tri_base / slot_table are rebuilt on the main stream: the lanes' rasterisers read them
     HIP_TRY(c, hipMemcpyAsync(c->canon.d_hdr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
     TRY(run_object_pass(c, c->canon, 0, 0, 0, c->tri_base.as<uint32_t>(), c->stream));
@@ -454,9 +547,17 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         r3n_destroy(c);
         return nullptr;
     }
+    if (hipHostMalloc((void **)&c->status_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->status_dev, c->status_host, 0) != hipSuccess) {
+        g_create_error = "host-mapped status word allocation failed";
+        r3n_destroy(c);
+        return nullptr;
+    }
+    c->status_host[0] = 0u;
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) { c->shadow_tiles = e4[0] == '1' || e4[0] == '2'; c->shadow_bin = e4[0] != '2'; }
+    if (const char *e5 = std::getenv("R3N_HIZ_FUSED")) c->hiz_fused = !(e5[0] == '0');
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
@@ -492,12 +593,27 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     }
     // empty light buffers: count = 0
     bool ok = ensure(c, c->srgb_lut, R3N_SRGB_LUT_SIZE, false, -1) == R3N_OK && ensure(c, c->srgb8_decode, 512 * 4, false, -1) == R3N_OK &&
-              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->tex_level_off, 64, false, 0) == R3N_OK && ensure(c, c->dir_buf, 16, false, 0) == R3N_OK && ensure(c, c->point_buf, 16, false, 0) == R3N_OK &&
+              ensure(c, c->tex_descs, sizeof(r3n_texture_desc32), false, 0) == R3N_OK && ensure(c, c->tex_texels, 4, false, 0) == R3N_OK && ensure(c, c->tex_level_off, 64, false, 0) == R3N_OK &&
               ensure(c, c->material_keys, 256, false, 0) == R3N_OK && ensure(c, c->materials, sizeof(r3n_material208), false, 0) == R3N_OK;
-    for (int lane = 0; ok && lane < 1 + R3N_QLANES; ++lane)
-        ok = ensure(c, c->big_count[lane], 64 * R3N_BIGQ * 4, false, 0) == R3N_OK &&
-             ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK &&
+    // frame-constants blocks (zero: light counts 0) and their pinned host images
+    for (int k = 0; ok && k < 2; ++k) ok = ensure(c, c->fb_dev[k], r3n_ctx::kFbBytes, false, 0) == R3N_OK;
+    for (int k = 0; ok && k < r3n_ctx::kFbHost; ++k)
+        ok = hipHostMalloc((void **)&c->fb_host[k], r3n_ctx::kFbBytes, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&c->fb_ev[k], hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        for (int k = 0; k < r3n_ctx::kFbHost; ++k) std::memset(c->fb_host[k], 0, r3n_ctx::kFbBytes);
+        c->fu.p = c->fb_dev[0].as<uint8_t>() + r3n_ctx::kFbUniforms; c->fu.bytes = 512;
+        c->dir_buf.p = c->fb_dev[0].as<uint8_t>() + r3n_ctx::kFbDir; c->dir_buf.bytes = r3n_ctx::kFbShadowHdr - r3n_ctx::kFbDir;
+        c->point_buf.p = c->fb_dev[0].as<uint8_t>() + r3n_ctx::kFbPoint; c->point_buf.bytes = 8448;
+    }
+    ok = ok && ensure(c, c->hiz_ticket, 256, false, 0) == R3N_OK;
+    ok = ok && ensure(c, c->big_count_all, (size_t)(1 + R3N_QLANES) * 64 * R3N_BIGQ * 4, false, 0) == R3N_OK;
+    for (int lane = 0; ok && lane < 1 + R3N_QLANES; ++lane) {
+        c->big_count[lane].p = c->big_count_all.as<uint32_t>() + (size_t)lane * 64 * R3N_BIGQ;  // not owned
+        c->big_count[lane].bytes = 64 * R3N_BIGQ * 4;
+        ok = ensure(c, c->big_items[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_item), false, -1) == R3N_OK &&
              ensure(c, c->big_uv[lane], (size_t)c->big_capacity * R3N_BIGQ * sizeof(r3n_big_uv), false, -1) == R3N_OK;
+    }
     if (ok) {
         (void)r3n_internal_build_srgb_lut(c->srgb_lut.as<unsigned char>(), c->stream);
         // sRGB8 -> linear decode table for texture fetches: built on the HOST (libm powf, like the oracle's), because
@@ -548,13 +664,17 @@ void r3n_destroy(r3n_ctx *c) {
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
         if (c->aux[k]) (void)hipStreamSynchronize(c->aux[k]);
     for (int lane = 0; lane < 1 + R3N_QLANES; ++lane)
-        for (DevBuf *b : {&c->big_items[lane], &c->big_uv[lane], &c->big_count[lane]})
+        for (DevBuf *b : {&c->big_items[lane], &c->big_uv[lane]})
             if (b->p) (void)hipFree(b->p);
-    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->dir_buf, &c->point_buf, &c->fu,
+    for (int k = 0; k < r3n_ctx::kFbHost; ++k) {
+        if (c->fb_host[k]) (void)hipHostFree(c->fb_host[k]);
+        if (c->fb_ev[k]) (void)hipEventDestroy(c->fb_ev[k]);
+    }
+    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->fb_dev[0], &c->fb_dev[1], &c->big_count_all, &c->hiz_ticket,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
-                      &c->skin_wave_first, &c->skin_joint_counts, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_fu, &c->alt_dir, &c->alt_point, &c->alt_vp_baked, &c->alt_vp_hdr, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
-                      &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys[0], &c->frag_keys[1], &c->frag_vals[0], &c->frag_vals[1],
-                      &c->frag_count, &c->sort_temp, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
+                      &c->skin_wave_first, &c->skin_joint_counts, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_vp_baked, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
+                      &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys, &c->frag_vals, &c->frag_head,
+                      &c->frag_count, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
                       &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
                       &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1]};
     for (DevBuf *b : bufs)
@@ -574,6 +694,11 @@ void r3n_destroy(r3n_ctx *c) {
         if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
     }
     if (c->stage) (void)hipHostFree(c->stage);
+    if (c->status_host) (void)hipHostFree(c->status_host);
+    for (auto &b : c->bulk) {
+        if (b.p) (void)hipHostFree(b.p);
+        if (b.ev) (void)hipEventDestroy(b.ev);
+    }
     for (auto e : c->stage_half_done)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -584,7 +709,8 @@ const char *r3n_last_error(const r3n_ctx *c) { return c ? c->err.c_str() : g_cre
 
 int r3n_sync(r3n_ctx *c) {
     if (!c) return R3N_ERR_INVALID_ARG;
-    return sync_all(c);
+    TRY(sync_all(c));
+    return check_async_status(c);
 }
 
 void *r3n_stream(r3n_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -837,7 +963,7 @@ int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void
         std::memcpy(&count, src, 4);
         if ((uint64_t)count * stride + 16 > bytes) return fail(c, R3N_ERR_INVALID_ARG, "lights write: count exceeds buffer");
         if (count > cap) return fail(c, R3N_ERR_UNSUPPORTED, "lights write: more lights than the LDS light list holds");
-        h.assign(static_cast<const uint8_t *>(src), static_cast<const uint8_t *>(src) + bytes);
+        h.assign(static_cast<const uint8_t *>(src), static_cast<const uint8_t *>(src) + 16u + (size_t)count * stride);  // what the shader reads: count + array
         return R3N_OK;
     };
     const std::vector<uint8_t> old_dir = c->h_dir, old_point = c->h_point;
@@ -848,12 +974,14 @@ int r3n_lights_write(r3n_ctx *c, const void *dir, uint64_t dir_bytes, const void
 }
 
 // ------------------------------------------------------------------------------------------------ frame
-int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint32_t h, uint32_t samples,
-                    const float clear_color[4], uint32_t atlas_w, uint32_t atlas_h) {
+// r3n_frame_begin; `d` (r3n_render_frame only) carries every camera header of the frame: they go up with the uniforms in one copy
+static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint32_t h, uint32_t samples,
+                            const float clear_color[4], uint32_t atlas_w, uint32_t atlas_h, const r3n_frame_desc *d) {
     if (!c || !u || !clear_color || !w || !h) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: bad args");
     if (samples != 1 && samples != 4) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: samples must be 1 or 4 (SampleCount::One | Four)");
     if (w > 65535 || h > 65535) return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: target larger than 65535");
     HIP_TRY(c, hipSetDevice(c->device));
+    TRY(check_async_status(c));
     if (w != c->width || h != c->height) {
         // resolution change invalidates the temporal history exactly like a new CullingBufferMap entry would
         c->viewport.has_prev = false;
@@ -861,30 +989,47 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     c->width = w; c->height = h; c->samples = samples; c->atlas_w = atlas_w; c->atlas_h = atlas_h;
     std::memcpy(c->clear, clear_color, 16);
     // frames in flight: this frame renders into the other set of targets / per-frame inputs
+    const int hs = (int)(c->frame_no % (uint64_t)r3n_ctx::kFbHost);
     c->slot = (int)(c->frame_no++ & 1u);
     std::swap(c->vis, c->alt_vis);
     std::swap(c->atlas, c->alt_atlas);
-    std::swap(c->fu, c->alt_fu);
-    std::swap(c->dir_buf, c->alt_dir);
-    std::swap(c->point_buf, c->alt_point);
     std::swap(c->viewport.baked, c->alt_vp_baked);
-    std::swap(c->viewport.d_hdr, c->alt_vp_hdr);
+    uint8_t *dev = c->fb_dev[c->slot].as<uint8_t>();
+    c->fu.p = dev + r3n_ctx::kFbUniforms;
+    c->dir_buf.p = dev + r3n_ctx::kFbDir;
+    c->point_buf.p = dev + r3n_ctx::kFbPoint;
+    c->viewport.d_hdr.p = dev + r3n_ctx::kFbViewportHdr; c->viewport.d_hdr.bytes = 256;
+    for (auto &kv : c->shadows) { kv.second.d_hdr.p = dev + r3n_ctx::kFbShadowHdr + 256u * (size_t)kv.first; kv.second.d_hdr.bytes = 256; }
     if (c->shade_pending[c->slot]) {  // the resolve that last read this set (two frames ago)
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->shade_done[c->slot], 0));
         c->shade_pending[c->slot] = false;
     }
-    if (c->slot_lights_version[c->slot] != c->lights_version) {
-        if (c->h_dir.size() < 16) c->h_dir.assign(16, 0);
-        if (c->h_point.size() < 16) c->h_point.assign(16, 0);
-        TRY(ensure(c, c->dir_buf, c->h_dir.size(), false, -1));
-        TRY(ensure(c, c->point_buf, c->h_point.size(), false, -1));
-        TRY(upload_small(c, c->dir_buf.p, c->h_dir.data(), c->h_dir.size()));
-        TRY(upload_small(c, c->point_buf.p, c->h_point.data(), c->h_point.size()));
+    // the frame's constants: uniforms + directional lights (they follow the camera: every frame) [+ every camera header], one copy
+    if (c->fb_pending[hs]) {  // the copy that last read this pinned image (kFbHost frames ago)
+        HIP_TRY(c, hipEventSynchronize(c->fb_ev[hs]));
+        c->fb_pending[hs] = false;
+    }
+    uint8_t *host = c->fb_host[hs];
+    std::memcpy(host + r3n_ctx::kFbUniforms, u, sizeof *u);
+    if (c->h_dir.size() < 16) c->h_dir.assign(16, 0);
+    if (c->h_point.size() < 16) c->h_point.assign(16, 0);
+    std::memcpy(host + r3n_ctx::kFbDir, c->h_dir.data(), c->h_dir.size());  // <= 16 + 128 * R3N_MAX_DIR_LIGHTS (r3n_lights_write)
+    size_t upto = r3n_ctx::kFbShadowHdr;
+    if (d) {
+        std::memcpy(host + r3n_ctx::kFbViewportHdr, d->viewport_header, sizeof(r3n_camera_header240));
+        for (uint32_t v = 0; v < d->n_shadow_views; ++v)
+            std::memcpy(host + r3n_ctx::kFbShadowHdr + 256u * (size_t)v, &d->shadow_views[v].header, sizeof(r3n_camera_header240));
+        upto += 256u * (size_t)d->n_shadow_views;
+    }
+    HIP_TRY(c, hipMemcpyAsync(dev, host, upto, hipMemcpyHostToDevice, c->stream));
+    if (c->slot_lights_version[c->slot] != c->lights_version) {  // point lights: only when they changed
+        std::memcpy(host + r3n_ctx::kFbPoint, c->h_point.data(), c->h_point.size());
+        HIP_TRY(c, hipMemcpyAsync(dev + r3n_ctx::kFbPoint, host + r3n_ctx::kFbPoint, c->h_point.size(), hipMemcpyHostToDevice, c->stream));
         c->slot_lights_version[c->slot] = c->lights_version;
     }
+    HIP_TRY(c, hipEventRecord(c->fb_ev[hs], c->stream));
+    c->fb_pending[hs] = true;
     const size_t npix = (size_t)w * h;
-    TRY(ensure(c, c->fu, sizeof *u, false, -1));
-    TRY(upload_small(c, c->fu.p, u, sizeof *u));
     TRY(ensure(c, c->vis, npix * samples * 8, false, -1));
     TRY(ensure(c, c->hdr16, npix * 8, false, -1));
     TRY(ensure(c, c->out8, npix * 4, false, -1));
@@ -897,7 +1042,11 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
         // depth clear 0.0 / no triangle (base.rs:259-263) and shadow atlas clear 0.0 (clear.rs:4-20)
         HIP_TRY(c, hipMemsetAsync(c->vis.p, 0, npix * samples * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->atlas.p, 0, apix * 4, c->stream));
+        // the work-queue counters of every r3n_forward of the frame, every lane (r3n_frame_end ordered the main stream behind the
+        // lanes' last use)
+        HIP_TRY(c, hipMemsetAsync(c->big_count_all.p, 0, c->big_count_all.bytes, c->stream));
     }
+    ++c->main_epoch;
     TRY(refresh_tri_base(c));
     c->in_frame = true;
     for (auto &f : c->forward_index_lane) f = 0;
@@ -907,6 +1056,11 @@ int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint
     c->viewport.culled = false;
     for (auto &kv : c->shadows) kv.second.culled = false;
     return R3N_OK;
+}
+
+int r3n_frame_begin(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t w, uint32_t h, uint32_t samples,
+                    const float clear_color[4], uint32_t atlas_w, uint32_t atlas_h) {
+    return frame_begin_impl(c, u, w, h, samples, clear_color, atlas_w, atlas_h, nullptr);
 }
 
 int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, const float *joint_matrices, uint32_t n_joints) {
@@ -969,10 +1123,7 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors above are temporaries
     }
     TRY(ensure(c, c->skin_matrices, (size_t)n_joints * 64, true, -1));
-    if (joint_matrices) {
-        HIP_TRY(c, hipMemcpyAsync(c->skin_matrices.p, joint_matrices, (size_t)n_joints * 64, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns `joint_matrices` only for the duration of the call
-    }
+    if (joint_matrices) TRY(upload_bulk(c, c->skin_matrices.p, joint_matrices, (size_t)n_joints * 64));  // pinned staging: no wait for the GPU
     if (c->n_pose_requests) {  // rend3-anim: poses queued by r3n_pose_skeletons overwrite their skeletons' matrices
         Timed t(c, R3N_STAGE_POSE);
         const int e = r3n_internal_pose_skeletons(c->pose_requests.p, c->n_pose_requests, c->anim_rigs.p, c->anim_joints.p, c->anim_clips.p,
@@ -983,6 +1134,7 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         if (e != 0) return fail(c, R3N_ERR_HIP, std::string("k_pose_skeletons: ") + hipGetErrorString((hipError_t)e));
     }
     if (c->skin_total_waves == 0) return R3N_OK;
+    ++c->main_epoch;  // the shadow lanes read the skinned attribute runs
     Timed t(c, R3N_STAGE_SKINNING);
     if (c->skinning_mode == R3N_SKIN_MFMA) {
         if (c->skin_max_joints > 4u) return fail(c, R3N_ERR_UNSUPPORTED, "skinning: R3N_SKIN_MFMA handles rigs of at most four joints (one 16 x 16 x 4 tile holds four joint matrices)");
@@ -1075,8 +1227,7 @@ int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t 
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(ensure(c, c->pose_requests, std::max<size_t>(n, 1) * sizeof *requests, false, -1));
     if (n) {
-        HIP_TRY(c, hipMemcpyAsync(c->pose_requests.p, requests, (size_t)n * sizeof *requests, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        TRY(upload_bulk(c, c->pose_requests.p, requests, (size_t)n * sizeof *requests));  // pinned staging: no wait for the GPU
     }
     c->n_pose_requests = n;
     c->pose_matrix_end = end;
@@ -1260,7 +1411,9 @@ static int flush_shadows(r3n_ctx *c) {
             for (size_t first = 0; first < hr[g][key].size(); first += per_launch) {
                 const unsigned nv = (unsigned)std::min<size_t>(per_launch, hr[g][key].size() - first);
                 const RasterArgs *views = c->shadow_rargs[key].as<RasterArgs>() + r_first[g][key] + first;
-                for (unsigned k = 0; k < nv; ++k) HIP_TRY(c, hipMemsetAsync(hr[g][key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
+                for (unsigned k = 0; k < nv; ++k)  // counters past the ones zeroed at frame begin
+                    if (hr[g][key][first + k].big_count == c->big_count[1 + g * (int)per_launch + (int)((first + k) % per_launch)].as<uint32_t>() + (size_t)63 * R3N_BIGQ)
+                        HIP_TRY(c, hipMemsetAsync(hr[g][key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
                 Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream);
                 const unsigned gs = c->shadow_bin ? R3N_FB_SMALL_GRID : R3N_SMALL_GRID, gb = c->shadow_bin ? R3N_FB_BIG_GRID : R3N_BIG_GRID;
                 if (tex) {
@@ -1287,8 +1440,10 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     s->hdr = *hdr;
     s->has_hdr = true;
     if (c->capacity == 0) return R3N_OK;  // culler.rs:449-451
-    TRY(ensure(c, s->d_hdr, sizeof *hdr, false, -1));
-    TRY(upload_small(c, s->d_hdr.p, hdr, sizeof *hdr));
+    // the camera's header lives in the frame-constants block of the current frame slot
+    s->d_hdr.p = c->fb_dev[c->slot].as<uint8_t>() + (cam == R3N_CAMERA_VIEWPORT ? r3n_ctx::kFbViewportHdr : r3n_ctx::kFbShadowHdr + 256u * (size_t)cam);
+    s->d_hdr.bytes = 256;
+    if (s->hdr_frame != c->frame_no) TRY(upload_small(c, s->d_hdr.p, hdr, sizeof *hdr));  // else: it went up with the frame's constants
     // per-camera buffer regrow preserves old matrices (disabled slots keep stale data, App. D.2)
     TRY(ensure(c, s->baked, (size_t)c->capacity * sizeof(r3n_baked128), true, 0));
     if (cam != R3N_CAMERA_VIEWPORT && c->shadow_tiles) {  // shadow views: issued batched over all views (flush_shadows)
@@ -1298,6 +1453,23 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     }
     if (cam == R3N_CAMERA_VIEWPORT) TRY(flush_shadows(c));  // reference order (base.rs:148-156): the shadow nodes precede the viewport's
     const int lane = cam_lane(c, cam);
+    if (c->fused_frame && c->in_frame && chained_pass_fits(c)) {
+        // r3n_render_frame: this camera's r3n_cull follows in the same frame with the same header and ranges, and its object pass
+        // (frustum test + slot assignment) depends on nothing the frame computes in between -- bake and object pass go out as ONE
+        // launch now; r3n_cull then issues the triangle cull alone (for the viewport that takes three launches off the serial
+        // chain between Hi-Z and the triangle cull)
+        TRY(ensure(c, s->chain, (size_t)((c->capacity + 255u) / 256u) * sizeof(ObjChainRec), false, 0));
+        TRY(ensure(c, s->vis_flags, c->capacity, false, -1));
+        TRY(ensure(c, s->vis_list, (size_t)(c->capacity + 1u) * sizeof(r3n_vis_entry), false, -1));
+        TRY(ensure(c, s->slot_base[s->cur], (size_t)c->capacity * 4u, true, 0xFF));
+        TRY(ensure(c, s->sub_counts[s->cur], sizeof(r3n_sub_counts), false, 0));
+        TRY(ensure(c, s->counts[s->cur], sizeof(r3n_cull_counts), false, 0));
+        TRY(fork_lane(c, lane));
+        TRY(run_bake_and_object_pass(c, *s, s->cur, s->range_set ? s->range_begin : c->range_begin, s->range_set ? s->range_end : c->range_end,
+                                     lane_stream(c, lane)));
+        s->object_pass_frame = c->frame_no;
+        return R3N_OK;
+    }
     TRY(fork_lane(c, lane));  // after the header upload (main stream)
     hipStream_t stream = lane_stream(c, lane);
     Timed t(c, R3N_STAGE_BAKE, stream);
@@ -1346,7 +1518,8 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     TRY(ensure(c, s->predicted[cur], list_bytes, false, -1));
     if (viewport) TRY(ensure(c, s->residual, list_bytes, false, -1));
     TRY(fork_lane(c, lane));
-    TRY(run_object_pass(c, *s, cur, s->range_set ? s->range_begin : c->range_begin, s->range_set ? s->range_end : c->range_end, nullptr, stream));
+    if (s->object_pass_frame != c->frame_no)  // else: issued with the bake (r3n_render_frame)
+        TRY(run_object_pass(c, *s, cur, s->range_set ? s->range_begin : c->range_begin, s->range_set ? s->range_end : c->range_end, nullptr, stream));
     TriCullArgs a{};
     a.hdr = s->d_hdr.as<r3n_camera_header240>();
     a.objects = c->objects.as<r3n_object128>();
@@ -1385,10 +1558,13 @@ int r3n_hi_z(r3n_ctx *c) {
     while (levels < 4u && levels + 1u < c->hizd.mips && ((c->width >> levels) % 2u == 0u) && ((c->height >> levels) % 2u == 0u) &&
            (c->width >> levels) >= 2u && (c->height >> levels) >= 2u)
         ++levels;
+    const bool has_tail = levels + 1u < c->hizd.mips;
+    // the tail: by the last block of the head launch to finish (ticket), or -- R3N_HIZ_FUSED=0 -- a second single-block launch
     hipLaunchKernelGGL(k_hiz_head, dim3((c->width + 31u) / 32u, (c->height + 31u) / 32u), dim3(256), 0, c->stream,
-                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples);
+                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples,
+                       has_tail && c->hiz_fused ? c->hiz_ticket.as<uint32_t>() : nullptr);
     c->hiz_plane_ready = false;
-    if (levels + 1u < c->hizd.mips)
+    if (has_tail && !c->hiz_fused)
         hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, c->stream, c->hiz.as<float>(), c->hizd, levels + 1u);
     return check_launch(c, "hi_z");
 }
@@ -1480,7 +1656,7 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.tex = texture_args(c);
     const uint32_t small_grid = R3N_SMALL_GRID;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
     TRY(fork_lane(c, lane));
-    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
+    if (fwd == 63u) HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));  // the first 63 calls of a lane have counters zeroed at frame begin
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
@@ -1622,10 +1798,6 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     return R3N_OK;
 }
 
-extern "C" int r3n_internal_sort_pairs(void *temp, size_t *temp_bytes, const unsigned long long *keys_in,
-                                       unsigned long long *keys_out, const unsigned int *vals_in, unsigned int *vals_out,
-                                       unsigned int n, int end_bit, hipStream_t stream);
-
 int r3n_blend_order_write(r3n_ctx *c, const uint32_t *objects, uint32_t n) {
     if (!c || (n && !objects)) return fail(c, R3N_ERR_INVALID_ARG, "blend order: null");
     std::vector<uint32_t> rank(n + 1, 0);
@@ -1640,13 +1812,15 @@ int r3n_blend_order_write(r3n_ctx *c, const uint32_t *objects, uint32_t n) {
     TRY(ensure(c, c->blend_order, (size_t)n * 4, false, -1));
     TRY(ensure(c, c->blend_rank_base, (size_t)(n + 1) * 4, false, -1));
     c->h_blend_order.assign(objects, objects + n);
-    HIP_TRY(c, hipMemcpyAsync(c->blend_order.p, objects, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->blend_rank_base.p, rank.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // both sources are caller / stack memory
+    // (the buffers are read by the transparent pass on the main stream: in order with this copy)
+    TRY(upload_bulk(c, c->blend_order.p, objects, (size_t)n * 4));  // through pinned staging: no wait for the GPU
+    TRY(upload_bulk(c, c->blend_rank_base.p, rank.data(), (size_t)(n + 1) * 4));
     return R3N_OK;
 }
 
-// Transparent pass (base.rs:181,451-465): collect -> sort -> ordered blend.  See kernels_raster.h.
+// Transparent pass (base.rs:181,451-465): collect the fragments into per-sample lists -> ordered blend.  See kernels_raster.h /
+// kernels_shade.h.  Nothing is read back: the launches do not depend on the fragment count, a full node buffer / work queue
+// raises the status word (check_async_status).
 static int forward_blend(r3n_ctx *c) {
     CamState &s = c->viewport;
     if (!s.culled || c->blend_tris == 0) return R3N_OK;  // nothing culled this frame / no blend triangles
@@ -1654,10 +1828,11 @@ static int forward_blend(r3n_ctx *c) {
     const uint32_t r0 = std::min(c->row_begin, c->height), r1 = std::min(c->row_end, c->height);
     if (r1 <= r0) return R3N_OK;
     const uint32_t S = c->samples;
-    for (int k = 0; k < 2; ++k) {
-        TRY(ensure(c, c->frag_keys[k], (size_t)c->frag_capacity * 8, false, -1));
-        TRY(ensure(c, c->frag_vals[k], (size_t)c->frag_capacity * 4, false, -1));
-    }
+    const size_t n_samples_all = (size_t)c->width * c->height * S;
+    if (n_samples_all > 0xFFFFFFFEull) return fail(c, R3N_ERR_UNSUPPORTED, "forward: transparent pass needs width * height * samples < 2^32");
+    TRY(ensure(c, c->frag_keys, (size_t)c->frag_capacity * 8, false, -1));
+    TRY(ensure(c, c->frag_vals, (size_t)c->frag_capacity * 4, false, -1));
+    TRY(ensure(c, c->frag_head, n_samples_all * 4, false, -1));
     TRY(ensure(c, c->frag_count, 16, false, 0));
     const int idx = s.cur;
     RasterArgs a{};
@@ -1678,10 +1853,12 @@ static int forward_blend(r3n_ctx *c) {
     a.big_capacity = c->big_capacity;
     a.big_uv = c->big_uv[0].as<r3n_big_uv>();
     a.tex = texture_args(c);
-    a.frag_keys = c->frag_keys[0].as<unsigned long long>();
-    a.frag_vals = c->frag_vals[0].as<uint32_t>();
+    a.frag_keys = c->frag_keys.as<unsigned long long>();
+    a.frag_vals = c->frag_vals.as<uint32_t>();
     a.frag_count = c->frag_count.as<uint32_t>();
     a.frag_capacity = c->frag_capacity;
+    a.frag_head = c->frag_head.as<uint32_t>();
+    a.status = c->status_dev;
     a.row_begin = r0; a.row_end = r1;
     BlendSetupArgs b{};
     b.order = c->blend_order.as<uint32_t>();
@@ -1690,8 +1867,10 @@ static int forward_blend(r3n_ctx *c) {
     b.mask = s.mask[idx].as<unsigned long long>();
     b.slot_base = s.slot_base[idx].as<uint32_t>();
     hipStream_t stream = c->stream;
-    HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
+    const size_t first_sample = (size_t)r0 * c->width * S, n_samples = (size_t)(r1 - r0) * c->width * S;
+    if (fwd == 63u) HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));
     HIP_TRY(c, hipMemsetAsync(a.frag_count, 0, 4, stream));
+    HIP_TRY(c, hipMemsetAsync(a.frag_head + first_sample, 0xFF, n_samples * 4, stream));  // R3N_INVALID: empty lists
     {
         Timed t(c, R3N_STAGE_RASTER, stream);
         hipLaunchKernelGGL(k_blend_setup, dim3((c->blend_tris + 255u) / 256u), dim3(256), 0, stream, a, b);
@@ -1702,30 +1881,13 @@ static int forward_blend(r3n_ctx *c) {
         else hipLaunchKernelGGL((k_raster_big<false, 1, false, true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a);
     }
     TRY(check_launch(c, "blend collect"));
-    // the sort needs the fragment count on the host (only frames with blend objects pay for this round trip)
-    uint32_t n_frag = 0, items[R3N_BIGQ];
-    HIP_TRY(c, hipMemcpyAsync(&n_frag, a.frag_count, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(c, hipMemcpyAsync(items, a.big_count, sizeof items, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(c, hipStreamSynchronize(stream));
-    for (uint32_t q = 0; q < R3N_BIGQ; ++q)
-        if (items[q] > c->big_capacity) return fail(c, R3N_ERR_CAPACITY, "forward: transparent pass overflowed the raster work queue (r3n_config.max_big_items)");
-    if (n_frag > c->frag_capacity) return fail(c, R3N_ERR_CAPACITY, "forward: transparent pass produced more fragments than the fragment buffer holds");
-    if (n_frag == 0) return R3N_OK;
-    int end_bit = 32;
-    for (uint64_t m = (uint64_t)c->width * c->height * S; m; m >>= 1) ++end_bit;
-    size_t temp_bytes = 0;
-    if (r3n_internal_sort_pairs(nullptr, &temp_bytes, nullptr, nullptr, nullptr, nullptr, n_frag, end_bit, stream) != 0)
-        return fail(c, R3N_ERR_HIP, "forward: radix sort sizing failed");
-    TRY(ensure(c, c->sort_temp, std::max<size_t>(temp_bytes, 16), false, -1));
-    if (r3n_internal_sort_pairs(c->sort_temp.p, &temp_bytes, c->frag_keys[0].as<unsigned long long>(),
-                                c->frag_keys[1].as<unsigned long long>(), c->frag_vals[0].as<uint32_t>(),
-                                c->frag_vals[1].as<uint32_t>(), n_frag, end_bit, stream) != 0)
-        return fail(c, R3N_ERR_HIP, "forward: radix sort failed");
     ShadeArgs sa = make_shade_args(c, r0, r1);
     BlendApplyArgs ba{};
-    ba.keys = c->frag_keys[1].as<unsigned long long>();
-    ba.vals = c->frag_vals[1].as<uint32_t>();
-    ba.n = n_frag;
+    ba.keys = c->frag_keys.as<unsigned long long>();
+    ba.vals = c->frag_vals.as<uint32_t>();
+    ba.head = c->frag_head.as<uint32_t>();
+    ba.first_sample = (uint32_t)first_sample;
+    ba.n_samples = (uint32_t)n_samples;
     ba.samples = S == 4 ? c->samples16.as<ushort4>() : c->hdr16.as<ushort4>();
     if (S == 4 && !c->samples16.p) return fail(c, R3N_ERR_STATE, "forward: r3n_blend_order_write must precede r3n_resolve_opaque");
     {
@@ -1850,11 +2012,21 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
         if (d->shadow_views[v].header.shadow_index != v) return fail(c, R3N_ERR_INVALID_ARG, "render_frame: shadow view i must carry shadow_index i");
     if (d->directional_buffer) TRY(r3n_lights_write(c, d->directional_buffer, d->directional_bytes, d->point_buffer, d->point_bytes));
     // clear_shadow_buffers + create_frame_uniforms (base.rs:139,142)
-    TRY(r3n_frame_begin(c, d->uniforms, d->width, d->height, d->samples, d->clear_color, d->shadow_atlas_width, d->shadow_atlas_height));
+    TRY(frame_begin_impl(c, d->uniforms, d->width, d->height, d->samples, d->clear_color, d->shadow_atlas_width, d->shadow_atlas_height, d));
+    // every camera header went up with the uniforms
+    c->viewport.hdr_frame = c->frame_no;
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v)
+        if (CamState *s = find_cam(c, v, true)) {
+            s->hdr_frame = c->frame_no;
+            s->d_hdr.p = c->fb_dev[c->slot].as<uint8_t>() + r3n_ctx::kFbShadowHdr + 256u * (size_t)v;
+            s->d_hdr.bytes = 256;
+        }
     struct Closer {  // an error in the middle must not leave the frame open
         r3n_ctx *c; bool armed = true;
         ~Closer() { if (armed && c->in_frame) { const std::string keep = c->err; (void)r3n_frame_end(c); c->err = keep; } }
     } closer{c};
+    struct Fused { r3n_ctx *c; ~Fused() { c->fused_frame = false; } } fused{c};
+    c->fused_frame = true;
     const bool masked = (d->flags & R3N_FRAME_SHADOW_MASK) != 0u;
     auto mine = [&](uint32_t v) { return !masked || ((d->shadow_view_mask >> v) & 1ull) != 0ull; };
     for (uint32_t v = 0; v < d->n_shadow_views; ++v) {
@@ -1982,7 +2154,7 @@ static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     TRY(join_shade(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return R3N_OK;
+    return check_async_status(c);
 }
 
 int r3n_readback_visible_objects(r3n_ctx *c, r3n_camera cam, uint8_t *flags, uint32_t capacity) {

@@ -8,7 +8,7 @@ extern "C" {
 int r3n_internal_blend_apply(const ShadeArgs *ap, const BlendApplyArgs *bp, uint32_t samples, int tex, hipStream_t stream) {
     const ShadeArgs &sa = *ap;
     const BlendApplyArgs &ba = *bp;
-    const dim3 g((ba.n + 255u) / 256u);
+    const dim3 g((ba.n_samples + 255u) / 256u);
     if (samples == 4) {
         if (tex) hipLaunchKernelGGL((k_blend_apply<4, true>), g, dim3(256), 0, stream, sa, ba);
         else hipLaunchKernelGGL((k_blend_apply<4, false>), g, dim3(256), 0, stream, sa, ba);

@@ -185,11 +185,12 @@ def load_image(g, r, cache, image_index, srgb):
     return cache[key]
 
 
-def material_from_gltf(g, index, mk, r=None, image_cache=None):
+def material_from_gltf(g, index, mk, r=None, image_cache=None, normal_y_down=False):
     """load_materials_and_textures (rend3-gltf/src/lib.rs:806-943): albedo = TextureVertexValue / ValueVertex
     {base_color_factor, srgb: false}; sampler from the base colour texture's magFilter; KHR_texture_transform of the
     base colour texture as uv_transform0; normal texture Bicomponent (2 components, e.g. BC5) / Tricomponent (>= 3) with
-    GltfLoadSettings::default().normal_direction = Up; AO / metallic-roughness packing Combined (same image) |
+    GltfLoadSettings::normal_direction (`normal_y_down`: NormalTextureYDirection::Down, the scene viewer's --normal-y-down);
+    AO / metallic-roughness packing Combined (same image) |
     Split (AO with < 3 components) | SwizzledSplit; emissive TextureValue; alpha mode -> transparency;
     KHR_materials_unlit.  load_default_material (:777-800) when the primitive has no material.
     `r` (a renderer with add_texture_2d) is only needed when the material has textures.
@@ -242,6 +243,7 @@ def material_from_gltf(g, index, mk, r=None, image_cache=None):
              albedo_texture=None if albedo is None else albedo[0], nearest=nearest, uv_transform0=uv_transform,
              normal_texture=normals[0] if normals is not None and normals[1] >= 2 else None,
              normal_mode="bicomponent" if normals is not None and normals[1] == 2 else "tricomponent",
+             normal_y_down=bool(normal_y_down),
              aomr=aomr, emissive_texture=None if emissive is None else emissive[0],
              roughness=pbr.get("roughnessFactor", 1.0), metallic=pbr.get("metallicFactor", 1.0),
              emissive=tuple(m.get("emissiveFactor", [0.0, 0.0, 0.0])),
@@ -251,7 +253,7 @@ def material_from_gltf(g, index, mk, r=None, image_cache=None):
 
 
 def instance_scene(g, r, hm, mk, scale=1.0, enable_directional=True, directional_light_shadow_distance=100.0,
-                   directional_light_resolution=2048):
+                   directional_light_resolution=2048, normal_y_down=False):
     """load_gltf + instance_loaded_scene (rend3-gltf/src/lib.rs:335-379, 493-562): node transforms in topological order
     under parent_transform = scale(s, s, -s for a left-handed renderer); one object per mesh primitive; a skeleton per
     primitive of a skinned node (joint matrices start as identity, add_mesh_by_index :411-457); winding flipped for
@@ -309,7 +311,7 @@ def instance_scene(g, r, hm, mk, scale=1.0, enable_directional=True, directional
                                                uv0=p.get("uv0"), colors=p.get("colors"), mesh_handedness=r.handedness), p["material"])
             mesh, mat_index = meshes[(mi, pi)]
             if mat_index not in materials:
-                rec, key = material_from_gltf(g, mat_index, mk, r, image_cache)
+                rec, key = material_from_gltf(g, mat_index, mk, r, image_cache, normal_y_down=normal_y_down)
                 materials[mat_index] = r.add_material(rec, key)
             if "skin" in node:
                 nj = len(out["inverse_bind_matrices"][node["skin"]])
