@@ -410,6 +410,11 @@ int r3n_render_frame(r3n_ctx *ctx, const r3n_frame_desc *desc);
 /* ---- multi-GPU support: object-range sharding (not in the reference).
  * Only objects with slot in [begin, end) are culled/drawn by this context; buffers stay replicated. */
 int r3n_set_object_range(r3n_ctx *ctx, uint32_t begin, uint32_t end);
+/* The same sharding by OWNER BYTE instead of slot range: this context culls / draws the opaque and cutout objects whose
+ * owners[slot] == rank (a spatial partition -- Morton order of the bounding-sphere centres -- gives every rank a compact region
+ * of the world and of the screen; its slots are not contiguous).  n >= the object capacity (re-send after the object buffer
+ * grows); owners == NULL returns to r3n_set_object_range.  Synchronises (world-edit rate). */
+int r3n_set_object_owners(r3n_ctx *ctx, const uint8_t *owners, uint32_t n, uint32_t rank);
 /* Device pointers + sizes of the exchange buffers, for RCCL (all-reduce MAX over ranks):
  * the 64-bit visibility/depth keys (width*height u64, as int64 non-negative) and the f32 shadow atlas. */
 /* this camera's own object-slot range, overriding r3n_set_object_range for it (a shadow view owned whole by one rank draws

@@ -53,6 +53,7 @@ SIGNATURES = {
     "r3n_frame_end": (cint, [vp]),
     "r3n_render_frame": (cint, [vp, vp]),
     "r3n_set_object_range": (cint, [vp, u32, u32]),
+    "r3n_set_object_owners": (cint, [vp, vp, u32, u32]),
     "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
     "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
     "r3n_exchange_depth": (cint, [vp, vp, vp]),

@@ -39,6 +39,17 @@ __global__ __launch_bounds__(256) void k_uniform_bake(const r3n_camera_header240
 struct ObjBlockSums {
     uint32_t visible, waves, tris_all, key_tris[3];
 };
+// Which opaque / cutout object slots this context culls and draws for a camera (multi-GPU sharding; everything on one GPU):
+// a contiguous slot range, or -- `owners` non-null -- the slots whose owner byte equals `rank` (spatial partitions: the slots of a
+// compact region of the world are not contiguous).
+struct ObjOwn {
+    uint32_t begin, end;
+    const uint8_t *owners;
+    uint32_t rank;
+};
+R3N_DEV bool obj_owned(const ObjOwn &o, uint32_t i) {
+    return o.owners != nullptr ? (uint32_t)o.owners[i] == o.rank : (i >= o.begin && i < o.end);
+}
 
 R3N_DEV uint32_t wave_reduce_add(uint32_t v) {
 #pragma unroll
@@ -57,8 +68,8 @@ R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
 
 // Pass A: frustum test (batching.rs:146, frustum.rs:148-161) + per-block totals.
 R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
-                                const uint8_t *__restrict__ material_keys, uint32_t n_materials, uint32_t range_begin,
-                                uint32_t range_end, uint8_t *__restrict__ vis_flags, ObjBlockSums *__restrict__ block_sums) {
+                                const uint8_t *__restrict__ material_keys, uint32_t n_materials, ObjOwn own,
+                                uint8_t *__restrict__ vis_flags, ObjBlockSums *__restrict__ block_sums) {
     __shared__ uint32_t red[4][6];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t cap = hdr->object_count;
@@ -73,7 +84,7 @@ R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, con
         if (key0 > 2u) key0 = 2u;
         // multi-rank sharding: a rank owns the opaque / cutout objects of its slot range; blend-key objects are culled and
         // drawn by every rank (ordered blending cannot be merged by the MAX reduce of the depth keys)
-        if (ntri > 0u && ((i >= range_begin && i < range_end) || key0 == 2u)) {
+        if (ntri > 0u && (obj_owned(own, i) || key0 == 2u)) {
             const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
             const float c[3] = {sph.x, sph.y, sph.z};
             const float neg_radius = -sph.w;
@@ -112,10 +123,9 @@ R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, con
 __global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240 *__restrict__ hdr,
                                                       const r3n_object128 *__restrict__ objects,
                                                       const uint8_t *__restrict__ material_keys, uint32_t n_materials,
-                                                      uint32_t range_begin, uint32_t range_end,
-                                                      uint8_t *__restrict__ vis_flags,
+                                                      ObjOwn own, uint8_t *__restrict__ vis_flags,
                                                       ObjBlockSums *__restrict__ block_sums) {
-    object_count_body(hdr, objects, material_keys, n_materials, range_begin, range_end, vis_flags, block_sums);
+    object_count_body(hdr, objects, material_keys, n_materials, own, vis_flags, block_sums);
 }
 
 struct ObjBlockOffsets {
@@ -281,8 +291,8 @@ __global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header2
 // launches, so the limit is one round; the small scenes of the tests and examples run through it.
 #define R3N_FUSED_OBJECT_PASS_MAX 1024u
 R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
-                                    const uint8_t *__restrict__ material_keys, uint32_t n_materials, uint32_t range_begin,
-                                    uint32_t range_end, uint8_t *__restrict__ vis_flags, r3n_cull_counts *__restrict__ counts,
+                                    const uint8_t *__restrict__ material_keys, uint32_t n_materials, ObjOwn own,
+                                    uint8_t *__restrict__ vis_flags, r3n_cull_counts *__restrict__ counts,
                                     r3n_vis_entry *__restrict__ vis_list, r3n_sub_counts *__restrict__ sub_counts,
                                     uint32_t *__restrict__ slot_base, uint32_t *__restrict__ tri_base) {
     __shared__ uint32_t wtot[16][3];
@@ -303,7 +313,7 @@ R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr
             const uint32_t mi0 = o->material_index;
             uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
             if (key0 > 2u) key0 = 2u;
-            if (ntri > 0u && ((i >= range_begin && i < range_end) || key0 == 2u)) {  // (see object_count_body)
+            if (ntri > 0u && (obj_owned(own, i) || key0 == 2u)) {  // (see object_count_body)
                 const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
                 const float c[3] = {sph.x, sph.y, sph.z};
                 const float neg_radius = -sph.w;
@@ -360,17 +370,18 @@ R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr
 __global__ __launch_bounds__(1024) void k_object_pass_fused(const r3n_camera_header240 *__restrict__ hdr,
                                                             const r3n_object128 *__restrict__ objects,
                                                             const uint8_t *__restrict__ material_keys, uint32_t n_materials,
-                                                            uint32_t range_begin, uint32_t range_end, uint8_t *__restrict__ vis_flags,
+                                                            ObjOwn own, uint8_t *__restrict__ vis_flags,
                                                             r3n_cull_counts *__restrict__ counts, r3n_vis_entry *__restrict__ vis_list,
                                                             r3n_sub_counts *__restrict__ sub_counts, uint32_t *__restrict__ slot_base,
                                                             uint32_t *__restrict__ tri_base) {
-    object_pass_fused_body(hdr, objects, material_keys, n_materials, range_begin, range_end, vis_flags, counts, vis_list, sub_counts,
+    object_pass_fused_body(hdr, objects, material_keys, n_materials, own, vis_flags, counts, vis_list, sub_counts,
                            slot_base, tri_base);
 }
 
 // Uniform bake + the three object passes in ONE multi-block launch (r3n_render_frame's path): a block bakes and counts its 256
 // object slots, PUBLISHES its six totals, reads the totals of every block in front of it (the exclusive prefix it needs;
-// agent-scope atomics: the L2 of another XCD is not coherent for plain loads) and scatters.  The last block also writes the
+// agent-scope atomics: the L2 of another XCD is not coherent for plain loads; no fences: every published word carries the
+// launch's epoch) and scatters.  The last block also writes the
 // totals.  Same outputs bit for bit as k_object_count / k_object_scan / k_object_scatter (slot order either way).  Records carry
 // the launch's epoch as their tag, so nothing has to be cleared between launches.  A block waits only for blocks with LOWER
 // indices; the host uses this form up to R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS blocks (all resident at once) and the three
@@ -378,15 +389,16 @@ __global__ __launch_bounds__(1024) void k_object_pass_fused(const r3n_camera_hea
 // the viewport's serial chain between Hi-Z and the triangle cull, and ~3 us each on the host.
 #define R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS 512u
 struct ObjChainRec {
-    uint32_t v[6];  // visible, waves, tris_all, key_tris[3]
-    uint32_t tag;   // epoch of the launch that wrote v
-    uint32_t _pad;
+    unsigned long long v[6];  // epoch of the launch that wrote it << 32 | visible, waves, tris_all, key_tris[3]: every word validates
+                              // itself, so publishing needs no release fence (an agent-scope release is a write-back of the XCD's
+                              // whole L2 on this part: measured 1 ms for 8 160 of them in a Hi-Z experiment)
+    unsigned long long _pad[2];
 };
 template <bool BAKE>
 __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_header240 *__restrict__ hdr,
                                                              const r3n_object128 *__restrict__ objects,
                                                              const uint8_t *__restrict__ material_keys, uint32_t n_materials,
-                                                             uint32_t range_begin, uint32_t range_end, uint8_t *__restrict__ vis_flags,
+                                                             ObjOwn own, uint8_t *__restrict__ vis_flags,
                                                              ObjChainRec *chain, uint32_t epoch, r3n_cull_counts *__restrict__ counts,
                                                              r3n_vis_entry *__restrict__ vis_list, r3n_sub_counts *__restrict__ sub_counts,
                                                              uint32_t *__restrict__ slot_base, r3n_baked128 *__restrict__ baked) {
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_he
         const uint32_t mi0 = o->material_index;
         uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
         if (key0 > 2u) key0 = 2u;
-        if (ntri > 0u && ((i >= range_begin && i < range_end) || key0 == 2u)) {
+        if (ntri > 0u && (obj_owned(own, i) || key0 == 2u)) {
             const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
             const float c[3] = {sph.x, sph.y, sph.z};
             const float neg_radius = -sph.w;
@@ -442,19 +454,24 @@ __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_he
         if (lane == 0u) red[wave][k] = sum;
     }
     __syncthreads();
-    uint32_t own = 0;
+    uint32_t mine = 0;
     if (t < 6u) {
-        own = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-        __hip_atomic_store(&chain[blockIdx.x].v[t], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        __hip_atomic_store(&chain[blockIdx.x].v[t], ((unsigned long long)epoch << 32) | (unsigned long long)mine, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();  // the six stores are issued ...
-    if (t == 0u) __hip_atomic_store(&chain[blockIdx.x].tag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // ... and published
     // ---- exclusive prefix over the blocks in front (object_scan_body's result for this block)
     uint32_t acc[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t j = t; j < blockIdx.x; j += 256u) {
-        while (__hip_atomic_load(&chain[j].tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += __hip_atomic_load(&chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 6; ++k) {
+            unsigned long long w = __hip_atomic_load(&chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((uint32_t)(w >> 32) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                w = __hip_atomic_load(&chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            acc[k] += (uint32_t)w;
+        }
     }
     __syncthreads();  // red is reused
 #pragma unroll
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_he
         }
         slot_base[i] = flag ? ws * 64u : R3N_INVALID;
     }
-    if (blockIdx.x == gridDim.x - 1u && t < 6u) red[0][t] = pre[t] + own;  // totals: everything in front + this block
+    if (blockIdx.x == gridDim.x - 1u && t < 6u) red[0][t] = pre[t] + mine;  // totals: everything in front + this block
     __syncthreads();
     if (blockIdx.x == gridDim.x - 1u && t == 0u) {
         counts->visible_objects = red[0][0];

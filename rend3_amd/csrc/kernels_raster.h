@@ -772,33 +772,13 @@ R3N_DEV void hiz_tail_body(float *__restrict__ pyr, const r3n_hiz_desc &d, uint3
         to_a = !to_a;
     }
 }
-// `ticket` != nullptr: the tail of the pyramid (levels + 1 .. mips - 1) is built by the LAST block of this launch to finish instead
-// of a second launch: every block fences its stores and takes a ticket; the block that draws the last one sees the whole level
-// `levels` (agent-scope fence on both sides: other XCDs' L2 slices are not coherent for plain accesses) and walks the remaining
-// levels -- the first one from memory, the small ones through LDS.  One launch less on the frame's serial chain (pass 1 -> Hi-Z ->
-// cull), and no 1024-thread workgroup waiting for half a CU while the previous frame's resolve fills the chip.
-#define R3N_HIZ_FUSED_LDS_A 2304u
-#define R3N_HIZ_FUSED_LDS_B 640u
+// (Measured and removed: building the tail inside this launch by its last block to finish -- every block fences its stores and
+// takes a ticket -- costs 1.0 ms instead of 0.044: an agent-scope release fence is a write-back of the XCD's whole L2 on this
+// part, and 8 160 blocks issue one each.  The tail stays a second, single-block launch.)
 __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__restrict__ vis, float *__restrict__ pyr,
-                                                  r3n_hiz_desc d, uint32_t levels, uint32_t samples, uint32_t *ticket) {
+                                                  r3n_hiz_desc d, uint32_t levels, uint32_t samples) {
     __shared__ float t[16][17];
-    __shared__ float tail_a[R3N_HIZ_FUSED_LDS_A];
-    __shared__ float tail_b[R3N_HIZ_FUSED_LDS_B];
-    __shared__ uint32_t last_block;
     hiz_head_body(vis, pyr, d, levels, samples, t);
-    if (ticket == nullptr) return;
-    __threadfence();  // this block's levels are visible device-wide before its ticket is
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        const uint32_t n = gridDim.x * gridDim.y;
-        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_block = mine == n - 1u ? 1u : 0u;
-        if (mine == n - 1u) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    }
-    __syncthreads();
-    if (last_block == 0u) return;
-    __threadfence();  // acquire: every other block's stores
-    hiz_tail_body(pyr, d, levels + 1u, 256u, tail_a, R3N_HIZ_FUSED_LDS_A, tail_b, R3N_HIZ_FUSED_LDS_B);
 }
 
 __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {

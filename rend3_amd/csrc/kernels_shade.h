@@ -676,6 +676,7 @@ template <bool TEX>
 __global__ __launch_bounds__(256) void k_vertex_stage(ShadeArgs a) {
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= a.total_tris || !a.seen[slot]) return;
+    a.seen[slot] = 0;  // consumed: the flags are all zero again when the launch ends (no clear between frames)
     TriRecord r;
     vertex_stage<TEX>(a, slot + 1u, r);
     r._pad[0] = r._pad[1] = r._pad[2] = r._pad[3] = r._pad[4] = 0u;
@@ -1085,7 +1086,7 @@ static __global__ __launch_bounds__(256) void k_tonemap(const ushort4 *__restric
 // Each returns the hipError_t of the launch as an int.  They only enqueue; ordering, timing spans and buffer sizing stay in r3n.hip.
 extern "C" {
 int r3n_internal_build_srgb_lut(unsigned char *lut, hipStream_t stream);
-// memset of a.seen + k_mark_visible over keys [first_key, first_key + n_keys) + k_vertex_stage over a.total_tris slots
+// k_mark_visible over keys [first_key, first_key + n_keys) + k_vertex_stage over a.total_tris slots
 int r3n_internal_shade_prepass(const ShadeArgs *a, int tex, size_t first_key, size_t n_keys, hipStream_t stream);
 // the resolve of rows [a.row_begin, a.row_end): samples 1 | 4; rec = a.tri_rec holds this frame's records; split = three-pass MSAA resolve
 // fast: R3N_SHADE_FAST (honoured by the single-sample record-based resolve; the other variants always run the exact arithmetic)

@@ -61,7 +61,7 @@ struct ShadowView {
     uint32_t subcap;
     uint32_t vp_x, vp_y, vp_size;      // the view's square viewport in the atlas
     uint32_t tiles_x;                  // ceil(vp_size / R3N_STILE)
-    uint32_t range_begin, range_end;   // object slots this view draws on this rank (multi-GPU sharding)
+    ObjOwn own;                        // object slots this view draws on this rank (multi-GPU sharding)
     uint32_t _pad;
 };
 
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_shadow_bake(ShadowBatchArgs a) {
 }
 __global__ __launch_bounds__(256) void k_shadow_object_count(ShadowBatchArgs a) {
     const ShadowView &V = a.views[blockIdx.y];
-    object_count_body(V.hdr, a.objects, a.material_keys, a.n_materials, V.range_begin, V.range_end, V.vis_flags, V.block_sums);
+    object_count_body(V.hdr, a.objects, a.material_keys, a.n_materials, V.own, V.vis_flags, V.block_sums);
 }
 __global__ __launch_bounds__(1024) void k_shadow_object_scan(ShadowBatchArgs a, uint32_t nblocks) {
     const ShadowView &V = a.views[blockIdx.y];

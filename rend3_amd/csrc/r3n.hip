@@ -130,8 +130,6 @@ struct r3n_ctx {
     bool resolved_this_frame = false;  // the resolve also wrote the tonemapped image
     DevBuf vis, hdr16, out8, out_f32, atlas, hiz;
     r3n_hiz_desc hizd{};
-    DevBuf hiz_ticket;             // k_hiz_head's last-block ticket (returns to 0 by itself)
-    bool hiz_fused = true;         // R3N_HIZ_FUSED=0: the pyramid's tail as its own launch
     bool hiz_plane_ready = false;  // mip 0 already holds the (merged) pass-1 depth: r3n_exchange_depth
     // transparent pass (row N3)
     DevBuf tri_rec, tri_seen;  // per-triangle vertex-stage records of the resolve (kernels_raster.h TriRecord)
@@ -166,6 +164,8 @@ struct r3n_ctx {
     bool shadow_bin = true;     // R3N_SHADOW_TILES=2: the batched path WITHOUT the tile pass (every view in one launch per stage, general rasteriser)
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
+    DevBuf owners;  // r3n_set_object_owners: owner rank per object slot (p == nullptr: slot ranges)
+    uint32_t owner_rank = 0, owners_n = 0;
     // pinned staging ring for small per-frame uploads (headers, uniforms, light buffers): the caller owns its
     // pointers only for the duration of a call, and the frame path must not synchronise with the GPU.
     static constexpr uint32_t kStageSlots = 256, kStageSlotBytes = 4096;
@@ -394,10 +394,18 @@ void free_cam(CamState &s) {
         if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
 }
 
+// the object slots a camera culls / draws here: its own range when it has one (a shadow view owned whole), else the context's
+// owner bytes (spatial partition) or slot range
+ObjOwn camera_own(const r3n_ctx *c, const CamState &s) {
+    if (s.range_set) return ObjOwn{s.range_begin, s.range_end, nullptr, 0u};
+    if (c->owners.p) return ObjOwn{0u, 0u, c->owners.as<uint8_t>(), c->owner_rank};
+    return ObjOwn{c->range_begin, c->range_end, nullptr, 0u};
+}
+
 uint32_t max_waves(const r3n_ctx *c) { return (uint32_t)(c->total_tris / 64u) + c->capacity + 1u; }
 
 // Object pass for one camera state (frustum cull + slot assignment); range (0,0) builds only tri_base.
-int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint32_t range_end, uint32_t *tri_base,
+int run_object_pass(r3n_ctx *c, CamState &s, int idx, ObjOwn own, uint32_t *tri_base,
                     hipStream_t stream) {
     const uint32_t cap = c->capacity;
     const uint32_t nblocks = (cap + 255u) / 256u;
@@ -411,14 +419,14 @@ int run_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint
     Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
     if (cap <= R3N_FUSED_OBJECT_PASS_MAX) {  // small worlds: the three passes in one single-block launch
         hipLaunchKernelGGL(k_object_pass_fused, dim3(1), dim3(1024), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
-                           c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin, range_end,
+                           c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, own,
                            s.vis_flags.as<uint8_t>(), s.counts[idx].as<r3n_cull_counts>(), s.vis_list.as<r3n_vis_entry>(),
                            s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(), tri_base);
         return check_launch(c, "object pass (fused)");
     }
     hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
-                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin,
-                       range_end, s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
+                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, own,
+                       s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
     hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, s.block_sums.as<ObjBlockSums>(), nblocks,
                        s.block_off.as<ObjBlockOffsets>(), s.counts[idx].as<r3n_cull_counts>(),
                        s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>());
@@ -434,7 +442,7 @@ bool chained_pass_fits(const r3n_ctx *c) {
     const uint32_t nblocks = (c->capacity + 255u) / 256u;
     return nblocks >= 1u && nblocks <= R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS;
 }
-int run_bake_and_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_begin, uint32_t range_end, hipStream_t stream) {
+int run_bake_and_object_pass(r3n_ctx *c, CamState &s, int idx, ObjOwn own, hipStream_t stream) {
     const uint32_t cap = c->capacity;
     const uint32_t nblocks = (cap + 255u) / 256u;
     TRY(ensure(c, s.vis_flags, cap, false, -1));
@@ -446,7 +454,7 @@ int run_bake_and_object_pass(r3n_ctx *c, CamState &s, int idx, uint32_t range_be
     if (++s.chain_epoch == 0u) ++s.chain_epoch;
     Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
     hipLaunchKernelGGL(k_object_pass_chained<true>, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
-                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, range_begin, range_end,
+                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, own,
                        s.vis_flags.as<uint8_t>(), s.chain.as<ObjChainRec>(), s.chain_epoch, s.counts[idx].as<r3n_cull_counts>(),
                        s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(),
                        s.baked.as<r3n_baked128>());
@@ -466,7 +474,7 @@ int refresh_tri_base(r3n_ctx *c) {
     ++c->main_epoch;  // tri_base / slot_table are rebuilt on the main stream: the lanes' rasterisers read them
     HIP_TRY(c, hipMemcpyAsync(c->canon.d_hdr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
-    TRY(run_object_pass(c, c->canon, 0, 0, 0, c->tri_base.as<uint32_t>(), c->stream));
+    TRY(run_object_pass(c, c->canon, 0, ObjOwn{0u, 0u, nullptr, 0u}, c->tri_base.as<uint32_t>(), c->stream));
     c->slot_table_size = (uint32_t)(c->total_tris >> R3N_SLOT_TABLE_SHIFT) + 1u;
     TRY(ensure(c, c->slot_table, (size_t)c->slot_table_size * 4u, false, -1));
     hipLaunchKernelGGL(k_build_slot_table, dim3((c->slot_table_size + 255u) / 256u), dim3(256), 0, c->stream,
@@ -507,6 +515,21 @@ int drain_timing(r3n_ctx *c) {
 }
 
 }  // namespace
+
+// The frame's clears in one launch: three zero fills (16-byte stores; a buffer's last < 4 words go singly).
+__global__ __launch_bounds__(256) static void k_frame_clear(uint32_t *__restrict__ a, size_t a_words, uint32_t *__restrict__ b, size_t b_words,
+                                                            uint32_t *__restrict__ c3, size_t c_words) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const size_t stride = (size_t)gridDim.x * 256u, t = (size_t)blockIdx.x * 256u + threadIdx.x;
+    for (size_t i = t; i < a_words / 4u; i += stride) reinterpret_cast<uint4 *>(a)[i] = z;
+    for (size_t i = t; i < b_words / 4u; i += stride) reinterpret_cast<uint4 *>(b)[i] = z;
+    for (size_t i = t; i < c_words / 4u; i += stride) reinterpret_cast<uint4 *>(c3)[i] = z;
+    if (t < 4u) {  // the last < 4 words of each
+        if ((a_words & ~(size_t)3u) + t < a_words) a[(a_words & ~(size_t)3u) + t] = 0u;
+        if ((b_words & ~(size_t)3u) + t < b_words) b[(b_words & ~(size_t)3u) + t] = 0u;
+        if ((c_words & ~(size_t)3u) + t < c_words) c3[(c_words & ~(size_t)3u) + t] = 0u;
+    }
+}
 
 extern "C" {
 
@@ -557,7 +580,6 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) { c->shadow_tiles = e4[0] == '1' || e4[0] == '2'; c->shadow_bin = e4[0] != '2'; }
-    if (const char *e5 = std::getenv("R3N_HIZ_FUSED")) c->hiz_fused = !(e5[0] == '0');
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
@@ -606,7 +628,6 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         c->dir_buf.p = c->fb_dev[0].as<uint8_t>() + r3n_ctx::kFbDir; c->dir_buf.bytes = r3n_ctx::kFbShadowHdr - r3n_ctx::kFbDir;
         c->point_buf.p = c->fb_dev[0].as<uint8_t>() + r3n_ctx::kFbPoint; c->point_buf.bytes = 8448;
     }
-    ok = ok && ensure(c, c->hiz_ticket, 256, false, 0) == R3N_OK;
     ok = ok && ensure(c, c->big_count_all, (size_t)(1 + R3N_QLANES) * 64 * R3N_BIGQ * 4, false, 0) == R3N_OK;
     for (int lane = 0; ok && lane < 1 + R3N_QLANES; ++lane) {
         c->big_count[lane].p = c->big_count_all.as<uint32_t>() + (size_t)lane * 64 * R3N_BIGQ;  // not owned
@@ -670,7 +691,7 @@ void r3n_destroy(r3n_ctx *c) {
         if (c->fb_host[k]) (void)hipHostFree(c->fb_host[k]);
         if (c->fb_ev[k]) (void)hipEventDestroy(c->fb_ev[k]);
     }
-    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->fb_dev[0], &c->fb_dev[1], &c->big_count_all, &c->hiz_ticket,
+    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->fb_dev[0], &c->fb_dev[1], &c->big_count_all, &c->owners,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
                       &c->skin_wave_first, &c->skin_joint_counts, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_vp_baked, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys, &c->frag_vals, &c->frag_head,
@@ -1039,12 +1060,11 @@ static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t
     TRY(ensure(c, c->atlas, apix * 4, false, -1));
     {
         Timed t(c, R3N_STAGE_CLEAR);
-        // depth clear 0.0 / no triangle (base.rs:259-263) and shadow atlas clear 0.0 (clear.rs:4-20)
-        HIP_TRY(c, hipMemsetAsync(c->vis.p, 0, npix * samples * 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->atlas.p, 0, apix * 4, c->stream));
-        // the work-queue counters of every r3n_forward of the frame, every lane (r3n_frame_end ordered the main stream behind the
-        // lanes' last use)
-        HIP_TRY(c, hipMemsetAsync(c->big_count_all.p, 0, c->big_count_all.bytes, c->stream));
+        // ONE launch: depth clear 0.0 / no triangle (base.rs:259-263), shadow atlas clear 0.0 (clear.rs:4-20), and the work-queue
+        // counters of every r3n_forward of the frame, every lane (r3n_frame_end ordered the main stream behind the lanes' last use)
+        hipLaunchKernelGGL(k_frame_clear, dim3(2048), dim3(256), 0, c->stream, c->vis.as<uint32_t>(), npix * samples * 2, c->atlas.as<uint32_t>(), apix,
+                           c->big_count_all.as<uint32_t>(), c->big_count_all.bytes / 4);
+        TRY(check_launch(c, "k_frame_clear"));
     }
     ++c->main_epoch;
     TRY(refresh_tri_base(c));
@@ -1313,8 +1333,7 @@ static int flush_shadows(r3n_ctx *c) {
         v.fb_counts = s.fb_counts.as<uint32_t>();
         v.subcap = subcap;
         v.vp_x = s.vp_x; v.vp_y = s.vp_y; v.vp_size = s.vp_size; v.tiles_x = tiles_x;
-        v.range_begin = s.range_set ? s.range_begin : c->range_begin;
-        v.range_end = s.range_set ? s.range_end : c->range_end;
+        v.own = camera_own(c, s);
         if (s.pend_bake) hv[g][0].push_back(v);
         if (s.pend_cull) hv[g][1].push_back(v);
         if (s.pend_draw[0]) hv[g][2].push_back(v);
@@ -1465,8 +1484,7 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
         TRY(ensure(c, s->sub_counts[s->cur], sizeof(r3n_sub_counts), false, 0));
         TRY(ensure(c, s->counts[s->cur], sizeof(r3n_cull_counts), false, 0));
         TRY(fork_lane(c, lane));
-        TRY(run_bake_and_object_pass(c, *s, s->cur, s->range_set ? s->range_begin : c->range_begin, s->range_set ? s->range_end : c->range_end,
-                                     lane_stream(c, lane)));
+        TRY(run_bake_and_object_pass(c, *s, s->cur, camera_own(c, *s), lane_stream(c, lane)));
         s->object_pass_frame = c->frame_no;
         return R3N_OK;
     }
@@ -1519,7 +1537,7 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     if (viewport) TRY(ensure(c, s->residual, list_bytes, false, -1));
     TRY(fork_lane(c, lane));
     if (s->object_pass_frame != c->frame_no)  // else: issued with the bake (r3n_render_frame)
-        TRY(run_object_pass(c, *s, cur, s->range_set ? s->range_begin : c->range_begin, s->range_set ? s->range_end : c->range_end, nullptr, stream));
+        TRY(run_object_pass(c, *s, cur, camera_own(c, *s), nullptr, stream));
     TriCullArgs a{};
     a.hdr = s->d_hdr.as<r3n_camera_header240>();
     a.objects = c->objects.as<r3n_object128>();
@@ -1558,13 +1576,10 @@ int r3n_hi_z(r3n_ctx *c) {
     while (levels < 4u && levels + 1u < c->hizd.mips && ((c->width >> levels) % 2u == 0u) && ((c->height >> levels) % 2u == 0u) &&
            (c->width >> levels) >= 2u && (c->height >> levels) >= 2u)
         ++levels;
-    const bool has_tail = levels + 1u < c->hizd.mips;
-    // the tail: by the last block of the head launch to finish (ticket), or -- R3N_HIZ_FUSED=0 -- a second single-block launch
     hipLaunchKernelGGL(k_hiz_head, dim3((c->width + 31u) / 32u, (c->height + 31u) / 32u), dim3(256), 0, c->stream,
-                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples,
-                       has_tail && c->hiz_fused ? c->hiz_ticket.as<uint32_t>() : nullptr);
+                       c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples);
     c->hiz_plane_ready = false;
-    if (has_tail && !c->hiz_fused)
+    if (levels + 1u < c->hizd.mips)
         hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, c->stream, c->hiz.as<float>(), c->hizd, levels + 1u);
     return check_launch(c, "hi_z");
 }
@@ -1760,7 +1775,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     // skipped for worlds whose record array would pass 8 GiB)
     if (c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30)) {
         TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
-        TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, -1));
+        TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, 0));  // zero: k_vertex_stage returns every flag it consumes to 0
         a.tri_rec = c->tri_rec.as<TriRecord>();
         a.seen = c->tri_seen.as<unsigned char>();
         Timed t(c, R3N_STAGE_VERTEX, stream);
@@ -2080,6 +2095,22 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
 int r3n_set_object_range(r3n_ctx *c, uint32_t begin, uint32_t end) {
     if (!c || begin > end) return fail(c, R3N_ERR_INVALID_ARG, "set_object_range: begin > end");
     c->range_begin = begin; c->range_end = end;
+    return R3N_OK;
+}
+int r3n_set_object_owners(r3n_ctx *c, const uint8_t *owners, uint32_t n, uint32_t rank) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));  // world-edit rate, not per frame
+    if (!owners || n == 0) {  // back to r3n_set_object_range
+        if (c->owners.p) { (void)hipFree(c->owners.p); c->owners.p = nullptr; c->owners.bytes = 0; }
+        c->owners_n = 0;
+        return R3N_OK;
+    }
+    if (n < c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "set_object_owners: one owner byte per object slot (n >= capacity)");
+    TRY(ensure(c, c->owners, n, false, -1));
+    HIP_TRY(c, hipMemcpy(c->owners.p, owners, n, hipMemcpyHostToDevice));
+    c->owners_n = n;
+    c->owner_rank = rank;
     return R3N_OK;
 }
 int r3n_set_camera_object_range(r3n_ctx *c, r3n_camera cam, uint32_t begin, uint32_t end) {

@@ -19,8 +19,7 @@ int r3n_internal_build_srgb_lut(unsigned char *lut, hipStream_t stream) {
 
 int r3n_internal_shade_prepass(const ShadeArgs *ap, int tex, size_t first_key, size_t n_keys, hipStream_t stream) {
     const ShadeArgs &a = *ap;
-    hipError_t e = hipMemsetAsync(a.seen, 0, (size_t)a.total_tris, stream);
-    if (e != hipSuccess) return (int)e;
+    // a.seen is all zero here: allocated zeroed, and k_vertex_stage clears every flag it consumes
     hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, stream, a.vis, a.seen, first_key, n_keys);
     const dim3 vgrid((unsigned)(((size_t)a.total_tris + 255) / 256));
     if (tex) hipLaunchKernelGGL(k_vertex_stage<true>, vgrid, dim3(256), 0, stream, a);

@@ -1121,7 +1121,6 @@ RUNTIME_SWITCHES = [
     {"R3N_PIPELINE": "0"},           # no frames in flight: the resolve on the main stream
     {"R3N_SINGLE_STREAM": "1"},      # every camera on the main stream
     {"R3N_FRAME_NODES": "1"},        # the host mirror issues the frame node by node (one C call per reference node) instead of r3n_render_frame
-    {"R3N_HIZ_FUSED": "0"},          # the Hi-Z pyramid's tail as its own launch instead of the head's last block
 ]
 
 
