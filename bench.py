@@ -135,6 +135,10 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4),
                     help="3 (default): BASELINE.json configs[2] stand-in, the config the metric is quoted on; 4: configs[3] stand-in "
                          "(emerald_like, 1 048 576 objects / 55 M triangles, 4 shadow views), the workload whose per-rank work is milliseconds")
+    ap.add_argument("--partition", choices=("spatial", "slots"), default="spatial",
+                    help="N > 1: how the viewport's objects are sharded -- spatial (default): owner bytes from the Morton order of the bounding-sphere "
+                         "centres, balanced by triangles, with the pass-1 / pass-2 exchanges limited to the rows inside each rank's screen extent; "
+                         "slots: contiguous object-slot ranges with whole-target collectives")
     ap.add_argument("--scene", default=None, metavar="FILE.glb|FILE.gltf",
                     help="run the benchmark on a real glTF asset through the scene-viewer harness (rend3_amd/scene_viewer.py; its flags "
                          "below; `data` becomes \"asset\"): hand it Bistro.glb with tools/scene_viewer.py's --bistro flags and the line is "
@@ -182,15 +186,21 @@ def main():
     hbm_measured = r.hbm_copy_rate(1 << 30, 5)
     exchange = None
     if distributed:
+        r.evaluate_instructions()  # flush the world: the object buffer's capacity is final
         counts = np.zeros(r.capacity, dtype=np.int64)
+        spheres = np.zeros((r.capacity, 4), dtype=np.float64)
         for h, m in r.object_meta.items():
             counts[h] = r.meshes[m["mesh"]].index_count // 3
-        begin, end = parallel.partition_objects(counts, world)[rank]
-        r.set_object_range(begin, end)
+            spheres[h] = m["sphere"]
         exchange = parallel.Exchange(r, device)
-        exchange.assign_shadow_views(len(r.dir_lights))  # shadow views by view: view v whole on rank v mod N
         rows = parallel.row_ranges(HEIGHT, world)
         exchange.rows_equal = HEIGHT % world == 0
+        if args.partition == "spatial" and exchange.rows_equal and args.samples == 1:
+            owners = parallel.partition_objects_spatial(spheres[:, :3], counts, world)
+            exchange.set_spatial_partition(owners, parallel.partition_bounds(owners, spheres[:, :3], spheres[:, 3], counts, world))
+        else:
+            begin, end = parallel.partition_objects(counts, world)[rank]
+            r.set_object_range(begin, end)
         r._check(r.lib.r3n_set_row_range(r.ctx, rows[rank][0], rows[rank][1]), "r3n_set_row_range")
 
     base = r3.BaseRenderGraph(r)
@@ -350,8 +360,12 @@ def main():
             "config": {"workload": info["workload"],
                        "shade_mode": args.shade_mode,
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
-                       "parallelism": "single GPU" if world == 1 else f"viewport objects by slot range x{world}, shadow views by view (broadcast), RCCL MAX all-reduce of "
-                                                                             "the pass-1 depth plane, MAX reduce-scatter of the pass-2 keys, row all-gather"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"viewport objects by spatial partition (Morton order, owner bytes) x{world}, shadow views by view (broadcast), pass-1 depth and pass-2 keys "
+                           "MAX-reduced onto the row-band owners over RCCL all-to-all limited to each rank's screen-row extent, depth bands + image rows all-gathered"
+                           if exchange is not None and exchange.sparse is not None else
+                           f"viewport objects by slot range x{world}, shadow views by view (broadcast), RCCL MAX all-reduce of the pass-1 depth plane, MAX reduce-scatter of "
+                           "the pass-2 keys, row all-gather")},
             "fps": round(args.steps / elapsed, 2),
             "culled_objects_per_s": round(info["objects"] * cameras / (cull_ms * 1e-3), 1) if cull_ms > 0 else None,
             "culled_mtris_per_s": round(info["triangles"] * cameras / (cull_ms * 1e-3) / 1e6, 1) if cull_ms > 0 else None,

@@ -457,7 +457,14 @@ class OracleRenderer:
         visible = np.zeros(cap, dtype=np.uint8)
         lib.r3o_frustum_cull(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(visible))
         whole_view = self.shadow_views_owned is not None and isinstance(spec, tuple)  # an owned shadow view draws every object
-        if self.object_range is not None and not whole_view:  # multi-rank sharding: this rank owns object slots [begin, end)
+        if getattr(self, "object_owners", None) is not None and not whole_view:  # multi-rank sharding by owner byte (spatial partition)
+            owners, my_rank = self.object_owners
+            _mats, mat_keys = self.material_buffers()
+            is_blend = mat_keys[np.minimum(self.objects[:, 22], len(mat_keys) - 1)] == BLEND
+            outside = np.ones(cap, dtype=bool)
+            outside[: len(owners)] = np.asarray(owners[:cap]) != my_rank
+            visible[outside & ~is_blend] = 0
+        elif self.object_range is not None and not whole_view:  # multi-rank sharding: this rank owns object slots [begin, end)
             b, e = self.object_range
             # ... of the opaque / cutout objects; blend objects are culled and drawn by every rank (ordered blending
             # cannot be merged by a MAX reduce)

@@ -211,6 +211,7 @@ class Renderer:
         self._fc = None  # persistent ctypes blocks of the one-call path
         self._lights_version = 0
         self._capacity_sent = None
+        self._resolution = (0, 0)
         self._write_objects([], force_capacity=True)
 
     def close(self):
@@ -499,6 +500,7 @@ class Renderer:
         self._mark(h, rec)
         # object.rs:273: a new object's sorting location is its transformed bounding-sphere centre
         self.object_meta[h]["location"] = rec.view(f32)[16:19].copy()
+        self.object_meta[h]["sphere"] = rec.view(f32)[16:20].copy()  # world-space bounding sphere (multi-GPU partitioning)
         return h
 
     def add_objects_bulk(self, mesh_ids, material_ids, transforms):
@@ -519,14 +521,16 @@ class Renderer:
         for i in range(n):
             h = self._alloc_handle()
             self.object_meta[h] = dict(mesh=int(mesh_ids[i]), material=int(material_ids[i]), transform=transforms[i], enabled=True,
-                                       location=recs[i].view(f32)[16:19].copy())
+                                       location=recs[i].view(f32)[16:19].copy(), sphere=recs[i].view(f32)[16:20].copy())
             self._mark(h, recs[i])
             handles.append(h)
         return handles
 
     def set_object_transform(self, h, transform):
         self.object_meta[h]["transform"] = np.asarray(transform, dtype=f32).copy()
-        self._mark(h, self._object_record(h))
+        rec = self._object_record(h)
+        self.object_meta[h]["sphere"] = rec.view(f32)[16:20].copy()
+        self._mark(h, rec)
         # object.rs:313: after a transform update the sorting location is the translation
         self.object_meta[h]["location"] = self.object_meta[h]["transform"][12:15].copy()
 
@@ -558,6 +562,20 @@ class Renderer:
         if self._camera is None:
             self._camera = host.CameraState(self._camera_inputs[0], self._camera_inputs[1], self.handedness, self.aspect_ratio)
         return self._camera
+
+    def current_view_proj(self):
+        """view_proj of the camera the last evaluated frame used (f32[16], column-major)."""
+        if self._fc is not None and not self.frame_nodes:
+            return np.array(self._fc["frame"].view_proj[:], dtype=f32)
+        return self.camera.view_proj
+
+    def current_resolution(self):
+        return self._resolution
+
+    def set_object_owners(self, owners, rank):
+        """Multi-GPU sharding by owner byte (parallel.partition_objects_spatial): this rank culls / draws the slots it owns."""
+        owners = np.ascontiguousarray(owners, dtype=np.uint8)
+        self._check(self.lib.r3n_set_object_owners(self.ctx, owners.ctypes.data if len(owners) else None, len(owners), rank), "r3n_set_object_owners")
 
     def set_object_range(self, begin, end):
         """Multi-GPU sharding (not in the reference): this rank culls/draws object slots [begin, end)."""
@@ -614,6 +632,7 @@ class Renderer:
                base=None, exchange=None):
         """The reference's per-frame driver (rend3-test/src/runner.rs:121-169): evaluate, build the graph with
         BaseRenderGraph::add_to_graph, execute.  `readback` additionally pulls the parity taps."""
+        self._resolution = (width, height)
         if not self.frame_nodes:
             eval_output = self.render_frame(width, height, samples, ambient, clear_color, exchange,
                                             viewport_first=bool(base is not None and base.viewport_first))

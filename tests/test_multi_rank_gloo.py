@@ -118,6 +118,123 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_sparse(rank, world, port, q):
+    """The spatial partition + row-limited exchanges: objects by Morton order of their bounding-sphere centres (owner bytes),
+    pass-1 depth and pass-2 keys reduced onto the row-band owners moving only the rows inside each rank's conservative screen
+    extent (parallel.rows_alltoall_max_ over extents every rank derives from the replicated world), merged depth bands
+    all-gathered, image rows all-gathered: equal to the unsharded oracle bit for bit."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rend3_amd import parallel
+    try:
+        full, oh, math = _scene()
+        shard, _, _ = _scene()
+        counts = ((shard.objects[:, 21] // 3) * (shard.objects[:, 29] != 0)).astype(np.int64)
+        spheres = shard.objects[:, 16:20].view(np.float32)
+        owners = parallel.partition_objects_spatial(spheres[:, :3], counts, world)
+        assert set(np.unique(owners[counts > 0])) == set(range(world))
+        loads = [int(counts[(owners == r) & (counts > 0)].sum()) for r in range(world)]
+        assert max(loads) <= 0.7 * sum(loads)
+        bounds = parallel.partition_bounds(owners, spheres[:, :3], spheres[:, 3], counts, world)
+        shard.object_owners = (owners, rank)
+        shard.shadow_views_owned = {v for v in range(len(shard.dir_lights)) if parallel.shadow_view_owner(v, world) == rank}
+        bands = parallel.row_ranges(H, world)
+        sent = {"pass1_depth": 0, "pass2": 0}
+        narrow = []
+
+        def exchange(what, arr, shadows=None):
+            if what == "shadow":
+                parallel.exchange_shadow_views_(torch.from_numpy(arr), shadows, rank, world)
+                return
+            extents = parallel.partition_row_extents(bounds, shard.camera.view_proj, H)
+            narrow.append(extents[rank][1] - extents[rank][0] < H)
+            if what == "pass1_depth":
+                plane = torch.from_numpy(arr)  # f32 depth plane, depth >= 0
+                sent[what] += parallel.rows_alltoall_max_(plane.view(H, W), extents, bands, rank, world)
+                parallel.allgather_rows_(plane, rank, world)
+            else:
+                keys = torch.from_numpy(arr.view(np.int64))
+                sent[what] += parallel.rows_alltoall_max_(keys.view(H, W), extents, bands, rank, world)
+
+        r0, r1 = bands[rank]
+        for f in range(FRAMES):
+            _camera(full, oh, math, f)
+            _camera(shard, oh, math, f)
+            ref = full.render(W, H, ambient=(0.1, 0.1, 0.1, 1), clear_color=(0.1, 0.2, 0.3, 1))
+            got = shard.render(W, H, ambient=(0.1, 0.1, 0.1, 1), clear_color=(0.1, 0.2, 0.3, 1), exchange=exchange)
+            # the Hi-Z every rank culled against is the global one; after the pass-2 exchange the rank's OWN rows are complete
+            assert np.array_equal(ref["hiz"].view(np.uint32), got["hiz"].view(np.uint32)), f"hi-z frame {f}"
+            assert np.array_equal(ref["vis"][r0:r1], got["vis"][r0:r1]), f"vis rows frame {f}"
+            assert np.array_equal(ref["atlas"].view(np.uint32), got["atlas"].view(np.uint32)), f"atlas frame {f}"
+            assert np.array_equal(ref["rgba8"][r0:r1], got["rgba8"][r0:r1]), f"image rows frame {f}"
+            mask = owners == rank
+            assert np.array_equal(got["visible"].astype(bool), ref["visible"].astype(bool) & mask), f"L1 frame {f}"
+            tri_obj = np.searchsorted(ref["tri_base"], np.arange(len(ref["pass"])), side="right") - 1
+            tmask = mask[tri_obj]
+            assert np.array_equal(got["pass"].astype(bool), ref["pass"].astype(bool) & tmask), f"L2 pass frame {f}"
+            assert np.array_equal(got["residual"].astype(bool), ref["residual"].astype(bool) & tmask), f"L2 residual frame {f}"
+            img = torch.from_numpy(got["rgba8"].copy().reshape(-1))
+            parallel.allgather_rows_(img, rank, world)
+            assert np.array_equal(img.numpy().reshape(H, W, 4), ref["rgba8"]), f"gather frame {f}"
+        # the extents did cut rows for somebody on some frame, and less than whole targets moved
+        flags = torch.tensor([1 if any(narrow) else 0, sent["pass2"]], dtype=torch.int64)
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+        assert flags[0].item() >= 1, "no rank ever had a partial row extent: the sparse path was not exercised"
+        assert flags[1].item() < FRAMES * world * (world - 1) / world * W * H * 8, "the row-limited exchange moved as much as the dense one"
+        q.put((rank, "ok"))
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + repr(exc) + "\n" + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spatial_partition_helpers():
+    from rend3_amd import parallel
+    rng = np.random.default_rng(7)
+    centres = rng.uniform(-100, 100, (4000, 3))
+    tris = rng.integers(0, 300, 4000)
+    for world in (2, 4, 8):
+        owners = parallel.partition_objects_spatial(centres, tris, world)
+        live = tris > 0
+        loads = [tris[(owners == r) & live].sum() for r in range(world)]
+        assert max(loads) <= 1.1 * sum(loads) / world
+        # compact: a partition's bounding box is much smaller than the world's
+        vol = [np.prod(np.ptp(centres[(owners == r) & live], axis=0)) for r in range(world)]
+        assert np.median(vol) <= 1.2 * np.prod(np.ptp(centres, axis=0)) / world * 2
+        assert (owners[~live] == 0).all()
+    bounds = parallel.partition_bounds(owners, centres, np.full(4000, 0.5), tris, 8)
+    # an orthographic-like camera looking down -z from far away: extents are conservative and inside the target
+    vp = np.array([0.01, 0, 0, 0, 0, 0.01, 0, 0, 0, 0, 0.001, 0, 0, 0, 0.5, 1], dtype=np.float32)
+    ext = parallel.partition_row_extents(bounds, vp, 1000)
+    for boxes, (y0, y1) in zip(bounds, ext):
+        lo, hi = np.min([b[0] for b in boxes], axis=0), np.max([b[1] for b in boxes], axis=0)
+        rows = (1.0 - np.array([lo[1], hi[1]]) * 0.01) * 500.0
+        assert 0 <= y0 <= max(rows.min(), 0) and min(rows.max(), 1000) <= y1 <= 1000 and y0 <= y1
+    # a corner behind the eye plane: the whole target
+    vp_persp = np.array([0.01, 0, 0, 0, 0, 0.01, 0, 0, 0, 0, 0, 1, 0, 0, 0.1, 0], dtype=np.float32)  # w = z, a very wide view
+    ext = parallel.partition_row_extents(bounds, vp_persp, 1000)
+    assert (0, 1000) in ext and all(0 <= a <= b <= 1000 for a, b in ext)  # boxes straddling the eye plane inside the view: whole target
+
+
+def test_two_rank_gloo_sparse_exact():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def test_partition_and_rows():
     from rend3_amd import parallel
     counts = np.array([10, 0, 0, 5000, 20, 20, 3000, 1, 1, 1, 4000, 7], dtype=np.int64)

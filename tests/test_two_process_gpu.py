@@ -1,0 +1,133 @@
+"""GPU, TWO processes: the multi-GPU path of the product itself (rend3_amd/parallel.py::Exchange driven from r3n_render_frame's
+exchange callbacks) with world size 2 -- one MI355X each over RCCL when the box has two, else both ranks on the one GPU with
+the collectives staged through the host (gloo): what is exercised either way is the product's own code: two HIP contexts in
+two processes, object sharding (slot ranges, and owner bytes from the spatial partition), shadow views by view + broadcast,
+the pass-1 depth exchange in front of Hi-Z, the pass-2 key reduction onto the row owners (dense and row-limited), the split
+resolve and the row gather -- and the result is compared with the SAME process's unsharded HIP render, bit for bit, over
+frames with camera motion (predicted / residual passes, frames in flight)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+W, H, FRAMES = 320, 192, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import math
+    import torch
+    import torch.distributed as dist
+    try:
+        n_dev = torch.cuda.device_count()
+        dev = rank if n_dev >= world else 0
+        torch.cuda.set_device(dev)
+        device = torch.device("cuda", dev)
+        import rend3_amd as r3
+        import scenes
+        from rend3_amd import parallel
+        hm = r3.host
+        f32 = np.float32
+
+        def make():
+            r = r3.Renderer(hm.LEFT, f32(W) / f32(H), device=dev)
+            scenes.build_random_scene(r, hm, r3.material_record, 200, 0xE5A1, lights=2, shadow_res=256, with_cutout=True)
+            return r
+
+        shard, full = make(), make()  # contexts first, the communication library second (r3n_create binds the hardware queues)
+        if n_dev >= world:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        shard.evaluate_instructions()
+        counts = np.zeros(shard.capacity, dtype=np.int64)
+        centres = np.zeros((shard.capacity, 3), dtype=np.float64)
+        radii = np.zeros(shard.capacity, dtype=np.float64)
+        for h, m in shard.object_meta.items():
+            counts[h] = shard.meshes[m["mesh"]].index_count // 3
+            centres[h], radii[h] = m["sphere"][:3], m["sphere"][3]
+        ex = parallel.Exchange(shard, device)
+        ex.rows_equal = H % world == 0
+        if mode == "slots":
+            b, e = parallel.partition_objects(counts, world)[rank]
+            shard.set_object_range(b, e)
+            mask = np.zeros(shard.capacity, dtype=bool)
+            mask[b:e] = True
+        else:
+            owners = parallel.partition_objects_spatial(centres, counts, world)
+            ex.set_spatial_partition(owners, parallel.partition_bounds(owners, centres, radii, counts, world))
+            mask = owners == rank
+        rows = parallel.row_ranges(H, world)
+        shard._check(shard.lib.r3n_set_row_range(shard.ctx, rows[rank][0], rows[rank][1]), "r3n_set_row_range")
+        kw = dict(ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.1, 0.2, 0.3, 1.0))
+        for f in range(FRAMES):
+            ang = 0.25 * f
+            view = hm.look_at_lh((3.0 * math.sin(ang), 1.5, -3.0 * math.cos(ang) - 6.0), (0, 0, 6), (0, 1, 0))
+            for r in (shard, full):
+                r.set_camera_data(view, ("perspective", 60.0, 0.1))
+            ref = full.render(W, H, **kw)
+            got = shard.render(W, H, exchange=ex, **kw)
+            ex.gather_rows(W, H, world)
+            shard.sync()
+            r0, r1 = rows[rank]
+            # this rank's rows of the keys are the unsharded ones after the pass-2 exchange; the atlas is whole everywhere
+            assert np.array_equal(ref["vis"][r0:r1], got["vis"][r0:r1]), f"{mode} rank {rank} frame {f}: keys of the own rows"
+            assert np.array_equal(ref["atlas"].view(np.uint32), got["atlas"].view(np.uint32)), f"{mode} rank {rank} frame {f}: atlas"
+            assert np.array_equal(ref["hdr16"][r0:r1], got["hdr16"][r0:r1]), f"{mode} rank {rank} frame {f}: HDR of the own rows"
+            # the gathered image: every row from its owner
+            out = np.zeros((H, W, 4), dtype=np.uint8)
+            shard._check(shard.lib.r3n_readback_output(shard.ctx, out.ctypes.data, None), "r3n_readback_output")
+            assert np.array_equal(out, ref["rgba8"]), f"{mode} rank {rank} frame {f}: gathered image"
+            # L1 / L2 sets: the unsharded sets restricted to this rank's objects (the Hi-Z it culled against was the global one)
+            assert np.array_equal(got["visible"].astype(bool), ref["visible"].astype(bool) & mask), f"{mode} L1 frame {f}"
+            tri_base = np.concatenate([[0], np.cumsum(counts)])[:-1]
+            tri_obj = np.searchsorted(tri_base, np.arange(len(ref["pass"])), side="right") - 1
+            tmask = mask[np.clip(tri_obj, 0, len(mask) - 1)]
+            n = int(counts.sum())
+            assert np.array_equal(got["pass"][:n].astype(bool), ref["pass"][:n].astype(bool) & tmask[:n]), f"{mode} L2 pass frame {f}"
+            assert np.array_equal(got["residual"][:n].astype(bool), ref["residual"][:n].astype(bool) & tmask[:n]), f"{mode} L2 residual frame {f}"
+        assert ref["residual"].sum() > 0 and ref["pass"].sum() > 100
+        shard.close(); full.close()
+        q.put((rank, "ok"))
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + repr(exc) + "\n" + traceback.format_exc()))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["slots", "spatial"])
+def test_two_processes_exchange_matches_unsharded(mode):
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
