@@ -1,6 +1,9 @@
 //! Owner of the `r3n_ctx` (one HIP device + its streams) and the error convention.
+use rend3::Renderer;
 use rend3_amd_sys as sys;
+use std::collections::HashMap;
 use std::ffi::CStr;
+use std::sync::{Arc, Mutex, OnceLock};
 
 /// Lives next to `Renderer::data_core` (rend3/src/renderer/mod.rs:54-106); created where `Renderer::new` creates the wgpu
 /// device (rend3/src/renderer/setup.rs:20-107), destroyed with the renderer.
@@ -11,8 +14,38 @@ pub struct AmdContext {
 // The reference serialises graph execution behind the data_core mutex (rend3/src/graph/graph.rs:265); the C ABI asks for the
 // same: one thread at a time.
 unsafe impl Send for AmdContext {}
+unsafe impl Sync for AmdContext {}
+
+/// One context per `Renderer`, found FROM the renderer: the routine constructors keep the reference's signatures
+/// (`BaseRenderGraph::new(&renderer, &spp)`, `PbrRoutine::new(&renderer, ...)`, ...), so no call site hands a context
+/// around.  The first constructor that asks creates it (HIP device `R3N_HIP_DEVICE`, default 0; `R3N_SHADE_FAST=1` opts into
+/// the fast fragment arithmetic) and parks a handle in the renderer's graph storage (`Renderer::add_graph_data`,
+/// rend3/src/renderer/mod.rs:385-393), where rend3 keeps cross-frame routine state; the map below is only the lookup.
+static CONTEXTS: OnceLock<Mutex<HashMap<usize, Arc<AmdContext>>>> = OnceLock::new();
 
 impl AmdContext {
+    /// The context of `renderer` (created on first use).
+    pub fn of(renderer: &Arc<Renderer>) -> Arc<AmdContext> {
+        let key = Arc::as_ptr(renderer) as usize;
+        let mut map = CONTEXTS.get_or_init(Default::default).lock().unwrap();
+        if let Some(ctx) = map.get(&key) {
+            return Arc::clone(ctx);
+        }
+        let device = std::env::var("R3N_HIP_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0);
+        let fast = std::env::var("R3N_SHADE_FAST").map_or(false, |v| v == "1");
+        let ctx = Arc::new(AmdContext::new(device, fast).unwrap_or_else(|e| panic!("r3n_create: {e}")));
+        // keeps the context alive as long as the renderer's graph storage (dropped with the renderer)
+        std::mem::forget(renderer.add_graph_data(Arc::clone(&ctx)));
+        map.insert(key, Arc::clone(&ctx));
+        ctx
+    }
+
+    /// Same lookup from a node body (`NodeExecutionContext::renderer` is a plain reference).
+    pub fn of_ref(renderer: &Renderer) -> Arc<AmdContext> {
+        let map = CONTEXTS.get_or_init(Default::default).lock().unwrap();
+        Arc::clone(map.get(&(renderer as *const Renderer as usize)).expect("no AmdContext for this renderer: construct BaseRenderGraph first"))
+    }
+
     /// `shade_fast`: opt into `R3N_SHADE_FAST` (fused multiply-add / hardware reciprocals in the fragment stage; framebuffer
     /// within 1e-3 after tonemap instead of bit-identical).
     pub fn new(hip_device: i32, shade_fast: bool) -> Result<Self, String> {

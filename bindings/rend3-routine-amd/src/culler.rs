@@ -1,28 +1,34 @@
-//! rend3-routine/src/culling/culler.rs:185-714 -- `GpuCuller` with the same two graph entry points.
+//! rend3-routine/src/culling/culler.rs:185-714 -- `GpuCuller` with the reference's constructor and graph entry points.
 use crate::amd::AmdContext;
 use glam::UVec2;
 use rend3::graph::{DataHandle, RenderGraph, RenderTargetHandle};
-use rend3::types::{Material, SampleCount};
+use rend3::types::{GraphDataHandle, Material, SampleCount};
+use rend3::{Renderer, ShaderPreProcessor};
 use rend3_amd_sys as sys;
 use rend3_routine::common::CameraSpecifier;
-use rend3_routine::culling::{DrawCallSet, PerCameraUniform};
+use rend3_routine::culling::{CullingBufferMap, DrawCallSet, PerCameraUniform};
 use std::sync::Arc;
 
 /// The reference's culler owns the K1 / K2 pipelines, the per-camera ping-pong buffers and `PerCameraPreviousInvocationsMap`
-/// (culler.rs:185-197); all of that state lives inside the `r3n_ctx` now, so this is a handle.
-pub struct GpuCuller<'a> {
-    pub amd: &'a AmdContext,
-    /// culler.rs:133-141: front-face / cull-mode folded into the header's flags by the caller exactly as before
-    pub winding: rend3::types::Handedness,
+/// (culler.rs:185-197); all of that state lives inside the `r3n_ctx` now.  `culling_buffer_map_handle` stays a public field
+/// because `PbrRoutine::new` takes it (pbr/routine.rs:40); nothing reads the map.
+pub struct GpuCuller {
+    pub amd: Arc<AmdContext>,
+    pub culling_buffer_map_handle: GraphDataHandle<CullingBufferMap>,
+    /// culler.rs:133-141: front face / cull mode folded into the header's flags exactly as before
+    winding: rend3::types::Handedness,
 }
 
-impl<'a> GpuCuller<'a> {
-    /// culler.rs:198-425 compiles the two compute pipelines; nothing to build here.
-    pub fn new<M: Material>(amd: &'a AmdContext, winding: rend3::types::Handedness) -> Self {
-        Self { amd, winding }
+impl GpuCuller {
+    /// culler.rs:199 -- same signature; the two compute pipelines it compiles there do not exist here.
+    pub fn new<M>(renderer: &Arc<Renderer>, _spp: &ShaderPreProcessor) -> Self
+    where
+        M: Material,
+    {
+        Self { amd: AmdContext::of(renderer), culling_buffer_map_handle: renderer.add_graph_data(CullingBufferMap::default()), winding: renderer.handedness }
     }
 
-    /// culler.rs:661-695 (`object_uniform_upload`, :427-529): header upload + K1 (`uniform_prep.wgsl`).
+    /// culler.rs:661-680 (`object_uniform_upload`, :427-529): header upload + K1 (`uniform_prep.wgsl`).
     pub fn add_object_uniform_upload_to_graph<'node, M: Material>(
         &'node self,
         graph: &mut RenderGraph<'node>,
@@ -46,7 +52,7 @@ impl<'a> GpuCuller<'a> {
         });
     }
 
-    /// culler.rs:697-712: `batch_objects` (CPU frustum cull + sort + 256-object batches, batching.rs:120-250) followed by one
+    /// culler.rs:682-713: `batch_objects` (CPU frustum cull + sort + 256-object batches, batching.rs:120-250) followed by one
     /// K2 dispatch per batch (:531-659).  Both halves run on the GPU behind one call; the handles stay in the signature so call
     /// sites compile unchanged, the draw-call set is owned by the context.
     pub fn add_culling_to_graph<'node, M: Material>(

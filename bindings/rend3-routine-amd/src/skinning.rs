@@ -1,30 +1,39 @@
 //! rend3-routine/src/skinning.rs:54-226: `build_gpu_skinning_input_buffers` + `add_skinning_to_graph`.
 use crate::amd::AmdContext;
 use rend3::graph::RenderGraph;
+use rend3::{Renderer, ShaderPreProcessor};
 use rend3_amd_sys as sys;
+use std::sync::Arc;
 
-pub struct GpuSkinner<'a> {
-    pub amd: &'a AmdContext,
+pub struct GpuSkinner {
+    amd: Arc<AmdContext>,
 }
 
-impl<'a> GpuSkinner<'a> {
-    /// skinning.rs:211-226: nothing to do without skeletons (:216-218); otherwise the 40-byte `GpuSkinningInput` records and
-    /// the joint matrices exactly as skinning.rs:54-139 collects them -- ONE launch covers every skeleton (the reference
-    /// dispatches per skeleton with a dynamic offset, :181-198).
-    pub fn add_skinning_to_graph<'node>(&'node self, graph: &mut RenderGraph<'node>) {
-        let mut node = graph.add_node("skinning");
-        node.add_side_effect();
-        node.build(move |ctx| {
-            let (inputs, matrices) = collect_skinning_inputs(&ctx.data_core.skeleton_manager, &ctx.data_core.mesh_manager);
-            if inputs.is_empty() {
-                return;
-            }
-            self.amd.check(
-                unsafe { sys::r3n_skinning(self.amd.ctx, inputs.as_ptr(), inputs.len() as u32, matrices.as_ptr().cast(), (matrices.len() / 16) as u32) },
-                "r3n_skinning",
-            );
-        });
+impl GpuSkinner {
+    /// skinning.rs:150 takes `&wgpu::Device`; the context hangs off the renderer, so this one takes the renderer
+    /// (`BaseRenderGraph::new` is its only caller, base.rs:121).
+    pub fn new(renderer: &Arc<Renderer>, _spp: &ShaderPreProcessor) -> GpuSkinner {
+        GpuSkinner { amd: AmdContext::of(renderer) }
     }
+}
+
+/// skinning.rs:211-226 -- same signature: nothing to do without skeletons (:216-218); otherwise the 40-byte `GpuSkinningInput`
+/// records and the joint matrices exactly as skinning.rs:54-139 collects them -- ONE launch covers every skeleton (the
+/// reference dispatches per skeleton with a dynamic offset, :181-198).
+pub fn add_skinning_to_graph<'node>(graph: &mut RenderGraph<'node>, gpu_skinner: &'node GpuSkinner) {
+    let mut node = graph.add_node("skinning");
+    node.add_side_effect();
+    node.build(move |ctx| {
+        let (inputs, matrices) = collect_skinning_inputs(&ctx.data_core.skeleton_manager, &ctx.data_core.mesh_manager);
+        if inputs.is_empty() {
+            return;
+        }
+        let amd = &gpu_skinner.amd;
+        amd.check(
+            unsafe { sys::r3n_skinning(amd.ctx, inputs.as_ptr(), inputs.len() as u32, matrices.as_ptr().cast(), (matrices.len() / 16) as u32) },
+            "r3n_skinning",
+        );
+    });
 }
 
 /// skinning.rs:54-139 without the buffer creation: per skeleton the attribute ranges of its mesh, its private output ranges

@@ -15,7 +15,7 @@ pub struct UniformInformation {
 
 /// Uploads the 496-byte `FrameUniforms` (built exactly as uniforms.rs:41-56 does), clears the frame's targets (depth 0.0 /
 /// colour, base.rs:245-263) and the shadow atlas (0.0), and places the shadow viewports (`ShadowDesc::map`).
-pub fn add_to_graph<'node>(graph: &mut RenderGraph<'node>, amd: &'node AmdContext, info: UniformInformation) {
+pub fn add_to_graph<'node>(graph: &mut RenderGraph<'node>, amd: &'node std::sync::Arc<AmdContext>, info: UniformInformation) {
     let mut builder = graph.add_node("build uniform data");
     builder.add_side_effect();
     builder.build(move |ctx| {

@@ -58,8 +58,27 @@ def test_adaptor_crate_calls_only_declared_symbols_and_covers_the_frame():
     formats = {c for c in consts if c.startswith("R3N_TEXTURE_") and c != "R3N_TEXTURE_FORMAT_COUNT"}
     assert len(formats) == 34 and formats <= used_consts, sorted(formats - used_consts)
     base = open(os.path.join(src_dir, "base.rs")).read()
-    base = base[base.index("let amd = self.amd;"):]  # the body of add_to_graph
+    base = base[base.index("let amd = &self.gpu_culler.amd;"):]  # the body of add_to_graph
     order = ["uniforms::add_to_graph", "add_skinning_to_graph", "Shadow Culling S", "pbr shadow renderering", "Uniform Bake", "PBR Forward Pass 1",
              "add_hi_z_to_graph", "Primary Culling", "PBR Forward Pass 2", "Resolve Opaque", "PBR Forward Transparent", "tonemapping.add_to_graph", "Frame End"]
     pos = [base.index(k) for k in order]
     assert pos == sorted(pos), "node order differs from base.rs:135-185"
+
+
+def test_adaptor_signatures_are_the_references():
+    """The adaptor's constructors and `add_*_to_graph` entry points carry the reference's signatures (SURVEY.md section 8b:
+    `BaseRenderGraph::new(renderer, spp)`, `GpuCuller::new::<M>(renderer, spp)`, `PbrRoutine::new(renderer, data_core, spp,
+    interfaces, culling_buffer_map_handle)`, `ForwardRoutine::new(args)`, ...), so the reference's examples construct and
+    use them unchanged.  The reference's signatures are pinned in tests/golden/rust_signatures.json (extracted by
+    tools/extract_reference_signatures.py); where the reference tree is present the fixture is re-derived and must match."""
+    import json
+    import extract_reference_signatures as E
+    fixture = json.load(open(E.FIXTURE))
+    assert len(fixture) == len(E.PINNED) == 13
+    if os.path.isdir("/root/reference/rend3-routine"):
+        assert E.from_reference("/root/reference") == fixture, "tests/golden/rust_signatures.json is stale: run tools/extract_reference_signatures.py"
+    src_dir = os.path.join(ROOT, "bindings", "rend3-routine-amd", "src")
+    for ref_file, adaptor_file, name, idx in E.PINNED:
+        want = fixture[f"{ref_file}::{name}#{idx}"]["signature"]
+        got = [sig for sig, _line in E.signatures(open(os.path.join(src_dir, adaptor_file)).read(), name)]
+        assert want in got, f"{adaptor_file}: no `pub fn {name}` with the signature of {ref_file}:{fixture[f'{ref_file}::{name}#{idx}']['line']}\n  want {want}\n  have {got}"
