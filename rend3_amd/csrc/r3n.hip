@@ -1745,6 +1745,25 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     CamState &s = c->viewport;
     if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
     TRY(flush_shadows(c));  // the resolve reads the shadow atlas
+    // (Re)allocations FIRST: ensure() fills and copies on the MAIN stream, and the event that orders the shade stream behind the
+    // main stream is recorded below -- a buffer zeroed after that event would race with the resolve's kernels (first frame /
+    // after the world grew: k_mark_visible's flags wiped by the late fill).
+    const bool use_records = c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30);
+    const uint64_t npix_all = (uint64_t)c->width * c->height;
+    const bool blend_samples = c->samples == 4 && c->blend_tris > 0;  // a transparent pass will blend into the individual samples
+    const bool split = c->samples == 4 && use_records && !blend_samples && npix_all < (1ull << 29) && R3N_MSAA_SPLIT;
+    uint32_t edge_cap = 0;
+    if (use_records) {
+        TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
+        TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, 0));  // zero: k_vertex_stage returns every flag it consumes to 0
+    }
+    if (blend_samples || split) TRY(ensure(c, c->samples16, (size_t)npix_all * 4 * 8, false, -1));
+    if (split) {
+        edge_cap = (uint32_t)((uint64_t)(r1 - r0) * c->width * 3u / R3N_EDGEQ) + 4096u;
+        if (c->edge_capacity_override) edge_cap = c->edge_capacity_override;  // R3N_EDGE_CAPACITY: exercises the overflow path in tests
+        TRY(ensure(c, c->edge_list, (size_t)edge_cap * R3N_EDGEQ * 4, false, -1));
+        TRY(ensure(c, c->edge_count, R3N_EDGEQ * 4, false, 0));
+    }
     // frames in flight: the resolve goes to the shade stream, ordered after this frame's viewport chain (main stream up
     // to here) and shadow views (lanes); the main stream is free to start the next frame.  Not when a transparent pass
     // follows (it continues on the main stream with the HDR target) or while stage timing is on.
@@ -1765,17 +1784,12 @@ int r3n_resolve_opaque(r3n_ctx *c) {
         TRY(join_shade(c));  // an earlier frame's resolve may still be writing the HDR / output targets
     }
     ShadeArgs a = make_shade_args(c, r0, r1);
-    if (c->samples == 4 && c->blend_tris > 0) {  // a transparent pass will blend into the individual samples
-        TRY(ensure(c, c->samples16, (size_t)c->width * c->height * 4 * 8, false, -1));
-        a.samples_out = c->samples16.as<ushort4>();
-    }
+    if (blend_samples) a.samples_out = c->samples16.as<ushort4>();
     c->resolved_this_frame = true;
     const bool tex = c->n_textures > 0;
     // the vertex stage runs once per visible triangle instead of once per pixel / sample (256 B per triangle slot;
     // skipped for worlds whose record array would pass 8 GiB)
-    if (c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30)) {
-        TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
-        TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, 0));  // zero: k_vertex_stage returns every flag it consumes to 0
+    if (use_records) {
         a.tri_rec = c->tri_rec.as<TriRecord>();
         a.seen = c->tri_seen.as<unsigned char>();
         Timed t(c, R3N_STAGE_VERTEX, stream);
@@ -1784,21 +1798,13 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     }
     {
         Timed t(c, R3N_STAGE_SHADE, stream);
-        const uint64_t npix_all = (uint64_t)c->width * c->height;
-        bool split = false;
-        if (c->samples == 4 && a.tri_rec != nullptr && a.samples_out == nullptr && npix_all < (1ull << 29) && R3N_MSAA_SPLIT) {
+        if (split) {
             // split resolve: first triangle of every pixel, the extra triangles of edge pixels in a dense second pass
-            uint32_t cap = (uint32_t)((uint64_t)(r1 - r0) * c->width * 3u / R3N_EDGEQ) + 4096u;
-            if (c->edge_capacity_override) cap = c->edge_capacity_override;  // R3N_EDGE_CAPACITY: exercises the overflow path in tests
-            TRY(ensure(c, c->samples16, (size_t)npix_all * 4 * 8, false, -1));
-            TRY(ensure(c, c->edge_list, (size_t)cap * R3N_EDGEQ * 4, false, -1));
-            TRY(ensure(c, c->edge_count, R3N_EDGEQ * 4, false, 0));
             a.samples_out = c->samples16.as<ushort4>();
             a.edge_list = c->edge_list.as<uint32_t>();
             a.edge_count = c->edge_count.as<uint32_t>();
-            a.edge_capacity = cap;
+            a.edge_capacity = edge_cap;
             HIP_TRY(c, hipMemsetAsync(a.edge_count, 0, R3N_EDGEQ * 4, stream));
-            split = true;
         }
         HIP_TRY(c, (hipError_t)r3n_internal_resolve(&a, c->samples, tex ? 1 : 0, a.tri_rec != nullptr ? 1 : 0, split ? 1 : 0,
                                                     c->shade_mode == R3N_SHADE_FAST ? 1 : 0, stream));

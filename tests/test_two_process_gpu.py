@@ -87,7 +87,17 @@ def _worker(rank, world, port, mode, q):
             # this rank's rows of the keys are the unsharded ones after the pass-2 exchange; the atlas is whole everywhere
             assert np.array_equal(ref["vis"][r0:r1], got["vis"][r0:r1]), f"{mode} rank {rank} frame {f}: keys of the own rows"
             assert np.array_equal(ref["atlas"].view(np.uint32), got["atlas"].view(np.uint32)), f"{mode} rank {rank} frame {f}: atlas"
-            assert np.array_equal(ref["hdr16"][r0:r1], got["hdr16"][r0:r1]), f"{mode} rank {rank} frame {f}: HDR of the own rows"
+            bad = (ref["hdr16"][r0:r1] != got["hdr16"][r0:r1]).any(axis=2)
+            if bad.any():
+                ys, xs = np.nonzero(bad)
+                y, x = int(ys[0]) + r0, int(xs[0])
+                slot = int(ref["vis"][y, x] & np.uint64(0xFFFFFFFF)) - 1
+                tri_base = np.concatenate([[0], np.cumsum(counts)])[:-1]
+                obj = int(np.searchsorted(tri_base, slot, side="right") - 1) if slot >= 0 else -1
+                raise AssertionError(f"{mode} rank {rank} frame {f}: HDR of the own rows differs in {int(bad.sum())} px, rows {ys.min() + r0}..{ys.max() + r0}, "
+                                     f"cols {xs.min()}..{xs.max()}; first ({x}, {y}): ref {ref['hdr16'][y, x]} got {got['hdr16'][y, x]}, object {obj} "
+                                     f"owned here: {bool(mask[obj]) if obj >= 0 else None}; differing px on own objects: "
+                                     f"{int(sum(1 for yy, xx in zip(ys[:2000], xs[:2000]) if (lambda sl: sl >= 0 and mask[int(np.searchsorted(tri_base, sl, side='right') - 1)])(int(ref['vis'][yy + r0, xx] & np.uint64(0xFFFFFFFF)) - 1)))} of {min(len(ys), 2000)}")
             # the gathered image: every row from its owner
             out = np.zeros((H, W, 4), dtype=np.uint8)
             shard._check(shard.lib.r3n_readback_output(shard.ctx, out.ctypes.data, None), "r3n_readback_output")
