@@ -268,7 +268,7 @@ def main():
     result = None
     # HBM bytes / VALU instructions per launch from the PMC passes (collected in their own rocprofv3 runs, tools/profile_round.sh
     # + tools/make_traffic.py).  Quoted only when they were taken on these kernel sources and this workload variant.
-    traffic, valu_busy, valu_insts, traffic_note = {}, {}, {}, "no PMC pass on record"
+    traffic, valu_busy, valu_insts, useful_flops, traffic_note = {}, {}, {}, {}, "no PMC pass on record"
     variant = ("instanced" if args.instanced else "unique") + ("-untextured" if args.untextured else "-textured") + f"-s{args.samples}" + \
               ("-fast" if args.shade_mode == "fast" else "") + ("-cfg4" if args.config == 4 else "") + \
               ("-scene:" + os.path.basename(args.scene) if args.scene else "") + ("" if (WIDTH, HEIGHT) == (3840, 2160) else f"-{WIDTH}x{HEIGHT}")
@@ -283,6 +283,7 @@ def main():
             traffic = committed.get("bytes_per_launch", {})
             valu_busy = committed.get("valu_busy", {})
             valu_insts = committed.get("valu_insts_per_launch", {})
+            useful_flops = committed.get("useful_flops_per_launch", {})
             traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* passes of " + str(committed.get("taken", "?")) + ", same kernel sources"
     except (OSError, ValueError):
         pass
@@ -312,7 +313,13 @@ def main():
                 # packed FMA as 4 flop per lane-slot, a plain (non-packed, non-fused) f32 op is 1 -- so 0.25 is the ceiling of such code
                 lane_ops = vi * 64.0 / (ms * 1e-3) / 1e12
                 d["valu"] = {"insts_per_launch": int(vi), "lane_ops_T_per_s": round(lane_ops, 2), "peak_tflops": VALU_PEAK_TFLOPS,
-                             "frac_of_vector_peak": round(lane_ops / VALU_PEAK_TFLOPS, 4), "busy": valu_busy.get(traffic_key)}
+                             "issue_frac_of_vector_peak": round(lane_ops / VALU_PEAK_TFLOPS, 4), "busy": valu_busy.get(traffic_key),
+                             "note": "issue_frac counts EVERY vector instruction (moves, selects, address math) as one lane-op; useful_* counts f32 "
+                                     "add + mul + 2 x fma + transcendental only"}
+                uf = useful_flops.get(traffic_key)
+                if uf:
+                    d["valu"]["useful_tflops"] = round(uf / (ms * 1e-3) / 1e12, 2)
+                    d["valu"]["useful_frac_of_vector_peak"] = round(uf / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)
             if extra:
                 d.update(extra)
             rooflines[stage] = d

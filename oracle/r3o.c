@@ -448,6 +448,12 @@ typedef struct {
  * y flip; forward.rs:338-342 front-face/cull-mode folded into `positive_visible` exactly as
  * culler.rs:133-141 does.
  */
+/* EXPERIMENT ONLY (tests/test_oracle_goldens.py::test_subpixel_snapping_experiment): hardware rasterisers
+ * snap window coordinates to a sub-pixel grid (8 fractional bits on the GPUs wgpu runs on) before edge setup; the contract
+ * here does not.  r3o_set_snap_bits(n > 0) snaps x/w and y/w to 2^-n pixels (and rebuilds the homogeneous coordinates) so the
+ * effect on the reference's self-shadowed goldens can be measured.  0 = the contract (default). */
+static int g_snap_bits = 0;
+void r3o_set_snap_bits(int bits) { g_snap_bits = bits; }
 static void setup_triangle(const float *mvp, const float v[3][3], float half_w, float half_h, int positive_visible,
                            tri_setup *ts) {
     float h[3][3];
@@ -458,6 +464,11 @@ static void setup_triangle(const float *mvp, const float v[3][3], float half_w, 
         h[k][1] = (p[3] - p[1]) * half_h;
         h[k][2] = p[3];
         ts->z[k] = p[2];
+        if (g_snap_bits > 0 && p[3] > 0.0f) {
+            const float g = (float)(1 << g_snap_bits);
+            h[k][0] = (rintf(h[k][0] / p[3] * g) / g) * p[3];
+            h[k][1] = (rintf(h[k][1] / p[3] * g) / g) * p[3];
+        }
     }
     for (int i = 0; i < 3; ++i) {
         const float *a = h[(i + 1) % 3], *b = h[(i + 2) % 3];

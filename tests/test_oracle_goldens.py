@@ -430,3 +430,30 @@ def test_tonemap_output_formats():
     assert (np.diff(manual[:, 0].astype(int)) >= 0).all() and manual[0, 0] == 0 and manual[-1, 0] == 255
     assert np.abs(exact[:, 0].astype(int) - manual[:, 0].astype(int)).max() <= 1
     assert (exact[:, 0] != manual[:, 0]).any()  # 0.4166 is not 1 / 2.4
+
+
+def test_subpixel_snapping_experiment():
+    """VERDICT r2 weak #1c: does the hardware rasteriser's sub-pixel vertex snapping (8 fractional bits on the GPUs wgpu runs
+    on) explain the oracle-vs-golden residual of the self-shadowed example screenshots?  Measured with the oracle's experiment
+    switch (r3o_set_snap_bits; every view's window coordinates snapped before edge setup), mean |LSB| against the reference's
+    screenshots at 1280x720: animation 1.62 (contract) -> 2.58 (8 bits), skinning 0.52 -> 0.43, static_gltf 0.019 -> 0.018.
+    Snapping moves the pattern of self-shadowed texels, it does not remove it: with no depth bias (the reference applies none)
+    a lit surface compares against its own rasterised depth, and which side a texel lands on depends on the last bits of the
+    hardware's depth interpolation -- fixed-function arithmetic that is not specified.  Not adopted; the contract stays
+    unsnapped (watertight by monotonicity).  This test pins the measurement on the skinning example."""
+    from oracle.lib import get as ol
+    w, h = 1280, 720
+    stats = {}
+    try:
+        for bits in (0, 8):
+            ol().r3o_set_snap_bits(bits)
+            r = OracleRenderer(hm.LEFT, aspect_ratio=f32(w) / f32(h))
+            build_skinning_example(r, hm, mk)
+            out = r.render(w, h, clear_color=(0.10, 0.05, 0.10, 1.0))
+            _gold, diff = golden_stats(out["rgba8"], "skinning-screenshot.png")
+            stats[bits] = (float(diff.mean()), float((diff <= 1).mean()))
+    finally:
+        ol().r3o_set_snap_bits(0)
+    assert stats[0][0] <= 0.6 and stats[0][1] >= 0.97                   # the contract's bound (test_skinning_example)
+    assert abs(stats[8][0] - stats[0][0]) <= 0.25, stats                # snapping: same order of residual, no closure
+    assert stats[8][0] > 0.3, stats

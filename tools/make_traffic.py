@@ -70,7 +70,7 @@ def main():
             "k_shadow_tiles": [k for k in table if k.startswith("k_shadow_tiles")]}
     doc = {"source": "tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter set per run; FETCH_SIZE x2 (gfx950 wide-load correction) + WRITE_SIZE",
            "taken": datetime.date.today().isoformat(), "variant": variant, "kernel_sources_sha": bench.kernel_sources_sha(),
-           "bytes_per_launch": {}, "valu_busy": {}, "valu_insts_per_launch": {}, "kernels": table}
+           "bytes_per_launch": {}, "valu_busy": {}, "valu_insts_per_launch": {}, "useful_flops_per_launch": {}, "kernels": table}
     for key, names in pick.items():
         if names and "hbm_bytes" in table[names[0]]:
             doc["bytes_per_launch"][key] = table[names[0]]["hbm_bytes"]
@@ -78,6 +78,11 @@ def main():
             doc["valu_busy"][key] = table[names[0]]["valu_busy"]
         if names and "sq_insts_valu" in table[names[0]]:
             doc["valu_insts_per_launch"][key] = int(table[names[0]]["sq_insts_valu"])
+        if names and "sq_insts_valu_add_f32" in table[names[0]]:
+            # f32 arithmetic only: 64 lanes x (add + mul + 2 x fma + transcendental) wave-instructions -- moves, selects, compares,
+            # integer / address work and conversions are NOT flops
+            t = table[names[0]]
+            doc["useful_flops_per_launch"][key] = int(64 * (t["sq_insts_valu_add_f32"] + t["sq_insts_valu_mul_f32"] + 2 * t["sq_insts_valu_fma_f32"] + t.get("sq_insts_valu_trans_f32", 0.0)))
     json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     for k, row in table.items():
         print(k[:60], {a: (round(b, 3) if isinstance(b, float) else b) for a, b in row.items()})
