@@ -65,11 +65,21 @@ def up_to_date():
 
 
 def build(force=False, verbose=False, extra=None, out=SO, obj_dir=OBJ):
-    """extra: additional compiler flags (variant builds, tools/variants.py); they go into their own object directory."""
+    """extra: additional compiler flags (variant builds, tools/variants.py; or R3N_EXTRA_CXXFLAGS): their objects go into a
+    directory of their own (named by a hash of the flags) and, unless `out` is given, into librend3_amd.<hash>.so -- load it with
+    R3N_LIB.  Returns the library's path."""
     if extra is None:
         extra = os.environ.get("R3N_EXTRA_CXXFLAGS", "").split()
     if not force and not extra and out == SO and up_to_date():
         return SO
+    if extra and obj_dir == OBJ:
+        # variant flags never share the default object directory (or, unless the caller named an output, the default library):
+        # a later plain build() would find "fresh" objects there and link the variant's kernels into the tested library
+        import hashlib
+        tag = hashlib.sha256(" ".join(extra).encode()).hexdigest()[:10]
+        obj_dir = os.path.join(CSRC, "_obj_" + tag)
+        if out == SO:
+            out = os.path.join(HERE, f"librend3_amd.{tag}.so")
     os.makedirs(obj_dir, exist_ok=True)
     todo = [u for u in UNITS if force or extra or _stale(u, obj_dir)]
 

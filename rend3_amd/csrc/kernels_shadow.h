@@ -378,9 +378,16 @@ __global__ __launch_bounds__(R3N_STILE_THREADS) void k_shadow_tiles(ShadowBatchA
         }
     }
     __syncthreads();
-    // the finished tile: plain stores, a 256-byte row segment per wavefront
+    // the finished tile, a 256-byte row segment per wavefront: MERGED with what the atlas already holds (max == the depth test) --
+    // the stages of a view can reach the atlas in more than one flush (a read-back or an exchange between a view's opaque and
+    // cutout draws), and a plain store would drop what an earlier flush rasterised there.  The tile is this workgroup's alone
+    // during the launch, so a read + max + store is enough.
     for (uint32_t i = threadIdx.x; i < R3N_STILE * R3N_STILE; i += R3N_STILE_THREADS) {
         const uint32_t x = (uint32_t)tx0 + (i & (R3N_STILE - 1u)), y = (uint32_t)ty0 + (i / R3N_STILE);
-        if (x < V.vp_size && y < V.vp_size) a.atlas[(size_t)(V.vp_y + y) * a.atlas_pitch + V.vp_x + x] = depth[i];
+        if (x < V.vp_size && y < V.vp_size) {
+            uint32_t *t = &a.atlas[(size_t)(V.vp_y + y) * a.atlas_pitch + V.vp_x + x];
+            const uint32_t have = *t;
+            if (depth[i] > have) *t = depth[i];
+        }
     }
 }

@@ -59,6 +59,8 @@ std::string g_create_error;
 #define R3N_AUX_STREAMS 2  // main + shade + these = the four hardware queues the runtime uses by default; 3 / 4 streams measured no faster (profiles/r02_summary.md section 9)
 #endif
 
+static_assert(R3N_AUX_STREAMS >= 1 && R3N_AUX_STREAMS <= R3N_QLANES, "every auxiliary stream (shadow lane) needs a work queue of its own: big_items / big_count / big_uv hold 1 + R3N_QLANES");
+
 struct r3n_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // main stream: uploads, viewport chain, resolve, tonemap, collectives
