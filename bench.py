@@ -243,6 +243,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---------------------------------------------------------------- host cost of a frame (outside the timed region)
+    # In the timed loop the host runs ahead of the GPU until it waits for a pinned frame image still in flight, so its enqueue time
+    # converges to the GPU's frame time.  Its OWN time per frame (Python glue + r3n_host_evaluate_frame + r3n_render_frame + the HIP
+    # runtime's launches): bursts of 3 frames right after a full synchronisation, median.
+    host_ms = None
+    if not distributed:
+        bursts, k0 = [], step0 + args.warmup
+        for b in range(12):
+            r.sync()
+            tb = time.perf_counter()
+            for j in range(3):
+                frame(k0 + (3 * b + j) % max(args.steps, 1))
+            bursts.append((time.perf_counter() - tb) / 3)
+        r.sync()
+        host_ms = round(1e3 * sorted(bursts)[len(bursts) // 2], 4)
+
     # ---------------------------------------------------------------- instrumented pass (outside the timed region)
     # HIP events on the context's stream around every kernel launch of each stage (include/r3n.h R3N_STAGE_*)
     # (single-stream here: a kernel's duration is inflated while kernels of other streams are co-resident)
@@ -374,6 +390,7 @@ def main():
                            f"viewport objects by slot range x{world}, shadow views by view (broadcast), RCCL MAX all-reduce of the pass-1 depth plane, MAX reduce-scatter of "
                            "the pass-2 keys, row all-gather")},
             "fps": round(args.steps / elapsed, 2),
+            "host_ms_per_frame": host_ms,
             "culled_objects_per_s": round(info["objects"] * cameras / (cull_ms * 1e-3), 1) if cull_ms > 0 else None,
             "culled_mtris_per_s": round(info["triangles"] * cameras / (cull_ms * 1e-3) / 1e6, 1) if cull_ms > 0 else None,
             "stage_ms_per_frame": {k: round(v, 4) for k, v in stage_ms.items()},

@@ -8,11 +8,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-for name in ("bench", "bench_fast", "bench_instanced", "bench_untextured", "bench_msaa4", "bench_shadow_tiles", "bench_under_rocprof",
-             "bench_under_rocprof_serial"):
+for name in ("bench", "bench_fast", "bench_instanced", "bench_untextured", "bench_msaa4", "bench_shadow_tiles", "bench_cfg4", "bench_scene",
+             "bench_exchange_spatial", "bench_exchange_slots", "bench_under_rocprof", "bench_under_rocprof_serial"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p):
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
@@ -27,6 +27,11 @@ for sub, out in (("pmc", "pmc_kernels"), ("pmc_fast", "pmc_kernels_fast")):
         shutil.copy(p, os.path.join(dst, f"{tag}_{out}.json"))
         if sub == "pmc":
             shutil.copy(p, os.path.join(dst, "traffic.json"))  # what bench.py quotes (stale-checked against the kernel sources)
+for name in ("host_rate.txt", "host_rate_nodes.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        keep = [l for l in open(p).read().splitlines() if "ms/frame" in l or "ms per frame" in l or "host time" in l]
+        open(os.path.join(dst, f"{tag}_{name}"), "w").write("\n".join(keep) + "\n")
 p = os.path.join(src, "configs.jsonl")
 if os.path.exists(p):
     rows = [json.loads(l) for l in open(p).read().splitlines() if l.startswith("{")]
