@@ -135,10 +135,11 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4),
                     help="3 (default): BASELINE.json configs[2] stand-in, the config the metric is quoted on; 4: configs[3] stand-in "
                          "(emerald_like, 1 048 576 objects / 55 M triangles, 4 shadow views), the workload whose per-rank work is milliseconds")
-    ap.add_argument("--partition", choices=("spatial", "slots"), default="spatial",
-                    help="N > 1: how the viewport's objects are sharded -- spatial (default): owner bytes from the Morton order of the bounding-sphere "
-                         "centres, balanced by triangles, with the pass-1 / pass-2 exchanges limited to the rows inside each rank's screen extent; "
-                         "slots: contiguous object-slot ranges with whole-target collectives")
+    ap.add_argument("--partition", choices=("spatial", "slots"), default="slots",
+                    help="N > 1: how the viewport's objects are sharded -- slots (default): contiguous object-slot ranges balanced by triangles, "
+                         "whole-target collectives; spatial: owner bytes from the Morton order of the bounding-sphere centres, with the pass-1 / pass-2 "
+                         "exchanges limited to the rows inside each rank's conservative screen extent (pays only when partitions are compact on "
+                         "screen: measured extents in DESIGN.md section 6)")
     ap.add_argument("--scene", default=None, metavar="FILE.glb|FILE.gltf",
                     help="run the benchmark on a real glTF asset through the scene-viewer harness (rend3_amd/scene_viewer.py; its flags "
                          "below; `data` becomes \"asset\"): hand it Bistro.glb with tools/scene_viewer.py's --bistro flags and the line is "

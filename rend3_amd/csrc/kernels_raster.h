@@ -781,8 +781,13 @@ __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__re
     hiz_head_body(vis, pyr, d, levels, samples, t);
 }
 
+#ifndef R3N_HIZ_PRIO
+#define R3N_HIZ_PRIO 3  // wave priority of the single-workgroup tail: it sits on the frame's serial chain while the CU it lands on is
+                        // shared with the shadow lanes' and the previous frame's resolve waves (85 us average in flight against 21 alone)
+#endif
 __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {
     __shared__ float lds_a[R3N_HIZ_LDS_A];
     __shared__ float lds_b[R3N_HIZ_LDS_B];
-    hiz_tail_body(pyr, d, first, 1024u, lds_a, R3N_HIZ_LDS_A, lds_b, R3N_HIZ_LDS_B);
+    __builtin_amdgcn_s_setprio(R3N_HIZ_PRIO);
+    hiz_tail_body(pyr, d, first, blockDim.x, lds_a, R3N_HIZ_LDS_A, lds_b, R3N_HIZ_LDS_B);
 }

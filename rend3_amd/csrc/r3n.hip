@@ -1581,8 +1581,25 @@ int r3n_hi_z(r3n_ctx *c) {
     hipLaunchKernelGGL(k_hiz_head, dim3((c->width + 31u) / 32u, (c->height + 31u) / 32u), dim3(256), 0, c->stream,
                        c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples);
     c->hiz_plane_ready = false;
-    if (levels + 1u < c->hizd.mips)
-        hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(1024), 0, c->stream, c->hiz.as<float>(), c->hizd, levels + 1u);
+    uint32_t first = levels + 1u;
+#ifndef R3N_HIZ_SPLIT
+#define R3N_HIZ_SPLIT 1
+#endif
+    if (R3N_HIZ_SPLIT && first < c->hizd.mips) {
+        // the first level behind the head is still thousands of texels (120 x 67 at 4K): a grid of workgroups builds it, so the
+        // single-workgroup tail -- which shares its CU with whatever else is resident -- starts from a level a quarter the size
+        const uint32_t dw = std::max(1u, c->width >> first), dh = std::max(1u, c->height >> first);
+        if ((size_t)dw * dh > 2304u) {
+            const uint32_t sw = std::max(1u, c->width >> (first - 1u)), sh = std::max(1u, c->height >> (first - 1u));
+            hipLaunchKernelGGL(k_hiz_downsample, dim3((dw + 15u) / 16u, (dh + 15u) / 16u), dim3(256), 0, c->stream, c->hiz.as<float>() + c->hizd.offset[first - 1u],
+                               c->hiz.as<float>() + c->hizd.offset[first], sw, sh, dw, dh);
+            ++first;
+        }
+    }
+    if (first < c->hizd.mips) {
+        const uint32_t n0 = std::max(1u, c->width >> first) * std::max(1u, c->height >> first);
+        hipLaunchKernelGGL(k_hiz_tail, dim3(1), dim3(n0 <= 2304u ? 256 : 1024), 0, c->stream, c->hiz.as<float>(), c->hizd, first);
+    }
     return check_launch(c, "hi_z");
 }
 
