@@ -168,6 +168,22 @@ R3N_DEV void setup_triangle(const float p[3][4], float half_w, float half_h, boo
 }
 
 // Edge functions at a pixel centre; true when covered under the top-left rule.
+R3N_DEV bool f32_positive(float a) { return (int)__float_as_uint(a) > 0; }             // a > 0 for non-NaN a (a positive NaN: true)
+// top-left rule as a per-edge threshold: 0 for a top / left edge, the smallest subnormal otherwise (see edge_eval)
+R3N_DEV float edge_threshold(float A, float B) {
+    return (A > 0.0f || (A == 0.0f && B > 0.0f)) ? 0.0f : 1.401298464324817e-45f;
+}
+// edge_eval with the three thresholds precomputed (the rasteriser's scan loops: once per triangle)
+R3N_DEV bool edge_eval_thr(const TriSetup &ts, const float thr[3], float px, float py, float E[3]) {
+    bool in = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float v = (ts.e[i][0] * px + ts.e[i][1] * py) + ts.e[i][2];
+        E[i] = v;
+        in = in && (v >= thr[i]);
+    }
+    return in;
+}
 R3N_DEV bool edge_eval(const TriSetup &ts, float px, float py, float E[3]) {
     bool in = true;
 #pragma unroll
@@ -178,7 +194,7 @@ R3N_DEV bool edge_eval(const TriSetup &ts, float px, float py, float E[3]) {
         // top-left rule: v > 0, or v == 0 on a top / left edge.  As ONE comparison against a per-edge threshold:
         // 0 for a top / left edge (accepts +-0), the smallest subnormal otherwise (accepts exactly v > 0; f32
         // subnormals are kept, float_denorm_mode_32 = 3).  NaN fails both forms.
-        const float thr = (A > 0.0f || (A == 0.0f && B > 0.0f)) ? 0.0f : 1.401298464324817e-45f;
+        const float thr = edge_threshold(A, B);
         in = in && (v >= thr);
     }
     return in;
@@ -188,7 +204,6 @@ R3N_DEV float frag_depth(const TriSetup &ts, const float E[3]) {
     float z = ((E[0] * ts.z[0] + E[1] * ts.z[1]) + E[2] * ts.z[2]) / ts.det;
     return z;
 }
-
 // Conservative integer pixel bounds inside a (vw x vh) viewport.  Returns false when no pixel can be covered.
 // Bounds only limit the scan (coverage is decided per pixel by edge_eval + the depth clip), so any conservative
 // box gives identical results.  Triangles that cross the depth-clip planes (0 <= z <= w, which also implies

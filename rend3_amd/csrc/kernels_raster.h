@@ -79,8 +79,10 @@ struct TriWork {
     float uv[3][2];                     // cutout key + albedo texture only
     bool alpha_tex;                     // the cutout alpha samples the albedo texture
     bool cutout;
+    float thr[3];    // device_math.h::edge_threshold of the three edges
     int x0, y0, x1, y1;
 };
+
 
 // TEX: the launch may meet cutout materials whose alpha comes from the albedo texture (row N2).  The lean variant
 // (no texture code, fewer registers) is launched whenever the world has no textures or the key is not cutout.
@@ -103,6 +105,8 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     setup_triangle(p, half_w, half_h, positive_visible, tw.ts);
     if (!tw.ts.valid) return false;
     if (!tri_bounds(p, half_w, half_h, (int)a.vp_w, (int)a.vp_h, tw.x0, tw.y0, tw.x1, tw.y1)) return false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tw.thr[i] = edge_threshold(tw.ts.e[i][0], tw.ts.e[i][1]);
     tw.cutout = a.key == R3N_KEY_CUTOUT;
     tw.material = ob.material_index < a.n_materials ? ob.material_index : 0u;
     tw.va[0] = tw.va[1] = tw.va[2] = 1.0f;
@@ -179,6 +183,19 @@ R3N_DEV void global_max_u64(unsigned long long *p, unsigned long long v) {
     typedef __attribute__((address_space(1))) unsigned long long *gp_t;
     (void)__hip_atomic_fetch_max((gp_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same with the target named as (wave-uniform base, 32-bit BYTE offset): the atomic then takes the base from scalar registers
+// and the offset from one vector register (global_atomic_* v_off, v_data, s[base]) -- no 64-bit address arithmetic per pixel
+// (v_mad_u64_u32 + two v_lshl_add_u64 per fragment before).  Targets stay below 4 GiB (r3n_frame_begin checks).
+R3N_DEV void global_max_u32_at(uint32_t *base, uint32_t byte_off, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint32_t *gp_t;
+    typedef __attribute__((address_space(1))) char *gc_t;
+    (void)__hip_atomic_fetch_max((gp_t)((gc_t)(unsigned long long)base + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+R3N_DEV void global_max_u64_at(unsigned long long *base, uint32_t byte_off, unsigned long long v) {
+    typedef __attribute__((address_space(1))) unsigned long long *gp_t;
+    typedef __attribute__((address_space(1))) char *gc_t;
+    (void)__hip_atomic_fetch_max((gp_t)((gc_t)(unsigned long long)base + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
@@ -191,7 +208,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         for (int sm = 0; sm < S; ++sm) {
             float E[3];
             const float sx = S == 1 ? 0.5f : k_sample_pos4[sm][0], sy = S == 1 ? 0.5f : k_sample_pos4[sm][1];
-            if (!edge_eval(tw.ts, (float)x + sx, (float)y + sy, E)) continue;
+            if (!edge_eval_thr(tw.ts, tw.thr, (float)x + sx, (float)y + sy, E)) continue;
             const float z = frag_depth(tw.ts, E);
             if (!(z >= 0.0f && z <= 1.0f)) continue;
             const size_t ps = pix * (size_t)S + (size_t)sm;
@@ -210,7 +227,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     }
     if (S == 1) {
         float E[3];
-        if (!edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
+        if (!edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E)) return;
         float z = frag_depth(tw.ts, E);
         if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
         if (z == 0.0f) z = 0.0f;                // canonicalise -0
@@ -219,17 +236,18 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
         }
-        const size_t pix = (size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x;
+        // rows and pitch are below 2^16 (r3n_frame_begin), the target below 2^29 samples: 24-bit multiply, 32-bit byte offsets
+        const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
         const uint32_t zb = __float_as_uint(z);
 #if R3N_ABLATE == 2
         asm volatile("" : : "v"(zb), "v"(pix));
         return;
 #endif
         if (DEPTH_ONLY) {
-            if (!PREREAD || zb > a.depth[pix]) global_max_u32(&a.depth[pix], zb);
+            if (!PREREAD || zb > a.depth[pix]) global_max_u32_at(a.depth, pix << 2, zb);
         } else {
             const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
-            if (!PREREAD || key > a.vis[pix]) global_max_u64(&a.vis[pix], key);
+            if (!PREREAD || key > a.vis[pix]) global_max_u64_at(a.vis, pix << 3, key);
         }
     } else {
         uint32_t mask = 0u;
@@ -238,7 +256,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         for (int sm = 0; sm < S; ++sm) {
             float E[3];
             zs[sm] = 0.0f;
-            if (!edge_eval(tw.ts, (float)x + k_sample_pos4[sm][0], (float)y + k_sample_pos4[sm][1], E)) continue;
+            if (!edge_eval_thr(tw.ts, tw.thr, (float)x + k_sample_pos4[sm][0], (float)y + k_sample_pos4[sm][1], E)) continue;
             float z = frag_depth(tw.ts, E);
             if (!(z >= 0.0f && z <= 1.0f)) continue;
             if (z == 0.0f) z = 0.0f;
@@ -248,7 +266,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         if (!mask) return;
         if (tw.cutout) {
             float E[3];
-            (void)edge_eval(tw.ts, (float)x + 0.5f, (float)y + 0.5f, E);
+            (void)edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E);
             const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
             const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;
@@ -291,7 +309,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 #define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
 #endif
 #ifndef R3N_FINE_PERMUTE
-#define R3N_FINE_PERMUTE 1  // fine mode: the surviving blocks compacted into a vector register (ds_permute) instead of walked bit by bit
+#define R3N_FINE_PERMUTE 0  // 1: fine mode compacts the surviving blocks into a vector register (ds_permute / ds_bpermute) instead of walking the mask on the scalar unit; kernel alone -2.5 %, frame +4 % (the LDS wait is the lgkm counter, which also holds the next record's prefetch): off
 #endif
 #ifndef R3N_FINE
 #define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block
@@ -459,7 +477,9 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float A = ts.e[i][0], B = ts.e[i][1];
-        const float px = A > 0.0f ? x_hi : x_lo, py = B > 0.0f ? y_hi : y_lo;
+        // sign tests on the bits (scalar unit for the work items' uniform coefficients, device_math.h::f32_positive); with a
+        // NaN coefficient v is NaN whichever corner is taken
+        const float px = f32_positive(A) ? x_hi : x_lo, py = f32_positive(B) ? y_hi : y_lo;
         const float v = (A * px + B * py) + ts.e[i][2];
         may = may && !(v < 0.0f);  // NaN keeps the block (per-pixel evaluation rejects it)
     }
@@ -553,6 +573,16 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         }
         w.ts.det = bf(12);
         w.ts.valid = true;
+        // edge thresholds on the SCALAR unit: the coefficients are wave-uniform, the scalar unit compares integers only, and
+        // behind the (empty) asm the compiler can no longer turn the bit tests back into vector float compares.  Same outcome
+        // as edge_threshold for every non-NaN pair; with a NaN coefficient the edge value is NaN and fails any threshold.
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            uint32_t ab = bu(3 * i), bb = bu(3 * i + 1);
+            asm("" : "+s"(ab), "+s"(bb));
+            const bool top_left = (int)ab > 0 || ((ab & 0x7FFFFFFFu) == 0u && (int)bb > 0);
+            w.thr[i] = __uint_as_float(top_left ? 0u : 1u);
+        }
         w.slot1 = bu(16);
         w.cutout = !BLEND && a.key == R3N_KEY_CUTOUT;  // launch-uniform
         w.material = bu(17);
@@ -624,7 +654,11 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                     blocks &= blocks - 1ull;
                 }
                 const int b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
-                const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
+                // (field << 2) + base as ONE shift-add each (the compiler's canonical (b << 2) & 28 form costs an instruction
+                // more per coordinate and cannot be talked out of it)
+                int x, y;
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7), "v"(rx0 + px));
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
                 if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
 #endif

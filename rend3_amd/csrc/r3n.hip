@@ -1003,6 +1003,9 @@ static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t
     if (!c || !u || !clear_color || !w || !h) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: bad args");
     if (samples != 1 && samples != 4) return fail(c, R3N_ERR_INVALID_ARG, "frame_begin: samples must be 1 or 4 (SampleCount::One | Four)");
     if (w > 65535 || h > 65535) return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: target larger than 65535");
+    // the rasteriser addresses its targets with 32-bit byte offsets (8 B per sample key, 4 B per atlas texel)
+    if ((uint64_t)w * h * samples >= (1ull << 29) || (uint64_t)atlas_w * atlas_h >= (1ull << 30) || atlas_w > 65535 || atlas_h > 65535)
+        return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: target of 2^29 samples or more / shadow atlas of 2^30 texels or more");
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(check_async_status(c));
     if (w != c->width || h != c->height) {

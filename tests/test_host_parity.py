@@ -219,3 +219,4 @@ def test_evaluate_frame_matches_the_oracle_host_math(hand):
                 v = fr.shadow_views[k]
                 assert (v.x, v.y, v.size, fr.shadow_handles[k]) == (sh["offset"][0], sh["offset"][1], sh["size"], sh["handle"])
                 assert bytes(v.header) == oh.camera_header(sh["camera"], k, (sh["size"], sh["size"]), 1, 4096, ol).tobytes()
+
