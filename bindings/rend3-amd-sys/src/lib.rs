@@ -364,6 +364,7 @@ extern "C" {
     pub fn r3n_set_camera_object_range(ctx: *mut r3n_ctx, camera: u32, begin: u32, end: u32) -> c_int;
     pub fn r3n_exchange_depth(ctx: *mut r3n_ctx, depth_f32: *mut *mut c_void, count: *mut u64) -> c_int;
     pub fn r3n_exchange_buffers(ctx: *mut r3n_ctx, visibility_keys: *mut *mut c_void, visibility_count: *mut u64, shadow_atlas: *mut *mut c_void, shadow_atlas_count: *mut u64) -> c_int;
+    pub fn r3n_exchange_shadow_stream(ctx: *mut r3n_ctx, shadow_atlas: *mut *mut c_void, shadow_atlas_count: *mut u64, stream: *mut *mut c_void) -> c_int;
     pub fn r3n_set_row_range(ctx: *mut r3n_ctx, row_begin: u32, row_end: u32) -> c_int;
     pub fn r3n_output_buffer(ctx: *mut r3n_ctx, rgba8: *mut *mut c_void, bytes: *mut u64) -> c_int;
     pub fn r3n_output_buffer_async(ctx: *mut r3n_ctx, rgba8: *mut *mut c_void, bytes: *mut u64, stream: *mut *mut c_void) -> c_int;

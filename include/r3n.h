@@ -373,7 +373,8 @@ typedef struct r3n_shadow_view272 {
 } r3n_shadow_view272;
 /* multi-GPU hook (not in the reference): called on the calling thread at the points where ranks merge -- after the shadow
  * nodes, after pass 1 (before r3n_hi_z), after pass 2 (before r3n_resolve_opaque); the callee enqueues its collectives on
- * r3n_stream() (r3n_exchange_depth / r3n_exchange_buffers give the buffers).  Non-zero return aborts the frame (R3N_ERR_STATE). */
+ * r3n_stream() (r3n_exchange_depth / r3n_exchange_buffers give the buffers), the shadow views' on the stream
+ * r3n_exchange_shadow_stream returns.  Non-zero return aborts the frame (R3N_ERR_STATE). */
 #define R3N_EXCHANGE_SHADOW 0u
 #define R3N_EXCHANGE_PASS1 1u
 #define R3N_EXCHANGE_PASS2 2u
@@ -426,6 +427,11 @@ int r3n_set_camera_object_range(r3n_ctx *ctx, r3n_camera camera, uint32_t begin,
 int r3n_exchange_depth(r3n_ctx *ctx, void **depth_f32, uint64_t *count);
 int r3n_exchange_buffers(r3n_ctx *ctx, void **visibility_keys, uint64_t *visibility_count,
                          void **shadow_atlas, uint64_t *shadow_atlas_count);
+/* The shadow atlas for the shadow-view exchange (a view's owner sends its atlas rectangle to the other ranks) WITHOUT ordering the
+ * main stream behind the shadow views: *stream = a shadow lane's HIP stream, ordered behind every lane that drew a view this
+ * frame (the main stream while R3N_SINGLE_STREAM=1).  Collectives enqueued there run beside the viewport's passes, which never
+ * read the atlas; the resolve -- its only reader -- waits for that lane as it does for the views themselves. */
+int r3n_exchange_shadow_stream(r3n_ctx *ctx, void **shadow_atlas, uint64_t *shadow_atlas_count, void **stream);
 /* Device pointer of the tonemapped Rgba8 image (width*height*4 bytes) and the rows [row_begin,row_end) this
  * rank resolves/tonemaps when screen-space work is split after the exchange. */
 int r3n_set_row_range(r3n_ctx *ctx, uint32_t row_begin, uint32_t row_end);

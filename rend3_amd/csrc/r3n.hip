@@ -2179,6 +2179,25 @@ int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atl
     if (atlas_count) *atlas_count = (uint64_t)c->atlas_w * c->atlas_h;
     return R3N_OK;
 }
+int r3n_exchange_shadow_stream(r3n_ctx *c, void **atlas, uint64_t *atlas_count, void **stream) {
+    if (!c || !c->atlas.p) return fail(c, R3N_ERR_STATE, "exchange_shadow_stream: no shadow atlas yet");
+    TRY(flush_shadows(c));
+    hipStream_t on = c->stream;
+    if (c->multi_stream) {
+        // lane 1 carries the exchange: behind the main stream's clears / uploads of this frame, and behind the other lanes' views
+        TRY(fork_lane(c, 1));
+        for (int k = 1; k < R3N_AUX_STREAMS; ++k)
+            if (c->aux_used[k]) {
+                HIP_TRY(c, hipEventRecord(c->join_ev[k], c->aux[k]));
+                HIP_TRY(c, hipStreamWaitEvent(c->aux[0], c->join_ev[k], 0));
+            }
+        on = c->aux[0];  // aux_used[0] is set (fork_lane): the resolve and r3n_frame_end wait for what is enqueued here
+    }
+    if (atlas) *atlas = c->atlas.p;
+    if (atlas_count) *atlas_count = (uint64_t)c->atlas_w * c->atlas_h;
+    if (stream) *stream = (void *)on;
+    return R3N_OK;
+}
 int r3n_set_row_range(r3n_ctx *c, uint32_t b, uint32_t e) {
     if (!c || b > e) return fail(c, R3N_ERR_INVALID_ARG, "set_row_range: begin > end");
     c->row_begin = b; c->row_end = e;

@@ -330,6 +330,12 @@ class Exchange:
                 Exchange._rows_groups[key] = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group))
             rows_group = Exchange._rows_groups[key]
         self.group_rows = rows_group
+        # the shadow-view exchange runs on a shadow lane's stream beside the viewport's passes (r3n_exchange_shadow_stream); for
+        # the same reason as the rows it has a communicator of its own: on the main one the pass-1 exchange would queue behind it
+        skey = ("shadow", id(group) if group is not None else None)
+        if skey not in Exchange._rows_groups:
+            Exchange._rows_groups[skey] = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group))
+        self.group_shadow = Exchange._rows_groups[skey]
         self.sparse = None    # spatial partition: dict(bounds=[...]) -- the exchanges then move only the rows a rank can have touched
         self.full_extent_frames = 0
         self._streams = {}
@@ -372,6 +378,30 @@ class Exchange:
     def __call__(self, what, renderer, ev=None, samples=1):
         dist, torch = self.dist, self.torch
         self._height = renderer.current_resolution()[1]
+        if what == "shadow":
+            # on the shadow lane's stream, not the main one: the viewport's passes (which never read the atlas) do not wait for it
+            if ev is None or not ev.shadows:
+                return
+            ct = self._ct
+            atlas, atlas_n, sp = ct.c_void_p(), ct.c_uint64(), ct.c_void_p()
+            r = self.r
+            r._check(r.lib.r3n_exchange_shadow_stream(r.ctx, ct.byref(atlas), ct.byref(atlas_n), ct.byref(sp)), "r3n_exchange_shadow_stream")
+            stream = self._streams.get(sp.value)
+            if stream is None:
+                stream = self._streams[sp.value] = torch.cuda.ExternalStream(sp.value, device=self.device)
+            with torch.cuda.stream(stream):
+                t0 = t1 = None
+                if self.timed:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(stream)
+                aw, ah = ev.shadow_target_size
+                a2 = device_tensor(atlas.value, atlas_n.value, "<f4", self.device).view(ah, aw)
+                exchange_shadow_views_(a2, ev.shadows, dist.get_rank(self.group_shadow), self.world, self.group_shadow)
+                self.bytes[what] = sum(4 * int(sh["size"]) ** 2 for sh in ev.shadows)
+                if self.timed:
+                    t1.record(stream)
+                    self.events.append((what, t0, t1))
+            return
         # the context's stream is made torch's current stream, so the collective is ordered after the kernels
         # already enqueued on it and the kernels enqueued next wait for the collective
         with torch.cuda.stream(self.stream):
@@ -379,14 +409,7 @@ class Exchange:
             if self.timed:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self.stream)
-            if what == "shadow":
-                vis, vis_n, atlas, atlas_n = self._buffers()
-                if atlas_n and ev is not None and ev.shadows:
-                    aw, ah = ev.shadow_target_size
-                    a2 = device_tensor(atlas, atlas_n, "<f4", self.device).view(ah, aw)
-                    exchange_shadow_views_(a2, ev.shadows, self.rank, self.world, self.group)
-                    self.bytes[what] = sum(4 * int(sh["size"]) ** 2 for sh in ev.shadows)
-            elif what == "pass1" and samples == 1:
+            if what == "pass1" and samples == 1:
                 ct = self._ct
                 plane, n = ct.c_void_p(), ct.c_uint64()
                 r = self.r

@@ -3,4 +3,4 @@ set -u
 out=gpurun_out/${1:-ab}; mkdir -p $out
 export TMPDIR=/tmp
 python tools/variants.py run --steps 150 > $out/variants.txt 2>&1; cat $out/variants.txt
-python tools/variants.py run --steps 150 > $out/variants2.txt 2>&1; cat $out/variants2.txt
+

@@ -1,0 +1,16 @@
+# the multi-GPU path on one box: two-process tests, the sharding tests, the exchange forced with one rank under RCCL
+set -u
+out=gpurun_out/${1:-ex}; mkdir -p $out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q -k "two_process or exchange or sharded" > $out/pytest.log 2>&1; echo "pytest rc=$?"; grep -E 'passed|failed|error' $out/pytest.log | tail -3
+for part in slots spatial; do
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-exchange --partition $part --steps 60 --warmup 8 > $out/bench_ex_$part.json 2> $out/bench_ex_$part.err; echo "exchange $part rc=$?"
+  python - $out/bench_ex_$part.json <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); print(d["ms_per_step"], d.get("exchange_ms_per_frame"), d.get("exchange_bytes_per_frame"))
+except Exception as e: print("FAILED", e)
+PY
+done
+timeout 300 python bench.py --no-cpu-baseline --steps 60 --warmup 8 > $out/bench_plain.json 2>/dev/null; python -c "
+import json;d=json.load(open('$out/bench_plain.json'));print('plain',d['ms_per_step'])"
