@@ -135,9 +135,10 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4),
                     help="3 (default): BASELINE.json configs[2] stand-in, the config the metric is quoted on; 4: configs[3] stand-in "
                          "(emerald_like, 1 048 576 objects / 55 M triangles, 4 shadow views), the workload whose per-rank work is milliseconds")
-    ap.add_argument("--partition", choices=("spatial", "slots"), default="slots",
-                    help="N > 1: how the viewport's objects are sharded -- slots (default): contiguous object-slot ranges balanced by triangles, "
-                         "whole-target collectives; spatial: owner bytes from the Morton order of the bounding-sphere centres, with the pass-1 / pass-2 "
+    ap.add_argument("--partition", choices=("rows", "spatial", "slots"), default="rows",
+                    help="N > 1: how the viewport is sharded -- rows (default, sort-first): every rank culls and draws every object but rasterises "
+                         "only its band of rows; the depth bands are all-gathered in front of Hi-Z and no keys are exchanged; slots: contiguous "
+                         "object-slot ranges balanced by triangles, whole-target MAX collectives of depth (pass 1) and keys (pass 2); spatial: owner bytes from the Morton order of the bounding-sphere centres, with the pass-1 / pass-2 "
                          "exchanges limited to the rows inside each rank's conservative screen extent (pays only when partitions are compact on "
                          "screen: measured extents in DESIGN.md section 6)")
     ap.add_argument("--scene", default=None, metavar="FILE.glb|FILE.gltf",
@@ -196,7 +197,9 @@ def main():
         exchange = parallel.Exchange(r, device)
         rows = parallel.row_ranges(HEIGHT, world)
         exchange.rows_equal = HEIGHT % world == 0
-        if args.partition == "spatial" and exchange.rows_equal and args.samples == 1:
+        if args.partition == "rows":
+            exchange.set_row_sharding(rows[rank][0], rows[rank][1])
+        elif args.partition == "spatial" and exchange.rows_equal and args.samples == 1:
             owners = parallel.partition_objects_spatial(spheres[:, :3], counts, world)
             exchange.set_spatial_partition(owners, parallel.partition_bounds(owners, spheres[:, :3], spheres[:, 3], counts, world))
         else:
@@ -385,6 +388,9 @@ def main():
                        "shade_mode": args.shade_mode,
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
                        "parallelism": "single GPU" if world == 1 else (
+                           f"sort-first: every rank culls + draws every object into its band of {HEIGHT // world} rows (x{world}), shadow views by view "
+                           "(broadcast on a shadow lane's stream), pass-1 depth bands all-gathered over RCCL in front of Hi-Z, no key exchange, image rows all-gathered"
+                           if exchange is not None and exchange.by_rows else
                            f"viewport objects by spatial partition (Morton order, owner bytes) x{world}, shadow views by view (broadcast), pass-1 depth and pass-2 keys "
                            "MAX-reduced onto the row-band owners over RCCL all-to-all limited to each rank's screen-row extent, depth bands + image rows all-gathered"
                            if exchange is not None and exchange.sparse is not None else

@@ -69,6 +69,8 @@ pub const R3N_EXCHANGE_PASS1: u32 = 1;
 pub const R3N_EXCHANGE_PASS2: u32 = 2;
 pub const R3N_FRAME_VIEWPORT_FIRST: u32 = 1;
 pub const R3N_FRAME_SHADOW_MASK: u32 = 2;
+pub const R3N_SHARD_OBJECTS: u32 = 0;
+pub const R3N_SHARD_ROWS: u32 = 1;
 pub const R3N_STAGE_BAKE: i32 = 0;
 pub const R3N_STAGE_OBJECT_CULL: i32 = 1;
 pub const R3N_STAGE_TRIANGLE_CULL: i32 = 2;
@@ -361,6 +363,7 @@ extern "C" {
     pub fn r3n_render_frame(ctx: *mut r3n_ctx, desc: *const r3n_frame_desc) -> c_int;
     pub fn r3n_set_object_range(ctx: *mut r3n_ctx, begin: u32, end: u32) -> c_int;
     pub fn r3n_set_object_owners(ctx: *mut r3n_ctx, owners: *const u8, n: u32, rank: u32) -> c_int;
+    pub fn r3n_set_shard_mode(ctx: *mut r3n_ctx, mode: u32) -> c_int;
     pub fn r3n_set_camera_object_range(ctx: *mut r3n_ctx, camera: u32, begin: u32, end: u32) -> c_int;
     pub fn r3n_exchange_depth(ctx: *mut r3n_ctx, depth_f32: *mut *mut c_void, count: *mut u64) -> c_int;
     pub fn r3n_exchange_buffers(ctx: *mut r3n_ctx, visibility_keys: *mut *mut c_void, visibility_count: *mut u64, shadow_atlas: *mut *mut c_void, shadow_atlas_count: *mut u64) -> c_int;

@@ -416,6 +416,17 @@ int r3n_set_object_range(r3n_ctx *ctx, uint32_t begin, uint32_t end);
  * of the world and of the screen; its slots are not contiguous).  n >= the object capacity (re-send after the object buffer
  * grows); owners == NULL returns to r3n_set_object_range.  Synchronises (world-edit rate). */
 int r3n_set_object_owners(r3n_ctx *ctx, const uint8_t *owners, uint32_t n, uint32_t rank);
+/* How the VIEWPORT camera is sharded over ranks (shadow views are sharded by view in both):
+ *   R3N_SHARD_OBJECTS (default): a rank draws its objects (r3n_set_object_range / r3n_set_object_owners) over the whole target;
+ *     ranks MAX-merge the depth plane after pass 1 and the keys after pass 2;
+ *   R3N_SHARD_ROWS (sort-first): a rank culls and draws EVERY object, but rasterises only the rows [row_begin, row_end) of
+ *     r3n_set_row_range -- its rows of the depth plane / keys are then final without a reduction: after pass 1 the ranks all-gather
+ *     their rows of the depth plane (every rank culls against the whole Hi-Z pyramid and arrives at the unsharded visible sets),
+ *     after pass 2 nothing is exchanged.  Culling is replicated, pixel work is divided, and the largest exchange (8 B per pixel of
+ *     keys) disappears.  Do not combine with object ranges / owners. */
+#define R3N_SHARD_OBJECTS 0u
+#define R3N_SHARD_ROWS 1u
+int r3n_set_shard_mode(r3n_ctx *ctx, uint32_t mode);
 /* Device pointers + sizes of the exchange buffers, for RCCL (all-reduce MAX over ranks):
  * the 64-bit visibility/depth keys (width*height u64, as int64 non-negative) and the f32 shadow atlas. */
 /* this camera's own object-slot range, overriding r3n_set_object_range for it (a shadow view owned whole by one rank draws

@@ -184,6 +184,7 @@ class OracleRenderer:
         self.frame_index = 0
         self.object_range = None
         self.shadow_views_owned = None  # multi-rank: set of shadow views this rank renders (whole); None = all, by object range
+        self.row_band = None            # multi-rank, sort-first: (row_begin, row_end) -- the viewport's passes touch these rows only
         self.skeletons = []  # dict(mesh, out_off[3], matrices)
 
     # ------------------------------------------------------------------ skeletons (rend3/src/managers/skeleton.rs:67-163)
@@ -575,6 +576,9 @@ class OracleRenderer:
                     lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
                                               lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
                                               lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, *self._tex_args(), lib.ptr(vis))
+            if self.row_band is not None:  # a rank sharded by rows rasterises its band only: elsewhere the keys stay clear
+                vis[: self.row_band[0]] = 0
+                vis[self.row_band[1]:] = 0
 
         # 8. pass 1: last frame's predicted triangles (forward.rs:224-232)
         predicted = self.cam_state.get("predicted_list")

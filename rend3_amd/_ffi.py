@@ -56,6 +56,7 @@ SIGNATURES = {
     "r3n_set_object_owners": (cint, [vp, vp, u32, u32]),
     "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
     "r3n_exchange_shadow_stream": (cint, [vp, vp, vp, vp]),
+    "r3n_set_shard_mode": (cint, [vp, u32]),
     "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
     "r3n_exchange_depth": (cint, [vp, vp, vp]),
     "r3n_set_row_range": (cint, [vp, u32, u32]),

@@ -46,7 +46,7 @@ struct RasterArgs {
     uint32_t frag_capacity;
     uint32_t *frag_head;                   // per pixel sample: first node of its list, R3N_INVALID = none
     uint32_t *status;                      // host-visible: bit 0 set when nodes / work items ran out (reported by a later call)
-    uint32_t row_begin, row_end;           // rows this rank resolves
+    uint32_t row_begin, row_end;           // rows of the viewport this launch may touch: everything ([0, 0xFFFFFFFF)) unless the rank is sharded by rows
 };
 
 // opaque.wgsl:214-235 / depth.wgsl:98-125 (untextured paths): alpha the cutout test compares with the threshold
@@ -105,6 +105,11 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     setup_triangle(p, half_w, half_h, positive_visible, tw.ts);
     if (!tw.ts.valid) return false;
     if (!tri_bounds(p, half_w, half_h, (int)a.vp_w, (int)a.vp_h, tw.x0, tw.y0, tw.x1, tw.y1)) return false;
+    // sort-first sharding (R3N_SHARD_ROWS): this rank scans rows [row_begin, row_end) only.  The box only limits the scan
+    // (coverage and depth are decided per pixel), so the rows inside come out exactly as in the unsharded frame.
+    tw.y0 = max(tw.y0, (int)a.row_begin);
+    tw.y1 = min(tw.y1, (int)min(a.row_end, a.vp_h) - 1);
+    if (tw.y0 > tw.y1) return false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tw.thr[i] = edge_threshold(tw.ts.e[i][0], tw.ts.e[i][1]);
     tw.cutout = a.key == R3N_KEY_CUTOUT;

@@ -166,6 +166,7 @@ struct r3n_ctx {
     bool shadow_bin = true;     // R3N_SHADOW_TILES=2: the batched path WITHOUT the tile pass (every view in one launch per stage, general rasteriser)
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
+    bool shard_rows = false;  // R3N_SHARD_ROWS: the viewport camera rasterises its row band only
     DevBuf owners;  // r3n_set_object_owners: owner rank per object slot (p == nullptr: slot ranges)
     uint32_t owner_rank = 0, owners_n = 0;
     // pinned staging ring for small per-frame uploads (headers, uniforms, light buffers): the caller owns its
@@ -1368,6 +1369,7 @@ static int flush_shadows(r3n_ctx *c) {
             a.tex = texture_args(c);
             a.vp_x = s.vp_x; a.vp_y = s.vp_y; a.vp_w = s.vp_size; a.vp_h = s.vp_size; a.target_pitch = c->atlas_w;
             a.depth = c->atlas.as<uint32_t>();
+            a.row_begin = 0; a.row_end = 0xFFFFFFFFu;
             hr[g][key].push_back(a);
         }
         s.pend_bake = s.pend_cull = s.pend_draw[0] = s.pend_draw[1] = false;
@@ -1694,9 +1696,11 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     const uint32_t small_grid = R3N_SMALL_GRID;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
     TRY(fork_lane(c, lane));
     if (fwd == 63u) HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));  // the first 63 calls of a lane have counters zeroed at frame begin
+    a.row_begin = 0; a.row_end = 0xFFFFFFFFu;
     if (viewport) {
         a.vp_x = 0; a.vp_y = 0; a.vp_w = c->width; a.vp_h = c->height; a.target_pitch = c->width;
         a.vis = c->vis.as<unsigned long long>();
+        if (c->shard_rows) { a.row_begin = std::min(c->row_begin, c->height); a.row_end = std::min(c->row_end, c->height); }
         // textured variant only where it can matter: cutout key and a non-empty texture array
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         auto launch = [&](auto small, auto big) {
@@ -2196,6 +2200,11 @@ int r3n_exchange_shadow_stream(r3n_ctx *c, void **atlas, uint64_t *atlas_count, 
     if (atlas) *atlas = c->atlas.p;
     if (atlas_count) *atlas_count = (uint64_t)c->atlas_w * c->atlas_h;
     if (stream) *stream = (void *)on;
+    return R3N_OK;
+}
+int r3n_set_shard_mode(r3n_ctx *c, uint32_t mode) {
+    if (!c || mode > R3N_SHARD_ROWS) return fail(c, R3N_ERR_INVALID_ARG, "set_shard_mode: unknown mode");
+    c->shard_rows = mode == R3N_SHARD_ROWS;
     return R3N_OK;
 }
 int r3n_set_row_range(r3n_ctx *c, uint32_t b, uint32_t e) {

@@ -336,6 +336,7 @@ class Exchange:
         if skey not in Exchange._rows_groups:
             Exchange._rows_groups[skey] = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group))
         self.group_shadow = Exchange._rows_groups[skey]
+        self.by_rows = False  # set_row_sharding: sort-first
         self.sparse = None    # spatial partition: dict(bounds=[...]) -- the exchanges then move only the rows a rank can have touched
         self.full_extent_frames = 0
         self._streams = {}
@@ -352,6 +353,16 @@ class Exchange:
         r._check(r.lib.r3n_set_object_owners(r.ctx, owners.ctypes.data, len(owners), self.rank), "r3n_set_object_owners")
         self.sparse = dict(bounds=bounds)
         self.full_extent_frames = 1
+
+    def set_row_sharding(self, row_begin, row_end):
+        """Sort-first: this rank culls and draws EVERY object but rasterises only its rows (r3n_set_shard_mode(R3N_SHARD_ROWS)).
+        Its rows of the pass-1 depth plane are then final: the pass-1 exchange becomes an all-gather of the row bands (every rank
+        culls against the whole Hi-Z pyramid, so the visible sets are the unsharded ones on every rank), and pass 2 needs no
+        exchange at all -- the 8 B per pixel key reduction of the object-sharded scheme disappears."""
+        r = self.r
+        r._check(r.lib.r3n_set_shard_mode(r.ctx, 1), "r3n_set_shard_mode")
+        r._check(r.lib.r3n_set_row_range(r.ctx, int(row_begin), int(row_end)), "r3n_set_row_range")
+        self.by_rows = True
 
     def _row_extents(self, renderer, height):
         if self.full_extent_frames > 0:
@@ -409,6 +420,29 @@ class Exchange:
             if self.timed:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(self.stream)
+            if self.by_rows:
+                if what == "pass1":
+                    ct = self._ct
+                    r = self.r
+                    if samples == 1:
+                        plane, n = ct.c_void_p(), ct.c_uint64()
+                        r._check(r.lib.r3n_exchange_depth(r.ctx, ct.byref(plane), ct.byref(n)), "r3n_exchange_depth")
+                        t = device_tensor(plane.value, n.value, "<f4", self.device)
+                    else:  # multisampled targets: Hi-Z reads the keys
+                        vis, vis_n, _atlas, _atlas_n = self._buffers()
+                        t = device_tensor(vis, vis_n, "<i8", self.device)
+                    if self.rows_equal:
+                        allgather_rows_(t, self.rank, self.world, self.group)
+                        self.bytes[what] = t.numel() * t.element_size() // self.world
+                    else:  # ragged bands: rows a rank does not own hold the clear value, which never wins a MAX
+                        allreduce_max_(t, self.group)
+                        self.bytes[what] = t.numel() * t.element_size()
+                else:
+                    self.bytes[what] = 0  # pass 2: every rank's rows are complete
+                if self.timed:
+                    t1.record(self.stream)
+                    self.events.append((what, t0, t1))
+                return
             if what == "pass1" and samples == 1:
                 ct = self._ct
                 plane, n = ct.c_void_p(), ct.c_uint64()

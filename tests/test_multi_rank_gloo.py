@@ -192,6 +192,75 @@ def _worker_sparse(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_rows(rank, world, port, q):
+    """Sort-first (R3N_SHARD_ROWS, Exchange.set_row_sharding): every rank culls and draws every object but keeps only its rows;
+    the depth bands are all-gathered in front of Hi-Z, nothing is exchanged after pass 2.  The visible sets are then the
+    UNSHARDED ones on every rank, the own rows of keys / image the unsharded ones, the gathered image the unsharded image."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rend3_amd import parallel
+    try:
+        full, oh, math = _scene()
+        shard, _, _ = _scene()
+        rows = parallel.row_ranges(H, world)
+        shard.row_band = rows[rank]
+        shard.shadow_views_owned = {v for v in range(len(shard.dir_lights)) if parallel.shadow_view_owner(v, world) == rank}
+        calls = []
+
+        def exchange(what, arr, shadows=None):
+            calls.append(what)
+            if what == "shadow":
+                parallel.exchange_shadow_views_(torch.from_numpy(arr), shadows, rank, world)
+            elif what in ("pass1_depth", "pass1"):  # the bands are final: gather, no reduction
+                parallel.allgather_rows_(torch.from_numpy(arr.reshape(-1).view(np.int64 if arr.dtype == np.uint64 else arr.dtype)), rank, world)
+            # pass2: nothing
+
+        for samples in (1, 4):
+            for f in range(FRAMES):
+                _camera(full, oh, math, f)
+                _camera(shard, oh, math, f)
+                kw = dict(samples=samples, ambient=(0.1, 0.1, 0.1, 1), clear_color=(0.1, 0.2, 0.3, 1))
+                ref = full.render(W, H, **kw)
+                got = shard.render(W, H, exchange=exchange, **kw)
+                r0, r1 = rows[rank]
+                assert np.array_equal(ref["vis"][r0:r1], got["vis"][r0:r1]), f"own rows of the keys, frame {f}"
+                assert not got["vis"][:r0].any() and not got["vis"][r1:].any()
+                assert np.array_equal(ref["atlas"].view(np.uint32), got["atlas"].view(np.uint32)), f"atlas frame {f}"
+                assert np.array_equal(ref["hiz"].view(np.uint32), got["hiz"].view(np.uint32)), f"Hi-Z pyramid frame {f}"
+                for k in ("visible", "pass", "residual"):
+                    assert np.array_equal(got[k], ref[k]), f"{k} frame {f}: the sets are the unsharded ones on every rank"
+                assert np.array_equal(ref["rgba8"][r0:r1], got["rgba8"][r0:r1]), f"own rows of the image, frame {f}"
+                img = torch.from_numpy(got["rgba8"].copy().reshape(-1))
+                parallel.allgather_rows_(img, rank, world)
+                assert np.array_equal(img.numpy().reshape(H, W, 4), ref["rgba8"]), f"gathered image frame {f}"
+            assert ref["residual"].sum() > 0
+        assert "pass1_depth" in calls and "pass1" in calls and "shadow" in calls
+        q.put((rank, "ok"))
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + repr(exc) + "\n" + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_rows_exact():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def test_spatial_partition_helpers():
     from rend3_amd import parallel
     rng = np.random.default_rng(7)

@@ -3,7 +3,8 @@ exchange callbacks) with world size 2 -- one MI355X each over RCCL when the box 
 the collectives staged through the host (gloo): what is exercised either way is the product's own code: two HIP contexts in
 two processes, object sharding (slot ranges, and owner bytes from the spatial partition), shadow views by view + broadcast,
 the pass-1 depth exchange in front of Hi-Z, the pass-2 key reduction onto the row owners (dense and row-limited), the split
-resolve and the row gather -- and the result is compared with the SAME process's unsharded HIP render, bit for bit, over
+resolve and the row gather; and the sort-first scheme (rows: every object on every rank, each rank rasterises its rows, the depth
+bands are all-gathered, no key exchange) -- and the result is compared with the SAME process's unsharded HIP render, bit for bit, over
 frames with camera motion (predicted / residual passes, frames in flight)."""
 import os
 import socket
@@ -67,6 +68,10 @@ def _worker(rank, world, port, mode, q):
             shard.set_object_range(b, e)
             mask = np.zeros(shard.capacity, dtype=bool)
             mask[b:e] = True
+        elif mode == "rows":  # sort-first: every object on every rank, each rank rasterises its rows only
+            rb, re_ = parallel.row_ranges(H, world)[rank]
+            ex.set_row_sharding(rb, re_)
+            mask = np.ones(shard.capacity, dtype=bool)
         else:
             owners = parallel.partition_objects_spatial(centres, counts, world)
             ex.set_spatial_partition(owners, parallel.partition_bounds(owners, centres, radii, counts, world))
@@ -124,7 +129,7 @@ def _worker(rank, world, port, mode, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["slots", "spatial"])
+@pytest.mark.parametrize("mode", ["slots", "spatial", "rows"])
 def test_two_processes_exchange_matches_unsharded(mode):
     import torch
     import torch.multiprocessing as mp

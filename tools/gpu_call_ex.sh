@@ -3,12 +3,12 @@ set -u
 out=gpurun_out/${1:-ex}; mkdir -p $out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q -k "two_process or exchange or sharded" > $out/pytest.log 2>&1; echo "pytest rc=$?"; grep -E 'passed|failed|error' $out/pytest.log | tail -3
-for part in slots spatial; do
+for part in rows slots; do
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-exchange --partition $part --steps 60 --warmup 8 > $out/bench_ex_$part.json 2> $out/bench_ex_$part.err; echo "exchange $part rc=$?"
   python - $out/bench_ex_$part.json <<'PY'
 import json,sys
 try:
-    d=json.load(open(sys.argv[1])); print(d["ms_per_step"], d.get("exchange_ms_per_frame"), d.get("exchange_bytes_per_frame"))
+    d=json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1]); print(d["ms_per_step"], d.get("exchange_ms_per_frame"), d.get("exchange_bytes_per_frame"))
 except Exception as e: print("FAILED", e)
 PY
 done
