@@ -141,6 +141,9 @@ def main():
                          "object-slot ranges balanced by triangles, whole-target MAX collectives of depth (pass 1) and keys (pass 2); spatial: owner bytes from the Morton order of the bounding-sphere centres, with the pass-1 / pass-2 "
                          "exchanges limited to the rows inside each rank's conservative screen extent (pays only when partitions are compact on "
                          "screen: measured extents in DESIGN.md section 6)")
+    ap.add_argument("--python-exchange", action="store_true",
+                    help="--partition rows through rend3_amd/parallel.py's Exchange (torch.distributed calls from the frame's callbacks) instead "
+                         "of the library's own RCCL calls (r3n_comm_init): A/B of the host cost")
     ap.add_argument("--scene", default=None, metavar="FILE.glb|FILE.gltf",
                     help="run the benchmark on a real glTF asset through the scene-viewer harness (rend3_amd/scene_viewer.py; its flags "
                          "below; `data` becomes \"asset\"): hand it Bistro.glb with tools/scene_viewer.py's --bistro flags and the line is "
@@ -186,7 +189,7 @@ def main():
     if args.shade_mode == "fast":
         r.set_shade_mode(1)
     hbm_measured = r.hbm_copy_rate(1 << 30, 5)
-    exchange = None
+    exchange, native_comm = None, False
     if distributed:
         r.evaluate_instructions()  # flush the world: the object buffer's capacity is final
         counts = np.zeros(r.capacity, dtype=np.int64)
@@ -194,10 +197,17 @@ def main():
         for h, m in r.object_meta.items():
             counts[h] = r.meshes[m["mesh"]].index_count // 3
             spheres[h] = m["sphere"]
-        exchange = parallel.Exchange(r, device)
         rows = parallel.row_ranges(HEIGHT, world)
-        exchange.rows_equal = HEIGHT % world == 0
-        if args.partition == "rows":
+        native_comm = args.partition == "rows" and not args.python_exchange
+        if native_comm:
+            # the library issues the exchanges itself (r3n_comm_init): no Exchange object, no torch collective on the frame path
+            r.comm_init_torch()
+        else:
+            exchange = parallel.Exchange(r, device)
+            exchange.rows_equal = HEIGHT % world == 0
+        if native_comm:
+            pass
+        elif args.partition == "rows":
             exchange.set_row_sharding(rows[rank][0], rows[rank][1])
         elif args.partition == "spatial" and exchange.rows_equal and args.samples == 1:
             owners = parallel.partition_objects_spatial(spheres[:, :3], counts, world)
@@ -205,7 +215,8 @@ def main():
         else:
             begin, end = parallel.partition_objects(counts, world)[rank]
             r.set_object_range(begin, end)
-        r._check(r.lib.r3n_set_row_range(r.ctx, rows[rank][0], rows[rank][1]), "r3n_set_row_range")
+        if not native_comm:
+            r._check(r.lib.r3n_set_row_range(r.ctx, rows[rank][0], rows[rank][1]), "r3n_set_row_range")
 
     base = r3.BaseRenderGraph(r)
 
@@ -252,7 +263,7 @@ def main():
     # converges to the GPU's frame time.  Its OWN time per frame (Python glue + r3n_host_evaluate_frame + r3n_render_frame + the HIP
     # runtime's launches): bursts of 3 frames right after a full synchronisation, median.
     host_ms = None
-    if not distributed:
+    if True:  # with the exchange too: the collectives' enqueue calls are part of the host's frame
         bursts, k0 = [], step0 + args.warmup
         for b in range(12):
             r.sync()
@@ -278,10 +289,16 @@ def main():
     r.sync()
     stages = r.stage_times(reset=True)
     r.timing_enable(False)
-    exchange_ms = None
+    exchange_ms, exchange_bytes = None, None
     if exchange is not None:  # HIP events on the context's stream around every collective of the instrumented frames
         exchange.timed = False
         exchange_ms = {k: round(v / n_inst, 4) for k, v in exchange.drain_timings().items()}
+        exchange_bytes = dict(exchange.bytes)
+    elif native_comm:  # the library's own stage events (R3N_STAGE_EXCHANGE_*)
+        exchange_ms = {"shadow": round(stages["exchange_shadow"][0] / n_inst, 4), "pass1": round(stages["exchange_depth"][0] / n_inst, 4),
+                       "pass2": 0.0, "rows": round(stages["exchange_rows"][0] / n_inst, 4)}
+        exchange_bytes = {"shadow": 4 * 4 * 2048 * 2048 if not args.scene else None, "pass1": (4 if args.samples == 1 else 8 * args.samples) * WIDTH * HEIGHT // world,
+                          "pass2": 0, "rows": 4 * WIDTH * HEIGHT // world}
     r.set_multi_stream(True)
     last = frame(step0 + args.warmup + args.steps + n_inst, readback=(world == 1))
 
@@ -390,7 +407,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else (
                            f"sort-first: every rank culls + draws every object into its band of {HEIGHT // world} rows (x{world}), shadow views by view "
                            "(broadcast on a shadow lane's stream), pass-1 depth bands all-gathered over RCCL in front of Hi-Z, no key exchange, image rows all-gathered"
-                           if exchange is not None and exchange.by_rows else
+                           + (" -- exchanges issued by the library itself (r3n_comm_init)" if native_comm else " -- exchanges through torch.distributed")
+                           if native_comm or (exchange is not None and exchange.by_rows) else
                            f"viewport objects by spatial partition (Morton order, owner bytes) x{world}, shadow views by view (broadcast), pass-1 depth and pass-2 keys "
                            "MAX-reduced onto the row-band owners over RCCL all-to-all limited to each rank's screen-row extent, depth bands + image rows all-gathered"
                            if exchange is not None and exchange.sparse is not None else
@@ -406,7 +424,7 @@ def main():
             "rooflines": {k: v for k, v in rooflines.items() if k != dominant},
             "hbm_copy_rate_measured_GBps": round(hbm_measured, 1),
             "exchange_ms_per_frame": exchange_ms,
-            "exchange_bytes_per_frame": dict(exchange.bytes) if exchange is not None else None,
+            "exchange_bytes_per_frame": exchange_bytes,
             "mesh_buffer_bytes": info.get("mesh_bytes"), "unique_triangles": info.get("unique_triangles"),
         }
 

@@ -71,6 +71,8 @@ pub const R3N_FRAME_VIEWPORT_FIRST: u32 = 1;
 pub const R3N_FRAME_SHADOW_MASK: u32 = 2;
 pub const R3N_SHARD_OBJECTS: u32 = 0;
 pub const R3N_SHARD_ROWS: u32 = 1;
+pub const R3N_COMM_ID_BYTES: i32 = 128;
+pub const R3N_COMM_IDS: i32 = 3;
 pub const R3N_STAGE_BAKE: i32 = 0;
 pub const R3N_STAGE_OBJECT_CULL: i32 = 1;
 pub const R3N_STAGE_TRIANGLE_CULL: i32 = 2;
@@ -85,7 +87,10 @@ pub const R3N_STAGE_SHADOW_RASTER_BIG: i32 = 10;
 pub const R3N_STAGE_SKINNING: i32 = 11;
 pub const R3N_STAGE_VERTEX: i32 = 12;
 pub const R3N_STAGE_POSE: i32 = 13;
-pub const R3N_STAGE_COUNT: i32 = 14;
+pub const R3N_STAGE_EXCHANGE_SHADOW: i32 = 14;
+pub const R3N_STAGE_EXCHANGE_DEPTH: i32 = 15;
+pub const R3N_STAGE_EXCHANGE_ROWS: i32 = 16;
+pub const R3N_STAGE_COUNT: i32 = 17;
 
 #[repr(C)]
 pub struct r3n_ctx {
@@ -364,6 +369,9 @@ extern "C" {
     pub fn r3n_set_object_range(ctx: *mut r3n_ctx, begin: u32, end: u32) -> c_int;
     pub fn r3n_set_object_owners(ctx: *mut r3n_ctx, owners: *const u8, n: u32, rank: u32) -> c_int;
     pub fn r3n_set_shard_mode(ctx: *mut r3n_ctx, mode: u32) -> c_int;
+    pub fn r3n_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn r3n_comm_init(ctx: *mut r3n_ctx, ids: *const u8, rank: u32, world: u32) -> c_int;
+    pub fn r3n_comm_destroy(ctx: *mut r3n_ctx) -> c_int;
     pub fn r3n_set_camera_object_range(ctx: *mut r3n_ctx, camera: u32, begin: u32, end: u32) -> c_int;
     pub fn r3n_exchange_depth(ctx: *mut r3n_ctx, depth_f32: *mut *mut c_void, count: *mut u64) -> c_int;
     pub fn r3n_exchange_buffers(ctx: *mut r3n_ctx, visibility_keys: *mut *mut c_void, visibility_count: *mut u64, shadow_atlas: *mut *mut c_void, shadow_atlas_count: *mut u64) -> c_int;

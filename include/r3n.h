@@ -427,6 +427,24 @@ int r3n_set_object_owners(r3n_ctx *ctx, const uint8_t *owners, uint32_t n, uint3
 #define R3N_SHARD_OBJECTS 0u
 #define R3N_SHARD_ROWS 1u
 int r3n_set_shard_mode(r3n_ctx *ctx, uint32_t mode);
+/* The exchanges of the sort-first split issued BY THE LIBRARY over RCCL, inside r3n_render_frame: no callback, no host-language
+ * collective calls on the frame path (Python's torch.distributed calls cost 0.33 ms per frame, more than a rank's GPU work at
+ * N = 8).  RCCL is bound at run time (the copy the process already holds -- PyTorch's -- else ROCm's librccl.so.1).
+ *   r3n_comm_unique_id   one ncclUniqueId (128 B); rank 0 makes R3N_COMM_IDS of them and hands them to every rank through
+ *                        whatever launched the ranks (torch.distributed broadcast, MPI, a file);
+ *   r3n_comm_init        collective: three communicators -- main stream (depth bands), shadow lane (shadow views), resolve stream
+ *                        (image rows) -- so that no exchange queues behind another stream's;  switches the context to
+ *                        R3N_SHARD_ROWS; from then on r3n_render_frame owns the shadow views v with v mod world == rank, rasterises
+ *                        the band of rows `rank` of r3n_host row ranges (rows split as evenly as possible, the first height mod world
+ *                        bands one row taller), broadcasts the shadow rectangles on the shadow lane's stream, all-gathers the
+ *                        depth bands in front of r3n_hi_z (keys under MSAA; a MAX all-reduce when the bands are ragged) and the
+ *                        Rgba8 rows behind the resolve.  r3n_frame_desc.exchange must be NULL then.
+ *   r3n_comm_destroy     collective; back to a single-rank context. */
+#define R3N_COMM_ID_BYTES 128
+#define R3N_COMM_IDS 3
+int r3n_comm_unique_id(uint8_t *id /* R3N_COMM_ID_BYTES */);
+int r3n_comm_init(r3n_ctx *ctx, const uint8_t *ids /* R3N_COMM_IDS x R3N_COMM_ID_BYTES */, uint32_t rank, uint32_t world);
+int r3n_comm_destroy(r3n_ctx *ctx);
 /* Device pointers + sizes of the exchange buffers, for RCCL (all-reduce MAX over ranks):
  * the 64-bit visibility/depth keys (width*height u64, as int64 non-negative) and the f32 shadow atlas. */
 /* this camera's own object-slot range, overriding r3n_set_object_range for it (a shadow view owned whole by one rank draws
@@ -499,7 +517,10 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_SKINNING 11
 #define R3N_STAGE_VERTEX 12         /* resolve pre-pass: flag the visible triangles + one vertex stage per flagged triangle */
 #define R3N_STAGE_POSE 13           /* animation poses evaluated in front of the skinning kernel */
-#define R3N_STAGE_COUNT 14
+#define R3N_STAGE_EXCHANGE_SHADOW 14 /* r3n_comm_init: shadow rectangles packed, broadcast, unpacked (shadow lane) */
+#define R3N_STAGE_EXCHANGE_DEPTH 15  /* depth bands (keys under MSAA) gathered in front of Hi-Z (main stream) */
+#define R3N_STAGE_EXCHANGE_ROWS 16   /* Rgba8 rows gathered behind the resolve (resolve's stream) */
+#define R3N_STAGE_COUNT 17
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
 /* Shadow views normally run on auxiliary streams concurrently with the viewport chain; per-kernel durations measured
  * while kernels of other streams are resident are inflated, so timing passes can serialise everything on the main

@@ -18,7 +18,9 @@ PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
-          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose"]
+          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth", "exchange_rows"]
+
+COMM_ID_BYTES, COMM_IDS = 128, 3  # R3N_COMM_ID_BYTES, R3N_COMM_IDS
 
 # every symbol include/r3n.h declares: (restype, argtypes)
 SIGNATURES = {
@@ -57,6 +59,9 @@ SIGNATURES = {
     "r3n_exchange_buffers": (cint, [vp, vp, vp, vp, vp]),
     "r3n_exchange_shadow_stream": (cint, [vp, vp, vp, vp]),
     "r3n_set_shard_mode": (cint, [vp, u32]),
+    "r3n_comm_unique_id": (cint, [vp]),
+    "r3n_comm_init": (cint, [vp, vp, u32, u32]),
+    "r3n_comm_destroy": (cint, [vp]),
     "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
     "r3n_exchange_depth": (cint, [vp, vp, vp]),
     "r3n_set_row_range": (cint, [vp, u32, u32]),

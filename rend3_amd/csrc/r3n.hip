@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.h"
 #include "kernels_cull.h"
 #include "kernels_raster.h"
 #include "kernels_shadow.h"
@@ -167,6 +168,13 @@ struct r3n_ctx {
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
     bool shard_rows = false;  // R3N_SHARD_ROWS: the viewport camera rasterises its row band only
+    // r3n_comm_init: the sort-first exchanges issued from r3n_render_frame over RCCL
+    struct Comm {
+        bool on = false;
+        uint32_t rank = 0, world = 1;
+        ncclComm_t main = nullptr, shadow = nullptr, rows = nullptr;
+        DevBuf stage[R3N_MAX_SHADOW_VIEWS];  // contiguous copies of the shadow rectangles (what a broadcast moves)
+    } comm;
     DevBuf owners;  // r3n_set_object_owners: owner rank per object slot (p == nullptr: slot ranges)
     uint32_t owner_rank = 0, owners_n = 0;
     // pinned staging ring for small per-frame uploads (headers, uniforms, light buffers): the caller owns its
@@ -683,6 +691,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
 void r3n_destroy(r3n_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)r3n_comm_destroy(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->shade) (void)hipStreamSynchronize(c->shade);
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
@@ -2047,6 +2056,133 @@ int r3n_frame_end(r3n_ctx *c) {
     return R3N_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ native exchange (r3n_comm_*)
+#define NCCL_TRY(c, expr)                                                                                          \
+    do {                                                                                                           \
+        ncclResult_t _r = (expr);                                                                                  \
+        if (_r != ncclSuccess) return fail(c, R3N_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(_r)); \
+    } while (0)
+
+// rows of band `r` of `world` (rend3_amd/parallel.py::row_ranges: as even as possible, the first height mod world one row taller)
+static void band_rows(uint32_t height, uint32_t world, uint32_t r, uint32_t &b, uint32_t &e) {
+    const uint32_t base = height / world, rem = height % world;
+    b = r * base + std::min(r, rem);
+    e = b + base + (r < rem ? 1u : 0u);
+}
+
+int r3n_comm_unique_id(uint8_t *id) {
+    static_assert(R3N_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "r3n.h mirrors ncclUniqueId's size");
+    if (!id || !rccl().load()) return R3N_ERR_UNSUPPORTED;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return R3N_ERR_HIP;
+    std::memcpy(id, u.internal, R3N_COMM_ID_BYTES);
+    return R3N_OK;
+}
+int r3n_comm_init(r3n_ctx *c, const uint8_t *ids, uint32_t rank, uint32_t world) {
+    if (!c || !ids || world == 0 || rank >= world) return fail(c, R3N_ERR_INVALID_ARG, "comm_init: bad arguments");
+    if (c->comm.on) return fail(c, R3N_ERR_STATE, "comm_init: the context already has communicators");
+    if (!rccl().load()) return fail(c, R3N_ERR_UNSUPPORTED, "comm_init: " + rccl().error);
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(sync_all(c));
+    ncclComm_t *dst[R3N_COMM_IDS] = {&c->comm.main, &c->comm.shadow, &c->comm.rows};
+    for (int k = 0; k < R3N_COMM_IDS; ++k) {
+        ncclUniqueId u;
+        std::memcpy(u.internal, ids + (size_t)k * R3N_COMM_ID_BYTES, R3N_COMM_ID_BYTES);
+        NCCL_TRY(c, rccl().CommInitRank(dst[k], (int)world, u, (int)rank));
+    }
+    c->comm.on = true; c->comm.rank = rank; c->comm.world = world;
+    c->shard_rows = true;
+    return R3N_OK;
+}
+int r3n_comm_destroy(r3n_ctx *c) {
+    if (!c) return R3N_ERR_INVALID_ARG;
+    if (!c->comm.on) return R3N_OK;
+    (void)hipSetDevice(c->device);
+    (void)sync_all(c);
+    for (ncclComm_t *k : {&c->comm.main, &c->comm.shadow, &c->comm.rows})
+        if (*k) { (void)rccl().CommDestroy(*k); *k = nullptr; }
+    for (DevBuf &b : c->comm.stage)
+        if (b.p) { (void)hipFree(b.p); b = DevBuf{}; }
+    c->comm.on = false; c->comm.world = 1; c->comm.rank = 0;
+    c->shard_rows = false; c->row_begin = 0; c->row_end = 0xFFFFFFFFu;
+    return R3N_OK;
+}
+// Shadow views by view: the owner's atlas rectangle to every rank, on the shadow lane's stream (r3n_exchange_shadow_stream).
+static int comm_exchange_shadows(r3n_ctx *c, const r3n_frame_desc *d) {
+    void *atlas = nullptr, *sp = nullptr;
+    uint64_t n = 0;
+    TRY(r3n_exchange_shadow_stream(c, &atlas, &n, &sp));
+    hipStream_t on = (hipStream_t)sp;
+    const uint32_t world = c->comm.world, rank = c->comm.rank, aw = c->atlas_w;
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v) {  // staging first: allocations synchronise
+        const size_t want = (size_t)d->shadow_views[v].size * d->shadow_views[v].size * 4;
+        DevBuf &b = c->comm.stage[v];
+        if (b.bytes < want) {
+            if (b.p) { TRY(sync_all(c)); HIP_TRY(c, hipFree(b.p)); b = DevBuf{}; }
+            HIP_TRY(c, hipMalloc(&b.p, want));
+            b.bytes = want;
+        }
+    }
+    Timed t(c, R3N_STAGE_EXCHANGE_SHADOW, on);
+    auto rect = [&](const r3n_shadow_view272 &sv) { return static_cast<char *>(atlas) + ((size_t)sv.y * aw + sv.x) * 4; };
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v)
+        if (v % world == rank) {
+            const r3n_shadow_view272 &sv = d->shadow_views[v];
+            HIP_TRY(c, hipMemcpy2DAsync(c->comm.stage[v].p, (size_t)sv.size * 4, rect(sv), (size_t)aw * 4, (size_t)sv.size * 4, sv.size, hipMemcpyDeviceToDevice, on));
+        }
+    NCCL_TRY(c, rccl().GroupStart());  // the views' broadcasts progress together
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v) {
+        const size_t count = (size_t)d->shadow_views[v].size * d->shadow_views[v].size;
+        NCCL_TRY(c, rccl().Broadcast(c->comm.stage[v].p, c->comm.stage[v].p, count, ncclFloat, (int)(v % world), c->comm.shadow, on));
+    }
+    NCCL_TRY(c, rccl().GroupEnd());
+    for (uint32_t v = 0; v < d->n_shadow_views; ++v)
+        if (v % world != rank) {
+            const r3n_shadow_view272 &sv = d->shadow_views[v];
+            HIP_TRY(c, hipMemcpy2DAsync(rect(sv), (size_t)aw * 4, c->comm.stage[v].p, (size_t)sv.size * 4, (size_t)sv.size * 4, sv.size, hipMemcpyDeviceToDevice, on));
+        }
+    return R3N_OK;
+}
+// `base`: a buffer of height rows of row_bytes each whose rows [band of this rank) are final: afterwards every rank holds every band
+static int comm_gather_bands(r3n_ctx *c, void *base, size_t row_bytes, ncclComm_t comm, hipStream_t on) {
+    const uint32_t world = c->comm.world, rank = c->comm.rank, h = c->height;
+    char *p = static_cast<char *>(base);
+    if (h % world == 0) {
+        const size_t chunk = (size_t)(h / world) * row_bytes;
+        NCCL_TRY(c, rccl().AllGather(p + (size_t)rank * chunk, p, chunk, ncclUint8, comm, on));  // in place
+        return R3N_OK;
+    }
+    NCCL_TRY(c, rccl().GroupStart());  // ragged bands: one broadcast per band
+    for (uint32_t r = 0; r < world; ++r) {
+        uint32_t b, e;
+        band_rows(h, world, r, b, e);
+        if (e > b) NCCL_TRY(c, rccl().Broadcast(p + (size_t)b * row_bytes, p + (size_t)b * row_bytes, (size_t)(e - b) * row_bytes, ncclUint8, (int)r, comm, on));
+    }
+    NCCL_TRY(c, rccl().GroupEnd());
+    return R3N_OK;
+}
+static int comm_exchange_pass1(r3n_ctx *c) {
+    if (c->samples == 1) {
+        void *plane = nullptr;
+        uint64_t n = 0;
+        TRY(r3n_exchange_depth(c, &plane, &n));  // mip 0 of the Hi-Z pyramid from the keys: this rank's rows are final
+        Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);
+        return comm_gather_bands(c, plane, (size_t)c->width * 4, c->comm.main, c->stream);
+    }
+    Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);  // multisampled: Hi-Z reads the keys
+    return comm_gather_bands(c, c->vis.p, (size_t)c->width * c->samples * 8, c->comm.main, c->stream);
+}
+static int comm_gather_rows(r3n_ctx *c) {
+    void *out = nullptr, *sp = nullptr;
+    uint64_t bytes = 0;
+    TRY(r3n_output_buffer_async(c, &out, &bytes, &sp));
+    {
+        Timed t(c, R3N_STAGE_EXCHANGE_ROWS, (hipStream_t)sp);
+        TRY(comm_gather_bands(c, out, (size_t)c->width * 4, c->comm.rows, (hipStream_t)sp));
+    }
+    return r3n_output_work_enqueued(c);
+}
+
 // ------------------------------------------------------------------------------------------------ the frame in one call
 // BaseRenderGraph::add_to_graph's node list (base.rs:135-185) issued from here: the per-node entry points above, in the reference's
 // order, without a host-language graph (or ~45 FFI crossings) between them.
@@ -2055,6 +2191,11 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     if (!d->uniforms || !d->viewport_header || (d->n_shadow_views && !d->shadow_views) || d->n_shadow_views > R3N_MAX_SHADOW_VIEWS)
         return fail(c, R3N_ERR_INVALID_ARG, "render_frame: null uniforms / headers, or too many shadow views");
     if (c->in_frame) return fail(c, R3N_ERR_STATE, "render_frame: a frame is already open");
+    const bool native = c->comm.on;
+    if (native) {
+        if (d->exchange) return fail(c, R3N_ERR_INVALID_ARG, "render_frame: an exchange callback AND r3n_comm_init communicators");
+        band_rows(d->height, c->comm.world, c->comm.rank, c->row_begin, c->row_end);
+    }
     for (uint32_t v = 0; v < d->n_shadow_views; ++v)
         if (d->shadow_views[v].header.shadow_index != v) return fail(c, R3N_ERR_INVALID_ARG, "render_frame: shadow view i must carry shadow_index i");
     if (d->directional_buffer) TRY(r3n_lights_write(c, d->directional_buffer, d->directional_bytes, d->point_buffer, d->point_bytes));
@@ -2074,8 +2215,11 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     } closer{c};
     struct Fused { r3n_ctx *c; ~Fused() { c->fused_frame = false; } } fused{c};
     c->fused_frame = true;
-    const bool masked = (d->flags & R3N_FRAME_SHADOW_MASK) != 0u;
-    auto mine = [&](uint32_t v) { return !masked || ((d->shadow_view_mask >> v) & 1ull) != 0ull; };
+    const bool masked = native || (d->flags & R3N_FRAME_SHADOW_MASK) != 0u;
+    auto mine = [&](uint32_t v) {
+        if (native) return v % c->comm.world == c->comm.rank;
+        return !masked || ((d->shadow_view_mask >> v) & 1ull) != 0ull;
+    };
     for (uint32_t v = 0; v < d->n_shadow_views; ++v) {
         const r3n_shadow_view272 &sv = d->shadow_views[v];
         TRY(r3n_shadow_viewport(c, v, sv.x, sv.y, sv.size));
@@ -2097,6 +2241,7 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
             }
         if (d->exchange && d->n_shadow_views && d->exchange(d->exchange_user, R3N_EXCHANGE_SHADOW) != 0)
             return fail(c, R3N_ERR_STATE, "render_frame: the shadow exchange callback failed");
+        if (native && d->n_shadow_views) TRY(comm_exchange_shadows(c, d));
         return R3N_OK;
     };
     auto viewport_pass1 = [&]() -> int {
@@ -2109,6 +2254,7 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     if (d->flags & R3N_FRAME_VIEWPORT_FIRST) { TRY(viewport_pass1()); TRY(shadow_nodes()); }
     else { TRY(shadow_nodes()); TRY(viewport_pass1()); }
     if (d->exchange && d->exchange(d->exchange_user, R3N_EXCHANGE_PASS1) != 0) return fail(c, R3N_ERR_STATE, "render_frame: the pass-1 exchange callback failed");
+    if (native) TRY(comm_exchange_pass1(c));
     TRY(r3n_hi_z(c));                         // hi_z (base.rs:162)
     TRY(r3n_cull(c, R3N_CAMERA_VIEWPORT));    // pbr_culling (base.rs:169)
     // pbr_render_opaque_residual_triangles (base.rs:172)
@@ -2119,6 +2265,7 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     // pbr_forward_rendering_transparent (base.rs:181)
     TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_BLEND));
     TRY(r3n_tonemap(c, nullptr, 0));          // tonemapping (base.rs:184)
+    if (native) TRY(comm_gather_rows(c));
     closer.armed = false;
     return r3n_frame_end(c);
 }

@@ -577,6 +577,35 @@ class Renderer:
         owners = np.ascontiguousarray(owners, dtype=np.uint8)
         self._check(self.lib.r3n_set_object_owners(self.ctx, owners.ctypes.data if len(owners) else None, len(owners), rank), "r3n_set_object_owners")
 
+    def comm_init(self, rank, world, share):
+        """Multi-GPU, native (r3n_comm_init): the sort-first exchanges are issued by the library itself over RCCL inside
+        r3n_render_frame -- no exchange object, no host-language collective on the frame path.  `share(ids or None) -> ids`: hands
+        rank 0's communicator ids (bytes) to every rank (comm_init_torch passes them through torch.distributed).  Collective."""
+        n = _ffi.COMM_IDS * _ffi.COMM_ID_BYTES
+        ids = None
+        if rank == 0:
+            buf = (ctypes.c_uint8 * n)()
+            for k in range(_ffi.COMM_IDS):
+                self._check(self.lib.r3n_comm_unique_id(ctypes.byref(buf, k * _ffi.COMM_ID_BYTES)), "r3n_comm_unique_id")
+            ids = bytes(buf)
+        ids = share(ids)
+        assert isinstance(ids, (bytes, bytearray)) and len(ids) == n
+        self._check(self.lib.r3n_comm_init(self.ctx, (ctypes.c_uint8 * n).from_buffer_copy(ids), rank, world), "r3n_comm_init")
+        self._comm = (int(rank), int(world))
+
+    def comm_init_torch(self, group=None):
+        import torch.distributed as dist
+
+        def share(ids):
+            box = [ids]
+            dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+            return box[0]
+        self.comm_init(dist.get_rank(group), dist.get_world_size(group), share)
+
+    def comm_destroy(self):
+        self._check(self.lib.r3n_comm_destroy(self.ctx), "r3n_comm_destroy")
+        self._comm = None
+
     def set_object_range(self, begin, end):
         """Multi-GPU sharding (not in the reference): this rank culls/draws object slots [begin, end)."""
         self._check(self.lib.r3n_set_object_range(self.ctx, begin, end), "r3n_set_object_range")
@@ -633,6 +662,9 @@ class Renderer:
         """The reference's per-frame driver (rend3-test/src/runner.rs:121-169): evaluate, build the graph with
         BaseRenderGraph::add_to_graph, execute.  `readback` additionally pulls the parity taps."""
         self._resolution = (width, height)
+        comm = getattr(self, "_comm", None)
+        if comm is not None and (self.frame_nodes or exchange is not None):
+            raise RuntimeError("comm_init: the library issues the exchanges inside r3n_render_frame (no exchange object, no per-node frame)")
         if not self.frame_nodes:
             eval_output = self.render_frame(width, height, samples, ambient, clear_color, exchange,
                                             viewport_first=bool(base is not None and base.viewport_first))
@@ -641,6 +673,8 @@ class Renderer:
             owned = None
             if exchange is not None and hasattr(exchange, "owns_shadow_view"):
                 owned = {si for si in range(len(eval_output.shadows)) if exchange.owns_shadow_view(si)}
+            elif comm is not None:
+                owned = {si for si in range(len(eval_output.shadows)) if si % comm[1] == comm[0]}
             return self.readback_frame(eval_output, width, height, samples, owned)
         eval_output = self.evaluate_instructions()
         base = base or BaseRenderGraph(self)

@@ -643,6 +643,43 @@ def test_exchange_path_single_rank(r3):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("samples,height", [(1, 192), (4, 192)])
+def test_native_comm_single_rank(r3, samples, height):
+    """r3n_comm_init: the sort-first exchanges issued by the library itself over RCCL (loaded at run time) inside
+    r3n_render_frame -- shadow rectangles packed / broadcast / unpacked on the shadow lane's stream, the depth bands (keys under
+    MSAA) gathered in place in front of Hi-Z, the Rgba8 rows gathered behind the resolve -- with a one-rank communicator set,
+    which runs every call of the path except the per-band broadcasts of a ragged row split (one rank always divides the
+    height): the frames equal the oracle's, also with frames in flight.
+    World size 2 of the same scheme: tests/test_two_process_gpu.py[rows] and test_two_rank_gloo_rows_exact (Python exchange)."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(height))
+    scenes.build_random_scene(o, oh, omk, 150, 0xE8C5, lights=2, with_cutout=True)
+    scenes.build_random_scene(p, oh, r3.material_record, 150, 0xE8C5, lights=2, with_cutout=True)
+    p.comm_init(0, 1, lambda ids: ids)
+    kw = dict(samples=samples, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+    for f in range(3):
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh((3.0 + f, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, height, **kw)
+        fp = p.render(320, height, **kw)
+        compare_frames(fo, fp, f"native comm frame {f}")
+    for f in range(3, 6):  # frames in flight
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh((3.0 + f, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, height, **kw)
+        assert p.render(320, height, readback=False, **kw) is None
+    fp = p.readback_frame(p.evaluate_instructions(), 320, height, samples)
+    compare_frames(fo, fp, "native comm, frames in flight, last frame")
+    st = p.stage_times()
+    assert st["exchange_shadow"][1] > 0 and st["exchange_depth"][1] > 0 and st["exchange_rows"][1] > 0
+    with pytest.raises(RuntimeError):
+        p.render(320, height, exchange=lambda *a, **k: None, **kw)
+    p.comm_destroy()
+    fo = o.render(320, height, **kw)
+    fp = p.render(320, height, **kw)  # back to a single-rank context
+    compare_frames(fo, fp, "after comm_destroy")
+    p.close()
+
+
 def test_golden_textured_quad_example(r3):
     """examples/src/textured_quad/mod.rs at 1280x720 (row N2): albedo texture, nearest sampler, sRGB decode -- HIP ==
     oracle bit for bit, and the HIP image against the reference's screenshot (Threshold::Mean(0.0): RGB exact)."""
