@@ -189,7 +189,7 @@ def main():
     if args.shade_mode == "fast":
         r.set_shade_mode(1)
     hbm_measured = r.hbm_copy_rate(1 << 30, 5)
-    exchange, native_comm = None, False
+    exchange, native_comm, comm_note = None, False, None
     if distributed:
         r.evaluate_instructions()  # flush the world: the object buffer's capacity is final
         counts = np.zeros(r.capacity, dtype=np.int64)
@@ -201,8 +201,12 @@ def main():
         native_comm = args.partition == "rows" and not args.python_exchange
         if native_comm:
             # the library issues the exchanges itself (r3n_comm_init): no Exchange object, no torch collective on the frame path
-            r.comm_init_torch()
-        else:
+            try:
+                r.comm_init_torch()
+            except Exception as exc:  # noqa: BLE001  (the same on every rank: RCCL not loadable / an id that cannot be shared) -> the Python exchange
+                native_comm, comm_note = False, f"r3n_comm_init failed ({exc}); exchanges through torch.distributed instead"
+                args.python_exchange = True
+        if not native_comm:
             exchange = parallel.Exchange(r, device)
             exchange.rows_equal = HEIGHT % world == 0
         if native_comm:
@@ -425,6 +429,7 @@ def main():
             "hbm_copy_rate_measured_GBps": round(hbm_measured, 1),
             "exchange_ms_per_frame": exchange_ms,
             "exchange_bytes_per_frame": exchange_bytes,
+            "exchange_note": comm_note,
             "mesh_buffer_bytes": info.get("mesh_bytes"), "unique_triangles": info.get("unique_triangles"),
         }
 

@@ -313,9 +313,6 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 #ifndef R3N_ABLATE
 #define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
 #endif
-#ifndef R3N_FINE_PERMUTE
-#define R3N_FINE_PERMUTE 0  // 1: fine mode compacts the surviving blocks into a vector register (ds_permute / ds_bpermute) instead of walking the mask on the scalar unit; kernel alone -2.5 %, frame +4 % (the LDS wait is the lgkm counter, which also holds the next record's prefetch): off
-#endif
 #ifndef R3N_FINE
 #define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block
 #endif
@@ -628,26 +625,6 @@ R3N_DEV void raster_big_body(RasterArgs a) {
 #endif
             const uint32_t grp = lane >> 4;
             const int px = (int)(lane & 3u), py = (int)((lane >> 2) & 3u);
-#if R3N_FINE_PERMUTE
-            // The surviving blocks as a compacted list in ONE vector register (lane r = the r-th surviving block): every candidate
-            // lane pushes its block id to lane `rank` (ds_permute: the LDS crossbar, no memory).  A step then PULLS the four ids
-            // of its block quartet (ds_bpermute) -- one vector instruction instead of four find-first / clear-lowest sequences on
-            // the scalar unit, which the counters showed nearly as loaded as the vector units (24 M scalar vs 31 M vector
-            // wave-instructions per launch).
-            const uint32_t nblk = (uint32_t)__popcll(blocks);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(blocks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)blocks, 0u));
-            // non-candidates push to lane 63: free whenever a non-candidate exists (then fewer than 64 blocks survive)
-            const int list = __builtin_amdgcn_ds_permute((int)((cand ? rank : 63u) << 2), (int)lane);
-            for (uint32_t s4 = 0; s4 < nblk; s4 += 4u) {
-#ifdef R3N_WAVE_TRACE
-                ++trace_steps;
-#endif
-                const uint32_t idx = s4 + grp;
-                const int b = __builtin_amdgcn_ds_bpermute((int)(idx << 2), list);
-                const int x = rx0 + (b & 7) * 4 + px, y = ry0 + (b >> 3) * 4 + py;
-                if (idx < nblk && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
-            }
-#else
             while (blocks) {
 #ifdef R3N_WAVE_TRACE
                 ++trace_steps;
@@ -666,7 +643,6 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
                 if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
-#endif
         } else if (R3N_ABLATE != 3) {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
             const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);

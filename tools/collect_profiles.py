@@ -12,7 +12,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 for name in ("bench", "bench_fast", "bench_instanced", "bench_untextured", "bench_msaa4", "bench_shadow_tiles", "bench_cfg4", "bench_scene",
-             "bench_exchange_spatial", "bench_exchange_slots", "bench_under_rocprof", "bench_under_rocprof_serial"):
+             "bench_exchange_rows", "bench_exchange_rows_python", "bench_exchange_spatial", "bench_exchange_slots", "bench_under_rocprof", "bench_under_rocprof_serial"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p):
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: everything behind profiles/rNN_*: bench lines of the build (default / fast / instanced / untextured / MSAA / config 4 /
-# a real asset through the scene-viewer harness / the multi-GPU exchange forced at N = 1 for both partitions), host cost per frame,
+# a real asset through the scene-viewer harness / the multi-GPU exchange forced at N = 1 for every split), host cost per frame,
 # rocprofv3 kernel traces (frames in flight and serial), the PMC passes (one counter set per run, kernel-trace only), the other
 # BASELINE.json configs.   gpurun --timeout 1800 -- 'bash tools/profile_round.sh r03'
 set -u
@@ -16,8 +16,9 @@ $B --steps 100 --warmup 10 --no-cpu-baseline --untextured > "$out/bench_untextur
 $B --steps 60 --warmup 10 --no-cpu-baseline --samples 4 > "$out/bench_msaa4.json" 2>/dev/null
 $B --steps 40 --warmup 8 --no-cpu-baseline --config 4 > "$out/bench_cfg4.json" 2>/dev/null
 $B --steps 60 --warmup 8 --cpu-sample-frames 3 --scene tests/golden/static_gltf-data.glb --directional-light=-1,-4,2 --directional-light-intensity 4 --shadow-distance 20 --camera=3,3,5,-0.55,-0.5 > "$out/bench_scene.json" 2>/dev/null
-for part in spatial slots; do
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-exchange --partition $part --steps 60 --warmup 8 > "$out/bench_exchange_$part.json" 2>/dev/null
+for part in rows rows_python spatial slots; do
+  flags="--partition $part"; [ $part = rows_python ] && flags="--partition rows --python-exchange"
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-exchange $flags --steps 60 --warmup 8 2>/dev/null | grep '^{' > "$out/bench_exchange_$part.json"
 done
 python tools/host_rate.py > "$out/host_rate.txt" 2>&1
 R3N_FRAME_NODES=1 python tools/host_rate.py > "$out/host_rate_nodes.txt" 2>&1
@@ -33,7 +34,7 @@ $B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"
 find "$out" -name "*_kernel_trace.csv" -size +8M -delete
 find "$out" -name "*counter_collection.csv" -size +8M -delete
 ls "$out"
-for f in bench bench_fast bench_instanced bench_untextured bench_msaa4 bench_cfg4 bench_scene bench_exchange_spatial bench_exchange_slots; do python - "$out/$f.json" <<'PY'
+for f in bench bench_fast bench_instanced bench_untextured bench_msaa4 bench_cfg4 bench_scene bench_exchange_rows bench_exchange_rows_python bench_exchange_spatial bench_exchange_slots; do python - "$out/$f.json" <<'PY'
 import json,sys
 try:
     line=[l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]
