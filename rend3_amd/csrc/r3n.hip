@@ -60,6 +60,18 @@ std::string g_create_error;
 #define R3N_AUX_STREAMS 2  // main + shade + these = the four hardware queues the runtime uses by default; 3 / 4 streams measured no faster (profiles/r02_summary.md section 9)
 #endif
 
+// Dynamic LDS bytes asked by the work-item rasteriser's launches.  The kernel uses no LDS: the allocation caps its workgroups per CU.
+// Shadow views at 32 KB (4 workgroups = 4 waves per SIMD instead of 8): the four launches take 444 instead of 466 us and the frame
+// 1.146 instead of 1.169 ms (two runs each) -- at full occupancy its fire-and-forget atomics queue up behind each other and its
+// idle waves hold slots the resolve of the previous frame could use.  54 KB (2 workgroups): 622 us.  The same cap on the viewport's
+// launches, on the per-triangle pass and on the triangle cull was measured: no gain alone, and any two caps together lose (kernels
+// that each reserve a third of a CU's LDS no longer co-reside).
+#ifndef R3N_BIG_LDS
+#define R3N_BIG_LDS 32768       // shadow views
+#endif
+#ifndef R3N_VIEWPORT_BIG_LDS
+#define R3N_VIEWPORT_BIG_LDS 0  // viewport
+#endif
 static_assert(R3N_AUX_STREAMS >= 1 && R3N_AUX_STREAMS <= R3N_QLANES, "every auxiliary stream (shadow lane) needs a work queue of its own: big_items / big_count / big_uv hold 1 + R3N_QLANES");
 
 struct r3n_ctx {
@@ -1714,7 +1726,7 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         auto launch = [&](auto small, auto big) {
             { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), R3N_VIEWPORT_BIG_LDS, stream, a); }
         };
         if (c->samples == 4) {
             if (tex) launch(k_raster_small<false, 4, true>, k_raster_big<false, 4, true>);
@@ -1731,10 +1743,10 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         if (tex) {
             { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
         } else {
             { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
         }
     }
     return check_launch(c, "raster");
