@@ -212,7 +212,18 @@ def reduce_scatter_max_rows_(tensor, rank, world_size, group=None):
     return tensor
 
 
-def direct_reduce_scatter_max_(tensor, rank, world_size, group=None):
+def _scratch(cache, key, like):
+    """A receive buffer shaped like `like`, kept in `cache` (a dict the caller owns, e.g. one per Exchange) across frames."""
+    import torch
+    if cache is None:
+        return torch.empty_like(like)
+    t = cache.get(key)
+    if t is None or t.shape != like.shape or t.dtype != like.dtype or t.device != like.device:
+        t = cache[key] = torch.empty_like(like)
+    return t
+
+
+def direct_reduce_scatter_max_(tensor, rank, world_size, group=None, cache=None):
     """The reduce-scatter of reduce_scatter_max_rows_ as ONE all-to-all + a local MAX: rank r sends its partial chunk j straight to
     rank j -- over the full xGMI mesh that is one point-to-point transfer per link, all seven links of a GPU busy at once, each
     carrying 1/N of the buffer -- and reduces the N chunks it received on its own.  Same result as the collective (MAX is exact and
@@ -224,19 +235,19 @@ def direct_reduce_scatter_max_(tensor, rank, world_size, group=None):
     if not _device_collectives(tensor, group):
         _staged(direct_reduce_scatter_max_, tensor, rank, world_size, group)
         return tensor
-    recv = torch.empty_like(tensor)
+    recv = _scratch(cache, ("a2a", tensor.dtype), tensor)  # the full-size receive buffer is not reallocated every frame
     dist.all_to_all_single(recv, tensor, group=group)
     tensor[rank * chunk:(rank + 1) * chunk].copy_(recv.view(world_size, chunk).amax(dim=0))
     return tensor
 
 
-def direct_allreduce_max_(tensor, rank, world_size, group=None):
+def direct_allreduce_max_(tensor, rank, world_size, group=None, cache=None):
     """MAX all-reduce as direct_reduce_scatter_max_ + an all-gather of the reduced chunks (buffers whose size divides by N)."""
     import torch.distributed as dist
     if not _device_collectives(tensor, group):
         _staged(direct_allreduce_max_, tensor, rank, world_size, group)
         return tensor
-    direct_reduce_scatter_max_(tensor, rank, world_size, group)
+    direct_reduce_scatter_max_(tensor, rank, world_size, group, cache)
     chunk = tensor.numel() // world_size
     mine = tensor[rank * chunk:(rank + 1) * chunk].clone()
     if hasattr(dist, "all_gather_into_tensor") and tensor.is_cuda:
@@ -340,6 +351,7 @@ class Exchange:
         self.sparse = None    # spatial partition: dict(bounds=[...]) -- the exchanges then move only the rows a rank can have touched
         self.full_extent_frames = 0
         self._streams = {}
+        self._scratch = {}    # receive buffers of the direct reductions, reused across frames
         self.timed = timed
         self.events = []      # (what, start event, end event)
         self.bytes = {}       # what -> bytes this rank hands to the collective per frame
@@ -461,7 +473,7 @@ class Exchange:
                         self.events.append((what, t0, t1))
                     return
                 if self.direct and n.value % self.world == 0:
-                    direct_allreduce_max_(t, self.rank, self.world, self.group)
+                    direct_allreduce_max_(t, self.rank, self.world, self.group, self._scratch)
                 else:
                     allreduce_max_(t, self.group)
                 self.bytes[what] = 4 * n.value
@@ -478,7 +490,7 @@ class Exchange:
                         self.events.append((what, t0, t1))
                     return
                 if self.direct:
-                    direct_reduce_scatter_max_(t, self.rank, self.world, self.group)
+                    direct_reduce_scatter_max_(t, self.rank, self.world, self.group, self._scratch)
                 else:
                     reduce_scatter_max_rows_(t, self.rank, self.world, self.group)
                 self.bytes[what] = 8 * vis_n
