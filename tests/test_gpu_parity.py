@@ -680,6 +680,21 @@ def test_native_comm_single_rank(r3, samples, height):
     p.close()
 
 
+def test_target_size_limits_fail_loudly(r3):
+    """The rasteriser addresses its targets with 32-bit byte offsets: r3n_frame_begin refuses a target of 2^29 samples or more
+    (and a side above 65 535) instead of rendering garbage -- before anything is allocated -- and the context stays usable."""
+    p = r3.Renderer(oh.LEFT, f32(1.0))
+    scenes.build_random_scene(p, r3.host, r3.material_record, 20, 0xE8C6, lights=1)
+    p.set_camera_data(oh.look_at_lh((3.0, 2.0, -6.0), (0, 0, 4), (0, 1, 0)), ("perspective", 60.0, 0.1))
+    for w, h, samples in ((32768, 16384, 1), (16384, 8192, 4), (70000, 16, 1)):
+        with pytest.raises(RuntimeError) as e:
+            p.render(w, h, samples=samples, readback=False)
+        assert "target" in str(e.value)
+    out = p.render(64, 48)
+    assert out["rgba8"].shape == (48, 64, 4)
+    p.close()
+
+
 def test_golden_textured_quad_example(r3):
     """examples/src/textured_quad/mod.rs at 1280x720 (row N2): albedo texture, nearest sampler, sRGB decode -- HIP ==
     oracle bit for bit, and the HIP image against the reference's screenshot (Threshold::Mean(0.0): RGB exact)."""
