@@ -192,7 +192,7 @@ def _worker_sparse(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _worker_rows(rank, world, port, q):
+def _worker_rows(rank, world, port, q, height=None):
     """Sort-first (R3N_SHARD_ROWS, Exchange.set_row_sharding): every rank culls and draws every object but keeps only its rows;
     the depth bands are all-gathered in front of Hi-Z, nothing is exchanged after pass 2.  The visible sets are then the
     UNSHARDED ones on every rank, the own rows of keys / image the unsharded ones, the gathered image the unsharded image."""
@@ -205,7 +205,9 @@ def _worker_rows(rank, world, port, q):
     try:
         full, oh, math = _scene()
         shard, _, _ = _scene()
-        rows = parallel.row_ranges(H, world)
+        H_ = height or H
+        rows = parallel.row_ranges(H_, world)
+        even = H_ % world == 0
         shard.row_band = rows[rank]
         shard.shadow_views_owned = {v for v in range(len(shard.dir_lights)) if parallel.shadow_view_owner(v, world) == rank}
         calls = []
@@ -215,7 +217,11 @@ def _worker_rows(rank, world, port, q):
             if what == "shadow":
                 parallel.exchange_shadow_views_(torch.from_numpy(arr), shadows, rank, world)
             elif what in ("pass1_depth", "pass1"):  # the bands are final: gather, no reduction
-                parallel.allgather_rows_(torch.from_numpy(arr.reshape(-1).view(np.int64 if arr.dtype == np.uint64 else arr.dtype)), rank, world)
+                flat = torch.from_numpy(arr.reshape(-1).view(np.int64 if arr.dtype == np.uint64 else arr.dtype))
+                if even:
+                    parallel.allgather_rows_(flat, rank, world)
+                else:  # ragged bands (Exchange.__call__ without rows_equal): rows a rank does not own hold the clear value, MAX merges them
+                    parallel.allreduce_max_(flat)
             # pass2: nothing
 
         for samples in (1, 4):
@@ -223,8 +229,8 @@ def _worker_rows(rank, world, port, q):
                 _camera(full, oh, math, f)
                 _camera(shard, oh, math, f)
                 kw = dict(samples=samples, ambient=(0.1, 0.1, 0.1, 1), clear_color=(0.1, 0.2, 0.3, 1))
-                ref = full.render(W, H, **kw)
-                got = shard.render(W, H, exchange=exchange, **kw)
+                ref = full.render(W, H_, **kw)
+                got = shard.render(W, H_, exchange=exchange, **kw)
                 r0, r1 = rows[rank]
                 assert np.array_equal(ref["vis"][r0:r1], got["vis"][r0:r1]), f"own rows of the keys, frame {f}"
                 assert not got["vis"][:r0].any() and not got["vis"][r1:].any()
@@ -233,9 +239,10 @@ def _worker_rows(rank, world, port, q):
                 for k in ("visible", "pass", "residual"):
                     assert np.array_equal(got[k], ref[k]), f"{k} frame {f}: the sets are the unsharded ones on every rank"
                 assert np.array_equal(ref["rgba8"][r0:r1], got["rgba8"][r0:r1]), f"own rows of the image, frame {f}"
-                img = torch.from_numpy(got["rgba8"].copy().reshape(-1))
-                parallel.allgather_rows_(img, rank, world)
-                assert np.array_equal(img.numpy().reshape(H, W, 4), ref["rgba8"]), f"gathered image frame {f}"
+                if even:
+                    img = torch.from_numpy(got["rgba8"].copy().reshape(-1))
+                    parallel.allgather_rows_(img, rank, world)
+                    assert np.array_equal(img.numpy().reshape(H_, W, 4), ref["rgba8"]), f"gathered image frame {f}"
             assert ref["residual"].sum() > 0
         assert "pass1_depth" in calls and "pass1" in calls and "shadow" in calls
         q.put((rank, "ok"))
@@ -246,12 +253,13 @@ def _worker_rows(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_rows_exact():
+@pytest.mark.parametrize("height", [H, H - 1])
+def test_two_rank_gloo_rows_exact(height):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, q, height)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]
