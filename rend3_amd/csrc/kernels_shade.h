@@ -21,6 +21,9 @@
 #ifndef R3N_TEX_OCC
 #define R3N_TEX_OCC 5  // min waves per SIMD asked of the textured record-based resolve (launch bound)
 #endif
+#ifndef R3N_PCF_WIDE
+#define R3N_PCF_WIDE 1
+#endif
 #ifndef R3N_SKIP_OCCLUDED
 #define R3N_SKIP_OCCLUDED 1
 #endif
@@ -195,6 +198,37 @@ R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t
     const uint32_t row = aw << 2;
     const uint32_t base = (__umul24((uint32_t)(int)f0y - 1u, aw) + ((uint32_t)(int)f0x - 1u)) << 2;  // byte offset of texel (cx - 1, cy - 1)
     const char *ap = reinterpret_cast<const char *>(atlas);
+#if R3N_PCF_WIDE
+    // the 12 texels as FOUR loads (2 + 4 + 4 + 2 texels: the block's rows are contiguous; dword-aligned multi-dword loads) instead of
+    // twelve: a third of the vector-memory instructions of the whole fragment stage were these
+    struct __attribute__((packed, aligned(4))) T2 { float v[2]; };
+    struct __attribute__((packed, aligned(4))) T4 { float v[4]; };
+    const T2 r0 = *reinterpret_cast<const T2 *>(ap + (base + 4u));
+    const T4 r1 = *reinterpret_cast<const T4 *>(ap + (base + row));
+    const T4 r2 = *reinterpret_cast<const T4 *>(ap + (base + 2u * row));
+    const T2 r3 = *reinterpret_cast<const T2 *>(ap + (base + 3u * row + 4u));
+    // The comparison results stay BOOLEANS (lane masks in scalar registers): a tap's c * weight with c in {0, 1} and a finite
+    // weight >= 0 is the weight or +0 exactly, i.e. a select -- no 1.0 / 0.0 floats, no multiplies by them.
+    const bool c01 = ref >= r0.v[0], c02 = ref >= r0.v[1];
+    const bool c10 = ref >= r1.v[0], c11 = ref >= r1.v[1], c12 = ref >= r1.v[2], c13 = ref >= r1.v[3];
+    const bool c20 = ref >= r2.v[0], c21 = ref >= r2.v[1], c22 = ref >= r2.v[2], c23 = ref >= r2.v[3];
+    const bool c31 = ref >= r3.v[0], c32 = ref >= r3.v[1];
+    // tap = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy with the products as selects (fx, fy in [0, 1) on this path)
+    auto tapb = [&](bool a, bool b, bool c, bool d, float fx, float fy) {
+        const float omx = 1.0f - fx;
+        const f2 tb = (f2){b ? fx : 0.0f, d ? fx : 0.0f} + (f2){a ? omx : 0.0f, c ? omx : 0.0f};
+        return M::mad(tb.y, fy, tb.x * (1.0f - fy));
+    };
+    {
+        float r = 0.0f;
+        r = r + tapb(c11, c12, c21, c22, fx0, fy0);  // ( 0,  0)
+        r = r + tapb(c21, c22, c31, c32, fx0, fyp);  // ( 0, +1)
+        r = r + tapb(c01, c02, c11, c12, fx0, fym);  // ( 0, -1)
+        r = r + tapb(c12, c13, c22, c23, fxp, fy0);  // (+1,  0)
+        r = r + tapb(c10, c11, c20, c21, fxm, fy0);  // (-1,  0)
+        return r * 0.2f;
+    }
+#else
     auto cmp = [&](uint32_t dy, uint32_t dx) { return ref >= *reinterpret_cast<const float *>(ap + (base + dy * row + (dx << 2))) ? 1.0f : 0.0f; };
     const float c01 = cmp(0, 1), c02 = cmp(0, 2);
     const float c10 = cmp(1, 0), c11 = cmp(1, 1), c12 = cmp(1, 2), c13 = cmp(1, 3);
@@ -212,6 +246,7 @@ R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t
     r = r + tap(c12, c13, c22, c23, fxp, fy0);  // (+1,  0)
     r = r + tap(c10, c11, c20, c21, fxm, fy0);  // (-1,  0)
     return r * 0.2f;
+#endif
 }
 
 struct PixelData {
