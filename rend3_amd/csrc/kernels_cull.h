@@ -668,6 +668,24 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
     return execute_culling_clip(p, flags, shadow, res_x, res_y, hz);
 }
 
+// Wave-uniform data through the SCALAR unit.  The address is made provably uniform (readfirstlane) and named in the constant
+// address space, which is what lets the compiler emit s_load; only for memory that no kernel of the same launch writes (the
+// scalar cache is not coherent with vector stores inside a launch; across launches it is invalidated).  A vector load of a
+// uniform value costs a full vector-memory round trip per wave AND blocks on vmcnt behind whatever else is in flight.
+#ifndef R3N_CULL_SCALAR
+#define R3N_CULL_SCALAR 1  // 0: the triangle cull reads its per-object data with vector loads (round 2's form)
+#endif
+typedef uint32_t r3n_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t r3n_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t r3n_u32x16 __attribute__((ext_vector_type(16)));
+template <class V> R3N_DEV V scalar_load(const void *p) {
+    const unsigned long long v = (unsigned long long)p;
+    // (the builtin returns int: through uint32_t first, or the low half sign-extends into the high one)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const unsigned long long u = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    return *reinterpret_cast<__attribute__((address_space(4))) const V *>(u);
+}
+
 #define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
 #define R3N_CHUNK_WAVES (4u * R3N_CHUNK_ITERS)   // wave slots per 256-thread block per chunk (4096 triangles)
 
@@ -719,10 +737,18 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
             uint32_t lo = 0, hi = nvis;
             while (hi - lo > 1u) {
                 const uint32_t mid = lo + (hi - lo) / 2u;
+#if R3N_CULL_SCALAR
+                if (scalar_load<uint32_t>(&a.vis_list[mid].wave_start) <= w0) lo = mid; else hi = mid;
+#else
                 if (a.vis_list[mid].wave_start <= w0) lo = mid; else hi = mid;
+#endif
             }
             e = lo;
+#if R3N_CULL_SCALAR
+            next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start);
+#else
             next_start = a.vis_list[e + 1u].wave_start;
+#endif
         }
         uint32_t c_p0 = 0, c_p1 = 0, c_p2 = 0, c_r0 = 0, c_r1 = 0, c_r2 = 0;
 
@@ -732,6 +758,49 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
             unsigned long long ballot = 0, resid = 0;
             uint32_t obj = 0, wrel = 0, key = 0;
             if (w < total_waves) {
+#if R3N_CULL_SCALAR
+                // Everything about the wave slot that is wave-uniform -- the list entry, four fields of the object record, the
+                // baked matrix, the material key, last frame's result bits -- comes through scalar loads: two scalar round trips
+                // (entry; then record + matrix + previous bits together) in front of the two vector ones (indices; positions)
+                // instead of seven dependent vector round trips, and the matrix lives in scalar registers.
+                while (w >= next_start) { ++e; next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start); }
+                const r3n_u32x2 ent = scalar_load<r3n_u32x2>(&a.vis_list[e]);
+                obj = ent.x;
+                wrel = w - ent.y;
+                // first_index, index_count, material_index, vertex_attribute_start_offsets[0]: bytes 80..95 of the record
+                const r3n_u32x4 of = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&a.objects[obj]) + offsetof(r3n_object128, first_index));
+                const r3n_u32x16 mw = scalar_load<r3n_u32x16>(a.baked[obj].model_view_proj);
+                uint32_t pb = R3N_INVALID;
+                if (!shadow && a.prev_slot_base != nullptr) pb = scalar_load<uint32_t>(&a.prev_slot_base[obj]);
+                const uint32_t mi = of.z;
+                uint32_t keyw = 0u;
+                if (mi < a.n_materials) keyw = scalar_load<uint32_t>(a.material_keys + (mi & ~3u)) >> ((mi & 3u) * 8u);
+                float mvp[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) mvp[k] = __uint_as_float(mw[k]);
+                const uint32_t ntri = of.y / 3u;
+                const uint32_t tri = wrel * 64u + lane;
+                bool pass = false;
+                if (tri < ntri) {
+                    const uint32_t first = of.x + tri * 3u;
+                    const uint32_t pos_off = of.w;
+                    float v[3][3];
+                    uint32_t idx[3];
+                    fetch_indices3(a.mesh, first, idx);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, pos_off, idx[k], v[k]);
+                    pass = execute_culling(mvp, v, flags, shadow, res_x, res_y, a.hiz);
+                }
+                ballot = __ballot(pass);
+                if (!shadow) {
+                    unsigned long long prev = 0;
+                    if (pb != R3N_INVALID) prev = scalar_load<unsigned long long>(&a.prev_mask[pb / 64u + wrel]);  // cull.wgsl:152-160
+                    resid = ballot & ~prev;
+                }
+                if (lane == 0) a.mask[w] = ballot;  // cull.wgsl:229-240: result bits, 64 per wave slot
+                key = keyw & 0xFFu;
+                key = key > 2u ? 2u : key;
+#else
                 while (w >= next_start) { ++e; next_start = a.vis_list[e + 1u].wave_start; }
                 obj = __builtin_amdgcn_readfirstlane(a.vis_list[e].object);
                 wrel = w - __builtin_amdgcn_readfirstlane(a.vis_list[e].wave_start);
@@ -762,6 +831,7 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
                 const uint32_t mi = ob->material_index;
                 key = mi < a.n_materials ? a.material_keys[mi] : 0u;
                 key = key > 2u ? 2u : key;
+#endif
                 const uint32_t np = (uint32_t)__popcll(ballot), nr = (uint32_t)__popcll(resid);
                 c_p0 += key == 0u ? np : 0u; c_p1 += key == 1u ? np : 0u; c_p2 += key == 2u ? np : 0u;
                 c_r0 += key == 0u ? nr : 0u; c_r1 += key == 1u ? nr : 0u; c_r2 += key == 2u ? nr : 0u;

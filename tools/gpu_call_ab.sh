@@ -5,5 +5,5 @@ export TMPDIR=/tmp
 python tools/variants.py run --steps 150 > $out/variants.txt 2>&1; cat $out/variants.txt
 python tools/variants.py run --steps 150 > $out/variants2.txt 2>&1; cat $out/variants2.txt
 if [ "${2:-}" = tests ]; then
-timeout 900 python -m pytest tests -m gpu -x -q -k "bistro or textured or config3 or random or golden or msaa" > $out/pytest.log 2>&1; echo "pytest rc=$?"; grep -E 'passed|failed|error' $out/pytest.log | tail -3; grep -E '^E ' $out/pytest.log | head -5
+timeout 900 python -m pytest tests -m gpu -x -q -k "bistro or textured or config or random or golden or msaa or runtime or large or material_key or sharded or two_process" > $out/pytest.log 2>&1; echo "pytest rc=$?"; grep -E 'passed|failed|error' $out/pytest.log | tail -3; grep -E '^E ' $out/pytest.log | head -5
 fi
