@@ -89,9 +89,15 @@ struct TriWork {
 template <bool DEPTH_ONLY, bool TEX>
 R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, bool positive_visible, TriWork &tw) {
     const r3n_object128 &ob = a.objects[obj];
-    if (ob.enabled == 0u) return false;  // opaque.wgsl:104-112 / depth.wgsl:64-72
-    const uint32_t first = ob.first_index + tri * 3u;
-    const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
+    // The record's fields this function needs in TWO loads issued together -- bytes 80..95 (first_index, index_count, material_index,
+    // the position attribute's offset) and `enabled` -- and waited for once: read field by field behind the `enabled` test they were
+    // three dependent round trips of the per-triangle chain (list entry -> record -> indices -> positions).
+    const uint4 of = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
+    const uint32_t enabled = ob.enabled;
+    asm volatile("" : : "v"(of.x), "v"(of.w), "v"(enabled));  // both loads in flight before the test below can split them
+    if (enabled == 0u) return false;  // opaque.wgsl:104-112 / depth.wgsl:64-72
+    const uint32_t first = of.x + tri * 3u;
+    const uint32_t pos_off = of.w;
     uint32_t idx[3];
     float p[3][4];
     fetch_indices3(a.mesh, first, idx);
@@ -113,7 +119,7 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 #pragma unroll
     for (int i = 0; i < 3; ++i) tw.thr[i] = edge_threshold(tw.ts.e[i][0], tw.ts.e[i][1]);
     tw.cutout = a.key == R3N_KEY_CUTOUT;
-    tw.material = ob.material_index < a.n_materials ? ob.material_index : 0u;
+    tw.material = of.z < a.n_materials ? of.z : 0u;
     tw.va[0] = tw.va[1] = tw.va[2] = 1.0f;
     tw.mat_flags = 0u; tw.mat_alpha = 1.0f; tw.mat_cutoff = 0.0f;
     tw.alpha_tex = false;

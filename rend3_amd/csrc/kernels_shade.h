@@ -360,7 +360,13 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
     }
     const uint32_t obj = lo, tri = slot - a.tri_base[obj];
     const r3n_object128 &ob = a.objects[obj];
-    const uint32_t mat_index = ob.material_index < a.n_materials ? ob.material_index : 0u;
+    // The record's index / material / attribute-offset fields (bytes 80..115) in three loads issued together, and the material's ten
+    // texture ids the same way below: read field by field -- the offsets one per attribute, the ids through a short-circuit `||` --
+    // they were up to a dozen DEPENDENT round trips in front of the vertex fetches of a kernel that is nothing but its load chain.
+    const uint4 of0 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + 80);   // first_index, index_count, material_index, offsets[0]
+    const uint4 of1 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + 96);   // offsets[1..4]
+    const uint32_t of5 = ob.vertex_attribute_start_offsets[5];
+    const uint32_t mat_index = of0.z < a.n_materials ? of0.z : 0u;
     const r3n_material208 &mat = a.materials[mat_index];
     const float *mv = a.baked[obj].model_view;
     r.object = obj;
@@ -370,14 +376,18 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
     uint32_t idx[3];
     float p[3][4];
     const float inv_s2[3] = {1.0f / dot3(mv, mv), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
-    const uint32_t first = ob.first_index + tri * 3u;
-    const uint32_t pos_off = ob.vertex_attribute_start_offsets[0];
-    const uint32_t nrm_off = ob.vertex_attribute_start_offsets[1];
-    const uint32_t col_off = ob.vertex_attribute_start_offsets[5];
-    bool any_tex = false;
+    const uint32_t first = of0.x + tri * 3u;
+    const uint32_t pos_off = of0.w;
+    const uint32_t nrm_off = of1.x;
+    const uint32_t tan_off = of1.y;
+    const uint32_t uv0_off = of1.z;
+    const uint32_t col_off = of5;
+    bool any_tex = false, normal_map = false;
     if (TEX) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) any_tex = any_tex || mat.textures[k] != 0u;
+        const uint4 t0 = *reinterpret_cast<const uint4 *>(&mat.textures[0]), t1 = *reinterpret_cast<const uint4 *>(&mat.textures[4]);
+        const uint2 t2 = *reinterpret_cast<const uint2 *>(&mat.textures[8]);
+        any_tex = (((t0.x | t0.y) | (t0.z | t0.w)) | ((t1.x | t1.y) | (t1.z | t1.w)) | (t2.x | t2.y)) != 0u;
+        normal_map = t0.y != 0u;
     }
     fetch_indices3(a.mesh, first, idx);
 #pragma unroll
@@ -391,9 +401,8 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
         const float sn[3] = {inv_s2[0] * nm[0], inv_s2[1] * nm[1], inv_s2[2] * nm[2]};
         mat3_mul_vec3(mv, mv + 4, mv + 8, sn, r.vn[k]);
         normalize3(r.vn[k]);
-        if (TEX && mat.textures[1] != 0u) {  // vs_out.tangent (opaque.wgsl:129); only the normal map reads it
+        if (TEX && normal_map) {  // vs_out.tangent (opaque.wgsl:129); only the normal map reads it
             float tg[3] = {0.0f, 0.0f, 0.0f};
-            const uint32_t tan_off = ob.vertex_attribute_start_offsets[2];
             if (tan_off != R3N_INVALID) fetch_vec3(a.mesh, tan_off, idx[k], tg);
             const float st[3] = {inv_s2[0] * tg[0], inv_s2[1] * tg[1], inv_s2[2] * tg[2]};
             mat3_mul_vec3(mv, mv + 4, mv + 8, st, r.vt[k]);
@@ -409,7 +418,7 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) r.vc[k][c] = 1.0f;
         }
-        if (TEX && any_tex) fetch_uv0(a.mesh, ob.vertex_attribute_start_offsets[3], idx[k], r.uv[k]);
+        if (TEX && any_tex) fetch_uv0(a.mesh, uv0_off, idx[k], r.uv[k]);
         else r.uv[k][0] = r.uv[k][1] = 0.0f;
     }
     TriSetup ts;
@@ -702,9 +711,11 @@ R3N_DEV void shade_fragment(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 static __global__ __launch_bounds__(256) void k_mark_visible(const unsigned long long *__restrict__ vis, unsigned char *__restrict__ seen,
                                                       size_t first_pixel, size_t n_pixels) {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_pixels) return;
-    const uint32_t id = (uint32_t)(vis[first_pixel + i] & 0xFFFFFFFFull);
-    if (id != 0u) seen[id - 1u] = 1;
+    const uint32_t id = i < n_pixels ? (uint32_t)(vis[first_pixel + i] & 0xFFFFFFFFull) : 0u;
+    // consecutive pixels of a row mostly belong to one triangle: only the first lane of a run stores (the lane to the left inside
+    // the 16-lane row, DPP row_shr:1; a row's first lane always does) -- 8.3 M byte stores to 130 k distinct bytes became ~1.5 M
+    const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)~id, (int)id, 0x111, 0xF, 0xF, false);
+    if (id != 0u && id != left) seen[id - 1u] = 1;
 }
 // One thread per canonical triangle slot: the vertex stage + setup of the flagged ones, once per frame.
 template <bool TEX>

@@ -100,7 +100,7 @@ struct r3n_cull_counts {
 
 // One compacted triangle reference (the "index buffer" of this implementation: 8 B instead of the
 // reference's 3 packed u32 because the rasteriser re-fetches indices through the object record).
-struct r3n_tri_ref {
+struct alignas(8) r3n_tri_ref {  // 8-byte aligned: one dwordx2 load / store per entry
     uint32_t object;
     uint32_t triangle;
 };
