@@ -686,7 +686,9 @@ template <class V> R3N_DEV V scalar_load(const void *p) {
     return *reinterpret_cast<__attribute__((address_space(4))) const V *>(u);
 }
 
+#ifndef R3N_CHUNK_ITERS
 #define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
+#endif
 #define R3N_CHUNK_WAVES (4u * R3N_CHUNK_ITERS)   // wave slots per 256-thread block per chunk (4096 triangles)
 
 struct TriCullArgs {
@@ -751,6 +753,12 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
 #endif
         }
         uint32_t c_p0 = 0, c_p1 = 0, c_p2 = 0, c_r0 = 0, c_r1 = 0, c_r2 = 0;
+#if R3N_CULL_SCALAR
+        uint32_t e_held = R3N_INVALID, pb = R3N_INVALID, keyw = 0u;  // the object whose data the scalar registers hold
+        r3n_u32x2 ent = {};
+        r3n_u32x4 of = {};
+        r3n_u32x16 mw = {};
+#endif
 
 #pragma unroll 1
         for (uint32_t it = 0; it < R3N_CHUNK_ITERS; ++it) {
@@ -764,17 +772,19 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
                 // (entry; then record + matrix + previous bits together) in front of the two vector ones (indices; positions)
                 // instead of seven dependent vector round trips, and the matrix lives in scalar registers.
                 while (w >= next_start) { ++e; next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start); }
-                const r3n_u32x2 ent = scalar_load<r3n_u32x2>(&a.vis_list[e]);
+                if (e != e_held) {  // consecutive wave slots mostly stay inside one object: its data is read once per object, not per slot
+                    e_held = e;
+                    ent = scalar_load<r3n_u32x2>(&a.vis_list[e]);
+                    // first_index, index_count, material_index, vertex_attribute_start_offsets[0]: bytes 80..95 of the record
+                    of = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&a.objects[ent.x]) + offsetof(r3n_object128, first_index));
+                    mw = scalar_load<r3n_u32x16>(a.baked[ent.x].model_view_proj);
+                    pb = R3N_INVALID;
+                    if (!shadow && a.prev_slot_base != nullptr) pb = scalar_load<uint32_t>(&a.prev_slot_base[ent.x]);
+                    keyw = 0u;
+                    if (of.z < a.n_materials) keyw = scalar_load<uint32_t>(a.material_keys + (of.z & ~3u)) >> ((of.z & 3u) * 8u);
+                }
                 obj = ent.x;
                 wrel = w - ent.y;
-                // first_index, index_count, material_index, vertex_attribute_start_offsets[0]: bytes 80..95 of the record
-                const r3n_u32x4 of = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&a.objects[obj]) + offsetof(r3n_object128, first_index));
-                const r3n_u32x16 mw = scalar_load<r3n_u32x16>(a.baked[obj].model_view_proj);
-                uint32_t pb = R3N_INVALID;
-                if (!shadow && a.prev_slot_base != nullptr) pb = scalar_load<uint32_t>(&a.prev_slot_base[obj]);
-                const uint32_t mi = of.z;
-                uint32_t keyw = 0u;
-                if (mi < a.n_materials) keyw = scalar_load<uint32_t>(a.material_keys + (mi & ~3u)) >> ((mi & 3u) * 8u);
                 float mvp[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) mvp[k] = __uint_as_float(mw[k]);
