@@ -672,8 +672,8 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
 // address space, which is what lets the compiler emit s_load; only for memory that no kernel of the same launch writes (the
 // scalar cache is not coherent with vector stores inside a launch; across launches it is invalidated).  A vector load of a
 // uniform value costs a full vector-memory round trip per wave AND blocks on vmcnt behind whatever else is in flight.
-#ifndef R3N_CULL_SCALAR
-#define R3N_CULL_SCALAR 1  // 0: the triangle cull reads its per-object data with vector loads (round 2's form)
+#ifndef R3N_CULL_PAIR
+#define R3N_CULL_PAIR 1  // the triangle cull fetches two wave slots of an object together
 #endif
 typedef uint32_t r3n_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t r3n_u32x4 __attribute__((ext_vector_type(4)));
@@ -739,116 +739,99 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
             uint32_t lo = 0, hi = nvis;
             while (hi - lo > 1u) {
                 const uint32_t mid = lo + (hi - lo) / 2u;
-#if R3N_CULL_SCALAR
                 if (scalar_load<uint32_t>(&a.vis_list[mid].wave_start) <= w0) lo = mid; else hi = mid;
-#else
-                if (a.vis_list[mid].wave_start <= w0) lo = mid; else hi = mid;
-#endif
             }
             e = lo;
-#if R3N_CULL_SCALAR
             next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start);
-#else
-            next_start = a.vis_list[e + 1u].wave_start;
-#endif
         }
         uint32_t c_p0 = 0, c_p1 = 0, c_p2 = 0, c_r0 = 0, c_r1 = 0, c_r2 = 0;
-#if R3N_CULL_SCALAR
         uint32_t e_held = R3N_INVALID, pb = R3N_INVALID, keyw = 0u;  // the object whose data the scalar registers hold
         r3n_u32x2 ent = {};
         r3n_u32x4 of = {};
         r3n_u32x16 mw = {};
-#endif
-
-#pragma unroll 1
-        for (uint32_t it = 0; it < R3N_CHUNK_ITERS; ++it) {
-            const uint32_t w = w0 + it;
-            unsigned long long ballot = 0, resid = 0;
-            uint32_t obj = 0, wrel = 0, key = 0;
-            if (w < total_waves) {
-#if R3N_CULL_SCALAR
-                // Everything about the wave slot that is wave-uniform -- the list entry, four fields of the object record, the
-                // baked matrix, the material key, last frame's result bits -- comes through scalar loads: two scalar round trips
-                // (entry; then record + matrix + previous bits together) in front of the two vector ones (indices; positions)
-                // instead of seven dependent vector round trips, and the matrix lives in scalar registers.
-                while (w >= next_start) { ++e; next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start); }
-                if (e != e_held) {  // consecutive wave slots mostly stay inside one object: its data is read once per object, not per slot
-                    e_held = e;
-                    ent = scalar_load<r3n_u32x2>(&a.vis_list[e]);
-                    // first_index, index_count, material_index, vertex_attribute_start_offsets[0]: bytes 80..95 of the record
-                    of = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&a.objects[ent.x]) + offsetof(r3n_object128, first_index));
-                    mw = scalar_load<r3n_u32x16>(a.baked[ent.x].model_view_proj);
-                    pb = R3N_INVALID;
-                    if (!shadow && a.prev_slot_base != nullptr) pb = scalar_load<uint32_t>(&a.prev_slot_base[ent.x]);
-                    keyw = 0u;
-                    if (of.z < a.n_materials) keyw = scalar_load<uint32_t>(a.material_keys + (of.z & ~3u)) >> ((of.z & 3u) * 8u);
-                }
-                obj = ent.x;
-                wrel = w - ent.y;
-                float mvp[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) mvp[k] = __uint_as_float(mw[k]);
-                const uint32_t ntri = of.y / 3u;
-                const uint32_t tri = wrel * 64u + lane;
-                bool pass = false;
-                if (tri < ntri) {
-                    const uint32_t first = of.x + tri * 3u;
-                    const uint32_t pos_off = of.w;
-                    float v[3][3];
-                    uint32_t idx[3];
-                    fetch_indices3(a.mesh, first, idx);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, pos_off, idx[k], v[k]);
-                    pass = execute_culling(mvp, v, flags, shadow, res_x, res_y, a.hiz);
-                }
-                ballot = __ballot(pass);
-                if (!shadow) {
-                    unsigned long long prev = 0;
-                    if (pb != R3N_INVALID) prev = scalar_load<unsigned long long>(&a.prev_mask[pb / 64u + wrel]);  // cull.wgsl:152-160
-                    resid = ballot & ~prev;
-                }
-                if (lane == 0) a.mask[w] = ballot;  // cull.wgsl:229-240: result bits, 64 per wave slot
-                key = keyw & 0xFFu;
-                key = key > 2u ? 2u : key;
-#else
-                while (w >= next_start) { ++e; next_start = a.vis_list[e + 1u].wave_start; }
-                obj = __builtin_amdgcn_readfirstlane(a.vis_list[e].object);
-                wrel = w - __builtin_amdgcn_readfirstlane(a.vis_list[e].wave_start);
-                const r3n_object128 *ob = &a.objects[obj];
-                const uint32_t ntri = ob->index_count / 3u;
-                const uint32_t tri = wrel * 64u + lane;
-                bool pass = false;
-                if (tri < ntri) {
-                    const uint32_t first = ob->first_index + tri * 3u;
-                    const uint32_t pos_off = ob->vertex_attribute_start_offsets[0];
-                    float v[3][3];
-                    uint32_t idx[3];
-                    fetch_indices3(a.mesh, first, idx);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, pos_off, idx[k], v[k]);
-                    pass = execute_culling(a.baked[obj].model_view_proj, v, flags, shadow, res_x, res_y, a.hiz);
-                }
-                ballot = __ballot(pass);
-                if (!shadow) {
-                    unsigned long long prev = 0;
-                    if (a.prev_slot_base != nullptr) {
-                        const uint32_t pb = a.prev_slot_base[obj];
-                        if (pb != R3N_INVALID) prev = a.prev_mask[pb / 64u + wrel];  // cull.wgsl:152-160
-                    }
-                    resid = ballot & ~prev;
-                }
-                if (lane == 0) a.mask[w] = ballot;  // cull.wgsl:229-240: result bits, 64 per wave slot
-                const uint32_t mi = ob->material_index;
-                key = mi < a.n_materials ? a.material_keys[mi] : 0u;
-                key = key > 2u ? 2u : key;
-#endif
-                const uint32_t np = (uint32_t)__popcll(ballot), nr = (uint32_t)__popcll(resid);
-                c_p0 += key == 0u ? np : 0u; c_p1 += key == 1u ? np : 0u; c_p2 += key == 2u ? np : 0u;
-                c_r0 += key == 0u ? nr : 0u; c_r1 += key == 1u ? nr : 0u; c_r2 += key == 2u ? nr : 0u;
+        // a wave slot's result: residual bits against last frame's (cull.wgsl:152-160), the result bits (cull.wgsl:229-240), the
+        // per-key counts and the LDS staging of the compaction
+        auto finish = [&](uint32_t w, uint32_t it, uint32_t obj, uint32_t wrel, uint32_t key, unsigned long long ballot) {
+            unsigned long long resid = 0;
+            if (!shadow) {
+                unsigned long long prev = 0;
+                if (pb != R3N_INVALID) prev = scalar_load<unsigned long long>(&a.prev_mask[pb / 64u + wrel]);
+                resid = ballot & ~prev;
             }
+            if (lane == 0) a.mask[w] = ballot;
+            const uint32_t np = (uint32_t)__popcll(ballot), nr = (uint32_t)__popcll(resid);
+            c_p0 += key == 0u ? np : 0u; c_p1 += key == 1u ? np : 0u; c_p2 += key == 2u ? np : 0u;
+            c_r0 += key == 0u ? nr : 0u; c_r1 += key == 1u ? nr : 0u; c_r2 += key == 2u ? nr : 0u;
             if (lane == 0) {
                 s_pass[wave][it] = ballot; s_resid[wave][it] = resid;
                 s_obj[wave][it] = obj; s_tri0[wave][it] = wrel * 64u; s_key[wave][it] = key;
+            }
+        };
+
+#pragma unroll 1
+        for (uint32_t it = 0; it < R3N_CHUNK_ITERS;) {
+            const uint32_t w = w0 + it;
+            if (w >= total_waves) {
+                if (lane == 0) { s_pass[wave][it] = 0ull; s_resid[wave][it] = 0ull; s_obj[wave][it] = 0u; s_tri0[wave][it] = 0u; s_key[wave][it] = 0u; }
+                ++it;
+                continue;
+            }
+            // Everything about the wave slot that is wave-uniform -- the list entry, four fields of the object record, the
+            // baked matrix, the material key, last frame's result bits -- comes through scalar loads: two scalar round trips
+            // (entry; then record + matrix + previous bits together) in front of the two vector ones (indices; positions)
+            // instead of seven dependent vector round trips, and the matrix lives in scalar registers.
+            while (w >= next_start) { ++e; next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start); }
+            if (e != e_held) {  // consecutive wave slots mostly stay inside one object: its data is read once per object, not per slot
+                e_held = e;
+                ent = scalar_load<r3n_u32x2>(&a.vis_list[e]);
+                // first_index, index_count, material_index, vertex_attribute_start_offsets[0]: bytes 80..95 of the record
+                of = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&a.objects[ent.x]) + offsetof(r3n_object128, first_index));
+                mw = scalar_load<r3n_u32x16>(a.baked[ent.x].model_view_proj);
+                pb = R3N_INVALID;
+                if (!shadow && a.prev_slot_base != nullptr) pb = scalar_load<uint32_t>(&a.prev_slot_base[ent.x]);
+                keyw = 0u;
+                if (of.z < a.n_materials) keyw = scalar_load<uint32_t>(a.material_keys + (of.z & ~3u)) >> ((of.z & 3u) * 8u);
+            }
+            const uint32_t obj = ent.x, wrel = w - ent.y;
+            float mvp[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mvp[k] = __uint_as_float(mw[k]);
+            const uint32_t ntri = of.y / 3u;  // >= 1: the list holds objects with triangles
+            uint32_t key = keyw & 0xFFu;
+            key = key > 2u ? 2u : key;
+            const uint32_t triA = wrel * 64u + lane;
+            // The next wave slot belongs to the same object (15 of 16 do on the bench scene): its index and position fetches go out
+            // together with this slot's -- two slots per pair of vector round trips.  Out-of-range lanes fetch the object's last
+            // triangle instead of branching, so the two slots' loads sit in one block of straight-line code.
+            const bool pair = R3N_CULL_PAIR && it + 1u < R3N_CHUNK_ITERS && w + 1u < next_start;
+            if (pair) {
+                const uint32_t triB = triA + 64u;
+                uint32_t idxA[3], idxB[3];
+                fetch_indices3(a.mesh, of.x + min(triA, ntri - 1u) * 3u, idxA);
+                fetch_indices3(a.mesh, of.x + min(triB, ntri - 1u) * 3u, idxB);
+                float vA[3][3], vB[3][3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, of.w, idxA[k], vA[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, of.w, idxB[k], vB[k]);
+                const bool passA = execute_culling(mvp, vA, flags, shadow, res_x, res_y, a.hiz) && triA < ntri;
+                const bool passB = execute_culling(mvp, vB, flags, shadow, res_x, res_y, a.hiz) && triB < ntri;
+                const unsigned long long bA = __ballot(passA), bB = __ballot(passB);
+                finish(w, it, obj, wrel, key, bA);
+                finish(w + 1u, it + 1u, obj, wrel + 1u, key, bB);
+                it += 2u;
+            } else {
+                bool pass = false;
+                if (triA < ntri) {
+                    float v[3][3];
+                    uint32_t idx[3];
+                    fetch_indices3(a.mesh, of.x + triA * 3u, idx);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fetch_vec3(a.mesh, of.w, idx[k], v[k]);
+                    pass = execute_culling(mvp, v, flags, shadow, res_x, res_y, a.hiz);
+                }
+                finish(w, it, obj, wrel, key, __ballot(pass));
+                ++it;
             }
         }
 
