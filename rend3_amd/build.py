@@ -23,6 +23,7 @@ COMMON = ["layouts.h", "device_math.h", "../../include/r3n.h"]
 UNITS = {
     "r3n.hip": ["texture.h", "kernels_cull.h", "kernels_raster.h", "kernels_shadow.h", "kernels_shade.h", "comm.h"],
     "shade.hip": ["texture.h", "kernels_shade.h"],
+    "shade_cls.hip": ["texture.h", "kernels_shade.h"],
     "shade_ms.hip": ["texture.h", "kernels_shade.h"],
     "shade_blend.hip": ["texture.h", "kernels_shade.h"],
     "texture_decode.hip": ["bc7_tables.h", "bc6h_tables.h"],

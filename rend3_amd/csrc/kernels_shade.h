@@ -65,8 +65,65 @@ struct ShadeArgs {
     // second, dense pass (R3N_EDGEQ sub-lists of pixel << 3 | leader sample << 1 | last-entry-of-the-pixel)
     uint32_t *edge_list, *edge_count;
     uint32_t edge_capacity;    // entries per sub-list
+    // single-sample record-based resolve, specialised per material class (see R3N_FEAT_* below)
+    const uint32_t *material_feat;  // per material: feature bits, computed by the host when the record is written
+    uint32_t variants;              // bit v set: variant v of the resolve runs this frame (more than one bit: tiles are classified)
 };
 #define R3N_EDGEQ 32u
+
+// ---- material classes of the resolve -------------------------------------------------------------------------------------
+// opaque.wgsl:203-424 branches on fifteen flag bits and ten texture slots at run time (material.wgsl:1-19).  A material's FEATURES
+// are the branches it can take; a resolve variant instantiated for a feature set K contains only the code of K's features and
+// shades exactly like the general kernel every material whose features are a subset of K (the tests of the remaining features
+// stay run-time tests; the removed ones would have been false).  The variants form a chain PLAIN < ALBEDO < PBR3 < ALL, so a
+// 16x16 tile is shaded by the variant of the OR of its pixels' features, and a world whose materials all map to one variant
+// needs no classification at all.
+#define R3N_FEAT_TEX_ALBEDO   0x001u  // slot 0 bound
+#define R3N_FEAT_TEX_NORMAL   0x002u  // slot 1 bound
+#define R3N_FEAT_TEX_AOMR     0x004u  // slot 2 bound
+#define R3N_FEAT_TEX_AOMR_X   0x008u  // slot 3 or 9 bound (the split layouts' other maps)
+#define R3N_FEAT_TEX_MISC     0x010u  // slot 4, 5, 6 or 7 bound (reflectance, clear coat, clear-coat roughness, emissive)
+#define R3N_FEAT_VCOLOR       0x020u  // ALBEDO_BLEND: the vertex colour multiplies the albedo
+#define R3N_FEAT_UNLIT        0x040u
+#define R3N_FEAT_NEAREST      0x080u  // nearest sampler
+#define R3N_FEAT_AOMR_SPLIT   0x100u  // slot 2 / 3 / 9 bound and the layout is not AOMR_COMBINED
+#define R3N_FEAT_CLEARCOAT    0x200u  // clear_coat factor != 0
+#define R3N_FEAT_NORMAL_FLAGS 0x400u  // BICOMPONENT / SWIZZLED / YDOWN normal map
+#define R3N_FEAT_ALBEDO_OFF   0x800u  // ALBEDO_ACTIVE clear
+#define R3N_FEAT_TEX_GENERAL  0x1000u // binds a texture outside the sampler's short path (set by the host's census, r3n.hip:
+                                      // extent not a power of two, float pool texels, pool beyond 2^30 texels, id out of range)
+#define R3N_FEAT_ALL          0x1FFFu
+#define R3N_CLS_PLAIN  0u
+#define R3N_CLS_ALBEDO (R3N_FEAT_TEX_ALBEDO)
+#define R3N_CLS_PBR3   (R3N_FEAT_TEX_ALBEDO | R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR)
+#define R3N_CLS_ALL    R3N_FEAT_ALL
+#define R3N_VARIANTS 4u  // 0 PLAIN, 1 ALBEDO, 2 PBR3, 3 ALL
+static inline uint32_t r3n_material_features(const r3n_material208 &m) {
+    const uint32_t f = m.flags;
+    uint32_t k = 0;
+    if (m.textures[0]) k |= R3N_FEAT_TEX_ALBEDO;
+    if (m.textures[1]) k |= R3N_FEAT_TEX_NORMAL;
+    if (m.textures[2]) k |= R3N_FEAT_TEX_AOMR;
+    if (m.textures[3] || m.textures[9]) k |= R3N_FEAT_TEX_AOMR_X;
+    if (m.textures[4] || m.textures[5] || m.textures[6] || m.textures[7]) k |= R3N_FEAT_TEX_MISC;
+    if (f & R3N_FLAGS_ALBEDO_BLEND) k |= R3N_FEAT_VCOLOR;
+    if (f & R3N_FLAGS_UNLIT) k |= R3N_FEAT_UNLIT;
+    if (f & R3N_FLAGS_NEAREST) k |= R3N_FEAT_NEAREST;
+    if ((m.textures[2] || m.textures[3] || m.textures[9]) && !(f & R3N_FLAGS_AOMR_COMBINED)) k |= R3N_FEAT_AOMR_SPLIT;
+    if (!(m.clear_coat == 0.0f)) k |= R3N_FEAT_CLEARCOAT;  // (NaN counts)
+    if (f & (R3N_FLAGS_BICOMPONENT_NORMAL | R3N_FLAGS_SWIZZLED_NORMAL | R3N_FLAGS_YDOWN_NORMAL)) k |= R3N_FEAT_NORMAL_FLAGS;
+    if (!(f & R3N_FLAGS_ALBEDO_ACTIVE)) k |= R3N_FEAT_ALBEDO_OFF;
+    return k;
+}
+// smallest variant of the chain whose feature set covers `feat`
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t r3n_variant_of(uint32_t feat) {
+    if (feat & ~R3N_CLS_PBR3) return 3u;
+    if (feat & ~R3N_CLS_ALBEDO) return 2u;
+    return feat ? 1u : 0u;
+}
 
 // What the vertex stage (opaque.wgsl:91-135) and the triangle setup produce for one triangle (see vertex_stage below).
 struct TriRecord {
@@ -77,7 +134,8 @@ struct TriRecord {
     float vc[3][4];     // vertex colours
     float uv[3][2];     // texture coordinates 0
     uint32_t object, material;
-    uint32_t _pad[5];
+    uint32_t feat;      // R3N_FEAT_* of the material (ShadeArgs::material_feat), R3N_FEAT_ALL without the table
+    uint32_t _pad[4];
 };
 static_assert(sizeof(TriRecord) == 256, "triangle record is 64 dwords");
 
@@ -138,42 +196,22 @@ R3N_DEV float pcf_texel_cmp(const float *__restrict__ atlas, uint32_t aw, uint32
 // shadow/pcf.wgsl: mean of 5 bilinear comparison taps (centre, +-1 texel in x and y).  The 5 taps touch 20 texels
 // of which only 12 are distinct (a 4x4 block without its corners): the comparisons are fetched once and every tap
 // then applies its own weights -- same values, same operation order as five independent sample_compare calls.
+// This is the path nobody takes (the regular form below covers every lookup whose 4x4 block lies inside the atlas), so it is
+// written for SIZE: rolled loops, one texel fetch site.  Unrolled, with a 64-bit Repeat remainder per texel, it was 13 000 of the
+// light loop's 13 800 instructions and its live ranges weighed on the register allocation of the whole fragment stage.
 template <class M>
 R3N_DEV float shadow_pcf5_general(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, float ref) {
-    const PcfTap c = pcf_tap(aw, ah, u, v, 0, 0);
-    // cmp[dy][dx] for texel (c.ix - 1 + dx, c.iy - 1 + dy); corners are never needed on the regular path
-    uint32_t xs[4];
-    const float *rows[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        xs[d] = wrap_texel(c.ix - 1 + d, aw);
-        rows[d] = atlas + (size_t)wrap_texel(c.iy - 1 + d, ah) * aw;
-    }
-    float cmp[4][4];
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) {
-            const bool corner = (dx == 0 || dx == 3) && (dy == 0 || dy == 3);
-            cmp[dy][dx] = corner ? 0.0f : (ref >= rows[dy][xs[dx]] ? 1.0f : 0.0f);
-        }
-    const int offs[5][2] = {{0, 0}, {0, 1}, {0, -1}, {1, 0}, {-1, 0}};
     float r = 0.0f;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 5; ++k) {
-        const PcfTap t = k == 0 ? c : pcf_tap(aw, ah, u, v, offs[k][0], offs[k][1]);
-        const int rx = t.ix - c.ix + 1, ry = t.iy - c.iy + 1;
-        float c00, c10, c01, c11;
-        // regular case: the tap's 2x2 footprint lies inside the fetched block (and off its corners)
-        if (rx == offs[k][0] + 1 && ry == offs[k][1] + 1) {
-            c00 = cmp[offs[k][1] + 1][offs[k][0] + 1]; c10 = cmp[offs[k][1] + 1][offs[k][0] + 2];
-            c01 = cmp[offs[k][1] + 2][offs[k][0] + 1]; c11 = cmp[offs[k][1] + 2][offs[k][0] + 2];
-        } else {  // adding the integer offset rounded across a texel boundary (or NaN input): fetch directly
-            c00 = pcf_texel_cmp(atlas, aw, ah, t.ix, t.iy, ref);     c10 = pcf_texel_cmp(atlas, aw, ah, t.ix + 1, t.iy, ref);
-            c01 = pcf_texel_cmp(atlas, aw, ah, t.ix, t.iy + 1, ref); c11 = pcf_texel_cmp(atlas, aw, ah, t.ix + 1, t.iy + 1, ref);
-        }
+        // tap offsets (0, 0), (0, 1), (0, -1), (1, 0), (-1, 0)
+        const int ox = k == 3 ? 1 : (k == 4 ? -1 : 0), oy = k == 1 ? 1 : (k == 2 ? -1 : 0);
+        const PcfTap t = pcf_tap(aw, ah, u, v, ox, oy);
+        float c[4];
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) c[j] = pcf_texel_cmp(atlas, aw, ah, t.ix + (j & 1), t.iy + (j >> 1), ref);
         // top = c00 * (1 - fx) + c10 * fx, bot = c01 * (1 - fx) + c11 * fx as one packed pair
-        const f2 tb = M::mad((f2){c10, c11}, splat2(t.fx), (f2){c00, c01} * splat2(1.0f - t.fx));
+        const f2 tb = M::mad((f2){c[1], c[3]}, splat2(t.fx), (f2){c[0], c[2]} * splat2(1.0f - t.fx));
         r = r + M::mad(tb.y, t.fy, tb.x * (1.0f - t.fy));
     }
     return r * 0.2f;
@@ -371,6 +409,7 @@ R3N_DEV void vertex_stage(const ShadeArgs &a, uint32_t id, TriRecord &r) {
     const float *mv = a.baked[obj].model_view;
     r.object = obj;
     r.material = mat_index;
+    r.feat = a.material_feat != nullptr ? a.material_feat[mat_index] : R3N_FEAT_ALL;
 
     // vertex stage for the 3 vertices (opaque.wgsl:114-134)
     uint32_t idx[3];
@@ -453,10 +492,20 @@ template <class M> R3N_DEV void interp_vec4(const float lam[3], const float a[3]
 // hardware reciprocal / rsqrt in the interpolation, filtering and BRDF arithmetic; the edge functions, the level-of-detail /
 // footprint selection, the shadow coordinates and the depth comparisons stay exact so that no pixel changes triangle, mip
 // level or shadow texel -- the result differs from the exact one by rounding only.
-template <bool TEX, class M = MathExact>
+// CLS: the features (R3N_FEAT_*) a material shaded here may have; the code of every other feature is not instantiated.
+template <bool TEX, class M = MathExact, uint32_t CLS = R3N_CLS_ALL>
 R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
                             uint32_t n_point, const TriRecord &r, uint32_t x, uint32_t y, float out[4]) {
     const r3n_material208 &mat = a.materials[r.material];
+    constexpr bool kVColor = (CLS & R3N_FEAT_VCOLOR) != 0u, kUnlit = (CLS & R3N_FEAT_UNLIT) != 0u, kNearest = (CLS & R3N_FEAT_NEAREST) != 0u;
+    constexpr bool kSplit = (CLS & R3N_FEAT_AOMR_SPLIT) != 0u, kNormalFlags = (CLS & R3N_FEAT_NORMAL_FLAGS) != 0u;
+    constexpr bool kAlbedoOff = (CLS & R3N_FEAT_ALBEDO_OFF) != 0u, kMisc = (CLS & R3N_FEAT_TEX_MISC) != 0u;
+    constexpr bool kClearCoat = (CLS & (R3N_FEAT_CLEARCOAT | R3N_FEAT_TEX_MISC)) != 0u;
+    constexpr bool kAnyTex = TEX && (CLS & (R3N_FEAT_TEX_ALBEDO | R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR | R3N_FEAT_TEX_AOMR_X | R3N_FEAT_TEX_MISC)) != 0u;
+    // texture slot -> the feature that binds it
+    constexpr uint32_t kSlotFeat[10] = {R3N_FEAT_TEX_ALBEDO, R3N_FEAT_TEX_NORMAL, R3N_FEAT_TEX_AOMR, R3N_FEAT_TEX_AOMR_X, R3N_FEAT_TEX_MISC,
+                                        R3N_FEAT_TEX_MISC, R3N_FEAT_TEX_MISC, R3N_FEAT_TEX_MISC, R3N_FEAT_TEX_MISC /* anisotropy: unread */,
+                                        R3N_FEAT_TEX_AOMR_X};
     TriSetup ts;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -473,7 +522,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     float vpos[4], nrm[3], col[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     interp_vec4<MathExact>(lam, r.vp, vpos);
     interp_vec3<M>(lam, r.vn, nrm);
-    if ((mat.flags & R3N_FLAGS_ALBEDO_ACTIVE) && (mat.flags & R3N_FLAGS_ALBEDO_BLEND))  // the only reader of vs_out.color
+    if (kVColor && (mat.flags & R3N_FLAGS_ALBEDO_ACTIVE) && (mat.flags & R3N_FLAGS_ALBEDO_BLEND))  // the only reader of vs_out.color
         interp_vec4<M>(lam, r.vc, col);
 
     // fragment stage (opaque.wgsl:203-424).  Texture slots (managers/material.rs:25-29 order): 0 albedo, 1 normal,
@@ -481,13 +530,14 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     PixelData px;
     const uint32_t mflags = mat.flags;
     bool any_tex = false;
-    if (TEX) {
+    if (kAnyTex) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) any_tex = any_tex || mat.textures[k] != 0u;
+        for (int k = 0; k < 10; ++k)
+            if (CLS & kSlotFeat[k]) any_tex = any_tex || mat.textures[k] != 0u;
     }
     float coords[2] = {0.0f, 0.0f}, ddx[2] = {0.0f, 0.0f}, ddy[2] = {0.0f, 0.0f};
-    const bool nearest = (mflags & R3N_FLAGS_NEAREST) != 0u;
-    if (TEX && any_tex && !(R3N_SHADE_ABLATE & 2)) {  // opaque.wgsl:207-209
+    const bool nearest = kNearest && (mflags & R3N_FLAGS_NEAREST) != 0u;
+    if (kAnyTex && any_tex && !(R3N_SHADE_ABLATE & 2)) {  // opaque.wgsl:207-209
         const f2 sr = interp2<M>(lam, (f2){r.uv[0][0], r.uv[0][1]}, (f2){r.uv[1][0], r.uv[1][1]}, (f2){r.uv[2][0], r.uv[2][1]});
         const float self_raw[2] = {sr.x, sr.y};
         frag_coords<M>(ts, r.uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
@@ -497,15 +547,17 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     auto tex4 = [&](int slot, float dst[4]) { dst[0] = coords[0]; dst[1] = coords[1]; dst[2] = ddx[0] + ddy[0]; dst[3] = ddx[1] + ddy[1] + (float)slot; };
     auto tex3 = tex4;
 #else
-    auto tex4 = [&](int slot, float dst[4]) { tex_sample_grad<M, true>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
-    auto tex3 = [&](int slot, float dst[4]) { tex_sample_grad<M, false>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    // (a class without TEX_GENERAL / NEAREST: every bound texture is on the sampler's short path -- the host's census says so)
+    constexpr bool kShortOnly = (CLS & (R3N_FEAT_TEX_GENERAL | R3N_FEAT_NEAREST)) == 0u;
+    auto tex4 = [&](int slot, float dst[4]) { tex_sample_grad<M, true, kShortOnly>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    auto tex3 = [&](int slot, float dst[4]) { tex_sample_grad<M, false, kShortOnly>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
 #endif
-    auto has = [&](int slot) { return TEX && mat.textures[slot] != 0u; };
-    if (mflags & R3N_FLAGS_ALBEDO_ACTIVE) {
+    auto has = [&](int slot) { return TEX && (CLS & kSlotFeat[slot]) != 0u && mat.textures[slot] != 0u; };
+    if (!kAlbedoOff || (mflags & R3N_FLAGS_ALBEDO_ACTIVE)) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
         if (has(0)) tex4(0, px.albedo);
-        if (mflags & R3N_FLAGS_ALBEDO_BLEND) {
+        if (kVColor && (mflags & R3N_FLAGS_ALBEDO_BLEND)) {
             if (mflags & R3N_FLAGS_ALBEDO_VERTEX_SRGB) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px.albedo[c] *= srgb_to_linear(col[c]);
@@ -525,7 +577,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         px.albedo[0] = rg.x; px.albedo[1] = rg.y; px.albedo[2] = ba.x; px.albedo[3] = ba.y;
     }
 
-    if (mflags & R3N_FLAGS_UNLIT) {
+    if (kUnlit && (mflags & R3N_FLAGS_UNLIT)) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
     } else {
@@ -533,7 +585,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         if (has(1) && !(R3N_SHADE_ABLATE & 16)) {
             float t[4], n[3];
             tex4(1, t);
-            if (mflags & R3N_FLAGS_BICOMPONENT_NORMAL) {
+            if (kNormalFlags && (mflags & R3N_FLAGS_BICOMPONENT_NORMAL)) {
                 float b0 = (mflags & R3N_FLAGS_SWIZZLED_NORMAL) ? t[3] : t[0], b1 = t[1];  // texture_read.ag : .rg
                 b0 = M::mad(b0, 2.0f, -1.0f);
                 b1 = M::mad(b1, 2.0f, -1.0f);
@@ -544,7 +596,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
                 for (int c = 0; c < 3; ++c) n[c] = M::mad(t[c], 2.0f, -1.0f);
                 normalize3m<M>(n);
             }
-            if (mflags & R3N_FLAGS_YDOWN_NORMAL) n[1] = -n[1];
+            if (kNormalFlags && (mflags & R3N_FLAGS_YDOWN_NORMAL)) n[1] = -n[1];
             float tng[3];
             interp_vec3<M>(lam, r.vt, tng);
             float nn[3] = {nrm[0], nrm[1], nrm[2]};
@@ -559,7 +611,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         normalize3m<M>(px.normal);
         // --- AO, metallic, roughness (opaque.wgsl:277-351)
         float ao = mat.ambient_occlusion, pr = mat.roughness, metallic = mat.metallic;
-        if (mflags & R3N_FLAGS_AOMR_COMBINED) {
+        if (!kSplit || (mflags & R3N_FLAGS_AOMR_COMBINED)) {  // (!kSplit: a bound slot 2 implies the combined layout)
             if (has(2)) {
                 float t[4];
                 tex3(2, t);
@@ -587,7 +639,9 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         if (has(4)) { float t[4]; tex3(4, t); reflectance = mat.reflectance * t[0]; }
         // --- clear coat (opaque.wgsl:363-391)
         float cc = mat.clear_coat, ccpr = mat.clear_coat_roughness;
-        if (mflags & R3N_FLAGS_CC_GLTF_COMBINED) {
+        if (!kMisc) {
+            // slots 5 / 6 unbound: the factors as they are
+        } else if (mflags & R3N_FLAGS_CC_GLTF_COMBINED) {
             if (has(5)) {
                 float t[4];
                 tex3(5, t);
@@ -618,7 +672,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         const float refl_omm = refl * omm;
 #pragma unroll
         for (int c = 0; c < 3; ++c) px.f0[c] = M::mad(px.albedo[c], metallic, refl_omm);
-        if (cc != 0.0f) {
+        if (kClearCoat && cc != 0.0f) {
             const float base_pr = fmaxf(pr, ccpr);
             pr = M::mad(base_pr, cc, pr * (1.0f - cc));
         }
@@ -725,7 +779,7 @@ __global__ __launch_bounds__(256) void k_vertex_stage(ShadeArgs a) {
     a.seen[slot] = 0;  // consumed: the flags are all zero again when the launch ends (no clear between frames)
     TriRecord r;
     vertex_stage<TEX>(a, slot + 1u, r);
-    r._pad[0] = r._pad[1] = r._pad[2] = r._pad[3] = r._pad[4] = 0u;
+    r._pad[0] = r._pad[1] = r._pad[2] = r._pad[3] = 0u;
     a.tri_rec[slot] = r;
 }
 
@@ -780,20 +834,16 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
 // REC: the per-triangle records exist: no vertex-stage code in the kernel at all.
 // FAST: the MathFast policy in the fragment stage (opt-in, r3n_config.shade_mode); instantiated for the record-based
 // single-sample resolve.
-template <int S, bool TEX, bool REC = false, bool SPLIT = false, bool FAST = false>
+// CLS / VARIANT (S == 1 with records): the material class this instantiation is compiled for and its place in the chain
+// (R3N_CLS_*).  With more than one variant in flight (a.variants) a workgroup first ORs its pixels' features and leaves
+// unless the tile is its own: the smallest launched variant that covers the tile.
+template <int S, bool TEX, bool REC = false, bool SPLIT = false, bool FAST = false, uint32_t CLS = R3N_CLS_ALL, uint32_t VARIANT = 3u>
 __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TEX_OCC : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
     typedef typename std::conditional<FAST, MathFast, MathExact>::type M;
+    static_assert(CLS == R3N_CLS_ALL || (S == 1 && REC), "material classes exist for the single-sample record-based resolve");
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
-    if (TEX) {  // texel decode tables into LDS (texture.h)
-        s_decode[threadIdx.x] = a.tex.decode[threadIdx.x];
-        s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
-        a.tex.decode = s_decode;
-    }
-    uint32_t n_dir, n_point;
-    stage_lights(a, s_dir, s_point, n_dir, n_point);
-
     // each wavefront shades an 8x8 pixel quad of the 16x16 tile (fewer distinct triangles / atlas texels per wave
     // than a 16x4 strip; measured 3 % faster)
     const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
@@ -811,18 +861,44 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
     const uint32_t x = bx * 16u + (ln & 7u) + 8u * (wv & 1u);
     const uint32_t y = a.row_begin + by * 16u + (ln >> 3) + 8u * (wv >> 1);
     const bool inside = x < a.width && y < a.row_end;
-    if (!inside && !SPLIT) return;  // SPLIT: every thread of the workgroup takes part in the queue reservation below
     const size_t pix = inside ? (size_t)y * a.width + x : 0u;
+    uint32_t id1 = 0u;  // S == 1: the pixel's triangle (canonical slot + 1), 0 = background
+    if (S == 1) {
+        id1 = inside ? (uint32_t)(a.vis[pix] & 0xFFFFFFFFull) : 0u;
+        if (REC && (a.variants & (a.variants - 1u)) != 0u) {  // (launch-uniform) several variants run: is this tile mine?
+            __shared__ uint32_t s_feat;
+            if (threadIdx.x == 0u) s_feat = 0u;
+            __syncthreads();
+            uint32_t f = id1 ? a.tri_rec[id1 - 1u].feat : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) f |= __shfl_xor(f, d);
+            if (ln == 0u && f) atomicOr(&s_feat, f);
+            __syncthreads();
+            // the tile's variant: the smallest launched one at or above the variant of the union (the chain's top is always
+            // launched when any material needs it: the census in r3n.hip)
+            uint32_t v = r3n_variant_of(s_feat);
+            while (v < R3N_VARIANTS - 1u && !((a.variants >> v) & 1u)) ++v;
+            if (v != VARIANT) return;  // (workgroup-uniform)
+        }
+    }
+    if (TEX) {  // texel decode tables into LDS (texture.h)
+        s_decode[threadIdx.x] = a.tex.decode[threadIdx.x];
+        s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
+        a.tex.decode = s_decode;
+    }
+    uint32_t n_dir, n_point;
+    stage_lights(a, s_dir, s_point, n_dir, n_point);
+    if (!inside && !SPLIT) return;  // SPLIT: every thread of the workgroup takes part in the queue reservation below
     float out[4];
     if (S == 1) {
-        const uint32_t id = (uint32_t)(a.vis[pix] & 0xFFFFFFFFull);
+        const uint32_t id = id1;
         if (id == 0u) {
             const ushort4 hc = pack_half4(a.clear);
             a.hdr_out[pix] = hc;
             a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc, a.out_bgr);
             return;
         }
-        if (REC) fragment_stage<TEX, M>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
+        if (REC) fragment_stage<TEX, M, CLS>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
         else shade_fragment<TEX, M>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
     } else {
         uint32_t ids[S];
@@ -1136,7 +1212,9 @@ int r3n_internal_build_srgb_lut(unsigned char *lut, hipStream_t stream);
 int r3n_internal_shade_prepass(const ShadeArgs *a, int tex, size_t first_key, size_t n_keys, hipStream_t stream);
 // the resolve of rows [a.row_begin, a.row_end): samples 1 | 4; rec = a.tri_rec holds this frame's records; split = three-pass MSAA resolve
 // fast: R3N_SHADE_FAST (honoured by the single-sample record-based resolve; the other variants always run the exact arithmetic)
+// single-sample record-based resolve: one launch per variant in a->variants (0: the general kernel alone)
 int r3n_internal_resolve(const ShadeArgs *a, uint32_t samples, int tex, int rec, int split, int fast, hipStream_t stream);
+int r3n_internal_resolve_class(const ShadeArgs *a, uint32_t variant, int fast, hipStream_t stream);  // shade_cls.hip: PLAIN / ALBEDO / PBR3, textured worlds
 int r3n_internal_blend_apply(const ShadeArgs *a, const BlendApplyArgs *b, uint32_t samples, int tex, hipStream_t stream);
 int r3n_internal_resolve_samples(const ushort4 *samples, ushort4 *hdr_out, size_t first_pixel, size_t n_pixels, hipStream_t stream);
 int r3n_internal_tonemap(const ushort4 *hdr, uchar4 *out, float4 *out_f32, size_t first_pixel, size_t n_pixels, const unsigned char *srgb_lut,

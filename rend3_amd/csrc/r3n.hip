@@ -97,6 +97,7 @@ struct r3n_ctx {
     int slot = 0;
     uint64_t frame_no = 0;
     bool overlap = true;
+    bool resolve_classes = true;  // R3N_RESOLVE_CLASSES=0: the general resolve kernel for every tile (A/B, tests)
     bool fused_frame = false;  // inside r3n_render_frame: a camera's bake and object pass are ONE launch, issued at its r3n_uniform_bake
     DevBuf alt_vis, alt_atlas, alt_vp_baked;
     // Frame-constants block: FrameUniforms, the viewport's camera header, the directional-light buffer, every shadow view's camera
@@ -125,6 +126,13 @@ struct r3n_ctx {
     std::vector<uint32_t> h_ntri;  // host mirror: triangles per enabled object slot
     std::vector<uint32_t> h_material;  // host mirror: material index per object slot
     std::vector<uint8_t> h_material_key;  // host mirror: Material::key() per material slot
+    // material classes of the single-sample resolve (kernels_shade.h R3N_FEAT_*): host mirror of the records, per-texture
+    // "the sampler's short path applies", the feature word per material on the device and the variants the census found
+    std::vector<r3n_material208> h_materials;
+    std::vector<uint8_t> h_tex_short;
+    DevBuf material_feat;
+    uint32_t resolve_variants = 0;
+    bool classes_dirty = true;
     bool key_census_dirty = true;
     uint64_t key_objects[3] = {0, 0, 0};  // enabled objects per material key
     uint64_t total_tris = 0;
@@ -602,6 +610,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     c->status_host[0] = 0u;
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
+    if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');
     if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) { c->shadow_tiles = e4[0] == '1' || e4[0] == '2'; c->shadow_bin = e4[0] != '2'; }
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
@@ -830,6 +839,9 @@ int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208
     c->h_material_key.resize(need, 0);
     for (uint32_t i = 0; i < n; ++i) c->h_material_key[slots[i]] = keys[i];
     c->key_census_dirty = true;
+    c->h_materials.resize(need, r3n_material208{});
+    for (uint32_t i = 0; i < n; ++i) c->h_materials[slots[i]] = records[i];
+    c->classes_dirty = true;
     for (uint32_t i = 0; i < n; ++i) {
         HIP_TRY(c, hipMemcpyAsync(c->materials.as<r3n_material208>() + slots[i], records + i, sizeof(r3n_material208),
                                   hipMemcpyHostToDevice, c->stream));
@@ -862,6 +874,13 @@ static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uin
             if (k < descs[i].mips) at += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k) * (descs[i].format == R3N_POOL_FLOAT ? 4u : 1u);
         }
     }
+    // which textures the sampler's short path covers (texture.h tex_sample_grad): power-of-two extents, RGBA8 pool texels
+    c->h_tex_short.assign(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t w = descs[i].width, h = descs[i].height;
+        c->h_tex_short[i] = (w && h && ((w & (w - 1u)) | (h & (h - 1u))) == 0u && descs[i].format < R3N_POOL_FLOAT) ? 1 : 0;
+    }
+    c->classes_dirty = true;
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->tex_level_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
@@ -1752,6 +1771,35 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     return check_launch(c, "raster");
 }
 
+// Census of the material classes (kernels_shade.h): the feature word of every material slot goes to the device, and the
+// variants of the resolve that some material maps to are the ones the frame launches.  A material that binds a texture the
+// sampler's short path does not cover (extent not a power of two, float pool texels, pool beyond 2^30 texels, id out of range)
+// carries R3N_FEAT_TEX_GENERAL and thereby goes to the general kernel.  Runs when materials or textures changed.
+static int refresh_material_classes(r3n_ctx *c) {
+    if (!c->classes_dirty) return R3N_OK;
+    const uint32_t n = c->n_materials;
+    c->h_materials.resize(n, r3n_material208{});
+    std::vector<uint32_t> feat(std::max(n, 1u), R3N_FEAT_ALL);
+    const bool small_pool = c->n_texels <= (1ull << 30);
+    uint32_t variants = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const r3n_material208 &m = c->h_materials[i];
+        uint32_t f = r3n_material_features(m);
+        for (int k = 0; k < 10; ++k) {
+            const uint32_t id = m.textures[k];
+            if (id && (!small_pool || id > c->n_textures || id > c->h_tex_short.size() || !c->h_tex_short[id - 1u])) f |= R3N_FEAT_TEX_GENERAL;
+        }
+        feat[i] = f;
+        variants |= 1u << r3n_variant_of(f);
+    }
+    TRY(ensure(c, c->material_feat, feat.size() * 4, false, -1));
+    HIP_TRY(c, hipMemcpyAsync(c->material_feat.p, feat.data(), feat.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `feat` is a temporary
+    c->resolve_variants = variants;
+    c->classes_dirty = false;
+    return R3N_OK;
+}
+
 static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     CamState &s = c->viewport;
     ShadeArgs a{};
@@ -1781,6 +1829,8 @@ static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     a.tri_rec = nullptr;
     a.seen = nullptr;
     a.total_tris = (uint32_t)c->total_tris;
+    a.material_feat = nullptr;
+    a.variants = 0u;
     return a;
 }
 
@@ -1800,6 +1850,9 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     const bool blend_samples = c->samples == 4 && c->blend_tris > 0;  // a transparent pass will blend into the individual samples
     const bool split = c->samples == 4 && use_records && !blend_samples && npix_all < (1ull << 29) && R3N_MSAA_SPLIT;
     uint32_t edge_cap = 0;
+    // single-sample record-based resolve of a textured world: one kernel per material class present (R3N_RESOLVE_CLASSES=0: the general kernel)
+    const bool classes = use_records && c->samples == 1 && c->n_textures > 0 && c->n_materials > 0 && c->resolve_classes;
+    if (classes) TRY(refresh_material_classes(c));
     if (use_records) {
         TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
         TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, 0));  // zero: k_vertex_stage returns every flag it consumes to 0
@@ -1832,6 +1885,10 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     }
     ShadeArgs a = make_shade_args(c, r0, r1);
     if (blend_samples) a.samples_out = c->samples16.as<ushort4>();
+    if (classes && c->resolve_variants != 0u) {
+        a.material_feat = c->material_feat.as<uint32_t>();
+        a.variants = c->resolve_variants;
+    }
     c->resolved_this_frame = true;
     const bool tex = c->n_textures > 0;
     // the vertex stage runs once per visible triangle instead of once per pixel / sample (256 B per triangle slot;

@@ -31,7 +31,20 @@ int r3n_internal_resolve(const ShadeArgs *ap, uint32_t samples, int tex, int rec
     if (samples == 4) return r3n_internal_resolve_ms(ap, tex, rec, split, stream);  // shade_ms.hip
     const ShadeArgs &a = *ap;
     const dim3 rgrid((a.width + 15u) / 16u, (a.row_end - a.row_begin + 15u) / 16u);
-    if (rec && fast) {
+    if (rec && tex && a.variants != 0u) {
+        // one launch per material class in flight (kernels_shade.h R3N_CLS_*); the general kernel is the chain's top
+        for (uint32_t v = 0; v < R3N_VARIANTS; ++v) {
+            if (!((a.variants >> v) & 1u)) continue;
+            if (v < R3N_VARIANTS - 1u) {
+                const int rc = r3n_internal_resolve_class(ap, v, fast, stream);
+                if (rc) return rc;
+            } else if (fast) {
+                hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), 0, stream, a);
+            } else {
+                hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), 0, stream, a);
+            }
+        }
+    } else if (rec && fast) {
         if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_resolve_opaque<1, false, true, false, true>), rgrid, dim3(256), 0, stream, a);
     } else if (rec) {

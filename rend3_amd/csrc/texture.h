@@ -160,6 +160,10 @@ struct TexLvlFast {
     uint32_t o00, o10, o01, o11;  // BYTE offsets of the four texels in the pool
     float fx, fy;
 };
+// TOTAL: instead of reporting wild coordinates the function handles them itself -- the footprint by the general formulas
+// (tex_level_footprint: `floor + 1` in float, NaN / huge -> texel 0), as a rarely taken block that only rewrites `l`.  The callers
+// of that form need no general path behind them.
+template <bool TOTAL = false>
 R3N_DEV bool tex_level_fast(uint32_t w, uint32_t h, uint32_t base, float u, float v, TexLvlFast &l) {
     const float tx = u * (float)w - 0.5f, ty = v * (float)h - 0.5f;
     const float fx0 = floorf(tx), fy0 = floorf(ty);
@@ -170,7 +174,16 @@ R3N_DEV bool tex_level_fast(uint32_t w, uint32_t h, uint32_t base, float u, floa
     const uint32_t y0 = __umul24((uint32_t)iy & (h - 1u), w), y1 = __umul24((uint32_t)(iy + 1) & (h - 1u), w);  // extents <= 65535
     l.o00 = (base + y0 + x0) << 2; l.o10 = (base + y0 + x1) << 2;
     l.o01 = (base + y1 + x0) << 2; l.o11 = (base + y1 + x1) << 2;
-    return fabsf(fx0) < 16777216.0f && fabsf(fy0) < 16777216.0f;  // NaN compares false
+    const bool tame = fabsf(fx0) < 16777216.0f && fabsf(fy0) < 16777216.0f;  // NaN compares false
+    if (TOTAL && !tame) {
+        TexFootprint::Lvl g;
+        tex_level_footprint(w, h, u, v, g);
+        l.o00 = (base + g.i00) << 2; l.o10 = (base + g.i10) << 2;
+        l.o01 = (base + g.i01) << 2; l.o11 = (base + g.i11) << 2;
+        l.fx = g.fx; l.fy = g.fy;
+        return true;
+    }
+    return tame;
 }
 template <bool NEED_A>
 R3N_DEV Texel4 tex_texel_at(const TextureArgs &t, const float *__restrict__ rgb, uint32_t byte_off) {
@@ -205,13 +218,15 @@ R3N_DEV Texel4 tex_bilinear_fast(const TextureArgs &t, const float *__restrict__
 // the chain, 32-bit byte offsets from the uniform pool pointer -- with one branch per sample instead of one per texel.
 // (Sharing one footprint between the maps of a material that have the same extent was measured: slower -- the cached
 // footprint stays live across the whole fragment stage and costs an occupancy step.)
-template <class M = MathExact, bool NEED_A = true>
+// SHORT_ONLY: the caller knows that the short path's conditions hold for this texture (the resolve's material classes,
+// kernels_shade.h R3N_FEAT_TEX_GENERAL): no general path is instantiated.
+template <class M = MathExact, bool NEED_A = true, bool SHORT_ONLY = false>
 R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, float u, float v, const float ddx[2],
                              const float ddy[2], float o[4]) {
-    if (id == 0u || id > t.count) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
+    if (id == 0u || (!SHORT_ONLY && id > t.count)) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const r3n_texture_desc32 d = t.descs[id - 1u];
     const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
-    if (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT) {
+    if (SHORT_ONLY || (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT)) {
         // level of detail exactly as tex_footprint derives it
         const float W = (float)d.width, H = (float)d.height;
         const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
@@ -229,10 +244,10 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
         const float *rgb = t.decode + (d.format == 1u ? 256 : 0);
         TexLvlFast l0, l1;
-        bool tame = tex_level_fast(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
+        bool tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
         const bool two = frac > 0.0f;  // then level + 1 <= mips - 1
-        if (two) tame = tex_level_fast(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
-        if (tame) {
+        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
+        if (SHORT_ONLY || tame) {
             Texel4 r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
             if (two) {
                 const Texel4 hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
@@ -245,6 +260,7 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
             return;
         }
     }
+    if (SHORT_ONLY) return;  // (not reached)
     TexFootprint f;
     tex_footprint(d, nearest, u, v, ddx, ddy, f);
     const Texel4 r = tex_apply<M, NEED_A>(t, d, f);
