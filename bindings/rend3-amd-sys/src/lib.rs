@@ -90,7 +90,8 @@ pub const R3N_STAGE_POSE: i32 = 13;
 pub const R3N_STAGE_EXCHANGE_SHADOW: i32 = 14;
 pub const R3N_STAGE_EXCHANGE_DEPTH: i32 = 15;
 pub const R3N_STAGE_EXCHANGE_ROWS: i32 = 16;
-pub const R3N_STAGE_COUNT: i32 = 17;
+pub const R3N_STAGE_EXCHANGE_KEYS: i32 = 17;
+pub const R3N_STAGE_COUNT: i32 = 18;
 
 #[repr(C)]
 pub struct r3n_ctx {
@@ -371,6 +372,7 @@ extern "C" {
     pub fn r3n_set_shard_mode(ctx: *mut r3n_ctx, mode: u32) -> c_int;
     pub fn r3n_comm_unique_id(id: *mut u8) -> c_int;
     pub fn r3n_comm_init(ctx: *mut r3n_ctx, ids: *const u8, rank: u32, world: u32) -> c_int;
+    pub fn r3n_comm_set_split(ctx: *mut r3n_ctx, mode: u32) -> c_int;
     pub fn r3n_comm_destroy(ctx: *mut r3n_ctx) -> c_int;
     pub fn r3n_set_camera_object_range(ctx: *mut r3n_ctx, camera: u32, begin: u32, end: u32) -> c_int;
     pub fn r3n_exchange_depth(ctx: *mut r3n_ctx, depth_f32: *mut *mut c_void, count: *mut u64) -> c_int;
@@ -399,6 +401,7 @@ extern "C" {
     pub fn r3n_set_multi_stream(ctx: *mut r3n_ctx, enable: c_int) -> c_int;
     pub fn r3n_stage_times(ctx: *mut r3n_ctx, ms: *mut f64, launches: *mut u64, reset: c_int) -> c_int;
     pub fn r3n_hbm_copy_rate(ctx: *mut r3n_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;
+    pub fn r3n_selftest_exact_math(hip_device: c_int, hist: *mut unsigned long long, guarded: *mut unsigned long long) -> c_int;
     pub fn r3n_host_mat4_mul(a: *const f32, b: *const f32, out: *mut f32);
     pub fn r3n_host_mat4_inverse(m: *const f32, out: *mut f32);
     pub fn r3n_host_look_at(eye: *const f32, center: *const f32, up: *const f32, rh: c_int, out: *mut f32);

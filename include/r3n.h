@@ -437,13 +437,23 @@ int r3n_set_shard_mode(r3n_ctx *ctx, uint32_t mode);
  *                        R3N_SHARD_ROWS; from then on r3n_render_frame owns the shadow views v with v mod world == rank, rasterises
  *                        the band of rows `rank` of r3n_host row ranges (rows split as evenly as possible, the first height mod world
  *                        bands one row taller), broadcasts the shadow rectangles on the shadow lane's stream, all-gathers the
- *                        depth bands in front of r3n_hi_z (keys under MSAA; a MAX all-reduce when the bands are ragged) and the
- *                        Rgba8 rows behind the resolve.  r3n_frame_desc.exchange must be NULL then.
- *   r3n_comm_destroy     collective; back to a single-rank context. */
+ *                        depth bands in front of r3n_hi_z (keys under MSAA; in place when the bands are equal, else one grouped
+ *                        broadcast per band) and the Rgba8 rows behind the resolve.  r3n_frame_desc.exchange must be NULL then.
+ *   r3n_comm_set_split   R3N_SHARD_ROWS (what r3n_comm_init selects) or R3N_SHARD_OBJECTS: the object-range split of BASELINE.json's
+ *                        north_star -- this rank culls + draws the viewport's objects of r3n_set_object_range / r3n_set_object_owners
+ *                        over the WHOLE target; r3n_render_frame then issues a MAX all-reduce of the pass-1 depth plane (f32;
+ *                        the u64 keys under MSAA) in front of r3n_hi_z and a MAX reduce-scatter of the u64 visibility keys onto
+ *                        the row bands behind pass 2 (an all-reduce when the bands are ragged); shadow views, resolve bands and
+ *                        the row gather as above.  Choose by workload: rows replicates the cull, objects moves 12 B per pixel.
+ *   r3n_comm_destroy     collective; back to a single-rank context.
+ * The three communicators run collectives concurrently on three streams; RCCL requires every rank to issue the collectives of one
+ * communicator in the same order, so r3n_frame_desc.flags, samples, the target size and n_shadow_views MUST be identical on
+ * every rank (tests/rccl_shim.cpp executes every collective synchronously and times out on an order mismatch). */
 #define R3N_COMM_ID_BYTES 128
 #define R3N_COMM_IDS 3
 int r3n_comm_unique_id(uint8_t *id /* R3N_COMM_ID_BYTES */);
 int r3n_comm_init(r3n_ctx *ctx, const uint8_t *ids /* R3N_COMM_IDS x R3N_COMM_ID_BYTES */, uint32_t rank, uint32_t world);
+int r3n_comm_set_split(r3n_ctx *ctx, uint32_t mode /* R3N_SHARD_OBJECTS | R3N_SHARD_ROWS */);
 int r3n_comm_destroy(r3n_ctx *ctx);
 /* Device pointers + sizes of the exchange buffers, for RCCL (all-reduce MAX over ranks):
  * the 64-bit visibility/depth keys (width*height u64, as int64 non-negative) and the f32 shadow atlas. */
@@ -520,7 +530,8 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_EXCHANGE_SHADOW 14 /* r3n_comm_init: shadow rectangles packed, broadcast, unpacked (shadow lane) */
 #define R3N_STAGE_EXCHANGE_DEPTH 15  /* depth bands (keys under MSAA) gathered in front of Hi-Z (main stream) */
 #define R3N_STAGE_EXCHANGE_ROWS 16   /* Rgba8 rows gathered behind the resolve (resolve's stream) */
-#define R3N_STAGE_COUNT 17
+#define R3N_STAGE_EXCHANGE_KEYS 17   /* object-range split: MAX reduce-scatter of the visibility keys onto the row bands (main stream) */
+#define R3N_STAGE_COUNT 18
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
 /* Shadow views normally run on auxiliary streams concurrently with the viewport chain; per-kernel durations measured
  * while kernels of other streams are resident are inflated, so timing passes can serialise everything on the main
@@ -532,6 +543,11 @@ int r3n_stage_times(r3n_ctx *ctx, double ms[R3N_STAGE_COUNT], uint64_t launches[
  * Cache when 1 GiB) repeated `repeats` times, HIP-event timed; *gb_per_s = (bytes read + bytes written) / best time.
  * Allocates and frees two scratch buffers; synchronises. */
 int r3n_hbm_copy_rate(r3n_ctx *ctx, uint64_t bytes, uint32_t repeats, double *gb_per_s);
+/* Self-test of the short correctly-rounded reciprocal / square root / reciprocal square root sequences the shading kernels use
+ * (csrc/exact_math.h): all 2^32 f32 bit patterns on the device against the compiler's IEEE expansions.  hist[3][512]: patterns
+ * on which the UNGUARDED sequences differ, by function (rcp, sqrt, rsqrt) and sign + biased exponent; guarded[3]: patterns on
+ * which the guarded functions -- what the library evaluates -- differ (must be 0).  Needs no context; returns a hipError_t. */
+int r3n_selftest_exact_math(int hip_device, unsigned long long *hist, unsigned long long *guarded);
 
 /* ---- host-side mirror of the reference's CPU math on the path (rend3_amd/csrc/host.cpp).
  * In a real integration these stay in Rust (rend3 core); they exist here so the standalone harness, the

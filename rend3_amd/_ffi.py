@@ -18,7 +18,7 @@ PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
-          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth", "exchange_rows"]
+          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth", "exchange_rows", "exchange_keys"]
 
 COMM_ID_BYTES, COMM_IDS = 128, 3  # R3N_COMM_ID_BYTES, R3N_COMM_IDS
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "r3n_comm_unique_id": (cint, [vp]),
     "r3n_comm_init": (cint, [vp, vp, u32, u32]),
     "r3n_comm_destroy": (cint, [vp]),
+    "r3n_comm_set_split": (cint, [vp, u32]),
     "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
     "r3n_exchange_depth": (cint, [vp, vp, vp]),
     "r3n_set_row_range": (cint, [vp, u32, u32]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "r3n_stage_times": (cint, [vp, vp, vp, cint]),
     "r3n_set_multi_stream": (cint, [vp, cint]),
     "r3n_hbm_copy_rate": (cint, [vp, u64, u32, vp]),
+    "r3n_selftest_exact_math": (cint, [cint, vp, vp]),
     "r3n_host_mat4_mul": (None, [vp, vp, vp]),
     "r3n_host_mat4_inverse": (None, [vp, vp]),
     "r3n_host_look_at": (None, [vp, vp, vp, cint, vp]),

@@ -28,6 +28,7 @@ UNITS = {
     "shade_blend.hip": ["texture.h", "kernels_shade.h"],
     "texture_decode.hip": ["bc7_tables.h", "bc6h_tables.h"],
     "anim.hip": [],
+    "selftest.hip": ["exact_math.h"],
     "skin_mfma.hip": [],
     "host.cpp": [],
 }

@@ -3,6 +3,9 @@
 // handful of entry points up in the copy the process has loaded, else loads ROCm's.
 #pragma once
 #include <dlfcn.h>
+
+#include <cstdlib>
+#include <string>
 #include <rccl/rccl.h>  // types and prototypes only
 
 struct Rccl {
@@ -16,11 +19,18 @@ struct Rccl {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     std::string error;
 
     bool load() {
         if (lib) return true;
+        // R3N_RCCL_LIB: bind another implementation of the same entry points (tests/rccl_shim.cpp: ranks that share one GPU)
+        if (const char *over = std::getenv("R3N_RCCL_LIB")) {
+            lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) { error = std::string("R3N_RCCL_LIB: ") + dlerror(); return false; }
+        }
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            if (lib) break;
             lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy already in the process (same soname: PyTorch's)
             if (lib) break;
         }
@@ -40,6 +50,7 @@ struct Rccl {
         Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
         AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+        ReduceScatter = reinterpret_cast<decltype(ReduceScatter)>(sym("ncclReduceScatter"));
         if (!error.empty()) { lib = nullptr; return false; }
         return true;
     }

@@ -305,6 +305,111 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     }
 }
 
+#ifndef R3N_BIG_LEAN
+#define R3N_BIG_LEAN 1  // the work-item kernel's scan step without intermediate branches (see shade_pixel_lean)
+#endif
+// One scan step of the work-item kernel at one sample per pixel, opaque key: the same coverage / depth-clip / target arithmetic as
+// shade_pixel, as STRAIGHT-LINE code -- every lane evaluates everything, the tests are combined into one predicate and only the
+// atomic is predicated.  Why: the kernel is bound by instruction ISSUE, and more by the scalar unit than by the vector units
+// (profiles/r04_summary.md: 31 M scalar against 27 M vector instructions per shadow launch, 78 % of a SIMD's scalar issue slots):
+// every early-out `if` costs a mask AND, an exec update and a branch on the scalar unit and saves vector work only when ALL 64
+// lanes fail, which the block rejection test in front of the step has already made rare.
+// R3N_BIG_LEAN == 2: the predicate as a chain of v_cmpx (each narrows EXEC on the vector unit: no mask ANDs, no exec update
+// and no branch on the scalar unit), the atomic under the narrowed mask, EXEC restored -- one asm statement.
+// fine: the step's lanes hold block index `b` (0xFFFFFFFF: none); coarse: b is not tested.
+template <bool DEPTH_ONLY, bool FINE>
+R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int y, uint32_t b, int rx1, int ry1) {
+    float E[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
+    const float z = frag_depth(tw.ts, E);
+    const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;  // accepted: [0, 1] or -0 (see shade_pixel_lean)
+    const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
+    unsigned long long save;
+    typedef __attribute__((address_space(1))) void *gv_t;
+#define R3N_CMPX_CHAIN                                                                                             \
+    "s_mov_b64 %[save], exec\n\t"                                                                                   \
+    "v_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"                                        \
+    "v_cmpx_le_f32 vcc, %[t0], %[e0]\n\tv_cmpx_le_f32 vcc, %[t1], %[e1]\n\tv_cmpx_le_f32 vcc, %[t2], %[e2]\n\t"     \
+    "v_cmpx_le_f32 vcc, 0, %[z]\n\tv_cmpx_ge_f32 vcc, 1.0, %[z]\n\t"
+    if (DEPTH_ONLY) {
+        if (FINE)
+            asm volatile("s_mov_b64 %[save], exec\n\tv_cmpx_gt_u32 vcc, 64, %[b]\n\t"
+                         "v_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"
+                         "v_cmpx_le_f32 vcc, %[t0], %[e0]\n\tv_cmpx_le_f32 vcc, %[t1], %[e1]\n\tv_cmpx_le_f32 vcc, %[t2], %[e2]\n\t"
+                         "v_cmpx_le_f32 vcc, 0, %[z]\n\tv_cmpx_ge_f32 vcc, 1.0, %[z]\n\t"
+                         "global_atomic_umax %[off], %[data], %[base]\n\t"
+                         "s_mov_b64 exec, %[save]"
+                         : [save] "=&s"(save)
+                         : [b] "v"(b), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                           [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 2),
+                           [data] "v"(zb), [base] "s"((gv_t)(unsigned long long)a.depth)
+                         : "vcc", "memory");
+        else
+            asm volatile(R3N_CMPX_CHAIN
+                         "global_atomic_umax %[off], %[data], %[base]\n\t"
+                         "s_mov_b64 exec, %[save]"
+                         : [save] "=&s"(save)
+                         : [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                           [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 2),
+                           [data] "v"(zb), [base] "s"((gv_t)(unsigned long long)a.depth)
+                         : "vcc", "memory");
+    } else {
+        const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
+        if (FINE)
+            asm volatile("s_mov_b64 %[save], exec\n\tv_cmpx_gt_u32 vcc, 64, %[b]\n\t"
+                         "v_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"
+                         "v_cmpx_le_f32 vcc, %[t0], %[e0]\n\tv_cmpx_le_f32 vcc, %[t1], %[e1]\n\tv_cmpx_le_f32 vcc, %[t2], %[e2]\n\t"
+                         "v_cmpx_le_f32 vcc, 0, %[z]\n\tv_cmpx_ge_f32 vcc, 1.0, %[z]\n\t"
+                         "global_atomic_umax_x2 %[off], %[data], %[base]\n\t"
+                         "s_mov_b64 exec, %[save]"
+                         : [save] "=&s"(save)
+                         : [b] "v"(b), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                           [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 3),
+                           [data] "v"(key), [base] "s"((gv_t)(unsigned long long)a.vis)
+                         : "vcc", "memory");
+        else
+            asm volatile(R3N_CMPX_CHAIN
+                         "global_atomic_umax_x2 %[off], %[data], %[base]\n\t"
+                         "s_mov_b64 exec, %[save]"
+                         : [save] "=&s"(save)
+                         : [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                           [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 3),
+                           [data] "v"(key), [base] "s"((gv_t)(unsigned long long)a.vis)
+                         : "vcc", "memory");
+    }
+#undef R3N_CMPX_CHAIN
+}
+
+template <bool DEPTH_ONLY>
+R3N_DEV void shade_pixel_lean(const RasterArgs &a, const TriWork &tw, int x, int y, bool active) {
+    float E[3];
+    bool ok = active;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
+        ok = ok & (E[i] >= tw.thr[i]);
+    }
+    float z = frag_depth(tw.ts, E);
+    ok = ok & (z >= 0.0f) & (z <= 1.0f);  // depth clip (unclipped_depth: false, forward.rs:343)
+    // an accepted z is in [0, 1] or -0: clearing the sign bit canonicalises -0 and changes nothing else
+    const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;
+    const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
+    if (ok) {
+        if (DEPTH_ONLY) global_max_u32_at(a.depth, pix << 2, zb);
+        else global_max_u64_at(a.vis, pix << 3, ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1);
+    }
+}
+
+// The three edge thresholds of a work item travel in the top bits of its `material` word (bit 29 + i set: edge i is NOT a
+// top / left edge, threshold = the smallest subnormal): the producer has them in registers, the consumer would spend two dozen
+// scalar instructions per item deriving them from the coefficients' bits.
+#define R3N_BIG_THR_SHIFT 29u
+#define R3N_BIG_MATERIAL_MASK 0x1FFFFFFFu
+R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
+    return ((thr[0] != 0.0f ? 1u : 0u) | (thr[1] != 0.0f ? 2u : 0u) | (thr[2] != 0.0f ? 4u : 0u)) << R3N_BIG_THR_SHIFT;
+}
+
 #ifndef R3N_SMALL_MAX
 #define R3N_SMALL_MAX 8
 #endif
@@ -365,7 +470,7 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
                     }
                     it.det = tw.ts.det;
                     it.slot1 = DEPTH_ONLY ? 0u : tw.slot1;
-                    it.material = tw.material;
+                    it.material = tw.material | pack_thresholds(tw.thr);  // (material indices stay below 2^29: r3n_materials_write)
                     it.xy0 = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
                     it.xy1 = (uint32_t)rx1 | ((uint32_t)ry1 << 16);
                     big[start + t] = it;
@@ -465,7 +570,7 @@ __global__ __launch_bounds__(256) void k_blend_setup(RasterArgs a, BlendSetupArg
         }
         it.det = tw.ts.det;
         it.slot1 = tw.slot1;
-        it.material = g;  // draw order
+        it.material = g | pack_thresholds(tw.thr);  // draw order (< 2^29: r3n_blend_order_write)
         it.xy0 = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
         it.xy1 = (uint32_t)rx1 | ((uint32_t)ry1 << 16);
         big[start + t] = it;
@@ -536,7 +641,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         if (!m) return nullptr;
         const uint32_t q = (uint32_t)__builtin_ctzll(m);
         const uint32_t qb = __builtin_amdgcn_readlane(excl, q);
-        return reinterpret_cast<const uint32_t *>(a.big_items + (size_t)q * cap + (flat - qb));
+        return reinterpret_cast<const uint32_t *>(a.big_items + (size_t)(q * cap + (flat - qb)));  // (queues hold < 2^32 items: r3n_create)
     };
     typedef __attribute__((address_space(4))) const uint32_t *sptr_t;
     // The record is read with SCALAR loads (constant address space + wave-uniform address => s_load into SGPRs).
@@ -584,16 +689,12 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         // edge thresholds on the SCALAR unit: the coefficients are wave-uniform, the scalar unit compares integers only, and
         // behind the (empty) asm the compiler can no longer turn the bit tests back into vector float compares.  Same outcome
         // as edge_threshold for every non-NaN pair; with a NaN coefficient the edge value is NaN and fails any threshold.
+        const uint32_t mt = bu(17);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            uint32_t ab = bu(3 * i), bb = bu(3 * i + 1);
-            asm("" : "+s"(ab), "+s"(bb));
-            const bool top_left = (int)ab > 0 || ((ab & 0x7FFFFFFFu) == 0u && (int)bb > 0);
-            w.thr[i] = __uint_as_float(top_left ? 0u : 1u);
-        }
+        for (int i = 0; i < 3; ++i) w.thr[i] = __uint_as_float((mt >> (R3N_BIG_THR_SHIFT + (uint32_t)i)) & 1u);  // 0 or the smallest subnormal
         w.slot1 = bu(16);
         w.cutout = !BLEND && a.key == R3N_KEY_CUTOUT;  // launch-uniform
-        w.material = bu(17);
+        w.material = mt & R3N_BIG_MATERIAL_MASK;
         w.mat_flags = 0u; w.mat_alpha = 1.0f; w.mat_cutoff = 0.0f;
         w.alpha_tex = false;
 #pragma unroll
@@ -631,6 +732,30 @@ R3N_DEV void raster_big_body(RasterArgs a) {
 #endif
             const uint32_t grp = lane >> 4;
             const int px = (int)(lane & 3u), py = (int)((lane >> 2) & 3u);
+            if (R3N_BIG_LEAN && S == 1 && !BLEND && !w.cutout) {
+                while (blocks) {
+#ifdef R3N_WAVE_TRACE
+                    ++trace_steps;
+#endif
+                    // four find-first / clear-bit pairs (an empty mask yields -1: no block, and clearing bit 63 of zero is harmless)
+                    // (one statement: between separate asm statements the compiler pads every scalar write with a hazard s_nop)
+                    uint32_t bsel[4];
+                    asm("s_ff1_i32_b64 %0, %4\n\ts_bitset0_b64 %4, %0\n\t"
+                        "s_ff1_i32_b64 %1, %4\n\ts_bitset0_b64 %4, %1\n\t"
+                        "s_ff1_i32_b64 %2, %4\n\ts_bitset0_b64 %4, %2\n\t"
+                        "s_ff1_i32_b64 %3, %4\n\ts_bitset0_b64 %4, %3"
+                        : "=&s"(bsel[0]), "=&s"(bsel[1]), "=&s"(bsel[2]), "=&s"(bsel[3]), "+s"(blocks));
+                    const uint32_t b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
+                    int x, y;
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7u), "v"(rx0 + px));
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
+#if R3N_BIG_LEAN >= 2
+                    shade_pixel_cmpx<DEPTH_ONLY, true>(a, w, x, y, b, rx1, ry1);
+#else
+                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (b < 64u) & (x <= rx1) & (y <= ry1));
+#endif
+                }
+            } else
             while (blocks) {
 #ifdef R3N_WAVE_TRACE
                 ++trace_steps;
@@ -653,6 +778,21 @@ R3N_DEV void raster_big_body(RasterArgs a) {
             const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
             const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
+            if (R3N_BIG_LEAN && S == 1 && !BLEND && !w.cutout) {
+                while (blocks) {
+#ifdef R3N_WAVE_TRACE
+                    ++trace_steps;
+#endif
+                    int b;
+                    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(b), "+s"(blocks));
+                    const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
+#if R3N_BIG_LEAN >= 2
+                    shade_pixel_cmpx<DEPTH_ONLY, false>(a, w, x, y, 0u, rx1, ry1);
+#else
+                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (x <= rx1) & (y <= ry1));
+#endif
+                }
+            } else
             while (blocks) {
 #ifdef R3N_WAVE_TRACE
                 ++trace_steps;

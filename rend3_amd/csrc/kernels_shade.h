@@ -293,24 +293,43 @@ struct PixelData {
 
 #define R3N_PI 3.14159265359f
 
+#ifndef R3N_BRDF_HOIST
+#define R3N_BRDF_HOIST 1
+#endif
+// The terms of surface_shading that do not depend on the light, evaluated once per pixel instead of once per light (same
+// expressions, same values: a square root, two dot products and a handful of multiplies per further light).
+struct BrdfPixel {
+    float nov, a2, f90, sqrt_v;  // N.V + 1e-5, roughness^2, the Fresnel f90, sqrt((-nov * a2 + nov) * nov + a2) of the visibility term
+};
+template <class M>
+R3N_DEV BrdfPixel brdf_pixel(const PixelData &px, const float v[3]) {
+    BrdfPixel b;
+    b.nov = fabsf(dot3m<M>(px.normal, v)) + 0.00001f;
+    const float c165[3] = {16.5f, 16.5f, 16.5f};
+    b.f90 = sat(dot3m<M>(px.f0, c165));
+    const float a = px.roughness;
+    b.a2 = a * a;
+    b.sqrt_v = M::sqrt(M::mad(M::mad(-b.nov, b.a2, b.nov), b.nov, b.a2));
+    return b;
+}
 // opaque.wgsl:440-468.  The r and g channels run as one packed pair, b on its own.
 template <class M>
 R3N_DEV void surface_shading(const float l[3], const float intensity[3], const PixelData &px, const float v[3],
-                             float occlusion, float out[3]) {
+                             float occlusion, float out[3], const BrdfPixel *pre = nullptr) {
     float h[3] = {v[0] + l[0], v[1] + l[1], v[2] + l[2]};
     normalize3m<M>(h);
-    const float nov = fabsf(dot3m<M>(px.normal, v)) + 0.00001f;
+    const float nov = pre ? pre->nov : fabsf(dot3m<M>(px.normal, v)) + 0.00001f;
     const float nol = sat(dot3m<M>(px.normal, l));
     const float noh = sat(dot3m<M>(px.normal, h));
     const float loh = sat(dot3m<M>(l, h));
     const float c165[3] = {16.5f, 16.5f, 16.5f};
-    const float f90 = sat(dot3m<M>(px.f0, c165));
-    const float a = px.roughness, a2 = a * a;
+    const float f90 = pre ? pre->f90 : sat(dot3m<M>(px.f0, c165));
+    const float a = px.roughness, a2 = pre ? pre->a2 : a * a;
     const float f = M::mad(M::mad(noh, a2, -noh), noh, 1.0f);             // (noh * a2 - noh) * noh + 1
     const float d = M::div(a2, (R3N_PI * f) * f);
     const float x = 1.0f - loh, x2 = x * x, x5 = (x2 * x2) * x;
     const float ggxl = nov * M::sqrt(M::mad(M::mad(-nol, a2, nol), nol, a2));  // (-nol * a2 + nol) * nol + a2
-    const float ggxv = nol * M::sqrt(M::mad(M::mad(-nov, a2, nov), nov, a2));
+    const float ggxv = nol * (pre ? pre->sqrt_v : M::sqrt(M::mad(M::mad(-nov, a2, nov), nov, a2)));
     const float vis = M::div(0.5f, ggxl + ggxv);
     const float k = nol * occlusion;
     const float dv = d * vis;
@@ -694,6 +713,12 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
                           (((fabsf(px.f0[2]) + fabsf(px.diffuse[0])) + (fabsf(px.diffuse[1]) + fabsf(px.diffuse[2]))) + fabsf(px.ao));
         const bool skip_ok = px.roughness >= 1e-9f && px.roughness <= 1e9f && mag < 1e30f;
 #endif
+#if R3N_BRDF_HOIST
+        const BrdfPixel pre_v = brdf_pixel<M>(px, vv);
+        const BrdfPixel *pre = &pre_v;
+#else
+        const BrdfPixel *pre = nullptr;
+#endif
         for (uint32_t i = 0; i < ((R3N_SHADE_ABLATE & 8) ? 0u : n_dir); ++i) {
             const LdsDirLight &L = s_dir[i];
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
@@ -729,7 +754,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             }
 #endif
             float res[3];
-            surface_shading<M>(L.l, L.color, px, vv, shadow * px.ao, res);
+            surface_shading<M>(L.l, L.color, px, vv, shadow * px.ao, res, pre);
 #pragma unroll
             for (int c = 0; c < 3; ++c) color[c] += res[c];
         }
@@ -743,7 +768,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             const float inten[3] = {P.color[0] * att, P.color[1] * att, P.color[2] * att};
             const float l[3] = {M::div(delta[0], d), M::div(delta[1], d), M::div(delta[2], d)};
             float res[3];
-            surface_shading<M>(l, inten, px, vv, px.ao, res);
+            surface_shading<M>(l, inten, px, vv, px.ao, res, pre);
 #pragma unroll
             for (int c = 0; c < 3; ++c) color[c] += (res[c] > 0.0f ? res[c] : 0.0f);
         }

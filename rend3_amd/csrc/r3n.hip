@@ -97,6 +97,7 @@ struct r3n_ctx {
     int slot = 0;
     uint64_t frame_no = 0;
     bool overlap = true;
+    bool always_fork = false;     // R3N_ALWAYS_FORK=1: the shadow lanes wait for the main stream at every fork (no epoch gate)
     bool resolve_classes = true;  // R3N_RESOLVE_CLASSES=0: the general resolve kernel for every tile (A/B, tests)
     bool fused_frame = false;  // inside r3n_render_frame: a camera's bake and object pass are ONE launch, issued at its r3n_uniform_bake
     DevBuf alt_vis, alt_atlas, alt_vp_baked;
@@ -191,6 +192,7 @@ struct r3n_ctx {
     // r3n_comm_init: the sort-first exchanges issued from r3n_render_frame over RCCL
     struct Comm {
         bool on = false;
+        bool by_objects = false;  // r3n_comm_set_split(R3N_SHARD_OBJECTS): object-range split (depth MAX all-reduce + key MAX reduce-scatter)
         uint32_t rank = 0, world = 1;
         ncclComm_t main = nullptr, shadow = nullptr, rows = nullptr;
         DevBuf stage[R3N_MAX_SHADOW_VIEWS];  // contiguous copies of the shadow rectangles (what a broadcast moves)
@@ -368,7 +370,10 @@ int fork_lane(r3n_ctx *c, int lane) {
     if (lane == 0) return R3N_OK;
     const int k = lane - 1;
     c->aux_used[k] = true;
-    if (c->lane_epoch[k] == c->main_epoch) return R3N_OK;  // already ordered behind everything the main stream holds for it
+    // already ordered behind everything the main stream holds for it.  (Every main-stream producer the lanes read must bump
+    // main_epoch; R3N_ALWAYS_FORK=1 forks unconditionally -- the test suite runs once that way, so a producer that forgets
+    // the bump shows up as a difference between the two runs instead of a silent race.)
+    if (c->lane_epoch[k] == c->main_epoch && !c->always_fork) return R3N_OK;
     HIP_TRY(c, hipEventRecord(c->fork_ev[k], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->aux[k], c->fork_ev[k], 0));
     c->lane_epoch[k] = c->main_epoch;
@@ -611,6 +616,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');
+    if (const char *e6 = std::getenv("R3N_ALWAYS_FORK")) c->always_fork = e6[0] == '1';
     if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) { c->shadow_tiles = e4[0] == '1' || e4[0] == '2'; c->shadow_bin = e4[0] != '2'; }
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
@@ -792,6 +798,17 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
     TRY(join_shade(c));
     TRY(ensure(c, c->objects, (size_t)capacity * sizeof(r3n_object128), true, 0));
     if (capacity != c->capacity) {
+        if (c->owners.p && c->owners_n < capacity) {
+            // owner bytes (r3n_set_object_owners) cover the old capacity: the kernels index them by slot, so the table grows with
+            // the world and the new slots belong to rank 0 until the caller sends a new partition (never uninitialised bytes:
+            // an object owned by no rank would vanish from every rank's frame)
+            TRY(sync_all(c));
+            TRY(ensure(c, c->owners, capacity, true, 0));
+            // (the allocation may already have been large enough, its tail never written)
+            HIP_TRY(c, hipMemsetAsync(c->owners.as<uint8_t>() + c->owners_n, 0, capacity - c->owners_n, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->owners_n = capacity;
+        }
         c->capacity = capacity;
         c->h_ntri.resize(capacity, 0);
         c->h_material.resize(capacity, 0);
@@ -2157,7 +2174,13 @@ int r3n_comm_init(r3n_ctx *c, const uint8_t *ids, uint32_t rank, uint32_t world)
     for (int k = 0; k < R3N_COMM_IDS; ++k) {
         ncclUniqueId u;
         std::memcpy(u.internal, ids + (size_t)k * R3N_COMM_ID_BYTES, R3N_COMM_ID_BYTES);
-        NCCL_TRY(c, rccl().CommInitRank(dst[k], (int)world, u, (int)rank));
+        const ncclResult_t rc = rccl().CommInitRank(dst[k], (int)world, u, (int)rank);
+        if (rc != ncclSuccess) {  // the communicators made so far must not outlive the failure (comm.on stays false: nobody else frees them)
+            const std::string why = rccl().GetErrorString(rc);
+            for (int j = 0; j < k; ++j) { (void)rccl().CommDestroy(*dst[j]); *dst[j] = nullptr; }
+            *dst[k] = nullptr;
+            return fail(c, R3N_ERR_HIP, "comm_init: ncclCommInitRank (communicator " + std::to_string(k) + "): " + why);
+        }
     }
     c->comm.on = true; c->comm.rank = rank; c->comm.world = world;
     c->shard_rows = true;
@@ -2172,7 +2195,7 @@ int r3n_comm_destroy(r3n_ctx *c) {
         if (*k) { (void)rccl().CommDestroy(*k); *k = nullptr; }
     for (DevBuf &b : c->comm.stage)
         if (b.p) { (void)hipFree(b.p); b = DevBuf{}; }
-    c->comm.on = false; c->comm.world = 1; c->comm.rank = 0;
+    c->comm.on = false; c->comm.by_objects = false; c->comm.world = 1; c->comm.rank = 0;
     c->shard_rows = false; c->row_begin = 0; c->row_end = 0xFFFFFFFFu;
     return R3N_OK;
 }
@@ -2240,6 +2263,37 @@ static int comm_exchange_pass1(r3n_ctx *c) {
     }
     Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);  // multisampled: Hi-Z reads the keys
     return comm_gather_bands(c, c->vis.p, (size_t)c->width * c->samples * 8, c->comm.main, c->stream);
+}
+// Object-range split (BASELINE.json north_star): every rank drew ITS objects over the whole target.
+// Pass 1: the Hi-Z cull needs the global depth -- element-wise MAX over ranks (reverse-Z: nearest = largest) of the f32 plane, or of
+// the keys under MSAA (Hi-Z reads them).  Pass 2: the nearest fragment of every pixel = MAX over ranks of the u64 keys
+// (depth bits << 32 | triangle), needed only by the rank that resolves the pixel's row: an in-place reduce-scatter onto the row
+// bands when they are equal, an all-reduce otherwise.
+static int comm_reduce_pass1(r3n_ctx *c) {
+    if (c->samples == 1) {
+        void *plane = nullptr;
+        uint64_t n = 0;
+        TRY(r3n_exchange_depth(c, &plane, &n));
+        Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);
+        NCCL_TRY(c, rccl().AllReduce(plane, plane, (size_t)n, ncclFloat32, ncclMax, c->comm.main, c->stream));
+        return R3N_OK;
+    }
+    Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);
+    NCCL_TRY(c, rccl().AllReduce(c->vis.p, c->vis.p, (size_t)c->width * c->height * c->samples, ncclUint64, ncclMax, c->comm.main, c->stream));
+    return R3N_OK;
+}
+static int comm_reduce_pass2(r3n_ctx *c) {
+    const uint32_t world = c->comm.world, rank = c->comm.rank, h = c->height;
+    const size_t row_keys = (size_t)c->width * c->samples;
+    unsigned long long *keys = c->vis.as<unsigned long long>();
+    Timed t(c, R3N_STAGE_EXCHANGE_KEYS, c->stream);
+    if (h % world == 0) {
+        const size_t chunk = (size_t)(h / world) * row_keys;
+        NCCL_TRY(c, rccl().ReduceScatter(keys, keys + (size_t)rank * chunk, chunk, ncclUint64, ncclMax, c->comm.main, c->stream));  // in place
+    } else {
+        NCCL_TRY(c, rccl().AllReduce(keys, keys, (size_t)h * row_keys, ncclUint64, ncclMax, c->comm.main, c->stream));
+    }
+    return R3N_OK;
 }
 static int comm_gather_rows(r3n_ctx *c) {
     void *out = nullptr, *sp = nullptr;
@@ -2323,13 +2377,14 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     if (d->flags & R3N_FRAME_VIEWPORT_FIRST) { TRY(viewport_pass1()); TRY(shadow_nodes()); }
     else { TRY(shadow_nodes()); TRY(viewport_pass1()); }
     if (d->exchange && d->exchange(d->exchange_user, R3N_EXCHANGE_PASS1) != 0) return fail(c, R3N_ERR_STATE, "render_frame: the pass-1 exchange callback failed");
-    if (native) TRY(comm_exchange_pass1(c));
+    if (native) TRY(c->comm.by_objects ? comm_reduce_pass1(c) : comm_exchange_pass1(c));
     TRY(r3n_hi_z(c));                         // hi_z (base.rs:162)
     TRY(r3n_cull(c, R3N_CAMERA_VIEWPORT));    // pbr_culling (base.rs:169)
     // pbr_render_opaque_residual_triangles (base.rs:172)
     TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_OPAQUE));
     TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_CUTOUT));
     if (d->exchange && d->exchange(d->exchange_user, R3N_EXCHANGE_PASS2) != 0) return fail(c, R3N_ERR_STATE, "render_frame: the pass-2 exchange callback failed");
+    if (native && c->comm.by_objects) TRY(comm_reduce_pass2(c));
     TRY(r3n_resolve_opaque(c));               // the opaque passes' fragment stages, deferred
     // pbr_forward_rendering_transparent (base.rs:181)
     TRY(r3n_forward(c, R3N_CAMERA_VIEWPORT, R3N_PASS_FORWARD, R3N_SOURCE_RESIDUAL, R3N_KEY_BLEND));
@@ -2416,6 +2471,13 @@ int r3n_exchange_shadow_stream(r3n_ctx *c, void **atlas, uint64_t *atlas_count, 
     if (atlas) *atlas = c->atlas.p;
     if (atlas_count) *atlas_count = (uint64_t)c->atlas_w * c->atlas_h;
     if (stream) *stream = (void *)on;
+    return R3N_OK;
+}
+int r3n_comm_set_split(r3n_ctx *c, uint32_t mode) {
+    if (!c || mode > R3N_SHARD_ROWS) return fail(c, R3N_ERR_INVALID_ARG, "comm_set_split: unknown split");
+    if (!c->comm.on) return fail(c, R3N_ERR_STATE, "comm_set_split: no communicators (r3n_comm_init)");
+    c->comm.by_objects = mode == R3N_SHARD_OBJECTS;
+    c->shard_rows = !c->comm.by_objects;  // rows: the viewport rasterises its band only; objects: its objects over the whole target
     return R3N_OK;
 }
 int r3n_set_shard_mode(r3n_ctx *c, uint32_t mode) {

@@ -363,7 +363,10 @@ class Exchange:
         owners = np.ascontiguousarray(owners, dtype=np.uint8)
         r = self.r
         r._check(r.lib.r3n_set_object_owners(r.ctx, owners.ctypes.data, len(owners), self.rank), "r3n_set_object_owners")
-        self.sparse = dict(bounds=bounds)
+        # the bounds describe the world as it is NOW: any later edit (add / move / remove an object, new joint matrices) makes
+        # them stale -- a rank that rasterises outside its old extent would not send those rows -- so the exchanges fall back
+        # to whole targets until a new partition is set (Renderer.world_version)
+        self.sparse = dict(bounds=bounds, version=r.world_version)
         self.full_extent_frames = 1
 
     def set_row_sharding(self, row_begin, row_end):
@@ -377,7 +380,7 @@ class Exchange:
         self.by_rows = True
 
     def _row_extents(self, renderer, height):
-        if self.full_extent_frames > 0:
+        if self.full_extent_frames > 0 or renderer.world_version != self.sparse.get("version"):
             return [(0, height)] * self.world
         return partition_row_extents(self.sparse["bounds"], renderer.current_view_proj(), height)
 

@@ -198,6 +198,7 @@ class Renderer:
         self.object_meta = {}
         self.free_handles, self.pending_free, self.deferred_removals = [], [], []
         self.next_handle = 0
+        self.world_version = 0  # bumped by every object / skeleton edit
         self.dirty_objects = {}
         self.dir_lights, self.point_lights = [], []
         self._camera_inputs = (host.identity(), ("raw", host.identity()))
@@ -313,6 +314,7 @@ class Renderer:
         return list(range(first, first + n))
 
     def set_skeleton_joint_matrices(self, sk, joint_matrices):
+        self.world_version += 1  # skinned vertices may leave the bounds the partition was built from
         self._pose_state.pop(sk, None)
         self.skeletons[sk]["matrices"] = np.ascontiguousarray(joint_matrices, dtype=f32).reshape(-1, 16)
 
@@ -344,6 +346,7 @@ class Renderer:
         (csrc/anim.hip) in front of every skinning pass, straight into the buffer the skinning kernel reads, until the
         skeleton gets another pose or explicit matrices (Renderer::set_skeleton_joint_matrices semantics: the last
         value set stays)."""
+        self.world_version += 1
         for clip, time, sk in requests:
             self._pose_state[sk] = (int(clip), np.float32(time))
 
@@ -477,6 +480,7 @@ class Renderer:
         return rec
 
     def _mark(self, h, rec):
+        self.world_version += 1  # an object was added / moved / removed (parallel.Exchange: host-side bounds are stale)
         self._blend_cache = None
         self._use_index(h)
         self.dirty_objects[h] = rec
@@ -601,6 +605,12 @@ class Renderer:
             dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
             return box[0]
         self.comm_init(dist.get_rank(group), dist.get_world_size(group), share)
+
+    def comm_set_split(self, by_objects):
+        """The split the library's own exchanges implement (r3n_comm_set_split): False = sort-first rows (what comm_init selects),
+        True = object ranges (set_object_range / owners): depth MAX all-reduce in front of Hi-Z + key MAX reduce-scatter behind
+        pass 2, issued by r3n_render_frame."""
+        self._check(self.lib.r3n_comm_set_split(self.ctx, 0 if by_objects else 1), "r3n_comm_set_split")
 
     def comm_destroy(self):
         self._check(self.lib.r3n_comm_destroy(self.ctx), "r3n_comm_destroy")

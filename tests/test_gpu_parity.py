@@ -1173,6 +1173,7 @@ RUNTIME_SWITCHES = [
     {"R3N_PIPELINE": "0"},           # no frames in flight: the resolve on the main stream
     {"R3N_SINGLE_STREAM": "1"},      # every camera on the main stream
     {"R3N_FRAME_NODES": "1"},        # the host mirror issues the frame node by node (one C call per reference node) instead of r3n_render_frame
+    {"R3N_ALWAYS_FORK": "1"},        # the shadow lanes wait for the main stream at every fork (no epoch gate): a main-stream producer that forgot its epoch bump would differ from the default run
     {"R3N_RESOLVE_CLASSES": "0"},    # the general resolve kernel for every tile instead of one kernel per material class (kernels_shade.h R3N_CLS_*)
 ]
 

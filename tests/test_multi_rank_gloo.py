@@ -339,3 +339,26 @@ def test_two_rank_gloo_exact():
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_stale_partition_bounds_fall_back_to_whole_targets():
+    """parallel.Exchange.set_spatial_partition captures host-side bounds of the world as it is then; after ANY world edit
+    (Renderer.world_version: add / move / remove an object, new joint matrices or poses) the row-limited exchanges must use
+    whole targets again, or a rank that now draws outside its old extent would silently not send those rows."""
+    from rend3_amd import parallel
+
+    class FakeRenderer:
+        world_version = 7
+
+        def current_view_proj(self):
+            raise AssertionError("stale bounds must not be projected")
+
+    ex = parallel.Exchange.__new__(parallel.Exchange)
+    ex.world, ex.full_extent_frames = 2, 0
+    ex.sparse = dict(bounds=None, version=6)  # the partition was set one edit ago
+    assert ex._row_extents(FakeRenderer(), 96) == [(0, 96), (0, 96)]
+    ex.sparse = dict(bounds=[], version=7)
+    projected = []
+    FakeRenderer.current_view_proj = lambda self: projected.append(1) or np.eye(4, dtype=np.float32)
+    ex._row_extents(FakeRenderer(), 96)  # up to date: the bounds are used
+    assert projected == [1]

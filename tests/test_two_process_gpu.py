@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-W, H, FRAMES = 320, 192, 4
+W, FRAMES = 320, 4
 
 
 def _free_port():
@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, H=192, samples=1, by_objects=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -49,9 +49,11 @@ def _worker(rank, world, port, mode, q):
             scenes.build_random_scene(r, hm, r3.material_record, 200, 0xE5A1, lights=2, shadow_res=256, with_cutout=True)
             return r
 
-        if mode == "native" and n_dev < world:  # RCCL refuses two ranks on one device: the library's own exchange needs two GPUs
-            q.put((rank, "skip"))
-            return
+        if mode == "native" and n_dev < world:
+            # RCCL refuses two ranks on one device: the library binds tests/rccl_shim.cpp instead (the same entry points between
+            # processes that share a GPU, staged through shared memory), so its N = 2 branches run on a one-GPU box too
+            import rccl_shim
+            os.environ["R3N_RCCL_LIB"] = rccl_shim.build()
         shard, full = make(), make()  # contexts first, the communication library second (r3n_create binds the hardware queues)
         if n_dev >= world:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -68,6 +70,12 @@ def _worker(rank, world, port, mode, q):
         if mode == "native":  # r3n_comm_init: the exchanges issued inside r3n_render_frame over RCCL, no exchange object
             shard.comm_init_torch()
             mask = np.ones(shard.capacity, dtype=bool)
+            if by_objects:  # north_star's object-range split, issued by the library: depth all-reduce + key reduce-scatter
+                shard.comm_set_split(True)
+                b, e = parallel.partition_objects(counts, world)[rank]
+                shard.set_object_range(b, e)
+                mask[:] = False
+                mask[b:e] = True
         else:
             ex = parallel.Exchange(shard, device)
             ex.rows_equal = H % world == 0
@@ -95,8 +103,8 @@ def _worker(rank, world, port, mode, q):
             view = hm.look_at_lh((3.0 * math.sin(ang), 1.5, -3.0 * math.cos(ang) - 6.0), (0, 0, 6), (0, 1, 0))
             for r in (shard, full):
                 r.set_camera_data(view, ("perspective", 60.0, 0.1))
-            ref = full.render(W, H, **kw)
-            got = shard.render(W, H, exchange=ex, **kw)
+            ref = full.render(W, H, samples=samples, **kw)
+            got = shard.render(W, H, samples=samples, exchange=ex, **kw)
             if ex is not None:
                 ex.gather_rows(W, H, world)
             shard.sync()
@@ -141,8 +149,14 @@ def _worker(rank, world, port, mode, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["slots", "spatial", "rows", "native"])
+@pytest.mark.parametrize("mode", ["slots", "spatial", "rows", "native", "native-ragged", "native-msaa",
+                                  "native-objects", "native-objects-ragged", "native-objects-msaa"])
 def test_two_processes_exchange_matches_unsharded(mode):
+    """native*: r3n_comm_init + the collectives r3n_render_frame issues itself -- sort-first rows (in-place all-gather of equal
+    bands; ragged: one broadcast per band, height 191; msaa: the keys' bands, four samples) and native-objects*: the
+    object-range split (r3n_comm_set_split: depth MAX all-reduce in front of Hi-Z, key MAX reduce-scatter onto the row bands, an
+    all-reduce when they are ragged) -- over RCCL with one GPU per rank, else over tests/rccl_shim.cpp with both ranks on the
+    one GPU."""
     import torch
     import torch.multiprocessing as mp
     assert torch.cuda.is_available()
@@ -150,7 +164,8 @@ def test_two_processes_exchange_matches_unsharded(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    height, samples = (191 if mode.endswith("ragged") else 192), (4 if mode.endswith("msaa") else 1)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode.split("-")[0], q, height, samples, "objects" in mode)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in range(world)]

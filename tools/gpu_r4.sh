@@ -27,6 +27,9 @@ pmc() {  # name, env, counters...
 for w in "$@"; do
   case $w in
     quick) timeout 900 python -m pytest tests -m gpu -x -q -k "textured or bistro or runtime or golden or float_textures or encoded or vertex_colour or material_key or frames_in_flight or shade_mode" > "$out/pytest_quick.log" 2>&1; echo "pytest quick rc=$?"; tail -4 "$out/pytest_quick.log"; grep -E '^E ' "$out/pytest_quick.log" | head -8;;
+    shim) timeout 900 python -m pytest tests/test_two_process_gpu.py -q -x > "$out/pytest_shim.log" 2>&1; echo "pytest two-process rc=$?"; tail -6 "$out/pytest_shim.log"; grep -E '^E |FAIL' "$out/pytest_shim.log" | head -12;;
+    probe) timeout 300 python tools/exact_math_probe.py > "$out/exact_math.txt" 2>&1; cat "$out/exact_math.txt" | head -80;;
+    quick_lean2) R3N_LIB=$root/variants/lib_lean2.so timeout 900 python -m pytest tests -m gpu -x -q -k "bistro or random or golden or config4_full or near_plane or large_scene or msaa_random or transparent" > "$out/pytest_lean2.log" 2>&1; echo "pytest lean2 rc=$?"; tail -4 "$out/pytest_lean2.log"; grep -E '^E ' "$out/pytest_lean2.log" | head -8;;
     tests) timeout 1500 python -m pytest tests -m gpu -q --durations=8 > "$out/pytest.log" 2>&1; echo "pytest rc=$?"; tail -15 "$out/pytest.log"; grep -E '^E ' "$out/pytest.log" | head -8;;
     bench) python bench.py --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"; line "$out/bench.json"; tail -3 "$out/bench.err";;
     classes)
