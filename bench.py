@@ -110,6 +110,45 @@ def build_workload(args, r, hm, mk):
     return info
 
 
+XGMI_LINK_GBS = 153.0   # per direction and link, 7 links per GPU, fully connected inside a node
+XGMI_EFFICIENCY = 0.7   # assumed fraction of the link rate a large RCCL message reaches; no multi-GPU box to measure it on
+COLLECTIVE_LATENCY_MS = 0.02
+
+
+def split_model(stage_ms, launches, world, width, height, samples, n_views, setup_frac=0.6):
+    """Predicted per-rank GPU time of one frame (ms) under the two splits the library issues natively, from THIS GPU's stand-alone
+    stage times of the unsharded frame (HIP events, single stream) and a direct-exchange model of the node's xGMI mesh
+    (every peer pair has its own link: a rank receives (N - 1) shares concurrently).
+      rows    (sort-first): the viewport's cull and per-triangle setup are REPLICATED, pixel work / N; depth bands all-gathered.
+      objects (north_star): the viewport's cull, setup and pixel work / N; depth plane MAX all-reduce + key MAX reduce-scatter.
+    Both: shadow views by view (ceil(V / N) per rank) + broadcast, resolve / N, row gather.  setup_frac: share of the per-triangle
+    pass that is per-triangle work (fetch + setup + work-item emission) rather than pixels -- an assumption, stated in the line."""
+    per = lambda st: stage_ms[st] / max(launches.get(st, 0) or 1, 1)  # noqa: E731
+    cams = 1 + n_views
+    # the stage table sums every camera's launches: a camera's share = the per-launch average (2 viewport draws: predicted + residual)
+    cull_vp = per("bake") * (1 if launches.get("bake") else 0) + per("object_cull") + per("triangle_cull")
+    small_vp, big_vp = stage_ms["raster"], stage_ms["raster_big"]
+    shadow = stage_ms["shadow_raster"] + stage_ms["shadow_raster_big"] + (cams - 1) * (per("object_cull") + per("triangle_cull"))
+    views_here = -(-n_views // world) if n_views else 0
+    px = width * height
+    link = XGMI_LINK_GBS * 1e9 * XGMI_EFFICIENCY
+    share = lambda bytes_total: 1e3 * (bytes_total / world) / link + COLLECTIVE_LATENCY_MS  # noqa: E731  one band / shard per link, all links at once
+    depth_bytes = px * (4 if samples == 1 else 8 * samples)
+    common = (shadow * views_here / n_views if n_views else 0.0) + (stage_ms["shade"] + stage_ms["vertex"]) / world + stage_ms["clear"] + stage_ms["hiz"] \
+        + ((1e3 * views_here * 4.0 * 2048 * 2048 / link + COLLECTIVE_LATENCY_MS) if n_views and world > 1 else 0.0) + (share(4.0 * px) if world > 1 else 0.0)
+    rows = common + cull_vp + small_vp * (setup_frac + (1.0 - setup_frac) / world) + big_vp / world + (share(depth_bytes) if world > 1 else 0.0)
+    objects = common + (cull_vp + small_vp + big_vp) / world + ((2.0 * share(depth_bytes) + share(8.0 * samples * px)) if world > 1 else 0.0)
+    single = stage_ms["shade"] + stage_ms["vertex"] + stage_ms["clear"] + stage_ms["hiz"] + shadow + cull_vp + small_vp + big_vp
+    return {"rows_ms": round(rows, 4), "objects_ms": round(objects, 4), "single_gpu_ms": round(single, 4),
+            "predicted_speedup": {"rows": round(single / rows, 2), "objects": round(single / objects, 2)},
+            "choice": "rows" if rows <= objects else "objects",
+            "inputs_ms": {"viewport_cull": round(cull_vp, 4), "viewport_per_triangle_pass": round(small_vp, 4), "viewport_work_items": round(big_vp, 4),
+                          "shadow_views_total": round(shadow, 4), "resolve": round(stage_ms["shade"] + stage_ms["vertex"], 4)},
+            "assumptions": f"stand-alone stage sums (no overlap between streams or frames), xGMI {XGMI_LINK_GBS:.0f} GB/s per link x {XGMI_EFFICIENCY} efficiency, "
+                           f"direct exchange (one share per peer link), {COLLECTIVE_LATENCY_MS} ms per collective, setup_frac {setup_frac}; "
+                           "nothing here was measured on more than one GPU"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +163,8 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange path (RCCL all-reduce / all-gather) even with one rank: plumbing check")
     ap.add_argument("--samples", type=int, default=1, choices=(1, 4),
-                    help="SampleCount of the viewport targets (the reference's scene_viewer default is 4); the headline metric is quoted at 1")
+                    help="SampleCount of the viewport targets (the reference's scene_viewer defaults to SampleCount::One, "
+                         "examples/src/scene_viewer/mod.rs:317; --msaa 4 is its option); the headline metric is quoted at 1")
     ap.add_argument("--cpu-sample-frames", type=int, default=5, help="steady-state oracle frames timed for cpu_baseline (median)")
     ap.add_argument("--shade-mode", choices=("exact", "fast"), default="exact",
                     help="fragment-stage arithmetic: exact (default; bit-identical to the oracle) or fast (r3n_set_shade_mode(R3N_SHADE_FAST): "
@@ -135,8 +175,12 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(3, 4),
                     help="3 (default): BASELINE.json configs[2] stand-in, the config the metric is quoted on; 4: configs[3] stand-in "
                          "(emerald_like, 1 048 576 objects / 55 M triangles, 4 shadow views), the workload whose per-rank work is milliseconds")
-    ap.add_argument("--partition", choices=("rows", "spatial", "slots"), default="rows",
-                    help="N > 1: how the viewport is sharded -- rows (default, sort-first): every rank culls and draws every object but rasterises "
+    ap.add_argument("--partition", choices=("auto", "rows", "objects", "spatial", "slots"), default="auto",
+                    help="N > 1: how the viewport is sharded -- auto (default): rows or objects, whichever the printed cost model (split_model in "
+                         "the line: replicated cull / setup against exchanged bytes over xGMI, from this rank's own stage times) predicts faster; "
+                         "objects: BASELINE.json north_star's object-range split issued by the library itself (r3n_comm_set_split: contiguous slot "
+                         "ranges balanced by triangles, MAX all-reduce of the pass-1 depth plane, MAX reduce-scatter of the pass-2 keys); "
+                         "rows (sort-first): every rank culls and draws every object but rasterises "
                          "only its band of rows; the depth bands are all-gathered in front of Hi-Z and no keys are exchanged; slots: contiguous "
                          "object-slot ranges balanced by triangles, whole-target MAX collectives of depth (pass 1) and keys (pass 2); spatial: owner bytes from the Morton order of the bounding-sphere centres, with the pass-1 / pass-2 "
                          "exchanges limited to the rows inside each rank's conservative screen extent (pays only when partitions are compact on "
@@ -189,7 +233,7 @@ def main():
     if args.shade_mode == "fast":
         r.set_shade_mode(1)
     hbm_measured = r.hbm_copy_rate(1 << 30, 5)
-    exchange, native_comm, comm_note = None, False, None
+    exchange, native_comm, comm_note, split = None, False, None, None
     if distributed:
         r.evaluate_instructions()  # flush the world: the object buffer's capacity is final
         counts = np.zeros(r.capacity, dtype=np.int64)
@@ -198,7 +242,28 @@ def main():
             counts[h] = r.meshes[m["mesh"]].index_count // 3
             spheres[h] = m["sphere"]
         rows = parallel.row_ranges(HEIGHT, world)
-        native_comm = args.partition == "rows" and not args.python_exchange
+        if args.partition == "auto":
+            # a few unsharded frames on this rank with stage timing: the inputs of the cost model; rank 0's choice is everybody's
+            r.set_multi_stream(False)
+            r.timing_enable(True)
+            for k in range(4):
+                r.set_camera_data(camera_path(r3.host, view0, k), info["camera"][1])
+                r.render(WIDTH, HEIGHT, samples=args.samples, ambient=ambient, clear_color=clear, readback=False)
+                if k == 0:
+                    r.sync()
+                    r.stage_times(reset=True)  # the first frame allocates
+            r.sync()
+            probe = r.stage_times(reset=True)
+            r.timing_enable(False)
+            r.set_multi_stream(True)
+            n_views_probe = len([l for l in r.dir_lights if l is not None])
+            split = split_model({st: ms / 3 for st, (ms, _n) in probe.items()}, {st: n / 3 for st, (_ms, n) in probe.items()}, world, WIDTH, HEIGHT,
+                                args.samples, n_views_probe)
+            box = [split]
+            dist.broadcast_object_list(box, src=0)
+            split = box[0]
+            args.partition = split["choice"]
+        native_comm = args.partition in ("rows", "objects") and not args.python_exchange
         if native_comm:
             # the library issues the exchanges itself (r3n_comm_init): no Exchange object, no torch collective on the frame path
             try:
@@ -210,7 +275,10 @@ def main():
             exchange = parallel.Exchange(r, device)
             exchange.rows_equal = HEIGHT % world == 0
         if native_comm:
-            pass
+            if args.partition == "objects":  # the library's own object-range exchanges (r3n_comm_set_split)
+                r.comm_set_split(True)
+                begin, end = parallel.partition_objects(counts, world)[rank]
+                r.set_object_range(begin, end)
         elif args.partition == "rows":
             exchange.set_row_sharding(rows[rank][0], rows[rank][1])
         elif args.partition == "spatial" and exchange.rows_equal and args.samples == 1:
@@ -299,10 +367,12 @@ def main():
         exchange_ms = {k: round(v / n_inst, 4) for k, v in exchange.drain_timings().items()}
         exchange_bytes = dict(exchange.bytes)
     elif native_comm:  # the library's own stage events (R3N_STAGE_EXCHANGE_*)
+        by_objects = args.partition == "objects"
         exchange_ms = {"shadow": round(stages["exchange_shadow"][0] / n_inst, 4), "pass1": round(stages["exchange_depth"][0] / n_inst, 4),
-                       "pass2": 0.0, "rows": round(stages["exchange_rows"][0] / n_inst, 4)}
-        exchange_bytes = {"shadow": 4 * 4 * 2048 * 2048 if not args.scene else None, "pass1": (4 if args.samples == 1 else 8 * args.samples) * WIDTH * HEIGHT // world,
-                          "pass2": 0, "rows": 4 * WIDTH * HEIGHT // world}
+                       "pass2": round(stages["exchange_keys"][0] / n_inst, 4), "rows": round(stages["exchange_rows"][0] / n_inst, 4)}
+        exchange_bytes = {"shadow": 4 * 4 * 2048 * 2048 if not args.scene else None,
+                          "pass1": (4 if args.samples == 1 else 8 * args.samples) * WIDTH * HEIGHT // (1 if by_objects else world),
+                          "pass2": 8 * args.samples * WIDTH * HEIGHT if by_objects else 0, "rows": 4 * WIDTH * HEIGHT // world}
     r.set_multi_stream(True)
     last = frame(step0 + args.warmup + args.steps + n_inst, readback=(world == 1))
 
@@ -361,6 +431,13 @@ def main():
                 if uf:
                     d["valu"]["useful_tflops"] = round(uf / (ms * 1e-3) / 1e12, 2)
                     d["valu"]["useful_frac_of_vector_peak"] = round(uf / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)
+            # counted traffic BELOW the algorithmic bytes: the kernel's inputs are served from the Infinity Cache (the frame's
+            # working set fits its 256 MB), so `achieved` is an on-die rate, not HBM bandwidth -- say so instead of calling it HBM
+            tr = d["traffic"]
+            if tr is not None and tr < 0.8 * bytes_per_launch:
+                d["cache_served"] = True
+                d["note"] += (f"; counted memory-side traffic ({tr / 1e6:.1f} MB) is below the algorithmic bytes ({bytes_per_launch / 1e6:.1f} MB): the inputs come "
+                              "from the Infinity Cache, `achieved` is algorithmic bytes / time, not HBM bandwidth")
             if extra:
                 d.update(extra)
             rooflines[stage] = d
@@ -398,8 +475,28 @@ def main():
         roofline_of("k_resolve_opaque", "shade", 20.0 * WIDTH * HEIGHT / world, "k_resolve_opaque",
                     f"8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; VALU-bound: {cameras - 1} lights x "
                     "(5-tap PCF + GGX)" + ("" if args.untextured else ", 3 trilinear maps, tangent frame"))
+        # the resolve is bound by vector issue, not by HBM: its roofline is the f32 vector peak, `frac` = useful flops (add + mul +
+        # 2 x fma + transcendental lane-ops, SQ_INSTS_VALU_*_F32 passes) / launch time / 157.3 TFLOP/s; the HBM figure stays beside it
+        rs = rooflines["shade"]
+        if rs.get("valu", {}).get("useful_tflops"):
+            rs.update({"bound": "valu", "frac_hbm": rs["frac"], "achieved_hbm_GBps": rs["achieved"], "peak_hbm_GBps": rs["peak"],
+                       "achieved": rs["valu"]["useful_tflops"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": rs["valu"]["useful_frac_of_vector_peak"],
+                       "frac_note": "useful f32 flops / vector peak; every vector instruction counted as one lane-op gives valu.issue_frac_of_vector_peak "
+                                    "(0.25 is the ceiling of unpacked, unfused f32 code), the ALUs are busy valu.busy of the launch"})
+        else:
+            rs["bound_note"] = "VALU-bound kernel (no PMC pass of these sources on record: only the HBM figure can be quoted)"
         dominant = max(rooflines, key=lambda st: stage_ms[st])
         roof = dict(rooflines[dominant], dominant_by="largest kernel time per frame in the HIP-event stage table")
+        # the whole frame against the HBM roofline: the sum of the stages' algorithmic bytes per frame over the frame time
+        frame_bytes = sum(v["bytes_per_launch"] * max(launches.get(k, 0), 0) for k, v in rooflines.items())
+        obj_bytes = (196.0 + 20.0 + 20.0) * info["objects"] * cameras          # bake + object cull + IndirectCall
+        px_bytes = (5.33 + 8.0) * WIDTH * HEIGHT                               # Hi-Z + the resolve pre-pass's key read
+        frame_bytes += obj_bytes + px_bytes
+        frame_roofline = {"bound": "hbm", "bytes_per_frame": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "sum over the frame of every stage's algorithmic bytes (triangle culls, shadow rasterisers, resolve, object passes, Hi-Z) / "
+                                  "ms_per_step; the frame is not one streaming kernel -- its largest stage is VALU-bound, the geometry stages issue- / latency-bound"}
         result = {
             "metric": "shaded Mpixels/s @4K (whole frame: cull+compact all cameras, 4 shadow views, PBR opaque, tonemap)",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -408,10 +505,17 @@ def main():
             "config": {"workload": info["workload"],
                        "shade_mode": args.shade_mode,
                        "objects": info["objects"], "triangles": info["triangles"], "cameras": cameras,
+                       "split_model": split,
                        "parallelism": "single GPU" if world == 1 else (
+                           f"object-range split issued by the library (r3n_comm_init + r3n_comm_set_split): viewport objects by contiguous slot range balanced by "
+                           f"triangles x{world}, shadow views by view (broadcast on a shadow lane's stream), RCCL MAX all-reduce of the pass-1 depth plane in front "
+                           f"of Hi-Z, MAX reduce-scatter of the pass-2 keys onto the bands of {HEIGHT // world} rows, image rows all-gathered"
+                           + ("" if split is None else f"; chosen by the cost model: predicted {split['predicted_speedup']['objects']}x against {split['predicted_speedup']['rows']}x for rows")
+                           if native_comm and args.partition == "objects" else
                            f"sort-first: every rank culls + draws every object into its band of {HEIGHT // world} rows (x{world}), shadow views by view "
                            "(broadcast on a shadow lane's stream), pass-1 depth bands all-gathered over RCCL in front of Hi-Z, no key exchange, image rows all-gathered"
                            + (" -- exchanges issued by the library itself (r3n_comm_init)" if native_comm else " -- exchanges through torch.distributed")
+                           + ("" if split is None else f"; chosen by the cost model: predicted {split['predicted_speedup']['rows']}x against {split['predicted_speedup']['objects']}x for objects")
                            if native_comm or (exchange is not None and exchange.by_rows) else
                            f"viewport objects by spatial partition (Morton order, owner bytes) x{world}, shadow views by view (broadcast), pass-1 depth and pass-2 keys "
                            "MAX-reduced onto the row-band owners over RCCL all-to-all limited to each rank's screen-row extent, depth bands + image rows all-gathered"
@@ -426,6 +530,7 @@ def main():
             "stage_launches_per_frame": launches,
             "roofline": roof,
             "rooflines": {k: v for k, v in rooflines.items() if k != dominant},
+            "frame_roofline": frame_roofline,
             "hbm_copy_rate_measured_GBps": round(hbm_measured, 1),
             "exchange_ms_per_frame": exchange_ms,
             "exchange_bytes_per_frame": exchange_bytes,

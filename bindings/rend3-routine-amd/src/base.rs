@@ -10,7 +10,8 @@ use crate::uniforms;
 use glam::{UVec2, Vec4};
 use rend3::graph::{DataHandle, RenderGraph, RenderPassTargets, RenderTargetHandle};
 use rend3::types::{GraphDataHandle, SampleCount};
-use rend3::{InstructionEvaluationOutput, Renderer, RendererDataCore, ShaderPreProcessor};
+use rend3::graph::InstructionEvaluationOutput;
+use rend3::{Renderer, RendererDataCore, ShaderPreProcessor};
 use rend3_amd_sys as sys;
 use rend3_routine::common::{self, CameraSpecifier, PerMaterialArchetypeInterface, WholeFrameInterfaces};
 use rend3_routine::culling::CullingBufferMap;

@@ -24,7 +24,7 @@ pub fn add_skinning_to_graph<'node>(graph: &mut RenderGraph<'node>, gpu_skinner:
     let mut node = graph.add_node("skinning");
     node.add_side_effect();
     node.build(move |ctx| {
-        let (inputs, matrices) = collect_skinning_inputs(&ctx.data_core.skeleton_manager, &ctx.data_core.mesh_manager);
+        let (inputs, matrices) = collect_skinning_inputs(&ctx.data_core.skeleton_manager);
         if inputs.is_empty() {
             return;
         }
@@ -36,29 +36,47 @@ pub fn add_skinning_to_graph<'node>(graph: &mut RenderGraph<'node>, gpu_skinner:
     });
 }
 
-/// skinning.rs:54-139 without the buffer creation: per skeleton the attribute ranges of its mesh, its private output ranges
-/// and the base index of its joint matrices in the flat matrix array.
-fn collect_skinning_inputs(
-    skeletons: &rend3::managers::SkeletonManager,
-    meshes: &rend3::managers::MeshManager,
-) -> (Vec<sys::r3n_skinning_input40>, Vec<f32>) {
+/// skinning.rs:54-139 without the buffer creation: per skeleton the source ranges of its mesh's attributes, its private output
+/// ranges and the base index of its joint matrices in the flat matrix array -- from `InternalSkeleton`'s public fields
+/// (rend3/src/managers/skeleton.rs:19-33), exactly the loop of skinning.rs:82-132.
+fn collect_skinning_inputs(skeletons: &rend3::managers::SkeletonManager) -> (Vec<sys::r3n_skinning_input40>, Vec<f32>) {
+    use rend3::types::{
+        VERTEX_ATTRIBUTE_JOINT_INDICES, VERTEX_ATTRIBUTE_JOINT_WEIGHTS, VERTEX_ATTRIBUTE_NORMAL, VERTEX_ATTRIBUTE_POSITION, VERTEX_ATTRIBUTE_TANGENT,
+    };
     let mut inputs = Vec::new();
     let mut matrices = Vec::new();
     for skeleton in skeletons.skeletons() {
-        let mesh = meshes.internal_data(skeleton.mesh_handle.get_raw());
-        let off = |range: Option<&std::ops::Range<u64>>| range.map_or(u32::MAX, |r| r.start as u32);
-        inputs.push(sys::r3n_skinning_input40 {
-            base_position_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_POSITION)),
-            base_normal_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_NORMAL)),
-            base_tangent_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_TANGENT)),
-            joint_indices_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_JOINT_INDICES)),
-            joint_weight_offset: off(mesh.get_attribute(&rend3::types::VERTEX_ATTRIBUTE_JOINT_WEIGHTS)),
-            updated_position_offset: off(skeleton.overridden_attribute_ranges.get(0)),
-            updated_normal_offset: off(skeleton.overridden_attribute_ranges.get(1)),
-            updated_tangent_offset: off(skeleton.overridden_attribute_ranges.get(2)),
+        let mut input = sys::r3n_skinning_input40 {
+            base_position_offset: u32::MAX,
+            base_normal_offset: u32::MAX,
+            base_tangent_offset: u32::MAX,
+            joint_indices_offset: u32::MAX,
+            joint_weight_offset: u32::MAX,
+            updated_position_offset: u32::MAX,
+            updated_normal_offset: u32::MAX,
+            updated_tangent_offset: u32::MAX,
             joint_matrix_base_offset: (matrices.len() / 16) as u32,
-            vertex_count: mesh.vertex_count as u32,
-        });
+            vertex_count: skeleton.vertex_count,
+        };
+        for (attribute, range) in &skeleton.source_attribute_ranges {
+            match attribute {
+                a if *a == *VERTEX_ATTRIBUTE_POSITION => input.base_position_offset = range.start as u32,
+                a if *a == *VERTEX_ATTRIBUTE_NORMAL => input.base_normal_offset = range.start as u32,
+                a if *a == *VERTEX_ATTRIBUTE_TANGENT => input.base_tangent_offset = range.start as u32,
+                a if *a == *VERTEX_ATTRIBUTE_JOINT_INDICES => input.joint_indices_offset = range.start as u32,
+                a if *a == *VERTEX_ATTRIBUTE_JOINT_WEIGHTS => input.joint_weight_offset = range.start as u32,
+                a => unreachable!("Unknown skinning input attribute {a:?}"),
+            }
+        }
+        for (attribute, range) in &skeleton.overridden_attribute_ranges {
+            match attribute {
+                a if *a == *VERTEX_ATTRIBUTE_POSITION => input.updated_position_offset = range.start as u32,
+                a if *a == *VERTEX_ATTRIBUTE_NORMAL => input.updated_normal_offset = range.start as u32,
+                a if *a == *VERTEX_ATTRIBUTE_TANGENT => input.updated_tangent_offset = range.start as u32,
+                a => unreachable!("Unknown skinning output attribute {a:?}"),
+            }
+        }
+        inputs.push(input);
         for m in &skeleton.joint_matrices {
             matrices.extend_from_slice(&m.to_cols_array());
         }

@@ -305,6 +305,9 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     }
 }
 
+#ifndef R3N_ABLATE
+#define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
+#endif
 #ifndef R3N_BIG_LEAN
 #define R3N_BIG_LEAN 1  // the work-item kernel's scan step without intermediate branches (see shade_pixel_lean)
 #endif
@@ -395,6 +398,10 @@ R3N_DEV void shade_pixel_lean(const RasterArgs &a, const TriWork &tw, int x, int
     // an accepted z is in [0, 1] or -0: clearing the sign bit canonicalises -0 and changes nothing else
     const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;
     const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
+#if R3N_ABLATE == 2
+    asm volatile("" : : "v"(zb), "v"(pix), "v"(ok ? 1u : 0u));
+    return;
+#endif
     if (ok) {
         if (DEPTH_ONLY) global_max_u32_at(a.depth, pix << 2, zb);
         else global_max_u64_at(a.vis, pix << 3, ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1);
@@ -421,8 +428,8 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 #ifndef R3N_SMALL_OCC
 #define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
 #endif
-#ifndef R3N_ABLATE
-#define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
+#ifndef R3N_ITEM_ALIGN
+#define R3N_ITEM_ALIGN 1  // (a power of two <= R3N_TILE)
 #endif
 #ifndef R3N_FINE
 #define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block
@@ -451,13 +458,18 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
             for (int y = tw.y0; y <= tw.y1; ++y)
                 for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
         } else {
-            const uint32_t tx = (uint32_t)(bw + (R3N_TILE - 1)) / R3N_TILE, ty = (uint32_t)(bh + (R3N_TILE - 1)) / R3N_TILE;
+            // Work items start on a multiple of R3N_ITEM_ALIGN pixels in x: the scan's 4x4 / 8x8 blocks then sit on the target's
+            // 64-byte lines (16 depth texels, 8 keys) instead of straddling them, and one atomic instruction touches fewer lines --
+            // the work-item kernel is bound by the number of line-sized atomic requests a CU can have in flight to the memory
+            // side (profiles/r04_summary.md).  The box only limits the scan: results are unchanged.
+            const int ax0 = tw.x0 & ~(R3N_ITEM_ALIGN - 1);
+            const uint32_t tx = (uint32_t)(tw.x1 - ax0 + R3N_TILE) / R3N_TILE, ty = (uint32_t)(bh + (R3N_TILE - 1)) / R3N_TILE;
             const uint32_t cnt = tx * ty;
             const uint32_t start = global_add_u32(&a.big_count[bq], cnt);
             r3n_big_item *big = a.big_items + (size_t)bq * a.big_capacity;
             for (uint32_t t = 0; t < cnt; ++t) {
                 const uint32_t ix = t % tx, iy = t / tx;
-                const int rx0 = tw.x0 + (int)ix * R3N_TILE, ry0 = tw.y0 + (int)iy * R3N_TILE;
+                const int rx0 = ax0 + (int)ix * R3N_TILE, ry0 = tw.y0 + (int)iy * R3N_TILE;
                 const int rx1 = min(rx0 + (R3N_TILE - 1), tw.x1), ry1 = min(ry0 + (R3N_TILE - 1), tw.y1);
                 if (start + t < a.big_capacity) {
                     r3n_big_item it;

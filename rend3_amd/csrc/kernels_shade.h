@@ -330,7 +330,7 @@ R3N_DEV void surface_shading(const float l[3], const float intensity[3], const P
     const float x = 1.0f - loh, x2 = x * x, x5 = (x2 * x2) * x;
     const float ggxl = nov * M::sqrt(M::mad(M::mad(-nol, a2, nol), nol, a2));  // (-nol * a2 + nol) * nol + a2
     const float ggxv = nol * (pre ? pre->sqrt_v : M::sqrt(M::mad(M::mad(-nov, a2, nov), nov, a2)));
-    const float vis = M::div(0.5f, ggxl + ggxv);
+    const float vis = M::half_over(ggxl + ggxv);  // 0.5 / (ggxl + ggxv)
     const float k = nol * occlusion;
     const float dv = d * vis;
     {
@@ -536,7 +536,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     // barycentrics and the view-space position: exact arithmetic under both policies.  The position feeds the shadow
     // coordinates and the comparison depth, and without a depth bias (reference behaviour) a lit surface compares against its
     // own rasterised depth -- a last-bit change of the position flips comparisons all over it.
-    const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+    const float rs = exact_math::rcp((E[0] + E[1]) + E[2]);  // 1 / sum, correctly rounded under both policies
     const float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
     float vpos[4], nrm[3], col[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     interp_vec4<MathExact>(lam, r.vp, vpos);

@@ -74,7 +74,7 @@ R3N_DEV void tex_footprint(const r3n_texture_desc32 &d, bool nearest, float u, f
     const float W = (float)d.width, H = (float)d.height;
     const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
     // max(sqrt(a), sqrt(b)) == sqrt(max(a, b)): correctly rounded sqrt is monotone
-    const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
+    const float rho = exact_math::sqrt(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
     uint32_t level = 0;
     float frac = 0.0f;
     if (rho > 1.0f && rho < INFINITY) {
@@ -230,7 +230,7 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         // level of detail exactly as tex_footprint derives it
         const float W = (float)d.width, H = (float)d.height;
         const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
-        const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
+        const float rho = exact_math::sqrt(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
         uint32_t level = 0;
         float frac = 0.0f;
         if (rho > 1.0f && rho < INFINITY) {

@@ -390,6 +390,28 @@ def test_config4_full_size(r3):
     p.close()
 
 
+def test_config4_full_size_four_shadow_views(r3):
+    """BASELINE.json configs[3] as bench.py --config 4 times it: the full-size world WITH the four directional lights and their
+    2048^2 shadow views (1 M objects through five cameras' culls, four shadow depth draws, the lit resolve): two frames against the
+    oracle, everything compare_frames checks -- also the four views' L1 / L2 sets and the 4096^2 atlas."""
+    import rend3_amd.scenes as S
+    w, h = 3840, 2160
+    o = OracleRenderer(oh.LEFT, f32(w) / f32(h))
+    p = r3.Renderer(oh.LEFT, f32(w) / f32(h))
+    io = S.emerald_like(o, oh, omk, n_lights=4)
+    ip = S.emerald_like(p, r3.host, r3.material_record, n_lights=4)
+    assert io["objects"] == ip["objects"] == 1 << 20
+    view0, proj = io["camera"]
+    for f, yaw in enumerate((0.0, 0.05)):
+        for r, hm in ((o, oh), (p, r3.host)):
+            r.set_camera_data(hm.mat4_mul(hm.rotation_y(yaw), view0), proj)
+        fo, fp = o.render(w, h, ambient=(0.1, 0.1, 0.1, 1)), p.render(w, h, ambient=(0.1, 0.1, 0.1, 1))
+        compare_frames(fo, fp, f"cfg4 full size with four shadow views, frame {f}")
+    assert len(fo["shadows"]) == 4 and all(s["pass"].sum() > 10_000 for s in fo["shadows"]) and (fo["atlas"] != 0).mean() > 0.05
+    assert 0 < fo["residual"].sum() < fo["pass"].sum()
+    p.close()
+
+
 def test_config4_million_objects_properties(r3):
     """BASELINE.json configs[3] shape: 1 048 576 objects (oracle too slow): properties only -- determinism across
     contexts, residual(frame 0) == pass(frame 0), call counts == popcounts, every nearest fragment from a drawn triangle,
