@@ -85,6 +85,7 @@ class OracleLib:
             "r3o_skinning": [vp, vp, ctypes.c_uint32, vp],
             "r3o_skinning_mfma_order": [vp, vp, ctypes.c_uint32, vp, vp],
             "r3o_set_snap_bits": [ctypes.c_int],
+            "r3o_set_depth_mode": [ctypes.c_int],
         }.items():
             fn = getattr(c, name)
             fn.restype = None

@@ -438,6 +438,8 @@ typedef struct {
     float z[3];      /* clip-space z per vertex */
     float det;       /* oriented determinant (> 0) */
     int valid;
+    /* EXPERIMENT ONLY (r3o_set_depth_mode != 0): window-space positions and z / w of the vertices, the depth plane through them */
+    float sx[3], sy[3], zn[3], dzdx, dzdy, zc;
 } tri_setup;
 
 /*
@@ -454,6 +456,18 @@ typedef struct {
  * effect on the reference's self-shadowed goldens can be measured.  0 = the contract (default). */
 static int g_snap_bits = 0;
 void r3o_set_snap_bits(int bits) { g_snap_bits = bits; }
+/* EXPERIMENT ONLY (tests/test_oracle_goldens.py::test_depth_interpolation_experiment): how a fixed-function rasteriser might
+ * interpolate depth, against the contract's sum(E_i * z_i) / det.  0 = the contract (default).  1 = plane equation: z / w per vertex,
+ * f32 gradients from the window-space triangle, z = zn0 + dzdx * (x - x0) + dzdy * (y - y0).  2 = barycentric weights first:
+ * l_i = E_i / det rounded one by one, z = (l0 * z0 + l1 * z1) + l2 * z2.  3 = mode 1 on vertices snapped to 8 sub-pixel bits. */
+/* Round 4: the plane through the window-space vertices (mode 1's idea) IS the contract now -- see setup_triangle -- because it
+ * reproduces the reference's self-shadowed screenshots (animation: mean 1.62 -> 0.02 LSB) where the homogeneous quotient
+ * sum(E_i * z_i) / det did not; 7 = that former contract, kept for the table in tests/test_oracle_goldens.py. */
+static int g_depth_mode = 0;
+/* 4 = mode 1 folded: z = (dzdx * x + dzdy * y) + c, c = zn0 - dzdx * x0 - dzdy * y0.  5 = the same plane from the homogeneous edge
+ * coefficients, no division by a vertex's w (valid for triangles that cross w = 0): dzdx = sum(A_i z_i) / det, dzdy = sum(B_i z_i) / det,
+ * c = sum(C_i z_i) / det.  6 = mode 5's gradients around the first vertex when all w > 0 (else mode 5). */
+void r3o_set_depth_mode(int mode) { g_depth_mode = mode; g_snap_bits = mode == 3 ? 8 : 0; }
 static void setup_triangle(const float *mvp, const float v[3][3], float half_w, float half_h, int positive_visible,
                            tri_setup *ts) {
     float h[3][3];
@@ -469,6 +483,17 @@ static void setup_triangle(const float *mvp, const float v[3][3], float half_w, 
             h[k][0] = (rintf(h[k][0] / p[3] * g) / g) * p[3];
             h[k][1] = (rintf(h[k][1] / p[3] * g) / g) * p[3];
         }
+        if (g_depth_mode != 0) {
+            ts->sx[k] = h[k][0] / p[3]; ts->sy[k] = h[k][1] / p[3]; ts->zn[k] = p[2] / p[3];
+        }
+    }
+    if (g_depth_mode == 1 || g_depth_mode == 3 || g_depth_mode == 4) {
+        const float ax = ts->sx[1] - ts->sx[0], ay = ts->sy[1] - ts->sy[0], bx = ts->sx[2] - ts->sx[0], by = ts->sy[2] - ts->sy[0];
+        const float az = ts->zn[1] - ts->zn[0], bz = ts->zn[2] - ts->zn[0];
+        const float area = ax * by - bx * ay;
+        ts->dzdx = (az * by - bz * ay) / area;
+        ts->dzdy = (bz * ax - az * bx) / area;
+        ts->zc = (ts->zn[0] - ts->dzdx * ts->sx[0]) - ts->dzdy * ts->sy[0];
     }
     for (int i = 0; i < 3; ++i) {
         const float *a = h[(i + 1) % 3], *b = h[(i + 2) % 3];
@@ -485,6 +510,42 @@ static void setup_triangle(const float *mvp, const float v[3][3], float half_w, 
             for (int c = 0; c < 3; ++c) ts->e[i][c] = -ts->e[i][c];
     }
     ts->det = det;
+    /* Depth plane (the contract): depth is affine in window space, z(x, y) = (dzdx * x + dzdy * y) + zc.
+     * With every vertex in front of the eye plane the plane is the one through the three window-space vertices
+     * (x / w, y / w, z / w), anchored at vertex 0 -- what a fixed-function rasteriser's setup computes, and what makes a surface's
+     * rasterised depth agree with the depth the fragment stage derives for the same surface when it looks itself up in a
+     * shadow map (no depth bias in the reference: that comparison is decided by the last bits).  A triangle with a vertex
+     * at w <= 0 (or a degenerate window-space area) takes the same plane from the homogeneous edge coefficients instead, which
+     * needs no division by w. */
+    if (g_depth_mode == 0) {
+        int planar = 0;
+        if (h[0][2] > 0.0f && h[1][2] > 0.0f && h[2][2] > 0.0f) {
+            float sxk[3], syk[3], znk[3];
+            for (int k = 0; k < 3; ++k) {
+                const float rw = 1.0f / h[k][2];
+                sxk[k] = h[k][0] * rw; syk[k] = h[k][1] * rw; znk[k] = ts->z[k] * rw;
+            }
+            const float ax = sxk[1] - sxk[0], ay = syk[1] - syk[0], bx = sxk[2] - sxk[0], by = syk[2] - syk[0];
+            const float az = znk[1] - znk[0], bz = znk[2] - znk[0];
+            const float ia = 1.0f / (ax * by - bx * ay);
+            const float gx = (az * by - bz * ay) * ia, gy = (bz * ax - az * bx) * ia;
+            const float c = (znk[0] - gx * sxk[0]) - gy * syk[0];
+            if (gx - gx == 0.0f && gy - gy == 0.0f && c - c == 0.0f) {
+                ts->dzdx = gx; ts->dzdy = gy; ts->zc = c;
+                planar = 1;
+            }
+        }
+        if (!planar) {
+            ts->dzdx = ((ts->e[0][0] * ts->z[0] + ts->e[1][0] * ts->z[1]) + ts->e[2][0] * ts->z[2]) / det;
+            ts->dzdy = ((ts->e[0][1] * ts->z[0] + ts->e[1][1] * ts->z[1]) + ts->e[2][1] * ts->z[2]) / det;
+            ts->zc = ((ts->e[0][2] * ts->z[0] + ts->e[1][2] * ts->z[1]) + ts->e[2][2] * ts->z[2]) / det;
+        }
+    }
+    if (g_depth_mode == 5 || g_depth_mode == 6) {
+        ts->dzdx = ((ts->e[0][0] * ts->z[0] + ts->e[1][0] * ts->z[1]) + ts->e[2][0] * ts->z[2]) / det;
+        ts->dzdy = ((ts->e[0][1] * ts->z[0] + ts->e[1][1] * ts->z[1]) + ts->e[2][1] * ts->z[2]) / det;
+        ts->zc = ((ts->e[0][2] * ts->z[0] + ts->e[1][2] * ts->z[1]) + ts->e[2][2] * ts->z[2]) / det;
+    }
     /* conservative pixel bounds are computed by the caller */
     (void)h;
 }
@@ -530,7 +591,15 @@ static void tri_bounds(const float *mvp, const float v[3][3], float half_w, floa
     *y1 = fy1 < 0.0f ? -1 : (fy1 > (float)(vh - 1) ? vh - 1 : (int)fy1);
 }
 
-static inline float frag_depth(const tri_setup *ts, const float E[3]) {
+static inline float frag_depth_at(const tri_setup *ts, const float E[3], float px, float py) {
+    if (g_depth_mode == 0) return (ts->dzdx * px + ts->dzdy * py) + ts->zc;
+    if (g_depth_mode == 1 || g_depth_mode == 3) return (ts->zn[0] + ts->dzdx * (px - ts->sx[0])) + ts->dzdy * (py - ts->sy[0]);
+    if (g_depth_mode == 4 || g_depth_mode == 5) return (ts->dzdx * px + ts->dzdy * py) + ts->zc;
+    if (g_depth_mode == 6) {
+        if (ts->sx[0] == ts->sx[0] && ts->sx[0] - ts->sx[0] == 0.0f) return (ts->zn[0] + ts->dzdx * (px - ts->sx[0])) + ts->dzdy * (py - ts->sy[0]);
+        return (ts->dzdx * px + ts->dzdy * py) + ts->zc;
+    }
+    if (g_depth_mode == 2) return ((E[0] / ts->det) * ts->z[0] + (E[1] / ts->det) * ts->z[1]) + (E[2] / ts->det) * ts->z[2];
     return ((E[0] * ts->z[0] + E[1] * ts->z[1]) + E[2] * ts->z[2]) / ts->det;
 }
 
@@ -834,7 +903,7 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
                 for (uint32_t sm = 0; sm < samples; ++sm) {
                     float E[3];
                     if (!edge_eval(&ts, (float)x + spos[sm][0], (float)y + spos[sm][1], E)) continue;
-                    float z = frag_depth(&ts, E);
+                    float z = frag_depth_at(&ts, E, (float)x + spos[sm][0], (float)y + spos[sm][1]);
                     if (!(z >= 0.0f && z <= 1.0f)) continue;
                     if (z == 0.0f) z = 0.0f; /* -0 -> +0 */
                     zs[sm] = z;
@@ -906,7 +975,7 @@ void r3o_raster_depth(const r3o_camera_header *hdr, const r3o_object *objects, c
             for (int x = x0; x <= x1; ++x) {
                 float E[3];
                 if (!edge_eval(&ts, (float)x + 0.5f, (float)y + 0.5f, E)) continue;
-                float z = frag_depth(&ts, E);
+                float z = frag_depth_at(&ts, E, (float)x + 0.5f, (float)y + 0.5f);
                 if (!(z >= 0.0f && z <= 1.0f)) continue;
                 if (need_alpha) {
                     float rs = 1.0f / ((E[0] + E[1]) + E[2]);
@@ -1369,7 +1438,7 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, co
                     for (uint32_t sm = 0; sm < samples; ++sm) {
                         float E[3];
                         if (!edge_eval(&ts, (float)x + spos[sm][0], (float)y + spos[sm][1], E)) continue;
-                        float z = frag_depth(&ts, E);
+                        float z = frag_depth_at(&ts, E, (float)x + spos[sm][0], (float)y + spos[sm][1]);
                         if (!(z >= 0.0f && z <= 1.0f)) continue;
                         uint32_t db = (uint32_t)(vis[pix * samples + sm] >> 32);
                         float dz; memcpy(&dz, &db, 4);

@@ -137,7 +137,7 @@ R3N_DEV void fetch_indices3(const uint32_t *__restrict__ mesh, uint32_t first, u
 // ---- homogeneous triangle setup (DESIGN.md "Rasteriser contract") --------------------------------
 struct TriSetup {
     float e[3][3];  // oriented edge functions (A,B,C), inside >= 0
-    float z[3];     // clip-space z per vertex
+    float z[3];     // the depth plane: depth(x, y) = (z[0] * x + z[1] * y) + z[2] in viewport pixels (see setup_triangle)
     float det;      // oriented determinant (> 0 when valid)
     bool valid;
 };
@@ -145,13 +145,13 @@ struct TriSetup {
 // p[k] = clip-space position of vertex k.  Pixel-space homogeneous coords: Xh = (x + w) * W/2,
 // Yh = (w - y) * H/2 (y down), third coordinate w.  e0 = v1 x v2, e1 = v2 x v0, e2 = v0 x v1.
 R3N_DEV void setup_triangle(const float p[3][4], float half_w, float half_h, bool positive_visible, TriSetup &ts) {
-    float h[3][3];
+    float h[3][3], zc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         h[k][0] = (p[k][0] + p[k][3]) * half_w;
         h[k][1] = (p[k][3] - p[k][1]) * half_h;
         h[k][2] = p[k][3];
-        ts.z[k] = p[k][2];
+        zc[k] = p[k][2];
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -170,6 +170,35 @@ R3N_DEV void setup_triangle(const float p[3][4], float half_w, float half_h, boo
             for (int c = 0; c < 3; ++c) ts.e[i][c] = -ts.e[i][c];
     }
     ts.det = det;
+    // Depth plane (the arithmetic contract since round 4, oracle/r3o.c setup_triangle): depth is affine in window space.  With
+    // every vertex in front of the eye plane: the plane through the window-space vertices (x / w, y / w, z / w), anchored at
+    // vertex 0 -- a rasterised depth that reproduces the vertices' own depths is what lets a lit surface pass the reference's
+    // unbiased shadow comparison against itself (profiles/r04_depth_modes.md: the homogeneous quotient sum(E_i z_i) / det left a
+    // 1.6 LSB speckle against the reference's screenshots, this form 0.02).  Otherwise (a vertex at w <= 0, a degenerate
+    // window-space area): the same plane from the homogeneous edge coefficients, which needs no division by w.
+    bool planar = false;
+    if (h[0][2] > 0.0f && h[1][2] > 0.0f && h[2][2] > 0.0f) {
+        float sx[3], sy[3], zn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float rw = exact_math::rcp(h[k][2]);  // 1 / w, correctly rounded
+            sx[k] = h[k][0] * rw; sy[k] = h[k][1] * rw; zn[k] = zc[k] * rw;
+        }
+        const float ax = sx[1] - sx[0], ay = sy[1] - sy[0], bx = sx[2] - sx[0], by = sy[2] - sy[0];
+        const float az = zn[1] - zn[0], bz = zn[2] - zn[0];
+        const float ia = exact_math::rcp(ax * by - bx * ay);
+        const float gx = (az * by - bz * ay) * ia, gy = (bz * ax - az * bx) * ia;
+        const float c = (zn[0] - gx * sx[0]) - gy * sy[0];
+        if (gx - gx == 0.0f && gy - gy == 0.0f && c - c == 0.0f) {  // finite
+            ts.z[0] = gx; ts.z[1] = gy; ts.z[2] = c;
+            planar = true;
+        }
+    }
+    if (!planar) {
+        ts.z[0] = ((ts.e[0][0] * zc[0] + ts.e[1][0] * zc[1]) + ts.e[2][0] * zc[2]) / det;
+        ts.z[1] = ((ts.e[0][1] * zc[0] + ts.e[1][1] * zc[1]) + ts.e[2][1] * zc[2]) / det;
+        ts.z[2] = ((ts.e[0][2] * zc[0] + ts.e[1][2] * zc[1]) + ts.e[2][2] * zc[2]) / det;
+    }
 }
 
 // Edge functions at a pixel centre; true when covered under the top-left rule.
@@ -205,10 +234,8 @@ R3N_DEV bool edge_eval(const TriSetup &ts, float px, float py, float E[3]) {
     return in;
 }
 
-R3N_DEV float frag_depth(const TriSetup &ts, const float E[3]) {
-    float z = ((E[0] * ts.z[0] + E[1] * ts.z[1]) + E[2] * ts.z[2]) / ts.det;
-    return z;
-}
+// depth at window position (px, py): the triangle's plane (setup_triangle)
+R3N_DEV float frag_depth(const TriSetup &ts, float px, float py) { return (ts.z[0] * px + ts.z[1] * py) + ts.z[2]; }
 // Conservative integer pixel bounds inside a (vw x vh) viewport.  Returns false when no pixel can be covered.
 // Bounds only limit the scan (coverage is decided per pixel by edge_eval + the depth clip), so any conservative
 // box gives identical results.  Triangles that cross the depth-clip planes (0 <= z <= w, which also implies

@@ -220,7 +220,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             float E[3];
             const float sx = S == 1 ? 0.5f : k_sample_pos4[sm][0], sy = S == 1 ? 0.5f : k_sample_pos4[sm][1];
             if (!edge_eval_thr(tw.ts, tw.thr, (float)x + sx, (float)y + sy, E)) continue;
-            const float z = frag_depth(tw.ts, E);
+            const float z = frag_depth(tw.ts, (float)x + sx, (float)y + sy);
             if (!(z >= 0.0f && z <= 1.0f)) continue;
             const size_t ps = pix * (size_t)S + (size_t)sm;
             const float dz = __uint_as_float((uint32_t)(a.vis[ps] >> 32));
@@ -239,7 +239,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (S == 1) {
         float E[3];
         if (!edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E)) return;
-        float z = frag_depth(tw.ts, E);
+        float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
         if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
         if (z == 0.0f) z = 0.0f;                // canonicalise -0
         if (tw.cutout) {
@@ -268,7 +268,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             float E[3];
             zs[sm] = 0.0f;
             if (!edge_eval_thr(tw.ts, tw.thr, (float)x + k_sample_pos4[sm][0], (float)y + k_sample_pos4[sm][1], E)) continue;
-            float z = frag_depth(tw.ts, E);
+            float z = frag_depth(tw.ts, (float)x + k_sample_pos4[sm][0], (float)y + k_sample_pos4[sm][1]);
             if (!(z >= 0.0f && z <= 1.0f)) continue;
             if (z == 0.0f) z = 0.0f;
             zs[sm] = z;
@@ -325,7 +325,7 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
     float E[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
-    const float z = frag_depth(tw.ts, E);
+    const float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
     const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;  // accepted: [0, 1] or -0 (see shade_pixel_lean)
     const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
     unsigned long long save;
@@ -393,7 +393,7 @@ R3N_DEV void shade_pixel_lean(const RasterArgs &a, const TriWork &tw, int x, int
         E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
         ok = ok & (E[i] >= tw.thr[i]);
     }
-    float z = frag_depth(tw.ts, E);
+    float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
     ok = ok & (z >= 0.0f) & (z <= 1.0f);  // depth clip (unclipped_depth: false, forward.rs:343)
     // an accepted z is in [0, 1] or -0: clearing the sign bit canonicalises -0 and changes nothing else
     const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;
@@ -429,7 +429,7 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 #define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
 #endif
 #ifndef R3N_ITEM_ALIGN
-#define R3N_ITEM_ALIGN 1  // (a power of two <= R3N_TILE)
+#define R3N_ITEM_ALIGN 16  // (a power of two <= R3N_TILE; measured: viewport work items 84.7 -> 73.2 us, shadow 85.0 -> 80.8 us per launch)
 #endif
 #ifndef R3N_FINE
 #define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block

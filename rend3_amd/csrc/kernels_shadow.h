@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_shadow_cull_bin(ShadowBatchArgs a) {
 R3N_DEV void shadow_tile_pixel(const TriSetup &ts, int x, int y, int tx0, int ty0, uint32_t *depth) {
     float E[3];
     if (!edge_eval(ts, (float)x + 0.5f, (float)y + 0.5f, E)) return;
-    float z = frag_depth(ts, E);
+    float z = frag_depth(ts, (float)x + 0.5f, (float)y + 0.5f);
     if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
     if (z == 0.0f) z = 0.0f;                // canonicalise -0
     atomicMax(&depth[(uint32_t)(y - ty0) * R3N_STILE + (uint32_t)(x - tx0)], __float_as_uint(z));
