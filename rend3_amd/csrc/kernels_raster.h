@@ -321,7 +321,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
 // and no branch on the scalar unit), the atomic under the narrowed mask, EXEC restored -- one asm statement.
 // fine: the step's lanes hold block index `b` (0xFFFFFFFF: none); coarse: b is not tested.
 template <bool DEPTH_ONLY, bool FINE>
-R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int y, uint32_t b, int rx1, int ry1) {
+R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int y, uint32_t b, int rx0, int rx1, int ry1) {
     float E[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
@@ -332,19 +332,19 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
     typedef __attribute__((address_space(1))) void *gv_t;
 #define R3N_CMPX_CHAIN                                                                                             \
     "s_mov_b64 %[save], exec\n\t"                                                                                   \
-    "v_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"                                        \
+    "v_cmpx_le_i32 vcc, %[rx0], %[x]\n\tv_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"                                        \
     "v_cmpx_le_f32 vcc, %[t0], %[e0]\n\tv_cmpx_le_f32 vcc, %[t1], %[e1]\n\tv_cmpx_le_f32 vcc, %[t2], %[e2]\n\t"     \
     "v_cmpx_le_f32 vcc, 0, %[z]\n\tv_cmpx_ge_f32 vcc, 1.0, %[z]\n\t"
     if (DEPTH_ONLY) {
         if (FINE)
             asm volatile("s_mov_b64 %[save], exec\n\tv_cmpx_gt_u32 vcc, 64, %[b]\n\t"
-                         "v_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"
+                         "v_cmpx_le_i32 vcc, %[rx0], %[x]\n\tv_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"
                          "v_cmpx_le_f32 vcc, %[t0], %[e0]\n\tv_cmpx_le_f32 vcc, %[t1], %[e1]\n\tv_cmpx_le_f32 vcc, %[t2], %[e2]\n\t"
                          "v_cmpx_le_f32 vcc, 0, %[z]\n\tv_cmpx_ge_f32 vcc, 1.0, %[z]\n\t"
                          "global_atomic_umax %[off], %[data], %[base]\n\t"
                          "s_mov_b64 exec, %[save]"
                          : [save] "=&s"(save)
-                         : [b] "v"(b), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                         : [b] "v"(b), [rx0] "s"(rx0), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
                            [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 2),
                            [data] "v"(zb), [base] "s"((gv_t)(unsigned long long)a.depth)
                          : "vcc", "memory");
@@ -353,7 +353,7 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
                          "global_atomic_umax %[off], %[data], %[base]\n\t"
                          "s_mov_b64 exec, %[save]"
                          : [save] "=&s"(save)
-                         : [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                         : [rx0] "s"(rx0), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
                            [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 2),
                            [data] "v"(zb), [base] "s"((gv_t)(unsigned long long)a.depth)
                          : "vcc", "memory");
@@ -361,13 +361,13 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
         const unsigned long long key = ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1;
         if (FINE)
             asm volatile("s_mov_b64 %[save], exec\n\tv_cmpx_gt_u32 vcc, 64, %[b]\n\t"
-                         "v_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"
+                         "v_cmpx_le_i32 vcc, %[rx0], %[x]\n\tv_cmpx_ge_i32 vcc, %[rx1], %[x]\n\tv_cmpx_ge_i32 vcc, %[ry1], %[y]\n\t"
                          "v_cmpx_le_f32 vcc, %[t0], %[e0]\n\tv_cmpx_le_f32 vcc, %[t1], %[e1]\n\tv_cmpx_le_f32 vcc, %[t2], %[e2]\n\t"
                          "v_cmpx_le_f32 vcc, 0, %[z]\n\tv_cmpx_ge_f32 vcc, 1.0, %[z]\n\t"
                          "global_atomic_umax_x2 %[off], %[data], %[base]\n\t"
                          "s_mov_b64 exec, %[save]"
                          : [save] "=&s"(save)
-                         : [b] "v"(b), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                         : [b] "v"(b), [rx0] "s"(rx0), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
                            [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 3),
                            [data] "v"(key), [base] "s"((gv_t)(unsigned long long)a.vis)
                          : "vcc", "memory");
@@ -376,7 +376,7 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
                          "global_atomic_umax_x2 %[off], %[data], %[base]\n\t"
                          "s_mov_b64 exec, %[save]"
                          : [save] "=&s"(save)
-                         : [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
+                         : [rx0] "s"(rx0), [rx1] "s"(rx1), [x] "v"(x), [ry1] "s"(ry1), [y] "v"(y), [t0] "s"(tw.thr[0]), [e0] "v"(E[0]),
                            [t1] "s"(tw.thr[1]), [e1] "v"(E[1]), [t2] "s"(tw.thr[2]), [e2] "v"(E[2]), [z] "v"(z), [off] "v"(pix << 3),
                            [data] "v"(key), [base] "s"((gv_t)(unsigned long long)a.vis)
                          : "vcc", "memory");
@@ -469,8 +469,11 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
             r3n_big_item *big = a.big_items + (size_t)bq * a.big_capacity;
             for (uint32_t t = 0; t < cnt; ++t) {
                 const uint32_t ix = t % tx, iy = t / tx;
-                const int rx0 = ax0 + (int)ix * R3N_TILE, ry0 = tw.y0 + (int)iy * R3N_TILE;
-                const int rx1 = min(rx0 + (R3N_TILE - 1), tw.x1), ry1 = min(ry0 + (R3N_TILE - 1), tw.y1);
+                // the item's box stays inside the triangle's (the scan never leaves the box the oracle scans: the boxes of
+                // triangles that cross the depth-clip planes are not supersets of their coverage); the consumer lays its block
+                // grid out from rx0 rounded down to R3N_ITEM_ALIGN, which is this column's aligned start
+                const int rx0 = max(ax0 + (int)ix * R3N_TILE, tw.x0), ry0 = tw.y0 + (int)iy * R3N_TILE;
+                const int rx1 = min(ax0 + (int)ix * R3N_TILE + (R3N_TILE - 1), tw.x1), ry1 = min(ry0 + (R3N_TILE - 1), tw.y1);
                 if (start + t < a.big_capacity) {
                     r3n_big_item it;
 #pragma unroll
@@ -478,19 +481,17 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) it.e[i][c] = tw.ts.e[i][c];
                         it.z[i] = tw.ts.z[i];
-                        it.va[i] = tw.va[i];
                     }
-                    it.det = tw.ts.det;
                     it.slot1 = DEPTH_ONLY ? 0u : tw.slot1;
                     it.material = tw.material | pack_thresholds(tw.thr);  // (material indices stay below 2^29: r3n_materials_write)
                     it.xy0 = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
                     it.xy1 = (uint32_t)rx1 | ((uint32_t)ry1 << 16);
                     big[start + t] = it;
-                    if (TEX && tw.alpha_tex) {
+                    if (tw.cutout) {  // (launch-uniform) vertex alpha, and the uvs of a textured alpha
                         r3n_big_uv bu;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) { bu.uv[k][0] = tw.uv[k][0]; bu.uv[k][1] = tw.uv[k][1]; }
-                        bu._pad[0] = bu._pad[1] = 0u;
+                        for (int k = 0; k < 3; ++k) { bu.uv[k][0] = tw.uv[k][0]; bu.uv[k][1] = tw.uv[k][1]; bu.va[k] = tw.va[k]; }
+                        bu._pad[0] = bu._pad[1] = bu._pad[2] = 0u;
                         a.big_uv[(size_t)bq * a.big_capacity + start + t] = bu;
                     }
                 } else {
@@ -578,9 +579,7 @@ __global__ __launch_bounds__(256) void k_blend_setup(RasterArgs a, BlendSetupArg
 #pragma unroll
             for (int c = 0; c < 3; ++c) it.e[i][c] = tw.ts.e[i][c];
             it.z[i] = tw.ts.z[i];
-            it.va[i] = 1.0f;
         }
-        it.det = tw.ts.det;
         it.slot1 = tw.slot1;
         it.material = g | pack_thresholds(tw.thr);  // draw order (< 2^29: r3n_blend_order_write)
         it.xy0 = (uint32_t)rx0 | ((uint32_t)ry0 << 16);
@@ -661,15 +660,12 @@ R3N_DEV void raster_big_body(RasterArgs a) {
     // record would then wait for every outstanding atomic of the previous item (measured: 2.4 us per item).
     // Scalar-cache coherence is not an issue: the queue was written by the previous kernel on this stream.
     typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint32_t flat = wave_global;
     const uint32_t *rec = locate(flat);
     u32x16 da = {}, na = {};
-    u32x4 db = {}, nb = {};
     if (rec) {
         sptr_t sp = (sptr_t)(unsigned long long)rec;
         da = *reinterpret_cast<__attribute__((address_space(4))) const u32x16 *>(sp);
-        db = *reinterpret_cast<__attribute__((address_space(4))) const u32x4 *>(sp + 16);
     }
     while (rec) {
         // The next record's scalar loads stay in flight while this item is scanned (the records come from HBM /
@@ -678,14 +674,10 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         // statement at the end of the iteration names both destinations (cdna_hip_programming.md section 5.7 (ii)).
         flat += nwaves;
         const uint32_t *nrec = locate(flat);
-        if (nrec)
-            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40"
-                         : "=&s"(na), "=&s"(nb) : "s"(nrec) : "memory");
-        uint32_t d[20];
+        if (nrec) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(na) : "s"(nrec) : "memory");
+        uint32_t d[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = da[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[16 + j] = db[j];
         auto bu = [&](int j) { return d[j]; };
         auto bf = [&](int j) { return __uint_as_float(d[j]); };
         TriWork w;
@@ -694,17 +686,17 @@ R3N_DEV void raster_big_body(RasterArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) w.ts.e[i][c] = bf(3 * i + c);
             w.ts.z[i] = bf(9 + i);
-            w.va[i] = bf(13 + i);
+            w.va[i] = 1.0f;
         }
-        w.ts.det = bf(12);
+        w.ts.det = 1.0f;  // (the scan does not use it)
         w.ts.valid = true;
         // edge thresholds on the SCALAR unit: the coefficients are wave-uniform, the scalar unit compares integers only, and
         // behind the (empty) asm the compiler can no longer turn the bit tests back into vector float compares.  Same outcome
         // as edge_threshold for every non-NaN pair; with a NaN coefficient the edge value is NaN and fails any threshold.
-        const uint32_t mt = bu(17);
+        const uint32_t mt = bu(13);
 #pragma unroll
         for (int i = 0; i < 3; ++i) w.thr[i] = __uint_as_float((mt >> (R3N_BIG_THR_SHIFT + (uint32_t)i)) & 1u);  // 0 or the smallest subnormal
-        w.slot1 = bu(16);
+        w.slot1 = bu(12);
         w.cutout = !BLEND && a.key == R3N_KEY_CUTOUT;  // launch-uniform
         w.material = mt & R3N_BIG_MATERIAL_MASK;
         w.mat_flags = 0u; w.mat_alpha = 1.0f; w.mat_cutoff = 0.0f;
@@ -717,26 +709,31 @@ R3N_DEV void raster_big_body(RasterArgs a) {
             w.mat_cutoff = __uint_as_float(mp[offsetof(r3n_material208, alpha_cutout) / 4]);
             w.mat_flags = mp[offsetof(r3n_material208, flags) / 4];
             w.alpha_tex = TEX && (w.mat_flags & R3N_FLAGS_ALBEDO_ACTIVE) && mp[0] != 0u;
-            if (TEX && w.alpha_tex) {  // rec - big_items = item index; the uv record has the same index
+            {  // rec - big_items = item index; the cutout record has the same index
                 const size_t item = (size_t)(reinterpret_cast<const r3n_big_item *>(rec) - a.big_items);
                 sptr_t up = (sptr_t)(unsigned long long)(a.big_uv + item);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { w.uv[k][0] = __uint_as_float(up[2 * k]); w.uv[k][1] = __uint_as_float(up[2 * k + 1]); }
+                for (int k = 0; k < 3; ++k) w.va[k] = __uint_as_float(up[6 + k]);
+                if (TEX && w.alpha_tex) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { w.uv[k][0] = __uint_as_float(up[2 * k]); w.uv[k][1] = __uint_as_float(up[2 * k + 1]); }
+                }
             }
         }
-        const uint32_t kxy0 = bu(18), kxy1 = bu(19);
+        const uint32_t kxy0 = bu(14), kxy1 = bu(15);
         const int rx0 = (int)(kxy0 & 0xFFFFu), ry0 = (int)(kxy0 >> 16);
         const int rx1 = (int)(kxy1 & 0xFFFFu), ry1 = (int)(kxy1 >> 16);
+        const int gx0 = rx0 & ~(R3N_ITEM_ALIGN - 1);  // origin of the block grid: blocks sit on the target's cache lines
 #if R3N_ABLATE == 3
         asm volatile("" : : "s"(rx0), "s"(ry0), "s"(rx1), "s"(ry1), "s"(w.ts.e[0][0]), "s"(w.ts.z[2]));
         if (false) {
 #else
-        if (R3N_FINE && rx1 - rx0 < 32 && ry1 - ry0 < 32) {
+        if (R3N_FINE && rx1 - gx0 < 32 && ry1 - ry0 < 32) {
 #endif
             // fine mode (regions up to 32x32 px): lane = 4x4 block for the rejection test; every step then scans
             // FOUR surviving blocks, 16 lanes each -- small triangles fill the wave far better than with 8x8 blocks
-            const int cbx = rx0 + lx * 4, cby = ry0 + ly * 4;
-            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<4, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
+            const int cbx = gx0 + lx * 4, cby = ry0 + ly * 4;
+            const bool cand = cbx <= rx1 && cbx + 3 >= rx0 && cby <= ry1 && block_may_cover<4, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
 #if R3N_ABLATE == 1
             asm volatile("" : : "s"(blocks));
@@ -759,12 +756,12 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                         : "=&s"(bsel[0]), "=&s"(bsel[1]), "=&s"(bsel[2]), "=&s"(bsel[3]), "+s"(blocks));
                     const uint32_t b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                     int x, y;
-                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7u), "v"(rx0 + px));
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7u), "v"(gx0 + px));
                     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
 #if R3N_BIG_LEAN >= 2
-                    shade_pixel_cmpx<DEPTH_ONLY, true>(a, w, x, y, b, rx1, ry1);
+                    shade_pixel_cmpx<DEPTH_ONLY, true>(a, w, x, y, b, rx0, rx1, ry1);
 #else
-                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (b < 64u) & (x <= rx1) & (y <= ry1));
+                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (b < 64u) & (x >= rx0) & (x <= rx1) & (y <= ry1));
 #endif
                 }
             } else
@@ -782,13 +779,13 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 // (field << 2) + base as ONE shift-add each (the compiler's canonical (b << 2) & 28 form costs an instruction
                 // more per coordinate and cannot be talked out of it)
                 int x, y;
-                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7), "v"(rx0 + px));
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7), "v"(gx0 + px));
                 asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
-                if (b < 64 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
+                if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
         } else if (R3N_ABLATE != 3) {
-            const int cbx = rx0 + lx * 8, cby = ry0 + ly * 8;
-            const bool cand = cbx <= rx1 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
+            const int cbx = gx0 + lx * 8, cby = ry0 + ly * 8;
+            const bool cand = cbx <= rx1 && cbx + 7 >= rx0 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
             if (R3N_BIG_LEAN && S == 1 && !BLEND && !w.cutout) {
                 while (blocks) {
@@ -797,11 +794,11 @@ R3N_DEV void raster_big_body(RasterArgs a) {
 #endif
                     int b;
                     asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(b), "+s"(blocks));
-                    const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
+                    const int x = gx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
 #if R3N_BIG_LEAN >= 2
-                    shade_pixel_cmpx<DEPTH_ONLY, false>(a, w, x, y, 0u, rx1, ry1);
+                    shade_pixel_cmpx<DEPTH_ONLY, false>(a, w, x, y, 0u, rx0, rx1, ry1);
 #else
-                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (x <= rx1) & (y <= ry1));
+                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (x >= rx0) & (x <= rx1) & (y <= ry1));
 #endif
                 }
             } else
@@ -811,17 +808,16 @@ R3N_DEV void raster_big_body(RasterArgs a) {
 #endif
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
-                const int x = rx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
+                const int x = gx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
+                if (x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
         }
 #ifdef R3N_WAVE_TRACE
         ++trace_items;
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na) : : "memory");
         rec = nrec;
         da = na;
-        db = nb;
     }
 #ifdef R3N_WAVE_TRACE
     if (DEPTH_ONLY && lane == 0u && wave_global < 32768u) {

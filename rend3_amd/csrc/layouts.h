@@ -107,24 +107,24 @@ struct alignas(8) r3n_tri_ref {  // 8-byte aligned: one dwordx2 load / store per
 
 // Raster work item for triangles larger than 8x8 px: one wavefront scans a <=64x64 px region.  The item carries
 // the finished triangle setup (the producer computed it to classify the triangle), so the consumer has no
-// dependent gather chain in front of its scan: one 80-byte record, broadcast through SGPRs.
+// dependent gather chain in front of its scan: one 64-byte record (one s_load_dwordx16), broadcast through SGPRs.
 struct r3n_big_item {
     float e[3][3];      // oriented edge functions
-    float z[3];         // clip-space z per vertex
-    float det;
-    float va[3];        // vertex alpha (cutout key only)
+    float z[3];         // the depth plane: (z[0] * x + z[1] * y) + z[2] (device_math.h setup_triangle)
     uint32_t slot1;     // canonical slot + 1 (forward only)
-    uint32_t material;  // material index (cutout key only)
+    uint32_t material;  // material index (cutout key) / draw order (blend) | the edge thresholds' bits << R3N_BIG_THR_SHIFT
     uint32_t xy0;       // x0 | y0 << 16
     uint32_t xy1;       // x1 | y1 << 16 (inclusive)
 };
-static_assert(sizeof(r3n_big_item) == 80, "big item is 20 dwords");
-// Same index as the item; written and read only for cutout triangles whose alpha comes from the albedo texture.
+static_assert(sizeof(r3n_big_item) == 64, "big item is 16 dwords: one s_load_dwordx16, one cache line");
+// Same index as the item; written and read only for cutout triangles (vertex alpha; the uvs when the alpha comes from the
+// albedo texture).
 struct r3n_big_uv {
     float uv[3][2];
-    uint32_t _pad[2];
+    float va[3];        // vertex alpha
+    uint32_t _pad[3];
 };
-static_assert(sizeof(r3n_big_uv) == 32, "big item uv record is 8 dwords");
+static_assert(sizeof(r3n_big_uv) == 48, "big item cutout record is 12 dwords");
 
 // Output lists and work queues are split into sub-queues so that appends do not serialise on one counter: a
 // returning atomic on a single address retires at only ~88 per microsecond on MI355X (MI355X_MICROARCH.md,

@@ -179,7 +179,7 @@ struct r3n_ctx {
     uint32_t shade_mode = R3N_SHADE_EXACT;
     DevBuf big_items[1 + R3N_QLANES], big_count[1 + R3N_QLANES];  // work queues: [0] the viewport's, 1.. one per concurrently drawn shadow view
     uint32_t forward_index_lane[1 + R3N_QLANES] = {};
-    uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (80 B) per work sub-queue (R3N_BIGQ of them)
+    uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (64 B) per work sub-queue (R3N_BIGQ of them)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
     DevBuf shadow_views[3], shadow_rargs[2];  // device arrays of the batched shadow stages: ShadowView per stage, RasterArgs per key

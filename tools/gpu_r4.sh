@@ -30,6 +30,12 @@ for w in "$@"; do
     shim) timeout 900 python -m pytest tests/test_two_process_gpu.py -q -x > "$out/pytest_shim.log" 2>&1; echo "pytest two-process rc=$?"; tail -6 "$out/pytest_shim.log"; grep -E '^E |FAIL' "$out/pytest_shim.log" | head -12;;
     probe) timeout 300 python tools/exact_math_probe.py > "$out/exact_math.txt" 2>&1; cat "$out/exact_math.txt" | head -80;;
     quick_lean2) R3N_LIB=$root/variants/lib_lean2.so timeout 900 python -m pytest tests -m gpu -x -q -k "bistro or random or golden or config4_full or near_plane or large_scene or msaa_random or transparent" > "$out/pytest_lean2.log" 2>&1; echo "pytest lean2 rc=$?"; tail -4 "$out/pytest_lean2.log"; grep -E '^E ' "$out/pytest_lean2.log" | head -8;;
+    bisect)
+      for lib in $root/variants/lib_*.so; do
+        name=$(basename $lib .so)
+        R3N_LIB=$lib timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_exact_math.py -m gpu -q -k "static_gltf or config3_4k or exact_math or config4_full or transparent or msaa_random or vertex_colour" > "$out/pytest_$name.log" 2>&1
+        echo "== $name: $(tail -1 $out/pytest_$name.log)"; grep -E '^E  +AssertionError' "$out/pytest_$name.log" | cut -c1-200
+      done;;
     tests) timeout 1500 python -m pytest tests -m gpu -q --durations=8 > "$out/pytest.log" 2>&1; echo "pytest rc=$?"; tail -15 "$out/pytest.log"; grep -E '^E ' "$out/pytest.log" | head -8;;
     bench) python bench.py --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"; line "$out/bench.json"; tail -3 "$out/bench.err";;
     classes)
