@@ -12,12 +12,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 for name in ("bench", "bench_fast", "bench_instanced", "bench_untextured", "bench_msaa4", "bench_shadow_tiles", "bench_cfg4", "bench_scene",
-             "bench_exchange_rows", "bench_exchange_rows_python", "bench_exchange_spatial", "bench_exchange_slots", "bench_under_rocprof", "bench_under_rocprof_serial"):
+             "bench_exchange_rows", "bench_exchange_objects", "bench_exchange_rows_python", "bench_exchange_spatial", "bench_exchange_slots", "bench_under_rocprof", "bench_under_rocprof_serial", "bench_under_rocprof_single"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p):
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
         json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
-for sub, out in (("kt", "kernel_stats"), ("kts", "kernel_stats_serial")):
+for sub, out in (("kt", "kernel_stats"), ("kts", "kernel_stats_serial"), ("kt1", "kernel_stats_single_stream")):
     f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, f"{tag}_bench_{out}.csv"))
@@ -32,6 +32,10 @@ for name in ("host_rate.txt", "host_rate_nodes.txt"):
     if os.path.exists(p):
         keep = [l for l in open(p).read().splitlines() if "ms/frame" in l or "ms per frame" in l or "host time" in l]
         open(os.path.join(dst, f"{tag}_{name}"), "w").write("\n".join(keep) + "\n")
+for name, out in (("exact_math.txt", "exact_math.txt"), ("stall/pmc_raster_table.md", "pmc_raster_table.md")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{out}"))
 p = os.path.join(src, "configs.jsonl")
 if os.path.exists(p):
     rows = [json.loads(l) for l in open(p).read().splitlines() if l.startswith("{")]

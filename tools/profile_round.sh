@@ -14,9 +14,9 @@ $B --steps 100 --warmup 10 --no-cpu-baseline --shade-mode fast > "$out/bench_fas
 $B --steps 100 --warmup 10 --no-cpu-baseline --instanced > "$out/bench_instanced.json" 2>/dev/null
 $B --steps 100 --warmup 10 --no-cpu-baseline --untextured > "$out/bench_untextured.json" 2>/dev/null
 $B --steps 60 --warmup 10 --no-cpu-baseline --samples 4 > "$out/bench_msaa4.json" 2>/dev/null
-$B --steps 40 --warmup 8 --no-cpu-baseline --config 4 > "$out/bench_cfg4.json" 2>/dev/null
+$B --steps 40 --warmup 8 --cpu-sample-frames 1 --config 4 > "$out/bench_cfg4.json" 2>/dev/null   # with the oracle's parity block (one sample frame)
 $B --steps 60 --warmup 8 --cpu-sample-frames 3 --scene tests/golden/static_gltf-data.glb --directional-light=-1,-4,2 --directional-light-intensity 4 --shadow-distance 20 --camera=3,3,5,-0.55,-0.5 > "$out/bench_scene.json" 2>/dev/null
-for part in rows rows_python spatial slots; do
+for part in rows objects rows_python spatial slots; do
   flags="--partition $part"; [ $part = rows_python ] && flags="--partition rows --python-exchange"
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-exchange $flags --steps 60 --warmup 8 2>/dev/null | grep '^{' > "$out/bench_exchange_$part.json"
 done
@@ -26,15 +26,20 @@ python tools/run_config.py cfg2 cfg4 cfg5 cfg5anim cfg5asset > "$out/configs.jso
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -o kt -- $B --no-cpu-baseline --steps 30 --warmup 5 > "$out/bench_under_rocprof.json" 2> "$out/kt.err"
 R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kts" -o kts -- $B --no-cpu-baseline --steps 30 --warmup 5 > "$out/bench_under_rocprof_serial.json" 2> "$out/kts.err"
+# everything on ONE stream, no frames in flight: a kernel's average duration here is its stand-alone time -- what the line's
+# rooflines.*.ms_per_launch (HIP events, single stream) must agree with
+R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1" -o kt1 -- $B --no-cpu-baseline --steps 30 --warmup 5 > "$out/bench_under_rocprof_single.json" 2> "$out/kt1.err"
+python $root/tools/exact_math_probe.py > "$out/exact_math.txt" 2>&1
 cd "$root"
 bash tools/gpu_pmc.sh "$tag/pmc" > "$out/pmc_table.txt" 2>&1
+bash tools/gpu_r4.sh "$tag/stall" pmc_raster > "$out/pmc_raster.txt" 2>&1
 # the headline line LAST, quoting the counter traffic of THIS build (bench.py refuses traffic.json of other kernel sources)
 [ -f "$out/pmc/traffic.json" ] && cp "$out/pmc/traffic.json" "$root/profiles/traffic.json"
 $B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"
 find "$out" -name "*_kernel_trace.csv" -size +8M -delete
 find "$out" -name "*counter_collection.csv" -size +8M -delete
 ls "$out"
-for f in bench bench_fast bench_instanced bench_untextured bench_msaa4 bench_cfg4 bench_scene bench_exchange_rows bench_exchange_rows_python bench_exchange_spatial bench_exchange_slots; do python - "$out/$f.json" <<'PY'
+for f in bench bench_fast bench_instanced bench_untextured bench_msaa4 bench_cfg4 bench_scene bench_exchange_rows bench_exchange_objects bench_exchange_rows_python bench_exchange_spatial bench_exchange_slots; do python - "$out/$f.json" <<'PY'
 import json,sys
 try:
     line=[l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]
