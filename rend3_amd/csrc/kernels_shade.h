@@ -34,6 +34,7 @@
 
 // ------------------------------------------------------------------------------------------------ K6 resolve
 struct TriRecord;
+struct ViewLights;
 struct ShadeArgs {
     const unsigned long long *vis;
     uint32_t width, height, row_begin, row_end;
@@ -66,6 +67,7 @@ struct ShadeArgs {
     uint32_t *edge_list, *edge_count;
     uint32_t edge_capacity;    // entries per sub-list
     // single-sample record-based resolve, specialised per material class (see R3N_FEAT_* below)
+    const ViewLights *view_lights;  // the frame's light lists in view space (k_stage_view_lights), or null: every workgroup stages its own
     const uint32_t *material_feat;  // per material: feature bits, computed by the host when the record is written
     uint32_t variants;              // bit v set: variant v of the resolve runs this frame (more than one bit: tiles are classified)
 };
@@ -150,20 +152,33 @@ struct BlendApplyArgs {
 
 #define R3N_SRGB_LUT_SIZE 0x3C00u  // half bits of 1.0
 
-#ifndef R3N_SHADE_DECL_ONLY
-
+// The light lists in view space, as the fragment stage reads them (stage_lights below).
 struct LdsDirLight {
     float m[16];      // light.view_proj * uniforms.inv_view (opaque.wgsl:491)
     float l[3];       // normalize(view_mat3 * -direction)   (opaque.wgsl:519)
     float color[3];
     float inv_res[2], offset[2], size[2];
     float sane;       // 1: |colour| <= 1e6 (lets the fragment stage skip fully occluded lights), else 0
+    float _pad[3];
 };
+static_assert(sizeof(LdsDirLight) == 128, "two s_load_dwordx16");
 struct LdsPointLight {
     float vpos[3];    // (uniforms.view * position).xyz (opaque.wgsl:528)
     float color[3];
     float radius;
+    float _pad;
 };
+static_assert(sizeof(LdsPointLight) == 32, "one s_load_dwordx8");
+// The same lists in GLOBAL memory, written once per frame by k_stage_view_lights: the single-sample resolve then reads a light
+// through scalar loads -- the light index is wave-uniform -- into scalar registers: no per-workgroup staging pass and barrier in
+// front of 32 400 workgroups, no LDS reads and no thirty vector registers per light in the light loop.
+struct ViewLights {
+    uint32_t n_dir, n_point, _pad[2];
+    LdsDirLight dir[R3N_MAX_DIR_LIGHTS];
+    LdsPointLight point[R3N_MAX_POINT_LIGHTS];
+};
+
+#ifndef R3N_SHADE_DECL_ONLY
 
 // shadow/pcf.wgsl + comparison sampler (samplers.rs:24,42-57): bilinear, GreaterEqual, Repeat.
 // Texel coordinates + bilinear weights of one comparison tap, exactly as sample_compare derives them.
@@ -512,7 +527,24 @@ template <class M> R3N_DEV void interp_vec4(const float lam[3], const float a[3]
 // footprint selection, the shadow coordinates and the depth comparisons stay exact so that no pixel changes triangle, mip
 // level or shadow texel -- the result differs from the exact one by rounding only.
 // CLS: the features (R3N_FEAT_*) a material shaded here may have; the code of every other feature is not instantiated.
-template <bool TEX, class M = MathExact, uint32_t CLS = R3N_CLS_ALL>
+// SL: s_dir / s_point are in global memory and a light is fetched with scalar loads (ViewLights); else they are the workgroup's LDS copies.
+template <class T, bool SL> R3N_DEV T load_light(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SL) {  // wave-uniform address + constant address space: s_load into scalar registers
+        static_assert(sizeof(T) % 4 == 0, "whole dwords");
+        const unsigned long long v = (unsigned long long)p;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        typedef __attribute__((address_space(4))) const uint32_t *sp_t;
+        const sp_t sp = (sp_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+        union { T t; uint32_t w[sizeof(T) / 4]; } u;
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = sp[k];
+        return u.t;
+    }
+#endif
+    return *p;
+}
+template <bool TEX, class M = MathExact, uint32_t CLS = R3N_CLS_ALL, bool SL = false>
 R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const LdsPointLight *s_point, uint32_t n_dir,
                             uint32_t n_point, const TriRecord &r, uint32_t x, uint32_t y, float out[4]) {
     const r3n_material208 &mat = a.materials[r.material];
@@ -720,7 +752,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         const BrdfPixel *pre = nullptr;
 #endif
         for (uint32_t i = 0; i < ((R3N_SHADE_ABLATE & 8) ? 0u : n_dir); ++i) {
-            const LdsDirLight &L = s_dir[i];
+            const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i);
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
             // (D <= 1/(pi a^2), V <= 0.5/(nov a), nov >= 1e-5), so the light adds exactly +0: skip the shadow lookup
             // and the BRDF.  `+= 0.0f` keeps the -0 -> +0 behaviour of the full expression.
@@ -759,7 +791,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             for (int c = 0; c < 3; ++c) color[c] += res[c];
         }
         for (uint32_t i = 0; i < n_point; ++i) {
-            const LdsPointLight &P = s_point[i];
+            const LdsPointLight P = load_light<LdsPointLight, SL>(s_point + i);
             const float delta[3] = {P.vpos[0] - vpos[0], P.vpos[1] - vpos[1], P.vpos[2] - vpos[2]};
             const float d = M::sqrt(dot3m<M>(delta, delta));
             const float s = sat(M::div(d, P.radius));
@@ -850,6 +882,13 @@ R3N_DEV void stage_lights(const ShadeArgs &a, LdsDirLight *s_dir, LdsPointLight 
     __syncthreads();
 }
 
+// The same once per frame into global memory (one workgroup), for the kernels that read lights through scalar loads.
+static __global__ __launch_bounds__(256) void k_stage_view_lights(ShadeArgs a, ViewLights *out) {
+    uint32_t n_dir, n_point;
+    stage_lights(a, out->dir, out->point, n_dir, n_point);
+    if (threadIdx.x == 0u) { out->n_dir = n_dir; out->n_point = n_point; out->_pad[0] = out->_pad[1] = 0u; }
+}
+
 // One thread per pixel, 16x16 pixel tiles; the light list is transformed once per workgroup and staged in LDS.
 // S = samples per pixel.  S == 4: every sample of the multisampled Rgba16Float target holds the half-rounded colour
 // of its nearest fragment (shaded once per distinct triangle, at the pixel centre) or the clear colour; the render
@@ -911,8 +950,21 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
         s_decode[256u + threadIdx.x] = a.tex.decode[256u + threadIdx.x];
         a.tex.decode = s_decode;
     }
+    // the single-sample record-based resolve reads the frame's light lists from global memory through scalar loads
+    // (ViewLights, written by k_stage_view_lights in front of this launch); the other forms stage them per workgroup in LDS
+    constexpr bool SL = S == 1 && REC;
     uint32_t n_dir, n_point;
-    stage_lights(a, s_dir, s_point, n_dir, n_point);
+    const LdsDirLight *dirs = s_dir;
+    const LdsPointLight *points = s_point;
+    if (SL) {
+        n_dir = load_light<uint32_t, true>(&a.view_lights->n_dir);
+        n_point = load_light<uint32_t, true>(&a.view_lights->n_point);
+        dirs = a.view_lights->dir;
+        points = a.view_lights->point;
+        if (TEX) __syncthreads();  // the decode tables
+    } else {
+        stage_lights(a, s_dir, s_point, n_dir, n_point);
+    }
     if (!inside && !SPLIT) return;  // SPLIT: every thread of the workgroup takes part in the queue reservation below
     float out[4];
     if (S == 1) {
@@ -923,7 +975,7 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TE
             a.ldr_out[pix] = tonemap_half4(a.srgb_lut, hc, a.out_bgr);
             return;
         }
-        if (REC) fragment_stage<TEX, M, CLS>(a, s_dir, s_point, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
+        if (REC) fragment_stage<TEX, M, CLS, SL>(a, dirs, points, n_dir, n_point, a.tri_rec[id - 1u], x, y, out);
         else shade_fragment<TEX, M>(a, s_dir, s_point, n_dir, n_point, id, x, y, out);
     } else {
         uint32_t ids[S];

@@ -132,6 +132,7 @@ struct r3n_ctx {
     std::vector<r3n_material208> h_materials;
     std::vector<uint8_t> h_tex_short;
     DevBuf material_feat;
+    DevBuf view_lights[2];  // ViewLights of the frame set (k_stage_view_lights writes it in front of the single-sample resolve)
     uint32_t resolve_variants = 0;
     bool classes_dirty = true;
     bool key_census_dirty = true;
@@ -736,7 +737,8 @@ void r3n_destroy(r3n_ctx *c) {
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys, &c->frag_vals, &c->frag_head,
                       &c->frag_count, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
                       &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
-                      &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1]};
+                      &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1], &c->material_feat, &c->view_lights[0],
+                      &c->view_lights[1]};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -1846,6 +1848,7 @@ static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     a.tri_rec = nullptr;
     a.seen = nullptr;
     a.total_tris = (uint32_t)c->total_tris;
+    a.view_lights = nullptr;
     a.material_feat = nullptr;
     a.variants = 0u;
     return a;
@@ -1870,6 +1873,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     // single-sample record-based resolve of a textured world: one kernel per material class present (R3N_RESOLVE_CLASSES=0: the general kernel)
     const bool classes = use_records && c->samples == 1 && c->n_textures > 0 && c->n_materials > 0 && c->resolve_classes;
     if (classes) TRY(refresh_material_classes(c));
+    if (use_records && c->samples == 1) TRY(ensure(c, c->view_lights[c->slot], sizeof(ViewLights), false, -1));
     if (use_records) {
         TRY(ensure(c, c->tri_rec, (size_t)c->total_tris * sizeof(TriRecord), false, -1));
         TRY(ensure(c, c->tri_seen, (size_t)c->total_tris, false, 0));  // zero: k_vertex_stage returns every flag it consumes to 0
@@ -1902,6 +1906,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     }
     ShadeArgs a = make_shade_args(c, r0, r1);
     if (blend_samples) a.samples_out = c->samples16.as<ushort4>();
+    if (use_records && c->samples == 1) a.view_lights = c->view_lights[c->slot].as<ViewLights>();
     if (classes && c->resolve_variants != 0u) {
         a.material_feat = c->material_feat.as<uint32_t>();
         a.variants = c->resolve_variants;

@@ -31,6 +31,10 @@ int r3n_internal_resolve(const ShadeArgs *ap, uint32_t samples, int tex, int rec
     if (samples == 4) return r3n_internal_resolve_ms(ap, tex, rec, split, stream);  // shade_ms.hip
     const ShadeArgs &a = *ap;
     const dim3 rgrid((a.width + 15u) / 16u, (a.row_end - a.row_begin + 15u) / 16u);
+    if (rec) {  // the record-based single-sample kernels read the lights from a.view_lights
+        if (!a.view_lights) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_stage_view_lights, dim3(1), dim3(256), 0, stream, a, const_cast<ViewLights *>(a.view_lights));
+    }
     if (rec && tex && a.variants != 0u) {
         // one launch per material class in flight (kernels_shade.h R3N_CLS_*); the general kernel is the chain's top
         for (uint32_t v = 0; v < R3N_VARIANTS; ++v) {

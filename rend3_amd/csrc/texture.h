@@ -16,6 +16,10 @@
 #pragma once
 #include "device_math.h"
 
+#ifndef R3N_TEX_SRGB_BRANCH
+#define R3N_TEX_SRGB_BRANCH 1  // short-path-only samplers (the resolve's material classes) branch on the texture's encoding: see tex_texel_at
+#endif
+
 struct TextureArgs {
     const r3n_texture_desc32 *descs;
     uint32_t count;
@@ -185,18 +189,22 @@ R3N_DEV bool tex_level_fast(uint32_t w, uint32_t h, uint32_t base, float u, floa
     }
     return tame;
 }
-template <bool NEED_A>
+// SRGB_SEL: 0 / 1 = the colour channels' decode table is known here (the unorm table at t.decode, the sRGB one 256 entries
+// further): its offset then folds into the LDS read's immediate and a channel's address is ONE instruction (a byte-select shift);
+// -1 = per-lane table pointer `rgb` (an extract and a shift-or per channel).
+template <bool NEED_A, int SRGB_SEL = -1>
 R3N_DEV Texel4 tex_texel_at(const TextureArgs &t, const float *__restrict__ rgb, uint32_t byte_off) {
     const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t.texels) + byte_off);  // uniform base + 32-bit offset
+    const float *tab = SRGB_SEL < 0 ? rgb : t.decode + (SRGB_SEL == 1 ? 256 : 0);
     Texel4 o;
-    o.rg = (f2){rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu]};
-    o.ba = (f2){rgb[(v >> 16) & 0xFFu], NEED_A ? t.decode[v >> 24] : 0.0f};
+    o.rg = (f2){tab[v & 0xFFu], tab[(v >> 8) & 0xFFu]};
+    o.ba = (f2){tab[(v >> 16) & 0xFFu], NEED_A ? t.decode[v >> 24] : 0.0f};
     return o;
 }
-template <class M, bool NEED_A>
+template <class M, bool NEED_A, int SRGB_SEL = -1>
 R3N_DEV Texel4 tex_bilinear_fast(const TextureArgs &t, const float *__restrict__ rgb, const TexLvlFast &l) {
-    const Texel4 c00 = tex_texel_at<NEED_A>(t, rgb, l.o00), c10 = tex_texel_at<NEED_A>(t, rgb, l.o10);
-    const Texel4 c01 = tex_texel_at<NEED_A>(t, rgb, l.o01), c11 = tex_texel_at<NEED_A>(t, rgb, l.o11);
+    const Texel4 c00 = tex_texel_at<NEED_A, SRGB_SEL>(t, rgb, l.o00), c10 = tex_texel_at<NEED_A, SRGB_SEL>(t, rgb, l.o10);
+    const Texel4 c01 = tex_texel_at<NEED_A, SRGB_SEL>(t, rgb, l.o01), c11 = tex_texel_at<NEED_A, SRGB_SEL>(t, rgb, l.o11);
     const float omx = 1.0f - l.fx, omy = 1.0f - l.fy;
     Texel4 o;
     o.rg = mix2<M>(mix2<M>(c00.rg, c10.rg, l.fx, omx), mix2<M>(c01.rg, c11.rg, l.fx, omx), l.fy, omy);
@@ -248,9 +256,21 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         const bool two = frac > 0.0f;  // then level + 1 <= mips - 1
         if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
-            Texel4 r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
+            Texel4 r, hi;
+#if R3N_TEX_SRGB_BRANCH
+            if (SHORT_ONLY && d.format == 1u) {  // (a material set's maps of one slot share their encoding: the branch is wave-uniform in practice)
+                r = tex_bilinear_fast<M, NEED_A, 1>(t, rgb, l0);
+                if (two) hi = tex_bilinear_fast<M, NEED_A, 1>(t, rgb, l1);
+            } else if (SHORT_ONLY) {
+                r = tex_bilinear_fast<M, NEED_A, 0>(t, rgb, l0);
+                if (two) hi = tex_bilinear_fast<M, NEED_A, 0>(t, rgb, l1);
+            } else
+#endif
+            {
+                r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
+                if (two) hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
+            }
             if (two) {
-                const Texel4 hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
                 const float omf = 1.0f - frac;
                 r.rg = mix2<M>(r.rg, hi.rg, frac, omf);
                 if (NEED_A) r.ba = mix2<M>(r.ba, hi.ba, frac, omf);
