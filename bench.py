@@ -361,6 +361,9 @@ def main():
     r.sync()
     stages = r.stage_times(reset=True)
     r.timing_enable(False)
+    import ctypes
+    span_overhead = ctypes.c_double(0.0)
+    r._check(r.lib.r3n_timing_overhead(r.ctx, ctypes.byref(span_overhead)), "r3n_timing_overhead")
     exchange_ms, exchange_bytes = None, None
     if exchange is not None:  # HIP events on the context's stream around every collective of the instrumented frames
         exchange.timed = False
@@ -528,6 +531,10 @@ def main():
             "culled_mtris_per_s": round(info["triangles"] * cameras / (cull_ms * 1e-3) / 1e6, 1) if cull_ms > 0 else None,
             "stage_ms_per_frame": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_launches_per_frame": launches,
+            "stage_timing": {"span_overhead_ms": round(span_overhead.value, 5),
+                             "note": "HIP events on the stream around every stage's launches, single stream, outside the timed region; the span of an "
+                                     "EMPTY launch between two events (measured on this box, above) is taken off every span, so the figures are kernel "
+                                     "time as rocprofv3's kernel trace reports it (profiles/r04_bench_kernel_stats_single_stream.csv)"},
             "roofline": roof,
             "rooflines": {k: v for k, v in rooflines.items() if k != dominant},
             "frame_roofline": frame_roofline,

@@ -398,6 +398,7 @@ extern "C" {
     pub fn r3n_readback_hdr(ctx: *mut r3n_ctx, rgba16f: *mut u16) -> c_int;
     pub fn r3n_readback_output(ctx: *mut r3n_ctx, rgba8: *mut u8, rgba_f32: *mut f32) -> c_int;
     pub fn r3n_timing_enable(ctx: *mut r3n_ctx, enable: c_int) -> c_int;
+    pub fn r3n_timing_overhead(ctx: *mut r3n_ctx, ms_per_span: *mut f64) -> c_int;
     pub fn r3n_set_multi_stream(ctx: *mut r3n_ctx, enable: c_int) -> c_int;
     pub fn r3n_stage_times(ctx: *mut r3n_ctx, ms: *mut f64, launches: *mut u64, reset: c_int) -> c_int;
     pub fn r3n_hbm_copy_rate(ctx: *mut r3n_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;

@@ -533,6 +533,9 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_EXCHANGE_KEYS 17   /* object-range split: MAX reduce-scatter of the visibility keys onto the row bands (main stream) */
 #define R3N_STAGE_COUNT 18
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
+/* What a timed span holds besides its kernels -- two event packets and a launch's dispatch, measured around an empty kernel when
+ * timing is first enabled (median of 32) -- and already taken off every span r3n_stage_times reports. */
+int r3n_timing_overhead(r3n_ctx *ctx, double *ms_per_span);
 /* Shadow views normally run on auxiliary streams concurrently with the viewport chain; per-kernel durations measured
  * while kernels of other streams are resident are inflated, so timing passes can serialise everything on the main
  * stream (enable = 0).  Only between frames. */

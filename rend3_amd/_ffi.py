@@ -63,6 +63,7 @@ SIGNATURES = {
     "r3n_comm_init": (cint, [vp, vp, u32, u32]),
     "r3n_comm_destroy": (cint, [vp]),
     "r3n_comm_set_split": (cint, [vp, u32]),
+    "r3n_timing_overhead": (cint, [vp, vp]),
     "r3n_set_camera_object_range": (cint, [vp, u32, u32, u32]),
     "r3n_exchange_depth": (cint, [vp, vp, vp]),
     "r3n_set_row_range": (cint, [vp, u32, u32]),

@@ -431,6 +431,9 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 #ifndef R3N_SMALL_OCC
 #define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
 #endif
+#ifndef R3N_BIG_XCD
+#define R3N_BIG_XCD 0
+#endif
 #ifndef R3N_ITEM_ALIGN
 #define R3N_ITEM_ALIGN 16  // (a power of two <= R3N_TILE; measured: viewport work items 84.7 -> 73.2 us, shadow 85.0 -> 80.8 us per launch)
 #endif
@@ -635,14 +638,27 @@ R3N_DEV void raster_big_body(RasterArgs a) {
     asm volatile("" : "+s"(a.target_pitch), "+s"(a.vp_x), "+s"(a.vp_y), "+s"(a.depth), "+s"(a.vis), "+s"(a.key),
                  "+s"(a.materials), "+s"(a.big_items), "+s"(a.big_count), "+s"(a.big_capacity));
     const uint32_t lane = threadIdx.x & 63u;
+#if R3N_BIG_XCD
+    // XCD affinity (speed only, never correctness): workgroup b is observed to run on XCD b mod 8, and the producers' waves of
+    // workgroup b append to sub-queues (4 b + wave) mod 32 -- so sub-queues 4 x .. 4 x + 3 were written on XCD x, and plain stores
+    // stay in that XCD's L2.  A consumer workgroup walks ONLY the four sub-queues of its own residue: the record loads then hit
+    // the local L2 instead of going to the memory side (35 % of this kernel is the latency of those loads).  Every sub-queue
+    // is consumed whatever the placement is; only the hit rate depends on it.
+    static_assert(R3N_BIGQ == 32u, "four sub-queues per XCD residue");
+    const uint32_t qgroup = (blockIdx.x & 7u) * 4u;
+    const uint32_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
+    const uint32_t nwaves = ((gridDim.x + 7u - (blockIdx.x & 7u)) >> 3) * 4u;  // workgroups of this residue x 4 waves
+#else
+    const uint32_t qgroup = 0u;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t nwaves = gridDim.x * 4u;
+#endif
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t cap = a.big_capacity;
     // Sub-queue bounds live in registers: lane q < R3N_BIGQ holds [excl, incl), the flat indices of sub-queue q in the
     // concatenation (one vector load + a wave scan at kernel start, before any atomic is in flight).  Locating an item
     // is then a ballot + readlane, with no memory access in the item loop.
-    const uint32_t qcnt_l = lane < R3N_BIGQ ? min(a.big_count[lane], cap) : 0u;
+    const uint32_t qcnt_l = lane < (R3N_BIG_XCD ? 4u : R3N_BIGQ) ? min(a.big_count[qgroup + lane], cap) : 0u;
     uint32_t incl = qcnt_l;
 #pragma unroll
     for (uint32_t d = 1; d < R3N_BIGQ; d <<= 1) {
@@ -655,7 +671,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         if (!m) return nullptr;
         const uint32_t q = (uint32_t)__builtin_ctzll(m);
         const uint32_t qb = __builtin_amdgcn_readlane(excl, q);
-        return reinterpret_cast<const uint32_t *>(a.big_items + (size_t)(q * cap + (flat - qb)));  // (queues hold < 2^32 items: r3n_create)
+        return reinterpret_cast<const uint32_t *>(a.big_items + (size_t)((qgroup + q) * cap + (flat - qb)));  // (queues hold < 2^32 items: r3n_create)
     };
     typedef __attribute__((address_space(4))) const uint32_t *sptr_t;
     // The record is read with SCALAR loads (constant address space + wave-uniform address => s_load into SGPRs).
