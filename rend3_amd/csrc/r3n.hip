@@ -163,6 +163,7 @@ struct r3n_ctx {
     std::vector<uint32_t> h_blend_order;
     uint32_t n_blend = 0, blend_tris = 0;
     uint32_t frag_capacity = 32u << 20;  // fragment nodes (12 B each), allocated on first use
+    DevBuf tex_texels_f;  // R3N_TEXEL_FLOAT: the RGBA8 pool decoded to float4 at upload
     DevBuf tex_descs, tex_texels, tex_level_off, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
     uint64_t n_texels = 0;
@@ -742,7 +743,7 @@ void r3n_destroy(r3n_ctx *c) {
                       &c->frag_count, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
                       &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
                       &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1], &c->material_feat, &c->view_lights[0],
-                      &c->view_lights[1]};
+                      &c->view_lights[1], &c->tex_texels_f};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -881,10 +882,21 @@ static TextureArgs texture_args(r3n_ctx *c) {
     t.texels = c->tex_texels.as<uint32_t>();
     t.decode = c->srgb8_decode.as<float>();
     t.level_off = c->tex_level_off.as<uint32_t>();
-    t.small_pool = c->n_texels <= (1ull << 30) ? 1u : 0u;  // byte offsets into the pool fit 32 bits: the sampler's short path
+    t.small_pool = c->n_texels <= (1ull << (R3N_TEXEL_FLOAT ? 28 : 30)) ? 1u : 0u;  // byte offsets into the pool fit 32 bits: the sampler's short path
+    t.texels_f = c->tex_texels_f.as<float4>();
     return t;
 }
 
+#if R3N_TEXEL_FLOAT
+__global__ __launch_bounds__(256) static void k_decode_pool(const uint32_t *__restrict__ texels, float4 *__restrict__ out, size_t n,
+                                                            const float *__restrict__ decode, uint32_t srgb) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = texels[i];
+    const float *rgb = decode + (srgb ? 256 : 0);
+    out[i] = make_float4(rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu], rgb[(v >> 16) & 0xFFu], decode[v >> 24]);
+}
+#endif
 // First word (pool index) of every level of every texture: R3N_TEX_LEVELS entries per texture, so that the sampler does not
 // walk the chain.  `descs` = the descriptors as the device holds them (offsets in pool words; a texel is one word, or four
 // for R3N_POOL_FLOAT textures).
@@ -904,6 +916,18 @@ static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uin
         c->h_tex_short[i] = (w && h && ((w & (w - 1u)) | (h & (h - 1u))) == 0u && descs[i].format < R3N_POOL_FLOAT) ? 1 : 0;
     }
     c->classes_dirty = true;
+#if R3N_TEXEL_FLOAT
+    if (n_texels && n_texels <= (1ull << 28)) {
+        TRY(ensure(c, c->tex_texels_f, (size_t)n_texels * 16, false, -1));
+        for (uint32_t i = 0; i < n; ++i) {
+            if (descs[i].format >= R3N_POOL_FLOAT) continue;
+            uint64_t cnt = 0;
+            for (uint32_t k = 0; k < descs[i].mips; ++k) cnt += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k);
+            hipLaunchKernelGGL(k_decode_pool, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->tex_texels.as<uint32_t>() + descs[i].offset,
+                               c->tex_texels_f.as<float4>() + descs[i].offset, (size_t)cnt, c->srgb8_decode.as<float>(), descs[i].format == 1u ? 1u : 0u);
+        }
+    }
+#endif
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->tex_level_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
@@ -1803,7 +1827,7 @@ static int refresh_material_classes(r3n_ctx *c) {
     const uint32_t n = c->n_materials;
     c->h_materials.resize(n, r3n_material208{});
     std::vector<uint32_t> feat(std::max(n, 1u), R3N_FEAT_ALL);
-    const bool small_pool = c->n_texels <= (1ull << 30);
+    const bool small_pool = c->n_texels <= (1ull << (R3N_TEXEL_FLOAT ? 28 : 30));
     uint32_t variants = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const r3n_material208 &m = c->h_materials[i];

@@ -17,7 +17,7 @@
 #include "device_math.h"
 
 #ifndef R3N_TEX_SRGB_BRANCH
-#define R3N_TEX_SRGB_BRANCH 1  // short-path-only samplers (the resolve's material classes) branch on the texture's encoding: see tex_texel_at
+#define R3N_TEX_SRGB_BRANCH 0  // (measured: resolve 439 vs 436 us with the branch off -- the divergent branch costs what the shorter addressing saves) short-path-only samplers (the resolve's material classes) branch on the texture's encoding: see tex_texel_at
 #endif
 
 struct TextureArgs {
@@ -31,7 +31,12 @@ struct TextureArgs {
                                   // same speed -- the kernel is bound by VALU work, not by the decode.)
     const uint32_t *level_off;    // R3N_TEX_LEVELS entries per texture: pool index of the first texel of each level
     uint32_t small_pool;          // 1: the pool holds <= 2^30 texels, so a texel's BYTE offset fits 32 bits
+    const float4 *texels_f;       // R3N_TEXEL_FLOAT: the RGBA8 texels of the pool decoded once, at upload (same index: texel i of the
+                                  // pool = texels_f[i]; the same values the tables give), or null
 };
+#ifndef R3N_TEXEL_FLOAT
+#define R3N_TEXEL_FLOAT 0  // experiment: the short-path samplers of the resolve's material classes read pre-decoded float4 texels
+#endif
 
 R3N_DEV uint32_t tex_mip_dim(uint32_t d, uint32_t k) {
     const uint32_t v = d >> k;
@@ -194,6 +199,12 @@ R3N_DEV bool tex_level_fast(uint32_t w, uint32_t h, uint32_t base, float u, floa
 // -1 = per-lane table pointer `rgb` (an extract and a shift-or per channel).
 template <bool NEED_A, int SRGB_SEL = -1>
 R3N_DEV Texel4 tex_texel_at(const TextureArgs &t, const float *__restrict__ rgb, uint32_t byte_off) {
+#if R3N_TEXEL_FLOAT
+    if (SRGB_SEL == 2) {  // pre-decoded pool: one 16-byte load, no decode (byte_off * 4 < 2^32: the pool holds < 2^28 texels then)
+        const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(t.texels_f) + (byte_off << 2));
+        return Texel4{(f2){f.x, f.y}, (f2){f.z, NEED_A ? f.w : 0.0f}};
+    }
+#endif
     const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t.texels) + byte_off);  // uniform base + 32-bit offset
     const float *tab = SRGB_SEL < 0 ? rgb : t.decode + (SRGB_SEL == 1 ? 256 : 0);
     Texel4 o;
@@ -257,7 +268,12 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             Texel4 r, hi;
-#if R3N_TEX_SRGB_BRANCH
+#if R3N_TEXEL_FLOAT
+            if (SHORT_ONLY) {
+                r = tex_bilinear_fast<M, NEED_A, 2>(t, rgb, l0);
+                if (two) hi = tex_bilinear_fast<M, NEED_A, 2>(t, rgb, l1);
+            } else
+#elif R3N_TEX_SRGB_BRANCH
             if (SHORT_ONLY && d.format == 1u) {  // (a material set's maps of one slot share their encoding: the branch is wave-uniform in practice)
                 r = tex_bilinear_fast<M, NEED_A, 1>(t, rgb, l0);
                 if (two) hi = tex_bilinear_fast<M, NEED_A, 1>(t, rgb, l1);

@@ -36,6 +36,7 @@ for w in "$@"; do
         R3N_LIB=$lib timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_exact_math.py -m gpu -q -k "static_gltf or config3_4k or exact_math or config4_full or transparent or msaa_random or vertex_colour" > "$out/pytest_$name.log" 2>&1
         echo "== $name: $(tail -1 $out/pytest_$name.log)"; grep -E '^E  +AssertionError' "$out/pytest_$name.log" | cut -c1-200
       done;;
+    quick_texf) R3N_LIB=$root/variants/lib_texf.so timeout 900 python -m pytest tests -m gpu -x -q -k "textured or bistro or golden_static or float_textures or encoded or scene_viewer" > "$out/pytest_texf.log" 2>&1; echo "pytest texf rc=$?"; tail -4 "$out/pytest_texf.log"; grep -E '^E ' "$out/pytest_texf.log" | head -8;;
     tests) timeout 1500 python -m pytest tests -m gpu -q --durations=8 > "$out/pytest.log" 2>&1; echo "pytest rc=$?"; tail -15 "$out/pytest.log"; grep -E '^E ' "$out/pytest.log" | head -8;;
     bench) python bench.py --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"; line "$out/bench.json"; tail -3 "$out/bench.err";;
     classes)
