@@ -34,7 +34,9 @@ extern "C" {
 #define R3N_ERR_NO_DEVICE (-3)
 #define R3N_ERR_STATE (-4)
 #define R3N_ERR_UNSUPPORTED (-5)
-#define R3N_ERR_CAPACITY (-6) /* a fixed-size internal buffer (raster work queue, blend fragment list) overflowed */
+#define R3N_ERR_CAPACITY (-6) /* a fixed-size internal buffer (raster work queue, blend fragment list) overflowed.  Raised by kernels, so it
+                                * surfaces later: r3n_frame_end / r3n_render_frame / r3n_sync / a read-back return it ONCE for an EARLIER frame
+                                * whose image is incomplete; the frame just closed is unaffected, and no frame is ever refused because of it */
 
 /* CameraSpecifier (rend3-routine/src/common/camera.rs:3-35): shadow index, or R3N_CAMERA_VIEWPORT
  * (== CameraSpecifier::Viewport.to_shader_index() == u32::MAX). */

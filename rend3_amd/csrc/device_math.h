@@ -9,6 +9,19 @@
 
 #define R3N_DEV __device__ __forceinline__
 
+// A wave-uniform value of read-only memory through the SCALAR unit (constant address space + readfirstlane'd address =>
+// s_load into SGPRs): one load for the wave instead of 64 lanes' worth, no vector registers, and VALU instructions take the
+// result as a scalar operand.  Only for memory no kernel of the same launch writes.
+typedef uint32_t r3n_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t r3n_u32x16 __attribute__((ext_vector_type(16)));
+template <class V> R3N_DEV V scalar_load(const void *p) {
+    const unsigned long long v = (unsigned long long)p;
+    // (the builtin returns int: through uint32_t first, or the low half sign-extends into the high one)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const unsigned long long u = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    return *reinterpret_cast<__attribute__((address_space(4))) const V *>(u);
+}
+
 // m * (x,y,z,w), column-major m: ((c0*x + c1*y) + c2*z) + c3*w
 R3N_DEV void mul_vec4(const float *__restrict__ m, float x, float y, float z, float w, float o[4]) {
 #pragma unroll

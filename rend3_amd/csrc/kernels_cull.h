@@ -676,15 +676,6 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
 #define R3N_CULL_PAIR 1  // the triangle cull fetches two wave slots of an object together
 #endif
 typedef uint32_t r3n_u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t r3n_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t r3n_u32x16 __attribute__((ext_vector_type(16)));
-template <class V> R3N_DEV V scalar_load(const void *p) {
-    const unsigned long long v = (unsigned long long)p;
-    // (the builtin returns int: through uint32_t first, or the low half sign-extends into the high one)
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    const unsigned long long u = ((unsigned long long)hi << 32) | (unsigned long long)lo;
-    return *reinterpret_cast<__attribute__((address_space(4))) const V *>(u);
-}
 
 #ifndef R3N_CHUNK_ITERS
 #define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk

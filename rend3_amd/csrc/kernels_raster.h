@@ -86,15 +86,30 @@ struct TriWork {
 
 // TEX: the launch may meet cutout materials whose alpha comes from the albedo texture (row N2).  The lean variant
 // (no texture code, fewer registers) is launched whenever the world has no textures or the key is not cutout.
-template <bool DEPTH_ONLY, bool TEX>
+// UNIFORM_OBJ: `obj` is wave-uniform (the caller's waterfall over the wave's distinct objects): the object record's fields and the
+// baked matrix come through scalar loads -- one fetch per wave instead of 64 lanes' worth of gathers, sixteen vector registers less,
+// and one round trip less in the per-triangle chain (list entry -> record -> indices -> positions); what paid in the triangle cull.
+template <bool DEPTH_ONLY, bool TEX, bool UNIFORM_OBJ = false>
 R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, bool positive_visible, TriWork &tw) {
     const r3n_object128 &ob = a.objects[obj];
     // The record's fields this function needs in TWO loads issued together -- bytes 80..95 (first_index, index_count, material_index,
     // the position attribute's offset) and `enabled` -- and waited for once: read field by field behind the `enabled` test they were
     // three dependent round trips of the per-triangle chain (list entry -> record -> indices -> positions).
-    const uint4 of = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
-    const uint32_t enabled = ob.enabled;
-    asm volatile("" : : "v"(of.x), "v"(of.w), "v"(enabled));  // both loads in flight before the test below can split them
+    uint4 of;
+    uint32_t enabled;
+    float mvp[16];
+    if (UNIFORM_OBJ) {
+        const r3n_u32x4 so = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
+        of = make_uint4(so.x, so.y, so.z, so.w);
+        enabled = scalar_load<uint32_t>(&ob.enabled);
+        const r3n_u32x16 sm = scalar_load<r3n_u32x16>(a.baked[obj].model_view_proj);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mvp[k] = __uint_as_float(sm[k]);
+    } else {
+        of = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
+        enabled = ob.enabled;
+        asm volatile("" : : "v"(of.x), "v"(of.w), "v"(enabled));  // both loads in flight before the test below can split them
+    }
     if (enabled == 0u) return false;  // opaque.wgsl:104-112 / depth.wgsl:64-72
     const uint32_t first = of.x + tri * 3u;
     const uint32_t pos_off = of.w;
@@ -105,7 +120,7 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     for (int k = 0; k < 3; ++k) {
         float v[3];
         fetch_vec3(a.mesh, pos_off, idx[k], v);
-        mul_point(a.baked[obj].model_view_proj, v, p[k]);
+        mul_point(UNIFORM_OBJ ? mvp : a.baked[obj].model_view_proj, v, p[k]);
     }
     const float half_w = (float)a.vp_w / 2.0f, half_h = (float)a.vp_h / 2.0f;
     setup_triangle(p, half_w, half_h, positive_visible, tw.ts);
@@ -434,6 +449,9 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 #ifndef R3N_BIG_XCD
 #define R3N_BIG_XCD 0
 #endif
+#ifndef R3N_SMALL_WATERFALL
+#define R3N_SMALL_WATERFALL 0  // per-triangle pass: object record + baked matrix through scalar loads, one round per distinct object of a wave -- measured SLOWER (viewport 22.9 -> 37.6 us, shadow 43.8 -> 45.9 us per launch): a wave's 64 entries span several objects often enough that the repeated setup rounds cost more than the gathers they replace
+#endif
 #ifndef R3N_ITEM_ALIGN
 #define R3N_ITEM_ALIGN 16  // (a power of two <= R3N_TILE; measured: viewport work items 84.7 -> 73.2 us, shadow 85.0 -> 80.8 us per launch)
 #endif
@@ -455,11 +473,34 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
     const uint32_t bq = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) % R3N_BIGQ);
     const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
     const uint32_t stride = (gridDim.x / R3N_SUBQ) * 256u;
+#if R3N_SMALL_WATERFALL
+    // every lane of the workgroup walks the same number of rounds (the waterfall below needs whole waves); lanes past the end idle
+    for (uint32_t i0 = (blockIdx.x / R3N_SUBQ) * 256u; i0 < n; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        r3n_tri_ref ref;
+        ref.object = 0u; ref.triangle = 0u;
+        if (live) ref = list[i];
+        TriWork tw;
+        bool ok = false;
+        // a wave's 64 list entries come from one or two objects (the cull appends an object's triangles together): one round
+        // of the setup per DISTINCT object, with that object's record and matrix in scalar registers
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const uint32_t obj_u = (uint32_t)__builtin_amdgcn_readlane((int)ref.object, (int)__builtin_ctzll(todo));
+            const bool mine = live && ref.object == obj_u;
+            if (mine) ok = prepare_triangle<DEPTH_ONLY, TEX, true>(a, obj_u, ref.triangle, positive_visible, tw);
+            todo &= ~__ballot(mine);
+        }
+        if (!ok) continue;
+        const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
+#else
     for (uint32_t i = (blockIdx.x / R3N_SUBQ) * 256u + threadIdx.x; i < n; i += stride) {
         const r3n_tri_ref ref = list[i];
         TriWork tw;
         if (!prepare_triangle<DEPTH_ONLY, TEX>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
+#endif
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
                 for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);

@@ -36,6 +36,7 @@ struct CamState {
     DevBuf d_hdr;                // NOT owned: points into the frame-constants block of the current frame slot (canon: into own_hdr)
     DevBuf own_hdr;
     uint64_t hdr_frame = ~0ull;  // frame whose constants block already carries this camera's header (r3n_render_frame)
+    uint64_t baked_frame = ~0ull;  // frame of the last r3n_uniform_bake: the header in THIS frame's constants block is only valid then
     DevBuf chain;                // k_object_pass_chained: one ObjChainRec per block, tagged with the launch's epoch
     uint32_t chain_epoch = 0;
     uint64_t object_pass_frame = ~0ull;  // frame whose object pass already ran, fused with the bake (r3n_render_frame)
@@ -1095,7 +1096,8 @@ static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t
     if ((uint64_t)w * h * samples >= (1ull << 29) || (uint64_t)atlas_w * atlas_h >= (1ull << 30) || atlas_w > 65535 || atlas_h > 65535)
         return fail(c, R3N_ERR_UNSUPPORTED, "frame_begin: target of 2^29 samples or more / shadow atlas of 2^30 texels or more");
     HIP_TRY(c, hipSetDevice(c->device));
-    TRY(check_async_status(c));
+    // (an overflow an earlier frame raised is reported by r3n_frame_end / r3n_sync / a read-back, never by refusing THIS frame:
+    // the frame that overflowed has been presented already, the next one must still render)
     if (w != c->width || h != c->height) {
         // resolution change invalidates the temporal history exactly like a new CullingBufferMap entry would
         c->viewport.has_prev = false;
@@ -1552,6 +1554,7 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     HIP_TRY(c, hipSetDevice(c->device));
     s->hdr = *hdr;
     s->has_hdr = true;
+    s->baked_frame = c->frame_no;
     if (c->capacity == 0) return R3N_OK;  // culler.rs:449-451
     // the camera's header lives in the frame-constants block of the current frame slot
     s->d_hdr.p = c->fb_dev[c->slot].as<uint8_t>() + (cam == R3N_CAMERA_VIEWPORT ? r3n_ctx::kFbViewportHdr : r3n_ctx::kFbShadowHdr + 256u * (size_t)cam);
@@ -1597,6 +1600,9 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     if (!s || !s->has_hdr) return fail(c, R3N_ERR_STATE, "cull: camera has no baked uniforms (culler.rs:572 panics here)");
     if (!c->in_frame) return fail(c, R3N_ERR_STATE, "cull: outside frame_begin/frame_end");
     if (c->capacity == 0) return R3N_OK;  // culler.rs:705-707
+    // the camera's header lives in the frame's constants block, which alternates between two sets: without a bake in THIS frame the
+    // kernels would read the header of two frames ago (the reference uploads it in front of every cull, base.rs:148-156)
+    if (s->baked_frame != c->frame_no) return fail(c, R3N_ERR_STATE, "cull: r3n_uniform_bake has not run for this camera in this frame");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     if (!viewport && c->shadow_tiles) {  // shadow views: issued batched over all views (flush_shadows)
@@ -2172,7 +2178,9 @@ int r3n_frame_end(r3n_ctx *c) {
     flip(c->viewport);
     for (auto &kv : c->shadows) flip(kv.second);
     c->in_frame = false;
-    return R3N_OK;
+    // this frame is closed and complete as far as the host can know; what the status word holds was raised by an EARLIER frame's
+    // kernels (fragment buffer / work queue full): report it here, once, without having refused any frame
+    return check_async_status(c);
 }
 
 // ------------------------------------------------------------------------------------------------ native exchange (r3n_comm_*)
