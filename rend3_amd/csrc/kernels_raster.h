@@ -223,6 +223,22 @@ R3N_DEV void global_max_u64_at(unsigned long long *base, uint32_t byte_off, unsi
     (void)__hip_atomic_fetch_max((gp_t)((gc_t)(unsigned long long)base + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Element index of pixel (x, y) of the viewport inside the target.  Rows and pitch are below 2^16 (r3n_frame_begin), the target
+// below 2^29 samples: 24-bit multiply, 32-bit offsets.
+#ifndef R3N_TILED_HACK
+#define R3N_TILED_HACK 0  // TIMING experiment only (wrong images): the depth atlas addressed in 4 x 4 texel tiles of one 64-byte line each
+#endif
+template <bool DEPTH_ONLY>
+R3N_DEV uint32_t target_pixel(const RasterArgs &a, uint32_t x, uint32_t y) {
+#if R3N_TILED_HACK
+    if (DEPTH_ONLY) {
+        const uint32_t X = a.vp_x + x, Y = a.vp_y + y;
+        return ((__umul24(Y >> 2, a.target_pitch >> 2) + (X >> 2)) << 4) + ((Y & 3u) << 2) + (X & 3u);
+    }
+#endif
+    return __umul24(a.vp_y + y, a.target_pitch) + (a.vp_x + x);
+}
+
 template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (BLEND) {
@@ -263,7 +279,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
         }
         // rows and pitch are below 2^16 (r3n_frame_begin), the target below 2^29 samples: 24-bit multiply, 32-bit byte offsets
-        const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
+        const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
         const uint32_t zb = __float_as_uint(z);
 #if R3N_ABLATE == 2
         asm volatile("" : : "v"(zb), "v"(pix));
@@ -345,7 +361,7 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
     for (int i = 0; i < 3; ++i) E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
     const float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
     const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;  // accepted: [0, 1] or -0 (see shade_pixel_lean)
-    const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
+    const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
     unsigned long long save;
     typedef __attribute__((address_space(1))) void *gv_t;
 #define R3N_CMPX_CHAIN                                                                                             \
@@ -415,7 +431,7 @@ R3N_DEV void shade_pixel_lean(const RasterArgs &a, const TriWork &tw, int x, int
     ok = ok & (z >= 0.0f) & (z <= 1.0f);  // depth clip (unclipped_depth: false, forward.rs:343)
     // an accepted z is in [0, 1] or -0: clearing the sign bit canonicalises -0 and changes nothing else
     const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;
-    const uint32_t pix = __umul24(a.vp_y + (uint32_t)y, a.target_pitch) + (a.vp_x + (uint32_t)x);
+    const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
 #if R3N_ABLATE == 2
     asm volatile("" : : "v"(zb), "v"(pix), "v"(ok ? 1u : 0u));
     return;
@@ -449,11 +465,24 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 #ifndef R3N_BIG_XCD
 #define R3N_BIG_XCD 0
 #endif
+#ifndef R3N_BIG_TOUCH
+#define R3N_BIG_TOUCH 0  // the work-item kernel pulls the record after the next one into the local L2 with an unwaited vector load --
+                         // measured: no effect (shadow 81.6 -> 81.3 us per launch stand-alone, frame 1.017 -> 1.024 ms): the record's latency is
+                         // not what a wave's progress waits for once enough waves are resident; off
+#endif
 #ifndef R3N_SMALL_WATERFALL
 #define R3N_SMALL_WATERFALL 0  // per-triangle pass: object record + baked matrix through scalar loads, one round per distinct object of a wave -- measured SLOWER (viewport 22.9 -> 37.6 us, shadow 43.8 -> 45.9 us per launch): a wave's 64 entries span several objects often enough that the repeated setup rounds cost more than the gathers they replace
 #endif
 #ifndef R3N_ITEM_ALIGN
 #define R3N_ITEM_ALIGN 16  // (a power of two <= R3N_TILE; measured: viewport work items 84.7 -> 73.2 us, shadow 85.0 -> 80.8 us per launch)
+#endif
+#ifndef R3N_FINE_LW_DEPTH
+#define R3N_FINE_LW_DEPTH 3  // log2 of the fine block's width on a depth target (2: 4x4, 3: 8x2, 4: 16x1 texels).  Measured (shadow work items
+                             // per launch stand-alone / frame): 4x4 81.5 us / 1.025 ms, 8x2 74.0 / 1.003, 16x1 76.4 / 1.033 (fewest lines per
+                             // step, but more steps: partly covered blocks along every edge)
+#endif
+#ifndef R3N_FINE_LW_VIS
+#define R3N_FINE_LW_VIS 3    // the same on the key target (a line is 8 keys): 4x4 72.6 us / 1.025 ms, 8x2 66.4 / 1.001; both 8x2: 1.003
 #endif
 #ifndef R3N_FINE
 #define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block
@@ -461,8 +490,17 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
+#ifdef R3N_WAVE_TRACE
+// diagnostics build only (tools/wave_trace.py): per wave of the shadow views' per-triangle launches {start, after the setup
+// of the last round, end (100 MHz ticks), triangles set up, largest in-place box (texels), work items emitted}
+__device__ uint32_t g_small_trace[4][8192][6];
+#endif
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
 R3N_DEV void raster_small_body(const RasterArgs &a) {
+#ifdef R3N_WAVE_TRACE
+    const uint32_t st_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    uint32_t st_prep = st_t0, st_tris = 0, st_box = 0, st_items = 0;
+#endif
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
     const uint32_t n = a.sub_counts[a.key * R3N_SUBQ + q];
@@ -501,11 +539,17 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
         if (!prepare_triangle<DEPTH_ONLY, TEX>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
 #endif
+#ifdef R3N_WAVE_TRACE
+        st_prep = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        ++st_tris;
+        if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) st_box = max(st_box, (uint32_t)(bw * bh));
+        else st_items += (uint32_t)(((tw.x1 - (tw.x0 & ~(R3N_ITEM_ALIGN - 1)) + R3N_TILE) / R3N_TILE) * ((bh + (R3N_TILE - 1)) / R3N_TILE));
+#endif
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
                 for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
         } else {
-            // Work items start on a multiple of R3N_ITEM_ALIGN pixels in x: the scan's 4x4 / 8x8 blocks then sit on the target's
+            // Work items start on a multiple of R3N_ITEM_ALIGN pixels in x: the scan's blocks then sit on the target's
             // 64-byte lines (16 depth texels, 8 keys) instead of straddling them, and one atomic instruction touches fewer lines --
             // the work-item kernel is bound by the number of line-sized atomic requests a CU can have in flight to the memory
             // side (profiles/r04_summary.md).  The box only limits the scan: results are unchanged.
@@ -549,6 +593,22 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
             }
         }
     }
+#ifdef R3N_WAVE_TRACE
+    if (DEPTH_ONLY) {
+        // wave totals through the lanes: triangles and items summed, the box and the setup time as maxima
+        uint32_t tris = st_tris, box = st_box, items = st_items, prep = st_prep - st_t0;
+        for (int d = 32; d > 0; d >>= 1) {
+            tris += __shfl_xor(tris, d); items += __shfl_xor(items, d);
+            box = max(box, (uint32_t)__shfl_xor(box, d)); prep = max(prep, (uint32_t)__shfl_xor(prep, d));
+        }
+        const uint32_t wv = blockIdx.x * 4u + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63u) == 0u && wv < 8192u) {
+            const uint32_t quad = (a.vp_x ? 1u : 0u) + (a.vp_y ? 2u : 0u);
+            uint32_t *t = g_small_trace[quad][wv];
+            t[0] = st_t0; t[1] = st_t0 + prep; t[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); t[3] = tris; t[4] = box; t[5] = items;
+        }
+    }
+#endif
 }
 
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
@@ -639,11 +699,11 @@ __global__ __launch_bounds__(256) void k_blend_setup(RasterArgs a, BlendSetupArg
 // f32 operation is monotone, so evaluating the same expression at the extreme corner gives the exact maximum of
 // the per-pixel values: a block with a negative maximum holds no covered pixel.
 // MS: the evaluation points are the 4x sample positions, which span [0.125, 0.875] of a pixel in x and y.
-template <int S = 8, bool MS = false>
+template <int S = 8, bool MS = false, int SH = S>  // S x SH pixels
 R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry1) {
     const float lo = MS ? 0.125f : 0.5f, hi = MS ? 0.875f : 0.5f;
     const float x_lo = (float)bx + lo, x_hi = (float)min(bx + (S - 1), rx1) + hi;
-    const float y_lo = (float)by + lo, y_hi = (float)min(by + (S - 1), ry1) + hi;
+    const float y_lo = (float)by + lo, y_hi = (float)min(by + (SH - 1), ry1) + hi;
     bool may = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -727,14 +787,31 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         sptr_t sp = (sptr_t)(unsigned long long)rec;
         da = *reinterpret_cast<__attribute__((address_space(4))) const u32x16 *>(sp);
     }
+#if R3N_BIG_TOUCH
+    // The record of the item AFTER the next one is pulled into this XCD's L2 by a vector load nobody waits for (its result is
+    // never read): the records were written by the previous kernel on other XCDs, so a scalar load of one goes all the way to
+    // the memory side (~1.4 us, and scalar loads return out of order: only one can usefully be in flight); behind the touch it
+    // is an L2 hit.  A second scalar prefetch cannot do this: 64 SGPRs of records make the compiler spill the destinations of
+    // loads that are still in flight.  `touch` is an in/out operand of every statement, which keeps its register out of the
+    // allocator's hands for the whole loop (the load writes it whenever it returns).
+    uint32_t touch = 0u;
+    const uint32_t touch_off = (lane & 15u) << 2;
+    const uint32_t *nrec = rec ? locate(flat + nwaves) : nullptr;
+#endif
     while (rec) {
         // The next record's scalar loads stay in flight while this item is scanned (the records come from HBM /
         // Infinity Cache: without the overlap every item costs a full memory latency per wave).  hipcc sinks a
         // plain load to its first use, so the prefetch is an asm load it does not track; the matching wait
         // statement at the end of the iteration names both destinations (cdna_hip_programming.md section 5.7 (ii)).
         flat += nwaves;
+#if R3N_BIG_TOUCH
+        const uint32_t *trec = nrec ? locate(flat + nwaves) : nullptr;
+        if (nrec) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(na) : "s"(nrec) : "memory");
+        if (trec) asm volatile("global_load_dword %0, %1, %2" : "+v"(touch) : "v"(touch_off), "s"(trec) : "memory");
+#else
         const uint32_t *nrec = locate(flat);
         if (nrec) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(na) : "s"(nrec) : "memory");
+#endif
         uint32_t d[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = da[j];
@@ -790,17 +867,21 @@ R3N_DEV void raster_big_body(RasterArgs a) {
 #else
         if (R3N_FINE && rx1 - gx0 < 32 && ry1 - ry0 < 32) {
 #endif
-            // fine mode (regions up to 32x32 px): lane = 4x4 block for the rejection test; every step then scans
-            // FOUR surviving blocks, 16 lanes each -- small triangles fill the wave far better than with 8x8 blocks
-            const int cbx = gx0 + lx * 4, cby = ry0 + ly * 4;
-            const bool cand = cbx <= rx1 && cbx + 3 >= rx0 && cby <= ry1 && block_may_cover<4, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
+            // fine mode (regions up to 32x32 px): lane = 16-pixel block for the rejection test; every step then scans
+            // FOUR surviving blocks, 16 lanes each -- small triangles fill the wave far better than with 8x8 blocks.
+            // The block is FW x FH pixels (FW * FH = 16): the shape decides how many of the target's 64-byte lines one
+            // atomic instruction touches (a line is 16 depth texels / 8 keys of ONE row), which is what bounds this kernel.
+            constexpr int LW = DEPTH_ONLY ? R3N_FINE_LW_DEPTH : R3N_FINE_LW_VIS, FW = 1 << LW, FH = 16 >> LW, LC = 5 - LW;  // LC: log2 of the block columns
+            static_assert(LW >= 2 && LW <= 4, "blocks of 4x4, 8x2 or 16x1 pixels");
+            const int cbx = gx0 + (int)(lane & ((1u << LC) - 1u)) * FW, cby = ry0 + (int)(lane >> LC) * FH;
+            const bool cand = cbx <= rx1 && cbx + (FW - 1) >= rx0 && cby <= ry1 && block_may_cover<FW, (S > 1), FH>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
 #if R3N_ABLATE == 1
             asm volatile("" : : "s"(blocks));
             blocks = 0ull;
 #endif
             const uint32_t grp = lane >> 4;
-            const int px = (int)(lane & 3u), py = (int)((lane >> 2) & 3u);
+            const int px = (int)(lane & (uint32_t)(FW - 1)), py = (int)((lane & 15u) >> LW);
             if (R3N_BIG_LEAN && S == 1 && !BLEND && !w.cutout) {
                 while (blocks) {
 #ifdef R3N_WAVE_TRACE
@@ -816,8 +897,8 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                         : "=&s"(bsel[0]), "=&s"(bsel[1]), "=&s"(bsel[2]), "=&s"(bsel[3]), "+s"(blocks));
                     const uint32_t b = grp == 0u ? bsel[0] : (grp == 1u ? bsel[1] : (grp == 2u ? bsel[2] : bsel[3]));
                     int x, y;
-                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7u), "v"(gx0 + px));
-                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
+                    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(x) : "v"(b & ((1u << LC) - 1u)), "v"(gx0 + px), "n"(LW));
+                    asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(y) : "v"(b >> LC), "v"(ry0 + py), "n"(4 - LW));
 #if R3N_BIG_LEAN >= 2
                     shade_pixel_cmpx<DEPTH_ONLY, true>(a, w, x, y, b, rx0, rx1, ry1);
 #else
@@ -839,8 +920,8 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 // (field << 2) + base as ONE shift-add each (the compiler's canonical (b << 2) & 28 form costs an instruction
                 // more per coordinate and cannot be talked out of it)
                 int x, y;
-                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(x) : "v"(b & 7), "v"(gx0 + px));
-                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(y) : "v"(b >> 3), "v"(ry0 + py));
+                asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(x) : "v"(b & ((1 << LC) - 1)), "v"(gx0 + px), "n"(LW));
+                asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(y) : "v"(b >> LC), "v"(ry0 + py), "n"(4 - LW));
                 if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
         } else if (R3N_ABLATE != 3) {
@@ -878,7 +959,14 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na) : : "memory");
         rec = nrec;
         da = na;
+#if R3N_BIG_TOUCH
+        nrec = trec;
+        asm volatile("" : "+v"(touch));
+#endif
     }
+#if R3N_BIG_TOUCH
+    asm volatile("" : : "v"(touch));
+#endif
 #ifdef R3N_WAVE_TRACE
     if (DEPTH_ONLY && lane == 0u && wave_global < 32768u) {
         const uint32_t quad = (a.vp_x ? 1u : 0u) + (a.vp_y ? 2u : 0u);

@@ -2739,6 +2739,11 @@ extern "C" int r3n_debug_wave_trace(r3n_ctx *c, uint32_t *dst) {  // diagnostics
     HIP_TRY(c, hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), sizeof(uint32_t) * 4 * 32768 * 4));
     return R3N_OK;
 }
+extern "C" int r3n_debug_small_trace(r3n_ctx *c, uint32_t *dst) {  // dst: [4][8192][6]
+    TRY(sync_all(c));
+    HIP_TRY(c, hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_small_trace), sizeof(uint32_t) * 4 * 8192 * 6));
+    return R3N_OK;
+}
 #endif
 
 __global__ static void k_empty() {}
