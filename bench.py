@@ -211,6 +211,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    # R3N_BENCH_SHARE_GPU=1 (tests/test_bench_two_ranks.py on the one-GPU boxes): every rank on cuda:0, torch's collectives over gloo
+    # and the library's over the library R3N_RCCL_LIB names (RCCL refuses two ranks on one device) -- exercises this file's N > 1
+    # branches (cost-model probe, split choice, native exchanges, max-over-ranks timing); its numbers mean nothing
+    share_gpu = os.environ.get("R3N_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_exchange
@@ -226,7 +232,10 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     info = build_workload(args, r, r3.host, r3.material_record)
     view0 = info["camera"][0]
     ambient, clear = info["ambient"], info["clear"]

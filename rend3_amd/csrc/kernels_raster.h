@@ -508,12 +508,12 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
     // producer side of the work queue: the sub-queue is chosen per WAVE.  readfirstlane makes the counter address
     // provably wave-uniform, which is what lets the compiler fold a wave's appends into ONE atomic (with a
     // per-lane address every lane issues its own returning atomic -- measured 4x slower kernels)
-    const uint32_t bq = __builtin_amdgcn_readfirstlane((blockIdx.x * 4u + (threadIdx.x >> 6)) % R3N_BIGQ);
+    const uint32_t bq = __builtin_amdgcn_readfirstlane((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % R3N_BIGQ);
     const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
-    const uint32_t stride = (gridDim.x / R3N_SUBQ) * 256u;
+    const uint32_t stride = (gridDim.x / R3N_SUBQ) * blockDim.x;
 #if R3N_SMALL_WATERFALL
     // every lane of the workgroup walks the same number of rounds (the waterfall below needs whole waves); lanes past the end idle
-    for (uint32_t i0 = (blockIdx.x / R3N_SUBQ) * 256u; i0 < n; i0 += stride) {
+    for (uint32_t i0 = (blockIdx.x / R3N_SUBQ) * blockDim.x; i0 < n; i0 += stride) {
         const uint32_t i = i0 + threadIdx.x;
         const bool live = i < n;
         r3n_tri_ref ref;
@@ -533,7 +533,7 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
         if (!ok) continue;
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
 #else
-    for (uint32_t i = (blockIdx.x / R3N_SUBQ) * 256u + threadIdx.x; i < n; i += stride) {
+    for (uint32_t i = (blockIdx.x / R3N_SUBQ) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const r3n_tri_ref ref = list[i];
         TriWork tw;
         if (!prepare_triangle<DEPTH_ONLY, TEX>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
@@ -601,7 +601,7 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
             tris += __shfl_xor(tris, d); items += __shfl_xor(items, d);
             box = max(box, (uint32_t)__shfl_xor(box, d)); prep = max(prep, (uint32_t)__shfl_xor(prep, d));
         }
-        const uint32_t wv = blockIdx.x * 4u + (threadIdx.x >> 6);
+        const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63u) == 0u && wv < 8192u) {
             const uint32_t quad = (a.vp_x ? 1u : 0u) + (a.vp_y ? 2u : 0u);
             uint32_t *t = g_small_trace[quad][wv];
@@ -751,8 +751,8 @@ R3N_DEV void raster_big_body(RasterArgs a) {
     const uint32_t nwaves = ((gridDim.x + 7u - (blockIdx.x & 7u)) >> 3) * 4u;  // workgroups of this residue x 4 waves
 #else
     const uint32_t qgroup = 0u;
-    const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
 #endif
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t cap = a.big_capacity;

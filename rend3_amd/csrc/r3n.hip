@@ -1357,6 +1357,15 @@ int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t 
                            // then balances the uneven item costs (measured on the bench scene, shadow views:
                            // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
 #endif
+// Workgroup sizes of the two rasteriser kernels (neither uses LDS or barriers: a workgroup is only the unit in which wave slots are
+// handed back to the dispatcher -- a 4-wave workgroup holds all four until its slowest wave is done).  The grids below are quoted in
+// 256-thread workgroups and scaled at the launch.
+#ifndef R3N_SMALL_BLOCK
+#define R3N_SMALL_BLOCK 256
+#endif
+#ifndef R3N_BIG_BLOCK
+#define R3N_BIG_BLOCK 256
+#endif
 #ifndef R3N_SMALL_GRID
 #define R3N_SMALL_GRID 2048
 #endif
@@ -1797,8 +1806,8 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         // textured variant only where it can matter: cutout key and a non-empty texture array
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         auto launch = [&](auto small, auto big) {
-            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), R3N_VIEWPORT_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_VIEWPORT_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
         };
         if (c->samples == 4) {
             if (tex) launch(k_raster_small<false, 4, true>, k_raster_big<false, 4, true>);
@@ -1814,11 +1823,11 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         a.depth = c->atlas.as<uint32_t>();
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         if (tex) {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
         } else {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
         }
     }
     return check_launch(c, "raster");
