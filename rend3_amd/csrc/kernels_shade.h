@@ -95,6 +95,9 @@ struct ShadeArgs {
 #define R3N_FEAT_TEX_GENERAL  0x1000u // binds a texture outside the sampler's short path (set by the host's census, r3n.hip:
                                       // extent not a power of two, float pool texels, pool beyond 2^30 texels, id out of range)
 #define R3N_FEAT_ALL          0x1FFFu
+#ifndef R3N_BATCH_OCC
+#define R3N_BATCH_OCC 4  // waves per SIMD asked of the PBR class's kernel: its batched sampler holds 24 texels in flight (128 VGPRs)
+#endif
 #define R3N_CLS_PLAIN  0u
 #define R3N_CLS_ALBEDO (R3N_FEAT_TEX_ALBEDO)
 #define R3N_CLS_PBR3   (R3N_FEAT_TEX_ALBEDO | R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR)
@@ -600,14 +603,33 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 #else
     // (a class without TEX_GENERAL / NEAREST: every bound texture is on the sampler's short path -- the host's census says so)
     constexpr bool kShortOnly = (CLS & (R3N_FEAT_TEX_GENERAL | R3N_FEAT_NEAREST)) == 0u;
-    auto tex4 = [&](int slot, float dst[4]) { tex_sample_grad<M, true, kShortOnly>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
-    auto tex3 = [&](int slot, float dst[4]) { tex_sample_grad<M, false, kShortOnly>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst); };
+    // classes that can bind more than one map: the maps share level of detail and footprints where their extents allow (texture.h TexShare)
+    constexpr bool kShare = R3N_TEX_SHARE && kShortOnly && (CLS & (R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR)) != 0u;
+    TexShare tshare;
+    tshare.width = 0u; tshare.height = 0u; tshare.mips = 0u; tshare.level = 0u; tshare.frac = 0.0f;
+    auto tex4 = [&](int slot, float dst[4]) { tex_sample_grad<M, true, kShortOnly, kShare>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst, &tshare); };
+    auto tex3 = [&](int slot, float dst[4]) { tex_sample_grad<M, false, kShortOnly, kShare>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst, &tshare); };
 #endif
     auto has = [&](int slot) { return TEX && (CLS & kSlotFeat[slot]) != 0u && mat.textures[slot] != 0u; };
+    // the PBR class (base colour + normal + AO / roughness / metallic maps, nothing else): its three maps in one batched pass
+    constexpr bool kBatch = R3N_TEX_BATCH && TEX && kShortOnly && CLS == R3N_CLS_PBR3 && (R3N_SHADE_ABLATE == 0);
+    float tb3[3][4];
+    bool batched = false;
+    if (kBatch && any_tex) {
+        const uint32_t ids[3] = {mat.textures[0], mat.textures[1], mat.textures[2]};
+        batched = tex_sample3_batched<M>(a.tex, ids, coords[0], coords[1], ddx, ddy, tb3);  // (wave-uniform)
+    }
+    auto tex_slot012 = [&](int slot, float dst[4], bool need_a) {
+        if (kBatch && batched) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[c] = tb3[slot][c];
+        } else if (need_a) tex4(slot, dst);
+        else tex3(slot, dst);
+    };
     if (!kAlbedoOff || (mflags & R3N_FLAGS_ALBEDO_ACTIVE)) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) px.albedo[c] = 1.0f;
-        if (has(0)) tex4(0, px.albedo);
+        if (has(0)) tex_slot012(0, px.albedo, true);
         if (kVColor && (mflags & R3N_FLAGS_ALBEDO_BLEND)) {
             if (mflags & R3N_FLAGS_ALBEDO_VERTEX_SRGB) {
 #pragma unroll
@@ -635,7 +657,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         // --- normal (opaque.wgsl:246-273)
         if (has(1) && !(R3N_SHADE_ABLATE & 16)) {
             float t[4], n[3];
-            tex4(1, t);
+            tex_slot012(1, t, true);
             if (kNormalFlags && (mflags & R3N_FLAGS_BICOMPONENT_NORMAL)) {
                 float b0 = (mflags & R3N_FLAGS_SWIZZLED_NORMAL) ? t[3] : t[0], b1 = t[1];  // texture_read.ag : .rg
                 b0 = M::mad(b0, 2.0f, -1.0f);
@@ -665,7 +687,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         if (!kSplit || (mflags & R3N_FLAGS_AOMR_COMBINED)) {  // (!kSplit: a bound slot 2 implies the combined layout)
             if (has(2)) {
                 float t[4];
-                tex3(2, t);
+                tex_slot012(2, t, false);
                 ao = mat.ambient_occlusion * t[0];
                 pr = mat.roughness * t[1];
                 metallic = mat.metallic * t[2];
@@ -902,7 +924,7 @@ static __global__ __launch_bounds__(256) void k_stage_view_lights(ShadeArgs a, V
 // (R3N_CLS_*).  With more than one variant in flight (a.variants) a workgroup first ORs its pixels' features and leaves
 // unless the tile is its own: the smallest launched variant that covers the tile.
 template <int S, bool TEX, bool REC = false, bool SPLIT = false, bool FAST = false, uint32_t CLS = R3N_CLS_ALL, uint32_t VARIANT = 3u>
-__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? R3N_TEX_OCC : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? ((R3N_TEX_BATCH && CLS == R3N_CLS_PBR3) ? R3N_BATCH_OCC : R3N_TEX_OCC) : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
     typedef typename std::conditional<FAST, MathFast, MathExact>::type M;
     static_assert(CLS == R3N_CLS_ALL || (S == 1 && REC), "material classes exist for the single-sample record-based resolve");
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];

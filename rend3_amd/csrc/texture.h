@@ -34,6 +34,9 @@ struct TextureArgs {
     const float4 *texels_f;       // R3N_TEXEL_FLOAT: the RGBA8 texels of the pool decoded once, at upload (same index: texel i of the
                                   // pool = texels_f[i]; the same values the tables give), or null
 };
+#ifndef R3N_TEX_SHARE
+#define R3N_TEX_SHARE 1  // the maps of a material share level of detail and footprints when their levels have the same extents (TexShare)
+#endif
 #ifndef R3N_TEXEL_FLOAT
 #define R3N_TEXEL_FLOAT 0  // experiment: the short-path samplers of the resolve's material classes read pre-decoded float4 texels
 #endif
@@ -194,6 +197,30 @@ R3N_DEV bool tex_level_fast(uint32_t w, uint32_t h, uint32_t base, float u, floa
     }
     return tame;
 }
+// The same footprint with the texel indices RELATIVE to the level's first texel: what two maps of one material share when their
+// levels have the same extents (tex_sample_grad's `share`).  Total like tex_level_fast<true>.
+struct TexLvlRel {
+    uint32_t r00, r10, r01, r11;
+    float fx, fy;
+};
+R3N_DEV void tex_level_rel(uint32_t w, uint32_t h, float u, float v, TexLvlRel &l) {
+    TexLvlFast f;
+    (void)tex_level_fast<true>(w, h, 0u, u, v, f);
+    l.r00 = f.o00 >> 2; l.r10 = f.o10 >> 2; l.r01 = f.o01 >> 2; l.r11 = f.o11 >> 2;
+    l.fx = f.fx; l.fy = f.fy;
+}
+// What a sample of the short path derives from (extent, mip count, coordinates, gradients) alone.  A material's maps are sampled at
+// the same coordinates with the same gradients (opaque.wgsl:207-215), so a second map of the same extent -- or of HALF the extent
+// with one level less, whose levels are the first map's levels from 1 on -- has the same footprints and the same blend fraction:
+// with W' = W / 2 every product of the level-of-detail arithmetic is exactly halved (powers of two; the squares of operands small
+// enough to round differently vanish in both), the correctly rounded sqrt of a quarter is the half, so rho' = rho / 2 bit for bit:
+// level' = level - 1 for level >= 1, the same mantissa, the same clamp (level' >= mips' - 1 <=> level >= mips - 1).
+struct TexShare {
+    uint32_t width, height, mips;  // of the map the entry was computed for; width == 0: empty
+    uint32_t level;
+    float frac;
+    TexLvlRel l0, l1;              // l1 only when frac > 0
+};
 // SRGB_SEL: 0 / 1 = the colour channels' decode table is known here (the unorm table at t.decode, the sRGB one 256 entries
 // further): its offset then folds into the LDS read's immediate and a channel's address is ONE instruction (a byte-select shift);
 // -1 = per-lane table pointer `rgb` (an extract and a shift-or per channel).
@@ -239,11 +266,59 @@ R3N_DEV Texel4 tex_bilinear_fast(const TextureArgs &t, const float *__restrict__
 // footprint stays live across the whole fragment stage and costs an occupancy step.)
 // SHORT_ONLY: the caller knows that the short path's conditions hold for this texture (the resolve's material classes,
 // kernels_shade.h R3N_FEAT_TEX_GENERAL): no general path is instantiated.
-template <class M = MathExact, bool NEED_A = true, bool SHORT_ONLY = false>
+template <class M = MathExact, bool NEED_A = true, bool SHORT_ONLY = false, bool SHARE = false>
 R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, float u, float v, const float ddx[2],
-                             const float ddy[2], float o[4]) {
+                             const float ddy[2], float o[4], TexShare *share = nullptr) {
     if (id == 0u || (!SHORT_ONLY && id > t.count)) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const r3n_texture_desc32 d = t.descs[id - 1u];
+#if R3N_TEX_SHARE
+    if (SHORT_ONLY && SHARE) {
+        // 0: same extents and mip count as the entry; 1: half the extents, one level less, and the entry's level >= 1
+        const bool same = share->width == d.width && share->height == d.height && share->mips == d.mips;
+        const bool half = share->width == d.width << 1 && share->height == d.height << 1 && share->mips == d.mips + 1u && share->level >= 1u && d.width != 0u;
+        if (!(same || half)) {
+            const float W = (float)d.width, H = (float)d.height;
+            const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
+            const float rho = exact_math::sqrt(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
+            uint32_t level = 0;
+            float frac = 0.0f;
+            if (rho > 1.0f && rho < INFINITY) {
+                const uint32_t bits = __float_as_uint(rho);
+                level = (bits >> 23) - 127u;
+                frac = (float)(bits & 0x7FFFFFu) / 8388608.0f;
+            } else if (rho == INFINITY) {
+                level = d.mips;
+            }
+            if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
+            share->width = d.width; share->height = d.height; share->mips = d.mips;
+            share->level = level; share->frac = frac;
+            tex_level_rel(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), u, v, share->l0);
+            if (frac > 0.0f) tex_level_rel(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), u, v, share->l1);
+        }
+        const uint32_t level = share->level - ((!same && half) ? 1u : 0u);
+        const float frac = share->frac;
+        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
+        const float *rgb = t.decode + (d.format == 1u ? 256 : 0);
+        const bool two = frac > 0.0f;
+        const uint32_t b0 = lo[level];
+        TexLvlFast l0, l1;
+        l0.o00 = (b0 + share->l0.r00) << 2; l0.o10 = (b0 + share->l0.r10) << 2; l0.o01 = (b0 + share->l0.r01) << 2; l0.o11 = (b0 + share->l0.r11) << 2;
+        l0.fx = share->l0.fx; l0.fy = share->l0.fy;
+        Texel4 r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
+        if (two) {
+            const uint32_t b1 = lo[level + 1u];
+            l1.o00 = (b1 + share->l1.r00) << 2; l1.o10 = (b1 + share->l1.r10) << 2; l1.o01 = (b1 + share->l1.r01) << 2; l1.o11 = (b1 + share->l1.r11) << 2;
+            l1.fx = share->l1.fx; l1.fy = share->l1.fy;
+            const Texel4 hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
+            const float omf = 1.0f - frac;
+            r.rg = mix2<M>(r.rg, hi.rg, frac, omf);
+            if (NEED_A) r.ba = mix2<M>(r.ba, hi.ba, frac, omf);
+            else r.ba.x = M::mad(hi.ba.x, frac, r.ba.x * omf);
+        }
+        o[0] = r.rg.x; o[1] = r.rg.y; o[2] = r.ba.x; o[3] = r.ba.y;
+        return;
+    }
+#endif
     const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
     if (SHORT_ONLY || (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT)) {
         // level of detail exactly as tex_footprint derives it
@@ -301,6 +376,158 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
     tex_footprint(d, nearest, u, v, ddx, ddy, f);
     const Texel4 r = tex_apply<M, NEED_A>(t, d, f);
     o[0] = r.rg.x; o[1] = r.rg.y; o[2] = r.ba.x; o[3] = r.ba.y;
+}
+
+// The three maps of a material (albedo, normal, AO / roughness / metallic: opaque.wgsl:207-351 samples them at the same coordinates
+// with the same gradients) in ONE pass whose memory operations go out in three batches -- the descriptors; the level offsets; the
+// (up to 24) texels -- instead of three dependent chains of descriptor -> level offset -> texels, one behind the other: the resolve is
+// bound by the LENGTH of its chain of dependent memory round trips at five waves per SIMD, not by instruction issue
+// (profiles/r04_summary.md: 8 % fewer vector instructions moved its time by 1 %).
+// Works on maps whose levels have the extents of the largest map's levels: the same extents and mip count, or half the extents with
+// one level less (TexShare: the level of detail is then the largest map's, shifted by one).  Returns false -- for the whole
+// wavefront, having done nothing -- when some lane binds a map that is neither; the caller samples one by one then.
+// Every bound id is on the sampler's short path (SHORT_ONLY's contract).  out[k] of an unbound slot (id 0) is zero.
+#ifndef R3N_TEX_BATCH
+#define R3N_TEX_BATCH 1
+#endif
+template <class M>
+R3N_DEV bool tex_sample3_batched(const TextureArgs &t, const uint32_t id[3], float u, float v, const float ddx[2], const float ddy[2],
+                                 float out[3][4]) {
+    bool present[3];
+    uint32_t w[3], h[3], mips[3], fmt[3];
+    const uint32_t *lo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        present[k] = id[k] != 0u;
+        const uint32_t idx = present[k] ? id[k] - 1u : 0u;   // (an unbound slot reads entry 0: valid memory, result unused)
+        const uint4 dw = *reinterpret_cast<const uint4 *>(&t.descs[idx]);  // offset, width, height, mips
+        w[k] = dw.y; h[k] = dw.z; mips[k] = dw.w;
+        fmt[k] = t.descs[idx].format;
+        lo[k] = t.level_off + (size_t)idx * R3N_TEX_LEVELS;
+    }
+    // the reference map: the widest bound one
+    uint32_t W = 0u, H = 0u, MI = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (present[k] && w[k] > W) { W = w[k]; H = h[k]; MI = mips[k]; }
+    bool ok = true, any_half = false, half[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool same = w[k] == W && h[k] == H && mips[k] == MI;
+        half[k] = present[k] && !same && (w[k] << 1) == W && (h[k] << 1) == H && mips[k] + 1u == MI;
+        ok = ok && (!present[k] || same || half[k]);
+        any_half = any_half || half[k];
+    }
+    if (!__all(ok)) return false;
+    // level of detail and footprints of the reference map, exactly as tex_sample_grad's short path derives them
+    uint32_t level = 0;
+    float frac = 0.0f;
+    {
+        const float Wf = (float)W, Hf = (float)H;
+        const float ax = ddx[0] * Wf, ay = ddx[1] * Hf, bx = ddy[0] * Wf, by = ddy[1] * Hf;
+        const float rho = exact_math::sqrt(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
+        if (rho > 1.0f && rho < INFINITY) {
+            const uint32_t bits = __float_as_uint(rho);
+            level = (bits >> 23) - 127u;
+            frac = (float)(bits & 0x7FFFFFu) / 8388608.0f;
+        } else if (rho == INFINITY) {
+            level = MI;
+        }
+        if (MI != 0u && level >= MI - 1u) { level = MI - 1u; frac = 0.0f; }
+    }
+    // f0: the footprint at the reference's level `level`, f1: at `level + 1` -- needed by a second level (frac > 0) and by a
+    // half-size map when level == 0 (its level 0 has the extents of the reference's level 1; rho / 2 <= 1 there: one level, no blend)
+    TexLvlRel f0, f1;
+    tex_level_rel(tex_mip_dim(W, level), tex_mip_dim(H, level), u, v, f0);
+    const bool need1 = frac > 0.0f || (any_half && level == 0u);
+    f1 = f0;
+    if (need1) tex_level_rel(tex_mip_dim(W, level + 1u), tex_mip_dim(H, level + 1u), u, v, f1);
+    // per map: its first level (with the footprint that level has), whether it blends a second one
+    uint32_t la[3], ba[3], bb[3];
+    bool first_is_f1[3], two[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        first_is_f1[k] = half[k] && level == 0u;
+        la[k] = half[k] ? (level == 0u ? 0u : level - 1u) : level;
+        two[k] = frac > 0.0f && !first_is_f1[k];
+    }
+    // batch 2: the level offsets
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // both offsets with ONE 8-byte load (dword-aligned) whether or not a second level is blended: fetched only where needed, the
+        // second one is a round trip of its own in front of the second level's texels (the compiler sinks a separate load under the
+        // condition).  The pair starts at the first level, or one before it at the table's last entry.
+        struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+        const uint32_t pb = la[k] + 1u < R3N_TEX_LEVELS ? la[k] : la[k] - 1u;
+        const Pair pr = *reinterpret_cast<const Pair *>(lo[k] + pb);
+        ba[k] = pb == la[k] ? pr.a : pr.b;
+        bb[k] = two[k] ? pr.b : ba[k];  // (two[k]: la + 1 <= mips - 1 < R3N_TEX_LEVELS, so pb == la)
+    }
+    // batch 3: the texels (byte offsets from the uniform pool pointer: the pool holds < 2^30 texels on the short path)
+    uint32_t ta[3][4], tb[3][4];
+    const char *pool = reinterpret_cast<const char *>(t.texels);
+    const bool any_two = __any(frac > 0.0f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const TexLvlRel &fa = first_is_f1[k] ? f1 : f0;
+        ta[k][0] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r00) << 2));
+        ta[k][1] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r10) << 2));
+        ta[k][2] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r01) << 2));
+        ta[k][3] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r11) << 2));
+    }
+    // (the second level's byte offsets are formed out here, in front of the wave-uniform branch: that is what puts the loads of their
+    // level offsets into batch 2 instead of a round trip of their own inside the branch)
+    uint32_t ob[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // (lanes without a second level read their first level's texels again)
+        const TexLvlRel &fb = two[k] ? f1 : (first_is_f1[k] ? f1 : f0);
+        ob[k][0] = (bb[k] + fb.r00) << 2; ob[k][1] = (bb[k] + fb.r10) << 2; ob[k][2] = (bb[k] + fb.r01) << 2; ob[k][3] = (bb[k] + fb.r11) << 2;
+    }
+    asm volatile("" : : "v"(ob[0][0]), "v"(ob[1][0]), "v"(ob[2][0]));
+    if (any_two) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tb[k][j] = *reinterpret_cast<const uint32_t *>(pool + ob[k][j]);
+    }
+    // decode + filter: the expressions of tex_texel_at / tex_bilinear_fast / tex_sample_grad
+    auto decode = [&](uint32_t word, const float *tab, bool need_a) {
+        Texel4 o;
+        o.rg = (f2){tab[word & 0xFFu], tab[(word >> 8) & 0xFFu]};
+        o.ba = (f2){tab[(word >> 16) & 0xFFu], need_a ? t.decode[word >> 24] : 0.0f};
+        return o;
+    };
+    auto bilinear = [&](const uint32_t q[4], const float *tab, bool need_a, const TexLvlRel &f) {
+        const Texel4 c00 = decode(q[0], tab, need_a), c10 = decode(q[1], tab, need_a), c01 = decode(q[2], tab, need_a), c11 = decode(q[3], tab, need_a);
+        const float omx = 1.0f - f.fx, omy = 1.0f - f.fy;
+        Texel4 o;
+        o.rg = mix2<M>(mix2<M>(c00.rg, c10.rg, f.fx, omx), mix2<M>(c01.rg, c11.rg, f.fx, omx), f.fy, omy);
+        if (need_a) {
+            o.ba = mix2<M>(mix2<M>(c00.ba, c10.ba, f.fx, omx), mix2<M>(c01.ba, c11.ba, f.fx, omx), f.fy, omy);
+        } else {
+            const float top = M::mad(c10.ba.x, f.fx, c00.ba.x * omx), bot = M::mad(c11.ba.x, f.fx, c01.ba.x * omx);
+            o.ba = (f2){M::mad(bot, f.fy, top * omy), 0.0f};
+        }
+        return o;
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool need_a = k != 2;  // albedo and the normal map are read with all four channels (tex4), slot 2 with three (tex3)
+        const float *tab = t.decode + (fmt[k] == 1u ? 256 : 0);
+        Texel4 r = bilinear(ta[k], tab, need_a, first_is_f1[k] ? f1 : f0);
+        if (any_two) {
+            const Texel4 hi = bilinear(tb[k], tab, need_a, f1);
+            if (two[k]) {
+                const float omf = 1.0f - frac;
+                r.rg = mix2<M>(r.rg, hi.rg, frac, omf);
+                if (need_a) r.ba = mix2<M>(r.ba, hi.ba, frac, omf);
+                else r.ba.x = M::mad(hi.ba.x, frac, r.ba.x * omf);
+            }
+        }
+        out[k][0] = present[k] ? r.rg.x : 0.0f; out[k][1] = present[k] ? r.rg.y : 0.0f;
+        out[k][2] = present[k] ? r.ba.x : 0.0f; out[k][3] = present[k] ? r.ba.y : 0.0f;
+    }
+    return true;
 }
 
 // vertex_attributes.wgsl: vec2<f32> texture coordinates (attribute 3); a missing attribute reads (0, 0)
