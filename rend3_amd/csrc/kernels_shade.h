@@ -305,12 +305,70 @@ R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t
 #endif
 }
 
+// The same lookup in two halves, for the light loop that issues the texel loads of several lights before it consumes any
+// (fragment_stage, R3N_LIGHT_GROUP): pcf5_issue derives what shadow_pcf5 derives in front of its loads and issues them,
+// pcf5_finish is what follows them.  Same expressions, same order.
+struct Pcf5Texels {
+    struct __attribute__((packed, aligned(4))) T2 { float v[2]; };
+    struct __attribute__((packed, aligned(4))) T4 { float v[4]; };
+    T2 r0, r3;
+    T4 r1, r2;
+    float fx0, fxp, fxm, fy0, fyp, fym;
+    bool regular;
+};
+R3N_DEV void pcf5_issue(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, Pcf5Texels &p) {
+    const float tx0 = u * (float)aw - 0.5f, ty0 = v * (float)ah - 0.5f;
+    const float txp = tx0 + 1.0f, txm = tx0 + -1.0f, typ = ty0 + 1.0f, tym = ty0 + -1.0f;
+    const float f0x = floorf(tx0), fpx = floorf(txp), fmx = floorf(txm);
+    const float f0y = floorf(ty0), fpy = floorf(typ), fmy = floorf(tym);
+    p.regular = fpx == f0x + 1.0f && fmx == f0x - 1.0f && fpy == f0y + 1.0f && fmy == f0y - 1.0f &&
+                f0x >= 1.0f && f0x <= (float)aw - 3.0f && f0y >= 1.0f && f0y <= (float)ah - 3.0f &&
+                ((unsigned long long)aw * ah <= (1ull << 30));
+    p.fx0 = tx0 - f0x; p.fxp = txp - fpx; p.fxm = txm - fmx;
+    p.fy0 = ty0 - f0y; p.fyp = typ - fpy; p.fym = tym - fmy;
+    if (p.regular) {
+        const uint32_t row = aw << 2;
+        const uint32_t base = (__umul24((uint32_t)(int)f0y - 1u, aw) + ((uint32_t)(int)f0x - 1u)) << 2;
+        const char *ap = reinterpret_cast<const char *>(atlas);
+        p.r0 = *reinterpret_cast<const Pcf5Texels::T2 *>(ap + (base + 4u));
+        p.r1 = *reinterpret_cast<const Pcf5Texels::T4 *>(ap + (base + row));
+        p.r2 = *reinterpret_cast<const Pcf5Texels::T4 *>(ap + (base + 2u * row));
+        p.r3 = *reinterpret_cast<const Pcf5Texels::T2 *>(ap + (base + 3u * row + 4u));
+    }
+}
+template <class M>
+R3N_DEV float pcf5_finish(const Pcf5Texels &p, float ref) {  // (p.regular)
+    const bool c01 = ref >= p.r0.v[0], c02 = ref >= p.r0.v[1];
+    const bool c10 = ref >= p.r1.v[0], c11 = ref >= p.r1.v[1], c12 = ref >= p.r1.v[2], c13 = ref >= p.r1.v[3];
+    const bool c20 = ref >= p.r2.v[0], c21 = ref >= p.r2.v[1], c22 = ref >= p.r2.v[2], c23 = ref >= p.r2.v[3];
+    const bool c31 = ref >= p.r3.v[0], c32 = ref >= p.r3.v[1];
+    auto tapb = [&](bool a, bool b, bool c, bool d, float fx, float fy) {
+        const float omx = 1.0f - fx;
+        const f2 tb = (f2){b ? fx : 0.0f, d ? fx : 0.0f} + (f2){a ? omx : 0.0f, c ? omx : 0.0f};
+        return M::mad(tb.y, fy, tb.x * (1.0f - fy));
+    };
+    float r = 0.0f;
+    r = r + tapb(c11, c12, c21, c22, p.fx0, p.fy0);  // ( 0,  0)
+    r = r + tapb(c21, c22, c31, c32, p.fx0, p.fyp);  // ( 0, +1)
+    r = r + tapb(c01, c02, c11, c12, p.fx0, p.fym);  // ( 0, -1)
+    r = r + tapb(c12, c13, c22, c23, p.fxp, p.fy0);  // (+1,  0)
+    r = r + tapb(c10, c11, c20, c21, p.fxm, p.fy0);  // (-1,  0)
+    return r * 0.2f;
+}
+
 struct PixelData {
     float albedo[4], diffuse[3], roughness, normal[3], f0[3], emissive[3], ao;
 };
 
 #define R3N_PI 3.14159265359f
 
+#ifndef R3N_LIGHT_GROUP_ALL
+#define R3N_LIGHT_GROUP_ALL 0  // 1: every record-based single-sample kernel groups its lights (and asks for four waves per SIMD), not only the PBR class's
+#endif
+#ifndef R3N_LIGHT_GROUP
+#define R3N_LIGHT_GROUP 1  // directional lights whose shadow texel loads are in flight together (1: one by one).  Measured: 2 -- resolve
+                           // 461.0 vs 460.6 us stand-alone, frame 1.007-1.017 vs 0.986-0.998 ms; 4 -- 624 us (three waves per SIMD): off
+#endif
 #ifndef R3N_BRDF_HOIST
 #define R3N_BRDF_HOIST 1
 #endif
@@ -773,6 +831,68 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 #else
         const BrdfPixel *pre = nullptr;
 #endif
+#if R3N_LIGHT_GROUP > 1 && R3N_PCF_WIDE && !R3N_SHADE_ABLATE
+        // (the kernels that hold a group's texels need the register budget of four waves per SIMD: k_resolve_opaque's launch bound)
+        if constexpr (SL && (CLS == R3N_CLS_PBR3 || R3N_LIGHT_GROUP_ALL)) {
+            // The directional lights in groups of R3N_LIGHT_GROUP: first every light of the group gets as far as its shadow texel
+            // loads (all of them in flight together), then each is finished and shaded in order -- the same values summed in the same
+            // order as the one-by-one loop below; what changes is that a group costs one round trip to the atlas instead of one per
+            // light (the resolve is bound by the length of its chain of dependent memory round trips).
+            for (uint32_t i0 = 0; i0 < n_dir; i0 += R3N_LIGHT_GROUP) {
+                Pcf5Texels pt[R3N_LIGHT_GROUP];
+                float pref[R3N_LIGHT_GROUP], pu[R3N_LIGHT_GROUP], pv[R3N_LIGHT_GROUP];
+                bool lit[R3N_LIGHT_GROUP], sampled[R3N_LIGHT_GROUP];
+#pragma unroll
+                for (uint32_t j = 0; j < R3N_LIGHT_GROUP; ++j) {
+                    lit[j] = false; sampled[j] = false; pref[j] = 0.0f; pu[j] = 0.0f; pv[j] = 0.0f; pt[j].regular = false;
+                    if (i0 + j >= n_dir) continue;  // (wave-uniform)
+                    const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i0 + j);
+                    const float nl_raw = dot3m<M>(px.normal, L.l);
+                    if (px.roughness > 0.0f && nl_raw == nl_raw && sat(nl_raw) == 0.0f) continue;
+                    lit[j] = true;
+                    float sn[4];
+                    mul_vec4m<MathExact>(L.m, vpos[0], vpos[1], vpos[2], vpos[3], sn);
+                    const float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
+                    const float local[2] = {fl[0], 1.0f - fl[1]};
+                    float tl[2] = {L.offset[0], L.offset[1]};
+                    float tr[2] = {tl[0] + L.size[0], tl[1] + L.size[1]};
+                    const float coords[2] = {tl[0] * (1.0f - local[0]) + tr[0] * local[0],
+                                             tl[1] * (1.0f - local[1]) + tr[1] * local[1]};
+                    const float border[2] = {L.inv_res[0] * 1.5f, L.inv_res[1] * 1.5f};
+                    tl[0] += border[0]; tl[1] += border[1];
+                    tr[0] -= border[0]; tr[1] -= border[1];
+                    pref[j] = sn[2]; pu[j] = coords[0]; pv[j] = coords[1];
+                    if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f) {
+                        sampled[j] = true;
+                        pcf5_issue(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], pt[j]);
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < R3N_LIGHT_GROUP; ++j) {
+                    if (i0 + j >= n_dir) continue;
+                    if (!lit[j]) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) color[c] += 0.0f;
+                        continue;
+                    }
+                    const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i0 + j);
+                    float shadow = 1.0f;
+                    if (sampled[j]) shadow = pt[j].regular ? pcf5_finish<M>(pt[j], pref[j]) : shadow_pcf5_general<M>(a.atlas, a.atlas_w, a.atlas_h, pu[j], pv[j], pref[j]);
+#if R3N_SKIP_OCCLUDED
+                    if (skip_ok && L.sane != 0.0f && shadow * px.ao == 0.0f) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) color[c] += 0.0f;
+                        continue;
+                    }
+#endif
+                    float res[3];
+                    surface_shading<M>(L.l, L.color, px, vv, shadow * px.ao, res, pre);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) color[c] += res[c];
+                }
+            }
+        } else
+#endif
         for (uint32_t i = 0; i < ((R3N_SHADE_ABLATE & 8) ? 0u : n_dir); ++i) {
             const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i);
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
@@ -924,7 +1044,7 @@ static __global__ __launch_bounds__(256) void k_stage_view_lights(ShadeArgs a, V
 // (R3N_CLS_*).  With more than one variant in flight (a.variants) a workgroup first ORs its pixels' features and leaves
 // unless the tile is its own: the smallest launched variant that covers the tile.
 template <int S, bool TEX, bool REC = false, bool SPLIT = false, bool FAST = false, uint32_t CLS = R3N_CLS_ALL, uint32_t VARIANT = 3u>
-__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? ((R3N_TEX_BATCH && CLS == R3N_CLS_PBR3) ? R3N_BATCH_OCC : R3N_TEX_OCC) : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
+__global__ __launch_bounds__(256, (S == 1 && REC && R3N_LIGHT_GROUP > 1 && R3N_LIGHT_GROUP_ALL) ? R3N_BATCH_OCC : ((S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? ((R3N_TEX_BATCH && CLS == R3N_CLS_PBR3) ? R3N_BATCH_OCC : R3N_TEX_OCC) : R3N_MS_OCC) : 1))) void k_resolve_opaque(ShadeArgs a) {
     typedef typename std::conditional<FAST, MathFast, MathExact>::type M;
     static_assert(CLS == R3N_CLS_ALL || (S == 1 && REC), "material classes exist for the single-sample record-based resolve");
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
@@ -949,6 +1069,13 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? ((R3N_
     const bool inside = x < a.width && y < a.row_end;
     const size_t pix = inside ? (size_t)y * a.width + x : 0u;
     uint32_t id1 = 0u;  // S == 1: the pixel's triangle (canonical slot + 1), 0 = background
+#ifdef R3N_RESOLVE_VGPR_PAD
+    // experiment: naming a high vector register as clobbered raises the kernel's register count, i.e. lowers its waves per SIMD,
+    // without touching its code (-DR3N_RESOLVE_VGPR_PAD=v135: 136 registers = three waves)
+#define R3N_STR2(x) #x
+#define R3N_STR(x) R3N_STR2(x)
+    if (S == 1 && REC) asm volatile("" : : : R3N_STR(R3N_RESOLVE_VGPR_PAD));
+#endif
     if (S == 1) {
         id1 = inside ? (uint32_t)(a.vis[pix] & 0xFFFFFFFFull) : 0u;
         if (REC && (a.variants & (a.variants - 1u)) != 0u) {  // (launch-uniform) several variants run: is this tile mine?
