@@ -1809,11 +1809,14 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
             { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
             { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_VIEWPORT_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
         };
+        const bool nocut = key != R3N_KEY_CUTOUT;  // the opaque key's instantiations carry nothing of the cutout test (kernels_raster.h NOCUT)
         if (c->samples == 4) {
             if (tex) launch(k_raster_small<false, 4, true>, k_raster_big<false, 4, true>);
+            else if (nocut) launch(k_raster_small<false, 4, false, true>, k_raster_big<false, 4, false, false, true>);
             else launch(k_raster_small<false, 4, false>, k_raster_big<false, 4, false>);
         } else {
             if (tex) launch(k_raster_small<false, 1, true>, k_raster_big<false, 1, true>);
+            else if (nocut) launch(k_raster_small<false, 1, false, true>, k_raster_big<false, 1, false, false, true>);
             else launch(k_raster_small<false, 1, false>, k_raster_big<false, 1, false>);
         }
     } else {
@@ -1825,6 +1828,9 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         if (tex) {
             { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
             { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
+        } else if (key != R3N_KEY_CUTOUT) {
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false, true>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false, false, true>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
         } else {
             { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
             { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
