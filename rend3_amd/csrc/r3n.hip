@@ -67,11 +67,14 @@ std::string g_create_error;
 // idle waves hold slots the resolve of the previous frame could use.  54 KB (2 workgroups): 622 us.  The same cap on the viewport's
 // launches, on the per-triangle pass and on the triangle cull was measured: no gain alone, and any two caps together lose (kernels
 // that each reserve a third of a CU's LDS no longer co-reside).
+// Round 4, with the resolve at four waves per SIMD and the slimmer per-triangle pass beside them: the cap pays on the viewport's
+// launches too, and three workgroups per CU beat four -- frame (same box, two runs each): shadow 32 KB / viewport none 0.982-0.993 ms;
+// 32 / 32 0.968-0.972; 48 / 32 0.961 (0.935 on another box against 0.968); 48 / 48 0.940; 64 / 48 (two workgroups) 1.061; no cap 1.049.
 #ifndef R3N_BIG_LDS
-#define R3N_BIG_LDS 32768       // shadow views
+#define R3N_BIG_LDS 49152       // shadow views
 #endif
 #ifndef R3N_VIEWPORT_BIG_LDS
-#define R3N_VIEWPORT_BIG_LDS 0  // viewport
+#define R3N_VIEWPORT_BIG_LDS 49152  // viewport
 #endif
 static_assert(R3N_AUX_STREAMS >= 1 && R3N_AUX_STREAMS <= R3N_QLANES, "every auxiliary stream (shadow lane) needs a work queue of its own: big_items / big_count / big_uv hold 1 + R3N_QLANES");
 
