@@ -32,10 +32,11 @@ R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-for
 python $root/tools/exact_math_probe.py > "$out/exact_math.txt" 2>&1
 cd "$root"
 bash tools/gpu_pmc.sh "$tag/pmc" > "$out/pmc_table.txt" 2>&1
-bash tools/gpu_r4.sh "$tag/stall" pmc_raster > "$out/pmc_raster.txt" 2>&1
 # the headline line LAST, quoting the counter traffic of THIS build (bench.py refuses traffic.json of other kernel sources)
 [ -f "$out/pmc/traffic.json" ] && cp "$out/pmc/traffic.json" "$root/profiles/traffic.json"
 $B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"
+# the rasterisers' stall / memory-side counter sets (eleven more passes) after the headline line: the part a short GPU budget may cut
+[ "${SKIP_STALL:-0}" = 1 ] || bash tools/gpu_r4.sh "$tag/stall" pmc_raster > "$out/pmc_raster.txt" 2>&1
 find "$out" -name "*_kernel_trace.csv" -size +8M -delete
 find "$out" -name "*counter_collection.csv" -size +8M -delete
 ls "$out"
