@@ -1,0 +1,49 @@
+"""CPU: bench.py's cost model for the multi-GPU split (split_model: replicated cull / setup against exchanged bytes over xGMI),
+fed with the stage tables of the committed single-GPU lines of the two workloads it has to tell apart: BASELINE.json configs[2]
+(3 000 objects: the replicated cull is cheap, sort-first rows win) and configs[3] (1 048 576 objects: north_star's object-range
+split has to come out from four ranks on).  VERDICT r3 item 4: "configs[3] must come out as object-range"."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _line(name):
+    with open(os.path.join(ROOT, "profiles", name)) as fh:
+        return json.load(fh)
+
+
+def _model(line, world):
+    import bench
+    return bench.split_model(line["stage_ms_per_frame"], line["stage_launches_per_frame"], world, 3840, 2160, 1, line["config"]["cameras"] - 1)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_configs2_choose_rows(world):
+    m = _model(_line("r04_bench.json"), world)
+    assert m["choice"] == "rows", m
+    assert m["rows_ms"] < m["objects_ms"]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_configs3_choose_objects(world):
+    m = _model(_line("r04_bench_cfg4.json"), world)
+    assert m["choice"] == "objects", m
+    assert m["objects_ms"] <= m["rows_ms"] and m["predicted_speedup"]["objects"] >= m["predicted_speedup"]["rows"] > 1.0  # (a tie at four ranks)
+
+
+def test_model_is_monotone_in_the_work_it_divides():
+    """More ranks never make the divided work of either split larger; the single-GPU figure is the sum of its inputs."""
+    line = _line("r04_bench_cfg4.json")
+    prev = None
+    for world in (1, 2, 4, 8):
+        m = _model(line, world)
+        if world == 1:
+            assert abs(m["rows_ms"] - m["single_gpu_ms"]) < 1e-3 and abs(m["objects_ms"] - m["single_gpu_ms"]) < 1e-3, m
+        if prev is not None and world > 2:  # (from 1 to 2 ranks the exchange terms appear)
+            assert m["objects_ms"] < prev["objects_ms"] and m["rows_ms"] < prev["rows_ms"]
+        prev = m
