@@ -485,7 +485,7 @@ def main():
         # section 5: ">= 16 B / shaded pixel") + 4 B for the Rgba8UnormSrgb blit fused into it.  VALU-bound, not HBM-bound, so its
         # fraction of the HBM roofline is small by construction; `valu` says how close it is to its own bound.
         roofline_of("k_resolve_opaque", "shade", 20.0 * WIDTH * HEIGHT / world, "k_resolve_opaque",
-                    f"8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; VALU-bound: {cameras - 1} lights x "
+                    f"8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; per pixel: {cameras - 1} lights x "
                     "(5-tap PCF + GGX)" + ("" if args.untextured else ", 3 trilinear maps, tangent frame"))
         # the resolve is bound by vector issue, not by HBM: its roofline is the f32 vector peak, `frac` = useful flops (add + mul +
         # 2 x fma + transcendental lane-ops, SQ_INSTS_VALU_*_F32 passes) / launch time / 157.3 TFLOP/s; the HBM figure stays beside it
@@ -495,7 +495,11 @@ def main():
                        "achieved": rs["valu"]["useful_tflops"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": rs["valu"]["useful_frac_of_vector_peak"],
                        "frac_note": "useful f32 flops / vector peak; every vector instruction counted as one lane-op gives valu.issue_frac_of_vector_peak "
-                                    "(0.25 is the ceiling of unpacked, unfused f32 code), the ALUs are busy valu.busy of the launch"})
+                                    "(0.25 is the ceiling of unpacked, unfused f32 code), the ALUs are busy valu.busy of the launch",
+                       "limiter": "measured (profiles/r04_summary.md section 6b): neither roofline binds -- 8 % fewer vector instructions moved "
+                                  "the launch by 1 %; its time is the length of a wave's chain of dependent memory round trips (key -> "
+                                  "record -> material -> descriptors -> level offsets -> texels -> one shadow lookup per light) at four "
+                                  "waves per SIMD.  `bound` keeps the label of the nearer roofline (the HBM figure is `frac_hbm`)"})
         else:
             rs["bound_note"] = "VALU-bound kernel (no PMC pass of these sources on record: only the HBM figure can be quoted)"
         dominant = max(rooflines, key=lambda st: stage_ms[st])
