@@ -750,6 +750,58 @@ def test_textured_scene_multi_frame(r3, handedness, samples):
         compare_frames(fo, fp, f"textured scene frame {f}")
 
 
+def test_pbr_class_map_extents(r3):
+    """The PBR class's batched three-map sampler (texture.h tex_sample3_batched: base colour + normal + AO / roughness / metallic
+    maps, plain flags) over every relation of the maps' extents it distinguishes -- the same extents, half the extents with one
+    level less (the level of detail of the largest map shifted by one; at level 0 the smaller map's footprint is the larger's
+    level 1), a map missing, the SMALLER map first in slot order -- and over extents it declines (a quarter, a rectangle against a
+    square, a short mip chain: the whole wavefront then samples one map at a time); one map per surface is magnified, the far ones
+    minified down to their last levels.  Keys, atlas and HDR bit-identical to the oracle, two frames."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    rng = np.random.default_rng(0x3A7)
+
+    def build(r, mk):
+        def tex(w, h, srgb, mips="maximum"):
+            img = np.random.default_rng(w * 131 + h * 7 + int(srgb)).integers(0, 256, (h, w, 4), dtype=np.uint8)
+            return r.add_texture_2d(img, srgb=srgb, mip_count=mips, mip_source="generated")
+        a64, n64, o64 = tex(64, 64, True), tex(64, 64, False), tex(64, 64, False)
+        o32, n32, o16 = tex(32, 32, False), tex(32, 32, False), tex(16, 16, False)
+        a128x32, a64short = tex(128, 32, True), tex(64, 64, True, mips=3)
+        combos = [(a64, n64, o64), (a64, n64, o32), (a64, n32, o32), (a64, n64, None), (None, n64, o32), (a64, None, o32),
+                  (a64, n64, o16), (a128x32, n64, o32), (a64short, n64, o32), (a64, n32, o64)]
+        mats = []
+        for (ta, tn, to) in combos:
+            kw = dict(roughness=0.6, metallic=0.3)
+            if ta is not None:
+                kw.update(albedo_mode="texture", albedo_texture=ta)
+            else:
+                kw.update(albedo=(0.8, 0.7, 0.6, 1.0), albedo_mode="value")
+            if tn is not None:
+                kw.update(normal_texture=tn)
+            if to is not None:
+                kw.update(aomr=("combined", to))
+            mats.append(r.add_material(mk(**kw)))
+        pq = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=f32)
+        iq = np.array([0, 2, 1, 0, 3, 2], dtype=np.uint32)
+        nq = np.tile(np.array([[0, 1, 0]], dtype=f32), (4, 1))
+        uv = np.array([[0, 0], [3, 0], [3, 3], [0, 3]], dtype=f32)
+        quad = r.add_mesh(pq, iq, normals=nq, uv0=uv, tangents=scenes._tangents(nq))
+        for k, m in enumerate(mats):  # a row of long strips running away from the camera: magnified near, minified far
+            r.add_object(quad, m, oh.mat4_mul(oh.translation((-9.0 + 2.0 * k, 0.0, 30.0)), oh.scale((0.95, 1.0, 32.0))))
+        r.add_directional_light(color=(1, 1, 1), intensity=3.0, direction=(0.3, -2.0, 0.4), distance=60.0, resolution=256)
+
+    build(o, omk)
+    build(p, r3.material_record)
+    for f in range(2):
+        eye = (0.5 * f, 1.2 + 0.8 * f, -2.5)
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh(eye, (0.0, 0.0, 20.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        fo = o.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        fp = p.render(320, 192, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+        compare_frames(fo, fp, f"pbr class extents frame {f}")
+    assert (fo["vis"] != 0).mean() > 0.3  # the strips fill a good part of the frame
+
+
 def test_generated_mip_chains_match_oracle(r3):
     """MipmapSource::Generated (rend3/src/util/mipmap.rs:139-236 + mipmap.wgsl, K11): the chain the library builds on the
     GPU at upload (Linear / ClampToEdge blit per level in the texture's own format; sRGB levels decoded, filtered and
