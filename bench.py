@@ -52,9 +52,9 @@ def compare_frames(fo, fp, fast=False):
     framebuffer is measured.  Same checks as tests/test_gpu_parity.py::compare_frames."""
     import numpy as np
     n = len(fo["pass"])
-    enabled = fo["objects"][:, 29] != 0
+    baked_slots = (fo["objects"][:, 29] != 0) & fo["visible"].astype(bool)  # the slots whose matrices are read (frustum-visible)
     out = {
-        "baked_matrices_equal": bool(np.array_equal(fo["baked"].view(np.uint32)[enabled], fp["baked"].view(np.uint32)[enabled])),
+        "baked_matrices_equal": bool(np.array_equal(fo["baked"].view(np.uint32)[baked_slots], fp["baked"].view(np.uint32)[baked_slots])),
         "visible_objects_differ": int((fo["visible"] != fp["visible"]).sum()),
         "pass_triangles_differ": int((fo["pass"] != fp["pass"][:n]).sum()),
         "residual_triangles_differ": int((fo["residual"] != fp["residual"][:n]).sum()),

@@ -108,7 +108,14 @@ impl GpuCuller {
     ) {
         let mut node = graph.add_node(name);
         node.add_side_effect();
-        node.build(move |_ctx| {
+        node.build(move |ctx| {
+            // culler.rs:705-707: the same early return as the bake node above -- with no object buffer the bake did not run this
+            // frame, and r3n_cull refuses (R3N_ERR_STATE) a camera whose header belongs to an earlier frame
+            let max_object_count = ctx.data_core.object_manager.buffer::<M>().map(wgpu::Buffer::size).unwrap_or(0)
+                / <rend3::managers::ShaderObject<M> as encase::ShaderSize>::SHADER_SIZE.get();
+            if max_object_count == 0 {
+                return;
+            }
             self.amd.check(unsafe { sys::r3n_cull(self.amd.ctx, camera_specifier.to_shader_index()) }, "r3n_cull");
         });
     }

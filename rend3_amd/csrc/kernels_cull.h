@@ -66,43 +66,87 @@ R3N_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
+// Structure-of-arrays view of what the object pass reads of an object (BASELINE.json north_star: "object transforms, bounding
+// spheres, material data ... live in HBM as structure-of-arrays").  rend3's 128-byte record (object.rs:23-36) stays the INPUT
+// contract of r3n_objects_write and the layout of the kernels that want a whole record; the object pass -- one thread per object
+// slot of the whole world, per camera -- reads 20 coalesced bytes per slot instead of four fields out of its own 128-byte line:
+//   spheres[i] = world-space bounding sphere (centre.xyz, radius)                      object.rs:30-31
+//   meta[i]    = (enabled ? index_count / 3 : 0) | Material::key() of its material << 30   object.rs:33,36; pbr/material.rs:497-499
+// r3n_objects_write scatters both beside the record; r3n_materials_write refreshes the key bits (r3n.hip refresh_obj_meta).
+struct ObjSoA {
+    const float4 *__restrict__ spheres;
+    const uint32_t *__restrict__ meta;
+};
+#define R3N_META_NTRI_MASK 0x3FFFFFFFu
+#define R3N_META_KEY_SHIFT 30u
+
+// batching.rs:146 + frustum.rs:148-161 on one object of the SoA view.  Two bits, the byte a camera's vis_flags holds per slot:
+//   R3N_VIS_INSIDE  the object has triangles and its sphere passes the frustum test -- whoever owns it.  This frame's and last
+//                   frame's bit decide which slots the chained pass bakes (k_object_pass_chained): a rank also RESOLVES pixels of
+//                   objects other ranks drew (their keys arrive through the exchange), and the resolve reads model_view;
+//   R3N_VIS_DRAWN   ... and this rank culls and draws it: the reference's visible set (L1).  Multi-rank sharding: a rank owns the
+//                   opaque / cutout objects of its slot range; blend-key objects are culled and drawn by every rank (ordered
+//                   blending cannot be merged by the MAX reduce of the depth keys).
+#define R3N_VIS_DRAWN 1u
+#define R3N_VIS_INSIDE 2u
+R3N_DEV uint32_t object_visible(const r3n_camera_header240 *__restrict__ hdr, const ObjOwn &own, uint32_t i, uint32_t meta, const float4 sph) {
+    const uint32_t ntri = meta & R3N_META_NTRI_MASK, key0 = meta >> R3N_META_KEY_SHIFT;
+    if (ntri == 0u) return 0u;
+    const float c[3] = {sph.x, sph.y, sph.z};
+    const float neg_radius = -sph.w;
+    bool inside = true;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
+        inside = inside && (d >= neg_radius);
+    }
+    if (!inside) return 0u;
+    return R3N_VIS_INSIDE | ((obj_owned(own, i) || key0 == 2u) ? R3N_VIS_DRAWN : 0u);
+}
+
+// first_entry[k] = the work-list entry that owns wave slot k * R3N_CHUNK_ITERS: where a wavefront of k_triangle_cull starts
+// (it replaces the reference's per-invocation binary search, cull.wgsl:181-207, and this implementation's former 12-step scalar
+// search per chunk).  Entry e owns wave slots [ws, ws + nw); it writes every k with ws <= k * R3N_CHUNK_ITERS < ws + nw: up to
+// eight stores by its own thread, larger objects by the whole wavefront.  Called convergently (ballot + lane reads inside).
+#ifndef R3N_CHUNK_ITERS
+#define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
+#endif
+R3N_DEV void write_first_entries(uint32_t *__restrict__ first_entry, uint32_t flag, uint32_t e, uint32_t ws, uint32_t nw, uint32_t lane) {
+    if (first_entry == nullptr) return;
+    uint32_t k_lo = 0u, cnt = 0u;
+    if (flag && nw) {
+        k_lo = (ws + R3N_CHUNK_ITERS - 1u) / R3N_CHUNK_ITERS;
+        const uint32_t k_end = (ws + nw - 1u) / R3N_CHUNK_ITERS + 1u;
+        cnt = k_end > k_lo ? k_end - k_lo : 0u;
+    }
+    if (cnt <= 8u)  // (objects of up to 2 048 triangles: a short divergent loop of stores)
+        for (uint32_t k = 0; k < cnt; ++k) first_entry[k_lo + k] = e;
+    unsigned long long big = __ballot(cnt > 8u);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1ull;
+        // (l is wave-uniform: v_readlane, not a ds_bpermute round trip per value)
+        const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)k_lo, l), bc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l),
+                       be = (uint32_t)__builtin_amdgcn_readlane((int)e, l);
+        for (uint32_t k = lane; k < bc; k += 64u) first_entry[bk + k] = be;
+    }
+}
+
 // Pass A: frustum test (batching.rs:146, frustum.rs:148-161) + per-block totals.
-R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
-                                const uint8_t *__restrict__ material_keys, uint32_t n_materials, ObjOwn own,
+R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, ObjSoA soa, ObjOwn own,
                                 uint8_t *__restrict__ vis_flags, ObjBlockSums *__restrict__ block_sums) {
     __shared__ uint32_t red[4][6];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t cap = hdr->object_count;
     uint32_t flag = 0, ntri_all = 0, ntri_vis = 0, key = 0;
     if (i < cap) {
-        const r3n_object128 *o = &objects[i];
-        const uint32_t enabled = o->enabled;
-        const uint32_t ntri = enabled ? o->index_count / 3u : 0u;
-        ntri_all = ntri;
-        const uint32_t mi0 = o->material_index;
-        uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
-        if (key0 > 2u) key0 = 2u;
-        // multi-rank sharding: a rank owns the opaque / cutout objects of its slot range; blend-key objects are culled and
-        // drawn by every rank (ordered blending cannot be merged by the MAX reduce of the depth keys)
-        if (ntri > 0u && (obj_owned(own, i) || key0 == 2u)) {
-            const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
-            const float c[3] = {sph.x, sph.y, sph.z};
-            const float neg_radius = -sph.w;
-            bool inside = true;
-#pragma unroll
-            for (int p = 0; p < 5; ++p) {
-                const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
-                inside = inside && (d >= neg_radius);
-            }
-            flag = inside ? 1u : 0u;
-        }
-        if (flag) {
-            ntri_vis = ntri;
-            const uint32_t mi = o->material_index;
-            key = mi < n_materials ? material_keys[mi] : 0u;
-            if (key > 2u) key = 2u;
-        }
-        vis_flags[i] = (uint8_t)flag;
+        const uint32_t meta = soa.meta[i];
+        const float4 sph = soa.spheres[i];
+        ntri_all = meta & R3N_META_NTRI_MASK;
+        const uint32_t bits = object_visible(hdr, own, i, meta, sph);
+        flag = bits & R3N_VIS_DRAWN;
+        if (flag) { ntri_vis = ntri_all; key = meta >> R3N_META_KEY_SHIFT; }
+        vis_flags[i] = (uint8_t)bits;
     }
     uint32_t vals[6] = {flag, flag ? (ntri_vis + 63u) / 64u : 0u, ntri_all, key == 0u ? ntri_vis : 0u,
                         key == 1u ? ntri_vis : 0u, key == 2u ? ntri_vis : 0u};
@@ -120,12 +164,10 @@ R3N_DEV void object_count_body(const r3n_camera_header240 *__restrict__ hdr, con
         dst[k] = s;
     }
 }
-__global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240 *__restrict__ hdr,
-                                                      const r3n_object128 *__restrict__ objects,
-                                                      const uint8_t *__restrict__ material_keys, uint32_t n_materials,
+__global__ __launch_bounds__(256) void k_object_count(const r3n_camera_header240 *__restrict__ hdr, ObjSoA soa,
                                                       ObjOwn own, uint8_t *__restrict__ vis_flags,
                                                       ObjBlockSums *__restrict__ block_sums) {
-    object_count_body(hdr, objects, material_keys, n_materials, own, vis_flags, block_sums);
+    object_count_body(hdr, soa, own, vis_flags, block_sums);
 }
 
 struct ObjBlockOffsets {
@@ -243,17 +285,17 @@ __global__ __launch_bounds__(1024) void k_object_scan(const ObjBlockSums *__rest
 // Pass C: scatter visible objects into the work list (object-slot order => deterministic layout).
 // slot_base[i] = first triangle slot of object i in this frame's result bitmask, or INVALID when the object
 // was not batched (== "not in current_invocation_map", batching.rs:226,230).  tri_base[i] = canonical base.
-R3N_DEV void object_scatter_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
+R3N_DEV void object_scatter_body(const r3n_camera_header240 *__restrict__ hdr, ObjSoA soa,
                                   const uint8_t *__restrict__ vis_flags, const ObjBlockOffsets *__restrict__ block_off,
                                   r3n_vis_entry *__restrict__ vis_list, uint32_t *__restrict__ slot_base,
-                                  uint32_t *__restrict__ tri_base) {
+                                  uint32_t *__restrict__ tri_base, uint32_t *__restrict__ first_entry) {
     __shared__ uint32_t wtot[4][3];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t cap = hdr->object_count;
     uint32_t flag = 0, nw = 0, ntri = 0;
     if (i < cap) {
-        flag = vis_flags[i];
-        ntri = objects[i].enabled ? objects[i].index_count / 3u : 0u;
+        flag = vis_flags[i] & R3N_VIS_DRAWN;
+        ntri = soa.meta[i] & R3N_META_NTRI_MASK;
         nw = flag ? (ntri + 63u) / 64u : 0u;
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -264,8 +306,8 @@ R3N_DEV void object_scatter_body(const r3n_camera_header240 *__restrict__ hdr, c
     __syncthreads();
     uint32_t p0 = block_off[blockIdx.x].visible, p1 = block_off[blockIdx.x].waves, p2 = block_off[blockIdx.x].tris_all;
     for (uint32_t w = 0; w < wave; ++w) { p0 += wtot[w][0]; p1 += wtot[w][1]; p2 += wtot[w][2]; }
+    const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
     if (i < cap) {
-        const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
         if (flag) {
             vis_list[e].object = i;
             vis_list[e].wave_start = ws;
@@ -273,15 +315,15 @@ R3N_DEV void object_scatter_body(const r3n_camera_header240 *__restrict__ hdr, c
         slot_base[i] = flag ? ws * 64u : R3N_INVALID;
         if (tri_base != nullptr) tri_base[i] = p2 + s2 - ntri;
     }
+    write_first_entries(first_entry, flag, e, ws, nw, lane);
 }
-__global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header240 *__restrict__ hdr,
-                                                        const r3n_object128 *__restrict__ objects,
+__global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header240 *__restrict__ hdr, ObjSoA soa,
                                                         const uint8_t *__restrict__ vis_flags,
                                                         const ObjBlockOffsets *__restrict__ block_off,
                                                         r3n_vis_entry *__restrict__ vis_list,
                                                         uint32_t *__restrict__ slot_base,
-                                                        uint32_t *__restrict__ tri_base) {
-    object_scatter_body(hdr, objects, vis_flags, block_off, vis_list, slot_base, tri_base);
+                                                        uint32_t *__restrict__ tri_base, uint32_t *__restrict__ first_entry) {
+    object_scatter_body(hdr, soa, vis_flags, block_off, vis_list, slot_base, tri_base, first_entry);
 }
 
 // The three passes above in ONE single-block launch, for worlds of up to R3N_FUSED_OBJECT_PASS_MAX object slots: the block
@@ -290,11 +332,11 @@ __global__ __launch_bounds__(256) void k_object_scatter(const r3n_camera_header2
 // scene (4096 slots, four rounds of dependent record loads in one block): 23 us per camera against 14 us for the three
 // launches, so the limit is one round; the small scenes of the tests and examples run through it.
 #define R3N_FUSED_OBJECT_PASS_MAX 1024u
-R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr, const r3n_object128 *__restrict__ objects,
-                                    const uint8_t *__restrict__ material_keys, uint32_t n_materials, ObjOwn own,
+R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr, ObjSoA soa, ObjOwn own,
                                     uint8_t *__restrict__ vis_flags, r3n_cull_counts *__restrict__ counts,
                                     r3n_vis_entry *__restrict__ vis_list, r3n_sub_counts *__restrict__ sub_counts,
-                                    uint32_t *__restrict__ slot_base, uint32_t *__restrict__ tri_base) {
+                                    uint32_t *__restrict__ slot_base, uint32_t *__restrict__ tri_base,
+                                    uint32_t *__restrict__ first_entry) {
     __shared__ uint32_t wtot[16][3];
     __shared__ uint32_t carry[3];
     __shared__ uint32_t ktot[3];
@@ -308,36 +350,24 @@ R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr
         const uint32_t i = base + t;
         uint32_t flag = 0, ntri = 0, nw = 0;
         if (i < cap) {
-            const r3n_object128 *o = &objects[i];
-            ntri = o->enabled ? o->index_count / 3u : 0u;
-            const uint32_t mi0 = o->material_index;
-            uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
-            if (key0 > 2u) key0 = 2u;
-            if (ntri > 0u && (obj_owned(own, i) || key0 == 2u)) {  // (see object_count_body)
-                const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
-                const float c[3] = {sph.x, sph.y, sph.z};
-                const float neg_radius = -sph.w;
-                bool inside = true;
-#pragma unroll
-                for (int p = 0; p < 5; ++p) {
-                    const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
-                    inside = inside && (d >= neg_radius);
-                }
-                flag = inside ? 1u : 0u;
-            }
+            const uint32_t meta = soa.meta[i];
+            const float4 sph = soa.spheres[i];
+            ntri = meta & R3N_META_NTRI_MASK;
+            const uint32_t bits = object_visible(hdr, own, i, meta, sph);
+            flag = bits & R3N_VIS_DRAWN;
             if (flag) {
                 nw = (ntri + 63u) / 64u;
-                kacc[key0] += ntri;
+                kacc[meta >> R3N_META_KEY_SHIFT] += ntri;
             }
-            vis_flags[i] = (uint8_t)flag;
+            vis_flags[i] = (uint8_t)bits;
         }
         const uint32_t s0 = wave_inclusive_scan(flag, lane), s1 = wave_inclusive_scan(nw, lane), s2 = wave_inclusive_scan(ntri, lane);
         if (lane == 63u) { wtot[wave][0] = s0; wtot[wave][1] = s1; wtot[wave][2] = s2; }
         __syncthreads();
         uint32_t p0 = carry[0], p1 = carry[1], p2 = carry[2];
         for (uint32_t w = 0; w < wave; ++w) { p0 += wtot[w][0]; p1 += wtot[w][1]; p2 += wtot[w][2]; }
+        const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
         if (i < cap) {
-            const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
             if (flag) {
                 vis_list[e].object = i;
                 vis_list[e].wave_start = ws;
@@ -345,6 +375,7 @@ R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr
             slot_base[i] = flag ? ws * 64u : R3N_INVALID;
             if (tri_base != nullptr) tri_base[i] = p2 + s2 - ntri;
         }
+        write_first_entries(first_entry, flag, e, ws, nw, lane);
         __syncthreads();  // everyone has read carry / wtot
         if (t == 1023u) { carry[0] = p0 + s0; carry[1] = p1 + s1; carry[2] = p2 + s2; }
         __syncthreads();
@@ -367,87 +398,104 @@ R3N_DEV void object_pass_fused_body(const r3n_camera_header240 *__restrict__ hdr
         vis_list[carry[0]].wave_start = carry[1];
     }
 }
-__global__ __launch_bounds__(1024) void k_object_pass_fused(const r3n_camera_header240 *__restrict__ hdr,
-                                                            const r3n_object128 *__restrict__ objects,
-                                                            const uint8_t *__restrict__ material_keys, uint32_t n_materials,
+__global__ __launch_bounds__(1024) void k_object_pass_fused(const r3n_camera_header240 *__restrict__ hdr, ObjSoA soa,
                                                             ObjOwn own, uint8_t *__restrict__ vis_flags,
                                                             r3n_cull_counts *__restrict__ counts, r3n_vis_entry *__restrict__ vis_list,
                                                             r3n_sub_counts *__restrict__ sub_counts, uint32_t *__restrict__ slot_base,
-                                                            uint32_t *__restrict__ tri_base) {
-    object_pass_fused_body(hdr, objects, material_keys, n_materials, own, vis_flags, counts, vis_list, sub_counts,
-                           slot_base, tri_base);
+                                                            uint32_t *__restrict__ tri_base, uint32_t *__restrict__ first_entry) {
+    object_pass_fused_body(hdr, soa, own, vis_flags, counts, vis_list, sub_counts, slot_base, tri_base, first_entry);
 }
 
-// Uniform bake + the three object passes in ONE multi-block launch (r3n_render_frame's path): a block bakes and counts its 256
-// object slots, PUBLISHES its six totals, reads the totals of every block in front of it (the exclusive prefix it needs;
-// agent-scope atomics: the L2 of another XCD is not coherent for plain loads; no fences: every published word carries the
-// launch's epoch) and scatters.  The last block also writes the
-// totals.  Same outputs bit for bit as k_object_count / k_object_scan / k_object_scatter (slot order either way).  Records carry
-// the launch's epoch as their tag, so nothing has to be cleared between launches.  A block waits only for blocks with LOWER
-// indices; the host uses this form up to R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS blocks (all resident at once) and the three
-// launches beyond.  Per camera and frame this is 1 launch instead of 4: the launches were 5-6 us each on the GPU, three of them on
-// the viewport's serial chain between Hi-Z and the triangle cull, and ~3 us each on the host.
+// Uniform bake + the three object passes in ONE multi-block launch (r3n_render_frame's path).  A block owns `rounds` x 256
+// consecutive object slots:
+//   phase 1  per round: 20 B of the SoA view per slot (four rounds' loads in flight together), frustum test, the wave's visible
+//            bits / bake bits / triangle counts into LDS, running totals;
+//   publish  the block's six totals; read the totals of every block in front (the exclusive prefix it needs; agent-scope atomics:
+//            the L2 of another XCD is not coherent for plain loads; no fences: every published word carries the launch's epoch);
+//   phase 3  per round and wave, without a barrier: list entry + slot base + first-entry table, and the UNIFORM BAKE
+//            (uniform_prep.wgsl:9-27) of the slots that need one.
+// Same lists bit for bit as k_object_count / k_object_scan / k_object_scatter (slot order either way).  A block waits only for
+// blocks with LOWER indices; the host keeps the grid at R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS blocks at most (more rounds per block
+// instead: every block reads every record in front of it) and falls back to the three launches beyond
+// MAX_BLOCKS x MAX_ROUNDS x 256 slots.  Per camera and frame this is 1 launch instead of 4.
+//
+// Which slots are baked: the reference bakes every enabled slot of the buffer (uniform_prep.wgsl:15-20) -- 196 B per slot and
+// camera, the largest stream of the front end on a million-object world -- but a baked matrix is read only through a triangle
+// list: this frame's lists hold objects that pass the frustum test now, last frame's predicted list (drawn in this frame's first
+// pass WITH THIS FRAME'S MATRICES, forward.rs:224-232) objects that passed it then.  So: R3N_VIS_INSIDE now, or
+// (viewport camera) in the byte the camera's previous object pass left in vis_flags -- the frustum bit, not the drawn bit: under
+// a multi-rank split the resolve also reads the matrices of objects other ranks drew.  Every matrix any kernel reads is the
+// reference's, the rest keep whatever they held (the `baked` parity tap compares the frustum-visible slots).
 #define R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS 512u
+#define R3N_CHAINED_OBJECT_PASS_MAX_ROUNDS 16u
 struct ObjChainRec {
     unsigned long long v[6];  // epoch of the launch that wrote it << 32 | visible, waves, tris_all, key_tris[3]: every word validates
                               // itself, so publishing needs no release fence (an agent-scope release is a write-back of the XCD's
                               // whole L2 on this part: measured 1 ms for 8 160 of them in a Hi-Z experiment)
     unsigned long long _pad[2];
 };
+struct ObjChainArgs {
+    const r3n_camera_header240 *__restrict__ hdr;
+    ObjSoA soa;
+    const r3n_object128 *__restrict__ objects;   // transforms of the slots that are baked
+    ObjOwn own;
+    uint8_t *__restrict__ vis_flags;
+    ObjChainRec *chain;
+    uint32_t epoch, rounds;
+    r3n_cull_counts *__restrict__ counts;
+    r3n_vis_entry *__restrict__ vis_list;
+    r3n_sub_counts *__restrict__ sub_counts;
+    uint32_t *__restrict__ slot_base;
+    uint32_t use_prev;                            // viewport camera with history: vis_flags still holds last frame's bytes
+    r3n_baked128 *__restrict__ baked;
+    uint32_t *__restrict__ first_entry;
+};
 template <bool BAKE>
-__global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_header240 *__restrict__ hdr,
-                                                             const r3n_object128 *__restrict__ objects,
-                                                             const uint8_t *__restrict__ material_keys, uint32_t n_materials,
-                                                             ObjOwn own, uint8_t *__restrict__ vis_flags,
-                                                             ObjChainRec *chain, uint32_t epoch, r3n_cull_counts *__restrict__ counts,
-                                                             r3n_vis_entry *__restrict__ vis_list, r3n_sub_counts *__restrict__ sub_counts,
-                                                             uint32_t *__restrict__ slot_base, r3n_baked128 *__restrict__ baked) {
+__global__ __launch_bounds__(256) void k_object_pass_chained(ObjChainArgs a) {
     __shared__ uint32_t red[4][6];
     __shared__ uint32_t pre[6];
-    __shared__ uint32_t wtot[4][2];
+    __shared__ unsigned long long s_vis[R3N_CHAINED_OBJECT_PASS_MAX_ROUNDS][4], s_need[R3N_CHAINED_OBJECT_PASS_MAX_ROUNDS][4];
+    __shared__ uint32_t s_ntri[R3N_CHAINED_OBJECT_PASS_MAX_ROUNDS][256];
+    __shared__ uint32_t s_wt[R3N_CHAINED_OBJECT_PASS_MAX_ROUNDS * 4u][2];  // per (round, wave): visible objects, wave slots -> their exclusive prefix
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
-    const uint32_t cap = hdr->object_count;
-    if (blockIdx.x == 0u && t < 2u * 3u * R3N_SUBQ) (&sub_counts->n[0][0][0])[t] = 0u;  // culler.rs:642 + cull.wgsl:47-61
-    if (BAKE) {  // uniform_prep.wgsl:9-27 for this block's 256 slots: thread (slot, column), four rounds of 64 slots
+    const uint32_t cap = a.hdr->object_count, rounds = a.rounds;
+    const uint32_t first = blockIdx.x * rounds * 256u;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    if (blockIdx.x == 0u && t < 2u * 3u * R3N_SUBQ) (&a.sub_counts->n[0][0][0])[t] = 0u;  // culler.rs:642 + cull.wgsl:47-61
+    // ---- phase 1: count (object_count_body)
+    uint32_t vals[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 4u) {
+        uint32_t meta[4], prev[4];
+        float4 sph[4];
 #pragma unroll
-        for (uint32_t r = 0; r < 4u; ++r) {
-            const uint32_t obj = blockIdx.x * 256u + r * 64u + (t >> 2), c = t & 3u;
-            if (obj < cap && objects[obj].enabled != 0u) {
-                const float4 col = reinterpret_cast<const float4 *>(objects[obj].transform)[c];
-                float mv[4], mvp[4];
-                mul_vec4(hdr->view, col.x, col.y, col.z, col.w, mv);
-                mul_vec4(hdr->view_proj, col.x, col.y, col.z, col.w, mvp);
-                reinterpret_cast<float4 *>(baked[obj].model_view)[c] = make_float4(mv[0], mv[1], mv[2], mv[3]);
-                reinterpret_cast<float4 *>(baked[obj].model_view_proj)[c] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t i = first + (r0 + k) * 256u + t;
+            const bool in = r0 + k < rounds && i < cap;
+            meta[k] = in ? a.soa.meta[i] : 0u;
+            sph[k] = in ? a.soa.spheres[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            prev[k] = (BAKE && in && a.use_prev != 0u) ? (uint32_t)a.vis_flags[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (r0 + k >= rounds) break;
+            const uint32_t i = first + (r0 + k) * 256u + t;
+            const uint32_t ntri = meta[k] & R3N_META_NTRI_MASK, key = meta[k] >> R3N_META_KEY_SHIFT;
+            const uint32_t bits = i < cap ? object_visible(a.hdr, a.own, i, meta[k], sph[k]) : 0u;
+            const uint32_t flag = bits & R3N_VIS_DRAWN;
+            if (i < cap) a.vis_flags[i] = (uint8_t)bits;
+            const uint32_t nw = flag ? (ntri + 63u) / 64u : 0u, ntri_vis = flag ? ntri : 0u;
+            const unsigned long long vb = __ballot(flag != 0u);
+            const unsigned long long nb = __ballot(ntri != 0u && ((bits | prev[k]) & R3N_VIS_INSIDE) != 0u);
+            const uint32_t wnw = wave_reduce_add(nw);
+            s_ntri[r0 + k][t] = ntri;
+            if (lane == 0u) {
+                s_vis[r0 + k][wave] = vb; s_need[r0 + k][wave] = nb;
+                s_wt[(r0 + k) * 4u + wave][0] = (uint32_t)__popcll(vb); s_wt[(r0 + k) * 4u + wave][1] = wnw;
             }
+            vals[0] += flag; vals[1] += nw; vals[2] += ntri;
+            vals[3] += key == 0u ? ntri_vis : 0u; vals[4] += key == 1u ? ntri_vis : 0u; vals[5] += key >= 2u ? ntri_vis : 0u;
         }
     }
-    // ---- count (object_count_body)
-    const uint32_t i = blockIdx.x * 256u + t;
-    uint32_t flag = 0, ntri = 0, nw = 0, key = 0;
-    if (i < cap) {
-        const r3n_object128 *o = &objects[i];
-        ntri = o->enabled ? o->index_count / 3u : 0u;
-        const uint32_t mi0 = o->material_index;
-        uint32_t key0 = mi0 < n_materials ? material_keys[mi0] : 0u;
-        if (key0 > 2u) key0 = 2u;
-        if (ntri > 0u && (obj_owned(own, i) || key0 == 2u)) {
-            const float4 sph = *reinterpret_cast<const float4 *>(o->bounding_sphere_center);
-            const float c[3] = {sph.x, sph.y, sph.z};
-            const float neg_radius = -sph.w;
-            bool inside = true;
-#pragma unroll
-            for (int p = 0; p < 5; ++p) {
-                const float d = dot3(hdr->frustum + 4 * p, c) + hdr->frustum[4 * p + 3];
-                inside = inside && (d >= neg_radius);
-            }
-            flag = inside ? 1u : 0u;
-        }
-        if (flag) { nw = (ntri + 63u) / 64u; key = key0; }
-        vis_flags[i] = (uint8_t)flag;
-    }
-    const uint32_t ntri_vis = flag ? ntri : 0u;
-    const uint32_t vals[6] = {flag, nw, ntri, key == 0u ? ntri_vis : 0u, key == 1u ? ntri_vis : 0u, key == 2u ? ntri_vis : 0u};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const uint32_t sum = wave_reduce_add(vals[k]);
@@ -457,7 +505,7 @@ __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_he
     uint32_t mine = 0;
     if (t < 6u) {
         mine = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-        __hip_atomic_store(&chain[blockIdx.x].v[t], ((unsigned long long)epoch << 32) | (unsigned long long)mine, __ATOMIC_RELAXED,
+        __hip_atomic_store(&a.chain[blockIdx.x].v[t], ((unsigned long long)a.epoch << 32) | (unsigned long long)mine, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- exclusive prefix over the blocks in front (object_scan_body's result for this block)
@@ -465,10 +513,10 @@ __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_he
     for (uint32_t j = t; j < blockIdx.x; j += 256u) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            unsigned long long w = __hip_atomic_load(&chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((uint32_t)(w >> 32) != epoch) {
+            unsigned long long w = __hip_atomic_load(&a.chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((uint32_t)(w >> 32) != a.epoch) {
                 __builtin_amdgcn_s_sleep(1);
-                w = __hip_atomic_load(&chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = __hip_atomic_load(&a.chain[j].v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             acc[k] += (uint32_t)w;
         }
@@ -481,34 +529,76 @@ __global__ __launch_bounds__(256) void k_object_pass_chained(const r3n_camera_he
     }
     __syncthreads();
     if (t < 6u) pre[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-    // ---- scatter (object_scatter_body)
-    const uint32_t s0 = wave_inclusive_scan(flag, lane), s1 = wave_inclusive_scan(nw, lane);
-    if (lane == 63u) { wtot[wave][0] = s0; wtot[wave][1] = s1; }
     __syncthreads();
-    uint32_t p0 = pre[0], p1 = pre[1];
-    for (uint32_t w = 0; w < wave; ++w) { p0 += wtot[w][0]; p1 += wtot[w][1]; }
-    if (i < cap) {
-        const uint32_t e = p0 + s0 - flag, ws = p1 + s1 - nw;
-        if (flag) {
-            vis_list[e].object = i;
-            vis_list[e].wave_start = ws;
+    // the block's (round, wave) totals -> exclusive prefixes, in slot order: one wavefront, lane = round * 4 + wave
+    if (wave == 0u) {
+        const bool in = lane < rounds * 4u;
+        const uint32_t v0 = in ? s_wt[lane][0] : 0u, v1 = in ? s_wt[lane][1] : 0u;
+        const uint32_t i0 = wave_inclusive_scan(v0, lane), i1 = wave_inclusive_scan(v1, lane);
+        if (in) { s_wt[lane][0] = pre[0] + i0 - v0; s_wt[lane][1] = pre[1] + i1 - v1; }
+    }
+    __syncthreads();
+    // ---- phase 3: scatter (object_scatter_body) + bake; no barrier between the rounds, a wavefront works on its own 64 slots
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = first + r * 256u + t;
+        const unsigned long long vb = s_vis[r][wave];
+        const uint32_t flag = (uint32_t)(vb >> lane) & 1u;
+        const uint32_t ntri = s_ntri[r][t];
+        const uint32_t nw = flag ? (ntri + 63u) / 64u : 0u;
+        const uint32_t e = s_wt[r * 4u + wave][0] + (uint32_t)__popcll(vb & lane_lt);
+        const uint32_t ws = s_wt[r * 4u + wave][1] + wave_inclusive_scan(nw, lane) - nw;
+        if (i < cap) {
+            if (flag) {
+                a.vis_list[e].object = i;
+                a.vis_list[e].wave_start = ws;
+            }
+            a.slot_base[i] = flag ? ws * 64u : R3N_INVALID;
         }
-        slot_base[i] = flag ? ws * 64u : R3N_INVALID;
+        write_first_entries(a.first_entry, flag, e, ws, nw, lane);
+        if (BAKE) {
+            // the wave's slots that need a matrix, compacted to the front of the wavefront by a forward permute (lanes without
+            // one fill the tail, so the permutation is total); then 16 slots per step, thread (slot, column): consecutive
+            // threads read consecutive 16-byte columns of a transform and write two 16-byte columns
+            const unsigned long long nb = s_need[r][wave];
+            const bool need = ((nb >> lane) & 1ull) != 0ull;
+            const uint32_t n = (uint32_t)__popcll(nb);
+            const uint32_t rank = need ? (uint32_t)__popcll(nb & lane_lt) : n + (uint32_t)__popcll(~nb & lane_lt);
+            const uint32_t list = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)i);
+            const uint32_t c = lane & 3u;
+            uint32_t obj[4];
+            float4 col[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {  // the (up to four) steps' transform columns in flight together
+                const uint32_t src = j * 16u + (lane >> 2);
+                obj[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)list);
+                col[j] = src < n ? reinterpret_cast<const float4 *>(a.objects[obj[j]].transform)[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                if (j * 16u + (lane >> 2) < n) {
+                    float mv[4], mvp[4];
+                    mul_vec4(a.hdr->view, col[j].x, col[j].y, col[j].z, col[j].w, mv);
+                    mul_vec4(a.hdr->view_proj, col[j].x, col[j].y, col[j].z, col[j].w, mvp);
+                    reinterpret_cast<float4 *>(a.baked[obj[j]].model_view)[c] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                    reinterpret_cast<float4 *>(a.baked[obj[j]].model_view_proj)[c] = make_float4(mvp[0], mvp[1], mvp[2], mvp[3]);
+                }
+            }
+        }
     }
     if (blockIdx.x == gridDim.x - 1u && t < 6u) red[0][t] = pre[t] + mine;  // totals: everything in front + this block
     __syncthreads();
     if (blockIdx.x == gridDim.x - 1u && t == 0u) {
-        counts->visible_objects = red[0][0];
-        counts->total_waves = red[0][1];
-        counts->total_triangles = red[0][2];
+        a.counts->visible_objects = red[0][0];
+        a.counts->total_waves = red[0][1];
+        a.counts->total_triangles = red[0][2];
         uint32_t rb = 0;
         for (int k = 0; k < 3; ++k) {
-            counts->key_triangles[k] = red[0][3 + k];
-            counts->region_base[k] = rb;
+            a.counts->key_triangles[k] = red[0][3 + k];
+            a.counts->region_base[k] = rb;
             rb += red[0][3 + k];
         }
-        vis_list[red[0][0]].object = R3N_INVALID;  // sentinel
-        vis_list[red[0][0]].wave_start = red[0][1];
+        a.vis_list[red[0][0]].object = R3N_INVALID;  // sentinel
+        a.vis_list[red[0][0]].wave_start = red[0][1];
     }
 }
 
@@ -677,9 +767,6 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
 #endif
 typedef uint32_t r3n_u32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef R3N_CHUNK_ITERS
-#define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
-#endif
 #define R3N_CHUNK_WAVES (4u * R3N_CHUNK_ITERS)   // wave slots per 256-thread block per chunk (4096 triangles)
 
 struct TriCullArgs {
@@ -690,6 +777,7 @@ struct TriCullArgs {
     const uint8_t *material_keys;
     uint32_t n_materials;
     const r3n_vis_entry *vis_list;
+    const uint32_t *first_entry;          // write_first_entries: the entry owning wave slot k * R3N_CHUNK_ITERS
     const r3n_cull_counts *counts;
     const uint32_t *prev_slot_base;       // per object, INVALID when absent last frame; may be null
     const unsigned long long *prev_mask;  // may be null
@@ -715,7 +803,6 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t total_waves = a.counts->total_waves;
-    const uint32_t nvis = a.counts->visible_objects;
     const uint32_t nchunks = (total_waves + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
     const uint32_t flags = a.hdr->flags;
     const bool shadow = a.hdr->shadow_index != R3N_INVALID;
@@ -724,15 +811,11 @@ __global__ __launch_bounds__(256) void k_triangle_cull(TriCullArgs a) {
 
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t w0 = chunk * R3N_CHUNK_WAVES + wave * R3N_CHUNK_ITERS;
-        // locate the entry owning wave slot w0: last e with wave_start[e] <= w0 (wave-uniform binary search)
+        // the entry owning wave slot w0 (the last e with wave_start[e] <= w0): one scalar load from the table the object pass
+        // wrote (write_first_entries) instead of the reference's binary search (cull.wgsl:181-207)
         uint32_t e = 0, next_start = 0;
         if (w0 < total_waves) {
-            uint32_t lo = 0, hi = nvis;
-            while (hi - lo > 1u) {
-                const uint32_t mid = lo + (hi - lo) / 2u;
-                if (scalar_load<uint32_t>(&a.vis_list[mid].wave_start) <= w0) lo = mid; else hi = mid;
-            }
-            e = lo;
+            e = scalar_load<uint32_t>(&a.first_entry[w0 / R3N_CHUNK_ITERS]);
             next_start = scalar_load<uint32_t>(&a.vis_list[e + 1u].wave_start);
         }
         uint32_t c_p0 = 0, c_p1 = 0, c_p2 = 0, c_r0 = 0, c_r1 = 0, c_r2 = 0;

@@ -68,6 +68,7 @@ struct ShadowView {
 struct ShadowBatchArgs {
     const ShadowView *views;
     const r3n_object128 *objects;
+    ObjSoA soa;                        // spheres + (triangle count | material key) per object slot: what the object pass reads
     const uint32_t *mesh;
     const uint8_t *material_keys;
     uint32_t n_materials;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void k_shadow_bake(ShadowBatchArgs a) {
 }
 __global__ __launch_bounds__(256) void k_shadow_object_count(ShadowBatchArgs a) {
     const ShadowView &V = a.views[blockIdx.y];
-    object_count_body(V.hdr, a.objects, a.material_keys, a.n_materials, V.own, V.vis_flags, V.block_sums);
+    object_count_body(V.hdr, a.soa, V.own, V.vis_flags, V.block_sums);
 }
 __global__ __launch_bounds__(1024) void k_shadow_object_scan(ShadowBatchArgs a, uint32_t nblocks) {
     const ShadowView &V = a.views[blockIdx.y];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_shadow_object_scan(ShadowBatchArgs a, 
 }
 __global__ __launch_bounds__(256) void k_shadow_object_scatter(ShadowBatchArgs a) {
     const ShadowView &V = a.views[blockIdx.y];
-    object_scatter_body(V.hdr, a.objects, V.vis_flags, V.block_off, V.vis_list, V.slot_base, nullptr);
+    object_scatter_body(V.hdr, a.soa, V.vis_flags, V.block_off, V.vis_list, V.slot_base, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ cull + setup + bin

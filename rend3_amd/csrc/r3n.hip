@@ -41,6 +41,7 @@ struct CamState {
     uint32_t chain_epoch = 0;
     uint64_t object_pass_frame = ~0ull;  // frame whose object pass already ran, fused with the bake (r3n_render_frame)
     DevBuf baked, vis_flags, vis_list, block_sums, block_off;
+    DevBuf first_entry;          // kernels_cull.h write_first_entries: the work-list entry owning every R3N_CHUNK_ITERS-th wave slot
     DevBuf slot_base[2], mask[2], predicted[2], sub_counts[2], counts[2];
     uint32_t subcap[2] = {0, 0};  // list entries reserved per (material key, sub-list)
     DevBuf residual;
@@ -127,6 +128,11 @@ struct r3n_ctx {
     std::string err;
     // world data
     DevBuf mesh, objects, materials, material_keys, dir_buf, point_buf, fu;
+    // structure-of-arrays view of the objects for the object pass (kernels_cull.h ObjSoA): bounding spheres, and per slot
+    // (enabled ? index_count / 3 : 0) | material key << 30 -- written beside the 128-byte records by r3n_objects_write, the key
+    // bits refreshed from the host mirrors when r3n_materials_write changed a key (refresh_obj_meta)
+    DevBuf spheres, obj_meta;
+    bool meta_dirty = false;
     uint32_t capacity = 0, n_materials = 0;
     std::vector<uint32_t> h_ntri;  // host mirror: triangles per enabled object slot
     std::vector<uint32_t> h_material;  // host mirror: material index per object slot
@@ -431,7 +437,7 @@ CamState *find_cam(r3n_ctx *c, r3n_camera cam, bool create) {
 }
 
 void free_cam(CamState &s) {
-    DevBuf *bufs[] = {&s.own_hdr, &s.chain, &s.baked, &s.vis_flags, &s.vis_list, &s.block_sums, &s.block_off, &s.slot_base[0],
+    DevBuf *bufs[] = {&s.own_hdr, &s.chain, &s.baked, &s.vis_flags, &s.vis_list, &s.first_entry, &s.block_sums, &s.block_off, &s.slot_base[0],
                       &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.sub_counts[0],
                       &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual, &s.recs, &s.tile_count, &s.tile_list, &s.fb_counts};
     for (DevBuf *b : bufs)
@@ -448,60 +454,107 @@ ObjOwn camera_own(const r3n_ctx *c, const CamState &s) {
 
 uint32_t max_waves(const r3n_ctx *c) { return (uint32_t)(c->total_tris / 64u) + c->capacity + 1u; }
 
+// ObjSoA.meta of a slot from the host mirrors: triangles of the enabled object | Material::key() of its material << 30 (a material
+// index beyond the table reads key 0, as the kernels' former `mi < n_materials ? keys[mi] : 0` did)
+uint32_t obj_meta_word(const r3n_ctx *c, uint32_t slot) {
+    const uint32_t mi = c->h_material[slot];
+    uint32_t key = mi < c->h_material_key.size() ? c->h_material_key[mi] : 0u;
+    if (key > 2u) key = 2u;
+    return c->h_ntri[slot] | (key << R3N_META_KEY_SHIFT);
+}
+ObjSoA obj_soa(const r3n_ctx *c) { return ObjSoA{c->spheres.as<float4>(), c->obj_meta.as<uint32_t>()}; }
+// r3n_materials_write changed a key (or the table grew under objects that already named the new slots): every slot's key bits
+// from the mirrors, one upload.  World-edit rate, in front of the next object pass.
+int refresh_obj_meta(r3n_ctx *c) {
+    if (!c->meta_dirty) return R3N_OK;
+    c->meta_dirty = false;
+    if (c->capacity == 0) return R3N_OK;
+    std::vector<uint32_t> meta(c->capacity);
+    for (uint32_t i = 0; i < c->capacity; ++i) meta[i] = obj_meta_word(c, i);
+    TRY(join_lanes(c));  // the lanes' object passes of the previous frame read the old words
+    ++c->main_epoch;
+    HIP_TRY(c, hipMemcpyAsync(c->obj_meta.p, meta.data(), (size_t)c->capacity * 4u, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a temporary
+    return R3N_OK;
+}
+
+// the first-entry table of a camera (kernels_cull.h write_first_entries): one word per R3N_CHUNK_ITERS wave slots
+size_t first_entry_bytes(const r3n_ctx *c) { return ((size_t)max_waves(c) / R3N_CHUNK_ITERS + 2u) * 4u; }
+
 // Object pass for one camera state (frustum cull + slot assignment); range (0,0) builds only tri_base.
 int run_object_pass(r3n_ctx *c, CamState &s, int idx, ObjOwn own, uint32_t *tri_base,
                     hipStream_t stream) {
     const uint32_t cap = c->capacity;
     const uint32_t nblocks = (cap + 255u) / 256u;
-    TRY(ensure(c, s.vis_flags, cap, false, -1));
+    TRY(ensure(c, s.vis_flags, cap, true, 0));
     TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
     TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
     TRY(ensure(c, s.block_off, (size_t)nblocks * sizeof(ObjBlockOffsets), false, -1));
     TRY(ensure(c, s.slot_base[idx], (size_t)cap * 4u, true, 0xFF));
     TRY(ensure(c, s.sub_counts[idx], sizeof(r3n_sub_counts), false, 0));
     TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
+    if (tri_base == nullptr) TRY(ensure(c, s.first_entry, first_entry_bytes(c), false, -1));  // (the canonical scan feeds no triangle cull)
+    uint32_t *const first_entry = tri_base == nullptr ? s.first_entry.as<uint32_t>() : nullptr;
     Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
     if (cap <= R3N_FUSED_OBJECT_PASS_MAX) {  // small worlds: the three passes in one single-block launch
-        hipLaunchKernelGGL(k_object_pass_fused, dim3(1), dim3(1024), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
-                           c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, own,
+        hipLaunchKernelGGL(k_object_pass_fused, dim3(1), dim3(1024), 0, stream, s.d_hdr.as<r3n_camera_header240>(), obj_soa(c), own,
                            s.vis_flags.as<uint8_t>(), s.counts[idx].as<r3n_cull_counts>(), s.vis_list.as<r3n_vis_entry>(),
-                           s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(), tri_base);
+                           s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(), tri_base, first_entry);
         return check_launch(c, "object pass (fused)");
     }
-    hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
-                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, own,
+    hipLaunchKernelGGL(k_object_count, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(), obj_soa(c), own,
                        s.vis_flags.as<uint8_t>(), s.block_sums.as<ObjBlockSums>());
     hipLaunchKernelGGL(k_object_scan, dim3(1), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, s.block_sums.as<ObjBlockSums>(), nblocks,
                        s.block_off.as<ObjBlockOffsets>(), s.counts[idx].as<r3n_cull_counts>(),
                        s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>());
     hipLaunchKernelGGL(k_object_scatter, dim3(nblocks), dim3(256), 0, stream,
-                       s.d_hdr.as<r3n_camera_header240>(), c->objects.as<r3n_object128>(), s.vis_flags.as<uint8_t>(),
+                       s.d_hdr.as<r3n_camera_header240>(), obj_soa(c), s.vis_flags.as<uint8_t>(),
                        s.block_off.as<ObjBlockOffsets>(), s.vis_list.as<r3n_vis_entry>(),
-                       s.slot_base[idx].as<uint32_t>(), tri_base);
+                       s.slot_base[idx].as<uint32_t>(), tri_base, first_entry);
     return check_launch(c, "object pass");
 }
 
 // Bake + object pass of one camera as ONE launch (k_object_pass_chained); false when the world is too large for the chained form.
-bool chained_pass_fits(const r3n_ctx *c) {
+// rounds of 256 slots per block: one up to MAX_BLOCKS x 256 slots, then as many as keep the grid at MAX_BLOCKS
+uint32_t chained_rounds(const r3n_ctx *c) {
     const uint32_t nblocks = (c->capacity + 255u) / 256u;
-    return nblocks >= 1u && nblocks <= R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS;
+    return std::max(1u, (nblocks + R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS - 1u) / R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS);
 }
-int run_bake_and_object_pass(r3n_ctx *c, CamState &s, int idx, ObjOwn own, hipStream_t stream) {
+bool chained_pass_fits(const r3n_ctx *c) {
+    return c->capacity >= 1u && chained_rounds(c) <= R3N_CHAINED_OBJECT_PASS_MAX_ROUNDS;
+}
+int run_bake_and_object_pass(r3n_ctx *c, CamState &s, int idx, ObjOwn own, hipStream_t stream, bool viewport) {
     const uint32_t cap = c->capacity;
-    const uint32_t nblocks = (cap + 255u) / 256u;
-    TRY(ensure(c, s.vis_flags, cap, false, -1));
+    const uint32_t rounds = chained_rounds(c);
+    const uint32_t grid = ((cap + 255u) / 256u + rounds - 1u) / rounds;
+    TRY(ensure(c, s.vis_flags, cap, true, 0));
     TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
     TRY(ensure(c, s.slot_base[idx], (size_t)cap * 4u, true, 0xFF));
     TRY(ensure(c, s.sub_counts[idx], sizeof(r3n_sub_counts), false, 0));
     TRY(ensure(c, s.counts[idx], sizeof(r3n_cull_counts), false, 0));
-    TRY(ensure(c, s.chain, (size_t)nblocks * sizeof(ObjChainRec), false, 0));  // zero tags: no launch has epoch 0
+    TRY(ensure(c, s.first_entry, first_entry_bytes(c), false, -1));
+    TRY(ensure(c, s.chain, (size_t)grid * sizeof(ObjChainRec), false, 0));  // zero tags: no launch has epoch 0
     if (++s.chain_epoch == 0u) ++s.chain_epoch;
+    ObjChainArgs a{};
+    a.hdr = s.d_hdr.as<r3n_camera_header240>();
+    a.soa = obj_soa(c);
+    a.objects = c->objects.as<r3n_object128>();
+    a.own = own;
+    a.vis_flags = s.vis_flags.as<uint8_t>();
+    a.chain = s.chain.as<ObjChainRec>();
+    a.epoch = s.chain_epoch;
+    a.rounds = rounds;
+    a.counts = s.counts[idx].as<r3n_cull_counts>();
+    a.vis_list = s.vis_list.as<r3n_vis_entry>();
+    a.sub_counts = s.sub_counts[idx].as<r3n_sub_counts>();
+    a.slot_base = s.slot_base[idx].as<uint32_t>();
+    // last frame's predicted list (this frame's first pass) names objects that passed the frustum test then: vis_flags still
+    // holds that object pass's bytes (slots the world has grown by since read 0: the buffer grows zero-filled)
+    a.use_prev = (viewport && s.has_prev) ? 1u : 0u;
+    a.baked = s.baked.as<r3n_baked128>();
+    a.first_entry = s.first_entry.as<uint32_t>();
     Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
-    hipLaunchKernelGGL(k_object_pass_chained<true>, dim3(nblocks), dim3(256), 0, stream, s.d_hdr.as<r3n_camera_header240>(),
-                       c->objects.as<r3n_object128>(), c->material_keys.as<uint8_t>(), c->n_materials, own,
-                       s.vis_flags.as<uint8_t>(), s.chain.as<ObjChainRec>(), s.chain_epoch, s.counts[idx].as<r3n_cull_counts>(),
-                       s.vis_list.as<r3n_vis_entry>(), s.sub_counts[idx].as<r3n_sub_counts>(), s.slot_base[idx].as<uint32_t>(),
-                       s.baked.as<r3n_baked128>());
+    hipLaunchKernelGGL(k_object_pass_chained<true>, dim3(grid), dim3(256), 0, stream, a);
     return check_launch(c, "k_object_pass_chained");
 }
 
@@ -740,7 +793,7 @@ void r3n_destroy(r3n_ctx *c) {
         if (c->fb_host[k]) (void)hipHostFree(c->fb_host[k]);
         if (c->fb_ev[k]) (void)hipEventDestroy(c->fb_ev[k]);
     }
-    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->materials, &c->material_keys, &c->fb_dev[0], &c->fb_dev[1], &c->big_count_all, &c->owners,
+    DevBuf *bufs[] = {&c->mesh, &c->objects, &c->spheres, &c->obj_meta, &c->materials, &c->material_keys, &c->fb_dev[0], &c->fb_dev[1], &c->big_count_all, &c->owners,
                       &c->tri_base, &c->slot_table, &c->skin_inputs, &c->skin_matrices, &c->skin_wave_skeleton,
                       &c->skin_wave_first, &c->skin_joint_counts, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_vp_baked, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys, &c->frag_vals, &c->frag_head,
@@ -808,6 +861,11 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(join_shade(c));
     TRY(ensure(c, c->objects, (size_t)capacity * sizeof(r3n_object128), true, 0));
+    TRY(ensure(c, c->spheres, (size_t)capacity * sizeof(float4), true, 0));
+    TRY(ensure(c, c->obj_meta, (size_t)capacity * 4u, true, 0));
+    for (uint32_t i = 0; i < n; ++i)
+        if (records[i].enabled && records[i].index_count / 3u > R3N_META_NTRI_MASK)
+            return fail(c, R3N_ERR_UNSUPPORTED, "objects write: more than 2^30 - 1 triangles in one object");
     if (capacity != c->capacity) {
         if (c->owners.p && c->owners_n < capacity) {
             // owner bytes (r3n_set_object_owners) cover the old capacity: the kernels index them by slot, so the table grows with
@@ -832,6 +890,8 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
                                   hipMemcpyHostToDevice, c->stream));
         i += run;
     }
+    std::vector<float4> h_sph(n);
+    std::vector<uint32_t> h_meta(n);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t nt = records[i].enabled ? records[i].index_count / 3u : 0u;
         // A slot rewritten in place with another triangle count (not reachable through rend3's own API, where a handle is
@@ -846,6 +906,17 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
         c->h_ntri[slots[i]] = nt;
         c->h_material[slots[i]] = records[i].material_index;
         c->key_census_dirty = true;
+        // the structure-of-arrays view of the object pass (kernels_cull.h ObjSoA)
+        h_sph[i] = make_float4(records[i].bounding_sphere_center[0], records[i].bounding_sphere_center[1],
+                               records[i].bounding_sphere_center[2], records[i].bounding_sphere_radius);
+        h_meta[i] = obj_meta_word(c, slots[i]);
+    }
+    for (uint32_t i = 0; i < n;) {
+        uint32_t run = 1;
+        while (i + run < n && slots[i + run] == slots[i] + run) ++run;
+        HIP_TRY(c, hipMemcpyAsync(c->spheres.as<float4>() + slots[i], h_sph.data() + i, (size_t)run * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->obj_meta.as<uint32_t>() + slots[i], h_meta.data() + i, (size_t)run * 4u, hipMemcpyHostToDevice, c->stream));
+        i += run;
     }
     if (n) c->tri_base_dirty = true;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -861,11 +932,19 @@ int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208
         if (keys[i] > R3N_KEY_BLEND) return fail(c, R3N_ERR_INVALID_ARG, "materials write: bad key");
         need = std::max(need, slots[i] + 1u);
     }
+    // a work item's `material` word carries the material index in bits 0..28 (edge thresholds in 29..31, kernels_raster.h)
+    if (need > (1u << 29)) return fail(c, R3N_ERR_UNSUPPORTED, "materials write: material slots must stay below 2^29");
     TRY(ensure(c, c->materials, (size_t)need * sizeof(r3n_material208), true, 0));
     TRY(ensure(c, c->material_keys, need, true, 0));
+    // objects carry their material's key in ObjSoA.meta: a key that changes, or a table that grows under objects which already name
+    // the new slots, re-derives those bits (refresh_obj_meta, in front of the next object pass)
+    if (need != c->n_materials && c->capacity) c->meta_dirty = true;
     c->n_materials = need;
     c->h_material_key.resize(need, 0);
-    for (uint32_t i = 0; i < n; ++i) c->h_material_key[slots[i]] = keys[i];
+    for (uint32_t i = 0; i < n; ++i) {
+        if (c->h_material_key[slots[i]] != keys[i] && c->capacity) c->meta_dirty = true;
+        c->h_material_key[slots[i]] = keys[i];
+    }
     c->key_census_dirty = true;
     c->h_materials.resize(need, r3n_material208{});
     for (uint32_t i = 0; i < n; ++i) c->h_materials[slots[i]] = records[i];
@@ -1165,6 +1244,7 @@ static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t
         TRY(check_launch(c, "k_frame_clear"));
     }
     ++c->main_epoch;
+    TRY(refresh_obj_meta(c));
     TRY(refresh_tri_base(c));
     c->in_frame = true;
     for (auto &f : c->forward_index_lane) f = 0;
@@ -1406,7 +1486,7 @@ static int flush_shadows(r3n_ctx *c) {
         CamState &s = *b.second;
         const int cur = s.cur;
         const int g = ngroups > 1 ? (int)(b.first % (uint32_t)ngroups) : 0;
-        TRY(ensure(c, s.vis_flags, cap, false, -1));
+        TRY(ensure(c, s.vis_flags, cap, true, 0));
         TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
         TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
         TRY(ensure(c, s.block_off, (size_t)nblocks * sizeof(ObjBlockOffsets), false, -1));
@@ -1500,6 +1580,7 @@ static int flush_shadows(r3n_ctx *c) {
         TRY(fork_lane(c, lane));  // after the header / descriptor uploads and the frame's clears (main stream)
         ShadowBatchArgs a{};
         a.objects = c->objects.as<r3n_object128>();
+        a.soa = obj_soa(c);
         a.mesh = c->mesh.as<uint32_t>();
         a.material_keys = c->material_keys.as<uint8_t>();
         a.n_materials = c->n_materials;
@@ -1568,6 +1649,7 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     s->has_hdr = true;
     s->baked_frame = c->frame_no;
     if (c->capacity == 0) return R3N_OK;  // culler.rs:449-451
+    TRY(refresh_obj_meta(c));
     // the camera's header lives in the frame-constants block of the current frame slot
     s->d_hdr.p = c->fb_dev[c->slot].as<uint8_t>() + (cam == R3N_CAMERA_VIEWPORT ? r3n_ctx::kFbViewportHdr : r3n_ctx::kFbShadowHdr + 256u * (size_t)cam);
     s->d_hdr.bytes = 256;
@@ -1586,14 +1668,15 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
         // (frustum test + slot assignment) depends on nothing the frame computes in between -- bake and object pass go out as ONE
         // launch now; r3n_cull then issues the triangle cull alone (for the viewport that takes three launches off the serial
         // chain between Hi-Z and the triangle cull)
-        TRY(ensure(c, s->chain, (size_t)((c->capacity + 255u) / 256u) * sizeof(ObjChainRec), false, 0));
-        TRY(ensure(c, s->vis_flags, c->capacity, false, -1));
+        TRY(ensure(c, s->chain, (size_t)R3N_CHAINED_OBJECT_PASS_MAX_BLOCKS * sizeof(ObjChainRec), false, 0));
+        TRY(ensure(c, s->vis_flags, c->capacity, true, 0));
         TRY(ensure(c, s->vis_list, (size_t)(c->capacity + 1u) * sizeof(r3n_vis_entry), false, -1));
         TRY(ensure(c, s->slot_base[s->cur], (size_t)c->capacity * 4u, true, 0xFF));
         TRY(ensure(c, s->sub_counts[s->cur], sizeof(r3n_sub_counts), false, 0));
         TRY(ensure(c, s->counts[s->cur], sizeof(r3n_cull_counts), false, 0));
+        TRY(ensure(c, s->first_entry, first_entry_bytes(c), false, -1));
         TRY(fork_lane(c, lane));
-        TRY(run_bake_and_object_pass(c, *s, s->cur, camera_own(c, *s), lane_stream(c, lane)));
+        TRY(run_bake_and_object_pass(c, *s, s->cur, camera_own(c, *s), lane_stream(c, lane), cam == R3N_CAMERA_VIEWPORT));
         s->object_pass_frame = c->frame_no;
         return R3N_OK;
     }
@@ -1630,13 +1713,14 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     // (re)allocations below run on the main stream: size everything first, then fork
     {
         const uint32_t cap0 = c->capacity, nblocks0 = (cap0 + 255u) / 256u;
-        TRY(ensure(c, s->vis_flags, cap0, false, -1));
+        TRY(ensure(c, s->vis_flags, cap0, true, 0));
         TRY(ensure(c, s->vis_list, (size_t)(cap0 + 1u) * sizeof(r3n_vis_entry), false, -1));
         TRY(ensure(c, s->block_sums, (size_t)nblocks0 * sizeof(ObjBlockSums), false, -1));
         TRY(ensure(c, s->block_off, (size_t)nblocks0 * sizeof(ObjBlockOffsets), false, -1));
         TRY(ensure(c, s->slot_base[cur], (size_t)cap0 * 4u, true, 0xFF));
         TRY(ensure(c, s->sub_counts[cur], sizeof(r3n_sub_counts), false, 0));
         TRY(ensure(c, s->counts[cur], sizeof(r3n_cull_counts), false, 0));
+        TRY(ensure(c, s->first_entry, first_entry_bytes(c), false, -1));
     }
     const uint32_t mw = max_waves(c);
     const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
@@ -1658,6 +1742,7 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     a.material_keys = c->material_keys.as<uint8_t>();
     a.n_materials = c->n_materials;
     a.vis_list = s->vis_list.as<r3n_vis_entry>();
+    a.first_entry = s->first_entry.as<uint32_t>();
     a.counts = s->counts[cur].as<r3n_cull_counts>();
     a.prev_slot_base = (viewport && s->has_prev) ? s->slot_base[prev].as<uint32_t>() : nullptr;
     a.prev_mask = (viewport && s->has_prev) ? s->mask[prev].as<unsigned long long>() : nullptr;
@@ -2003,6 +2088,10 @@ int r3n_blend_order_write(r3n_ctx *c, const uint32_t *objects, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) {
         if (objects[i] >= c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "blend order: object slot >= capacity");
         rank[i + 1] = rank[i] + c->h_ntri[objects[i]];
+        // a blend work item's `material` word carries the draw order in bits 0..28 and the edge thresholds in bits 29..31
+        // (kernels_raster.h pack_thresholds): an order beyond that would corrupt both
+        if (rank[i + 1] >= (1u << 29) || rank[i + 1] < rank[i])
+            return fail(c, R3N_ERR_UNSUPPORTED, "blend order: more than 2^29 blend triangles in draw order");
     }
     c->n_blend = n;
     c->blend_tris = rank[n];
@@ -2184,8 +2273,10 @@ int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
     return R3N_OK;
 }
 
-int r3n_frame_end(r3n_ctx *c) {
-    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "frame_end: no frame in flight");
+// Closes the frame (flushes the batched shadow stages, joins the lanes, flips every camera's ping-pong state) WITHOUT looking at the
+// asynchronous status word: r3n_frame_end reports that word once, and an error path that merely has to close the frame
+// (r3n_render_frame's Closer) must not consume the report of an earlier frame's overflow.
+static int close_frame(r3n_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(flush_shadows(c));
     TRY(join_lanes(c));  // the next frame's clears (main stream) must not overtake this frame's shadow work
@@ -2196,6 +2287,12 @@ int r3n_frame_end(r3n_ctx *c) {
     flip(c->viewport);
     for (auto &kv : c->shadows) flip(kv.second);
     c->in_frame = false;
+    return R3N_OK;
+}
+
+int r3n_frame_end(r3n_ctx *c) {
+    if (!c || !c->in_frame) return fail(c, R3N_ERR_STATE, "frame_end: no frame in flight");
+    TRY(close_frame(c));
     // this frame is closed and complete as far as the host can know; what the status word holds was raised by an EARLIER frame's
     // kernels (fragment buffer / work queue full): report it here, once, without having refused any frame
     return check_async_status(c);
@@ -2393,7 +2490,7 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
         }
     struct Closer {  // an error in the middle must not leave the frame open
         r3n_ctx *c; bool armed = true;
-        ~Closer() { if (armed && c->in_frame) { const std::string keep = c->err; (void)r3n_frame_end(c); c->err = keep; } }
+        ~Closer() { if (armed && c->in_frame) { const std::string keep = c->err; (void)close_frame(c); c->err = keep; } }
     } closer{c};
     struct Fused { r3n_ctx *c; ~Fused() { c->fused_frame = false; } } fused{c};
     c->fused_frame = true;
@@ -2585,7 +2682,9 @@ int r3n_readback_visible_objects(r3n_ctx *c, r3n_camera cam, uint8_t *flags, uin
     CamState *s = c ? find_cam(c, cam, false) : nullptr;
     if (!s || s->last < 0 || !flags) return fail(c, R3N_ERR_STATE, "readback_visible_objects: camera never culled");
     if (capacity < c->capacity) return fail(c, R3N_ERR_INVALID_ARG, "readback_visible_objects: buffer too small");
-    return d2h(c, flags, s->vis_flags.p, c->capacity);
+    TRY(d2h(c, flags, s->vis_flags.p, c->capacity));
+    for (uint32_t i = 0; i < c->capacity; ++i) flags[i] &= (uint8_t)R3N_VIS_DRAWN;  // (bit 1: frustum test alone, kernels_cull.h R3N_VIS_INSIDE)
+    return R3N_OK;
 }
 
 int r3n_readback_draw_calls(r3n_ctx *c, r3n_camera cam, r3n_indirect_call calls[6]) {

@@ -399,7 +399,7 @@ R3N_DEV bool tex_sample3_batched(const TextureArgs &t, const uint32_t id[3], flo
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         present[k] = id[k] != 0u;
-        const uint32_t idx = present[k] ? id[k] - 1u : 0u;   // (an unbound slot reads entry 0: valid memory, result unused)
+        const uint32_t idx = present[k] ? id[k] - 1u : 0u;   // (an unbound slot reads descriptor 0: valid memory; its texel addresses are forced into the pool below)
         const uint4 dw = *reinterpret_cast<const uint4 *>(&t.descs[idx]);  // offset, width, height, mips
         w[k] = dw.y; h[k] = dw.z; mips[k] = dw.w;
         fmt[k] = t.descs[idx].format;
@@ -462,6 +462,11 @@ R3N_DEV bool tex_sample3_batched(const TextureArgs &t, const uint32_t id[3], flo
         const Pair pr = *reinterpret_cast<const Pair *>(lo[k] + pb);
         ba[k] = pb == la[k] ? pr.a : pr.b;
         bb[k] = two[k] ? pr.b : ba[k];  // (two[k]: la + 1 <= mips - 1 < R3N_TEX_LEVELS, so pb == la)
+        // An unbound slot still issues its texel loads (results discarded): they go to the START of the pool plus the reference
+        // map's footprint offsets, which are smaller than that map's level `level` and therefore than the pool that holds the map --
+        // provably inside the allocation wherever the caller placed its textures (entry 0's level offsets plus another map's
+        // footprint could point past the pool's end when texture 1 sits last in it).
+        if (!present[k]) { ba[k] = 0u; bb[k] = 0u; }
     }
     // batch 3: the texels (byte offsets from the uniform pool pointer: the pool holds < 2^30 texels on the short path)
     uint32_t ta[3][4], tb[3][4];

@@ -37,8 +37,10 @@ def compare_frames(o, p, tag=""):
     cap = o["capacity"]
     assert p["capacity"] == cap
     if "visible" in p:
-        enabled = o["objects"][:, 29] != 0
-        assert np.array_equal(o["baked"].view(np.uint32)[enabled], p["baked"].view(np.uint32)[enabled]), tag + " baked"
+        # the matrices any kernel reads: r3n_render_frame bakes the slots that pass the frustum test (or were batched last
+        # frame), not the whole buffer (kernels_cull.h k_object_pass_chained); the per-node path bakes every enabled slot
+        baked_slots = (o["objects"][:, 29] != 0) & o["visible"].astype(bool)
+        assert np.array_equal(o["baked"].view(np.uint32)[baked_slots], p["baked"].view(np.uint32)[baked_slots]), tag + " baked"
         assert np.array_equal(o["visible"], p["visible"]), tag + " L1 visible objects"
         n = len(o["pass"])
         assert np.array_equal(o["pass"], p["pass"][:n]), tag + f" L2 pass set ({(o['pass'] != p['pass'][:n]).sum()} differ)"

@@ -38,6 +38,33 @@ def test_extern_block_matches_header_and_library():
         assert n == len(_ffi.SIGNATURES[name][1]), name
 
 
+def test_sys_crate_spells_every_type_in_rust():
+    """`*mut unsigned long long` once reached the extern block -- no toolchain here compiles the crate, so
+    this is the lint that stands in for `cargo check`: every type token of every struct field, fn-pointer and extern fn is a
+    Rust primitive, a std::os::raw alias, or an r3n_* item the file itself defines."""
+    import gen_rust_sys
+    rs = _sys_rs()
+    defined = set(re.findall(r"pub (?:struct|type) (r3n_\w+)", rs))
+    allowed = gen_rust_sys.RUST_WORDS | {"Option", "unsafe", "extern", "fn", "as"}
+    sites = re.findall(r"pub fn r3n_\w+\(([^)]*)\)(?: -> ([^;]+))?;", rs)
+    types = [t for params, ret in sites for t in [q.split(":", 1)[1] for q in params.split(",") if ":" in q] + ([ret] if ret else [])]
+    types += re.findall(r"^    pub \w+: ([^\n]+),$", rs, flags=re.M)
+    types += re.findall(r"pub type r3n_\w+ = ([^;]+);", rs)
+    assert len(types) > 300
+    for t in types:
+        for tok in re.findall(r"[A-Za-z_]\w*", re.sub(r'"C"', " ", t)):
+            if tok in allowed or tok in defined or re.fullmatch(r"R3N_\w+", tok):
+                continue
+            # parameter names inside fn-pointer types: `name: type`
+            if re.search(r"\b" + tok + r"\s*:", t):
+                continue
+            raise AssertionError(f"not a Rust type: {tok!r} in {t!r}")
+    # and the generator refuses what it cannot spell instead of passing it through
+    import pytest
+    with pytest.raises(ValueError):
+        gen_rust_sys.rust_type("unsigned short *")
+
+
 def test_adaptor_crate_calls_only_declared_symbols_and_covers_the_frame():
     declared = set(re.findall(r"pub fn (r3n_\w+)\(", _sys_rs()))
     src_dir = os.path.join(ROOT, "bindings", "rend3-routine-amd", "src")

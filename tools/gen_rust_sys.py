@@ -11,7 +11,10 @@ HEADER = os.path.join(ROOT, "include", "r3n.h")
 OUT = os.path.join(ROOT, "bindings", "rend3-amd-sys", "src", "lib.rs")
 
 SCALARS = {"int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "uint16_t": "u16", "int32_t": "i32",
-           "float": "f32", "double": "f64", "r3n_camera": "u32", "char": "c_char", "void": "c_void"}
+           "float": "f32", "double": "f64", "r3n_camera": "u32", "char": "c_char", "void": "c_void",
+           "unsigned long long": "u64", "long long": "i64", "unsigned": "u32", "unsigned int": "u32", "size_t": "usize"}
+# what a type of the generated file may be made of: anything else is a C spelling that leaked through (rustc would reject it)
+RUST_WORDS = {"c_int", "c_char", "c_void", "u8", "u16", "u32", "u64", "i32", "i64", "f32", "f64", "usize", "const", "mut"}
 
 
 def strip_comments(text):
@@ -30,6 +33,8 @@ def rust_type(ctype):
     if base.startswith("struct "):
         base = base[7:]
     r = SCALARS.get(base, base)
+    if r not in RUST_WORDS and not re.fullmatch(r"r3n_\w+", r):
+        raise ValueError(f"gen_rust_sys: no Rust spelling for the C type {ctype!r} (add it to SCALARS)")
     for k in range(stars):
         r = ("*const " if (const and k == 0) else "*mut ") + r
     return r
