@@ -43,8 +43,8 @@ def hipcc():
     raise RuntimeError("hipcc not found: rend3_amd needs ROCm's hipcc to build its gfx950 kernels")
 
 
-def _deps(unit):
-    return [os.path.join(CSRC, d) for d in [unit] + UNITS[unit] + COMMON]
+def _deps(unit, csrc=None):
+    return [os.path.join(csrc or CSRC, d) for d in [unit] + UNITS[unit] + COMMON]
 
 
 def _obj(unit, obj_dir=OBJ):
@@ -66,10 +66,14 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for u in UNITS for d in _deps(u))
 
 
-def build(force=False, verbose=False, extra=None, out=SO, obj_dir=OBJ):
+def build(force=False, verbose=False, extra=None, out=SO, obj_dir=OBJ, csrc=None):
     """extra: additional compiler flags (variant builds, tools/variants.py; or R3N_EXTRA_CXXFLAGS): their objects go into a
     directory of their own (named by a hash of the flags) and, unless `out` is given, into librend3_amd.<hash>.so -- load it with
-    R3N_LIB.  Returns the library's path."""
+    R3N_LIB.  csrc: another source directory with the same layout (tools/variants.py: a patched copy of csrc/; `out` and
+    `obj_dir` must then be given).  Returns the library's path."""
+    src = csrc or CSRC
+    if csrc is not None and (out == SO or obj_dir == OBJ):
+        raise ValueError("a build from another source directory needs its own `out` and `obj_dir`")
     if extra is None:
         extra = os.environ.get("R3N_EXTRA_CXXFLAGS", "").split()
     if not force and not extra and out == SO and up_to_date():
@@ -86,7 +90,7 @@ def build(force=False, verbose=False, extra=None, out=SO, obj_dir=OBJ):
     todo = [u for u in UNITS if force or extra or _stale(u, obj_dir)]
 
     def compile_unit(u):
-        cmd = [hipcc()] + FLAGS + extra + ["-c", "-o", _obj(u, obj_dir), os.path.join(CSRC, u)]
+        cmd = [hipcc()] + FLAGS + extra + ["-c", "-o", _obj(u, obj_dir), os.path.join(src, u)]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         return u, subprocess.run(cmd, capture_output=True, text=True)

@@ -12,10 +12,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#ifndef R3N_EXACT_FAST
-#define R3N_EXACT_FAST 1
-#endif
-
 namespace exact_math {
 
 // the guard: x is a positive normal number with exponent in [lo, hi) (biased exponent field), as ONE unsigned compare of the bits
@@ -44,36 +40,26 @@ __device__ __forceinline__ float sqrt_core(float x) {
 // Measured on MI355X (r3n_selftest_exact_math, all 2^32 patterns): rcp_core differs from 1 / x only for biased exponents 0
 // (subnormal x) and 253-255 (subnormal quotient, inf, NaN); sqrt_core only below exponent 23 (the residual x - s * s' underflows)
 // and never above; their composition only below 22 and at 255.  The guards keep one exponent of margin.
-#ifndef R3N_RCP_LO
 #define R3N_RCP_LO 2u
 #define R3N_RCP_HI 252u
 #define R3N_SQRT_LO 24u
 #define R3N_SQRT_HI 254u
-#endif
 
 __device__ __forceinline__ float rcp(float x) {  // 1.0f / x
-#if R3N_EXACT_FAST
     if (in_range<R3N_RCP_LO, R3N_RCP_HI>(x)) return rcp_core(x);
-#endif
     return 1.0f / x;
 }
 __device__ __forceinline__ float sqrt(float x) {  // sqrtf(x)
-#if R3N_EXACT_FAST
     if (in_range<R3N_SQRT_LO, R3N_SQRT_HI>(x)) return sqrt_core(x);
-#endif
     return sqrtf(x);
 }
 __device__ __forceinline__ float rsqrt(float x) {  // 1.0f / sqrtf(x): two roundings, as the contract writes it
-#if R3N_EXACT_FAST
     if (in_range<R3N_SQRT_LO, R3N_SQRT_HI>(x)) return rcp_core(sqrt_core(x));  // the root of a guarded x is far inside rcp's guard
-#endif
     return 1.0f / sqrtf(x);
 }
 
 __device__ __forceinline__ float half_rcp(float x) {  // 0.5f / x: inside rcp's guard the quotient is normal, and halving it is exact
-#if R3N_EXACT_FAST
     if (in_range<R3N_RCP_LO, R3N_RCP_HI>(x)) return 0.5f * rcp_core(x);
-#endif
     return 0.5f / x;
 }
 

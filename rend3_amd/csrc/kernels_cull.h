@@ -108,9 +108,7 @@ R3N_DEV uint32_t object_visible(const r3n_camera_header240 *__restrict__ hdr, co
 // (it replaces the reference's per-invocation binary search, cull.wgsl:181-207, and this implementation's former 12-step scalar
 // search per chunk).  Entry e owns wave slots [ws, ws + nw); it writes every k with ws <= k * R3N_CHUNK_ITERS < ws + nw: up to
 // eight stores by its own thread, larger objects by the whole wavefront.  Called convergently (ballot + lane reads inside).
-#ifndef R3N_CHUNK_ITERS
 #define R3N_CHUNK_ITERS 4u                      // wave slots per wavefront per chunk
-#endif
 R3N_DEV void write_first_entries(uint32_t *__restrict__ first_entry, uint32_t flag, uint32_t e, uint32_t ws, uint32_t nw, uint32_t lane) {
     if (first_entry == nullptr) return;
     uint32_t k_lo = 0u, cnt = 0u;
@@ -762,9 +760,7 @@ R3N_DEV bool execute_culling(const float *__restrict__ mvp, const float v[3][3],
 // address space, which is what lets the compiler emit s_load; only for memory that no kernel of the same launch writes (the
 // scalar cache is not coherent with vector stores inside a launch; across launches it is invalidated).  A vector load of a
 // uniform value costs a full vector-memory round trip per wave AND blocks on vmcnt behind whatever else is in flight.
-#ifndef R3N_CULL_PAIR
 #define R3N_CULL_PAIR 1  // the triangle cull fetches two wave slots of an object together
-#endif
 typedef uint32_t r3n_u32x2 __attribute__((ext_vector_type(2)));
 
 #define R3N_CHUNK_WAVES (4u * R3N_CHUNK_ITERS)   // wave slots per 256-thread block per chunk (4096 triangles)

@@ -86,30 +86,15 @@ struct TriWork {
 
 // TEX: the launch may meet cutout materials whose alpha comes from the albedo texture (row N2).  The lean variant
 // (no texture code, fewer registers) is launched whenever the world has no textures or the key is not cutout.
-// UNIFORM_OBJ: `obj` is wave-uniform (the caller's waterfall over the wave's distinct objects): the object record's fields and the
-// baked matrix come through scalar loads -- one fetch per wave instead of 64 lanes' worth of gathers, sixteen vector registers less,
-// and one round trip less in the per-triangle chain (list entry -> record -> indices -> positions); what paid in the triangle cull.
-template <bool DEPTH_ONLY, bool TEX, bool UNIFORM_OBJ = false, bool NOCUT = false>
+template <bool DEPTH_ONLY, bool TEX, bool NOCUT = false>
 R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, bool positive_visible, TriWork &tw) {
     const r3n_object128 &ob = a.objects[obj];
     // The record's fields this function needs in TWO loads issued together -- bytes 80..95 (first_index, index_count, material_index,
     // the position attribute's offset) and `enabled` -- and waited for once: read field by field behind the `enabled` test they were
     // three dependent round trips of the per-triangle chain (list entry -> record -> indices -> positions).
-    uint4 of;
-    uint32_t enabled;
-    float mvp[16];
-    if (UNIFORM_OBJ) {
-        const r3n_u32x4 so = scalar_load<r3n_u32x4>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
-        of = make_uint4(so.x, so.y, so.z, so.w);
-        enabled = scalar_load<uint32_t>(&ob.enabled);
-        const r3n_u32x16 sm = scalar_load<r3n_u32x16>(a.baked[obj].model_view_proj);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mvp[k] = __uint_as_float(sm[k]);
-    } else {
-        of = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
-        enabled = ob.enabled;
-        asm volatile("" : : "v"(of.x), "v"(of.w), "v"(enabled));  // both loads in flight before the test below can split them
-    }
+    const uint4 of = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(&ob) + offsetof(r3n_object128, first_index));
+    const uint32_t enabled = ob.enabled;
+    asm volatile("" : : "v"(of.x), "v"(of.w), "v"(enabled));  // both loads in flight before the test below can split them
     if (enabled == 0u) return false;  // opaque.wgsl:104-112 / depth.wgsl:64-72
     const uint32_t first = of.x + tri * 3u;
     const uint32_t pos_off = of.w;
@@ -120,7 +105,7 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     for (int k = 0; k < 3; ++k) {
         float v[3];
         fetch_vec3(a.mesh, pos_off, idx[k], v);
-        mul_point(UNIFORM_OBJ ? mvp : a.baked[obj].model_view_proj, v, p[k]);
+        mul_point(a.baked[obj].model_view_proj, v, p[k]);
     }
     const float half_w = (float)a.vp_w / 2.0f, half_h = (float)a.vp_h / 2.0f;
     setup_triangle(p, half_w, half_h, positive_visible, tw.ts);
@@ -159,19 +144,12 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
     return true;
 }
 
-#ifndef R3N_PREREAD_SMALL
+// (constants, not build options: the measurements that fixed them are in profiles/r0N_summary.md; an experiment is a patch)
 #define R3N_PREREAD_SMALL 0
-#endif
-#ifndef R3N_PREREAD_MS
 #define R3N_PREREAD_MS 1        // work-item kernel on a multisampled viewport: read the pixel's keys before the atomics
-#endif
-#ifndef R3N_PREREAD_VIEWPORT
 #define R3N_PREREAD_VIEWPORT 0  // the same at one sample per pixel: the kernel alone gains (168 -> 152 us) but the frame with
                                 // frames in flight loses (1.18 -> 1.20 ms): off
-#endif
-#ifndef R3N_PREREAD_BIG
 #define R3N_PREREAD_BIG 0
-#endif
 // PREREAD: plain load + compare before the atomic.  It filters occluded fragments cheaply (the load may be
 // stale, which is only conservative because keys grow monotonically) but puts a dependent load in front of every
 // atomic; without it the atomic is fire-and-forget.
@@ -229,17 +207,10 @@ R3N_DEV void global_max_u64_at(unsigned long long *base, uint32_t byte_off, unsi
 
 // Element index of pixel (x, y) of the viewport inside the target.  Rows and pitch are below 2^16 (r3n_frame_begin), the target
 // below 2^29 samples: 24-bit multiply, 32-bit offsets.
-#ifndef R3N_TILED_HACK
-#define R3N_TILED_HACK 0  // TIMING experiment only (wrong images): the depth atlas addressed in 4 x 4 texel tiles of one 64-byte line each
-#endif
+// (a 4 x 4-texel tiled atlas was timed in round 4 -- shadow work items -22 % -- and not built: the PCF's footprints would straddle
+// tiles in the kernel the frame waits for; profiles/r04_summary.md section 6c)
 template <bool DEPTH_ONLY>
 R3N_DEV uint32_t target_pixel(const RasterArgs &a, uint32_t x, uint32_t y) {
-#if R3N_TILED_HACK
-    if (DEPTH_ONLY) {
-        const uint32_t X = a.vp_x + x, Y = a.vp_y + y;
-        return ((__umul24(Y >> 2, a.target_pitch >> 2) + (X >> 2)) << 4) + ((Y & 3u) << 2) + (X & 3u);
-    }
-#endif
     return __umul24(a.vp_y + y, a.target_pitch) + (a.vp_x + x);
 }
 
@@ -285,10 +256,6 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         // rows and pitch are below 2^16 (r3n_frame_begin), the target below 2^29 samples: 24-bit multiply, 32-bit byte offsets
         const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
         const uint32_t zb = __float_as_uint(z);
-#if R3N_ABLATE == 2
-        asm volatile("" : : "v"(zb), "v"(pix));
-        return;
-#endif
         if (DEPTH_ONLY) {
             if (!PREREAD || zb > a.depth[pix]) global_max_u32_at(a.depth, pix << 2, zb);
         } else {
@@ -318,10 +285,6 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;
         }
         const size_t pix = ((size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x) * (size_t)S;
-#if R3N_ABLATE == 2
-        asm volatile("" : : "v"(zs[0]), "v"(zs[1]), "v"(zs[2]), "v"(zs[3]), "v"(mask), "v"(pix));
-        return;
-#endif
         // PREREAD (the work-item kernel under MSAA): the pixel's four keys are 32 contiguous bytes; read them once and
         // skip the atomics that cannot win.  Memory-side atomics are 65 % of that kernel at 4 samples (ablation,
         // bench scene: 1.43 ms -> 0.50 ms without them); the read removes the overdrawn ones: 1.43 -> 1.04 ms.  Keys only
@@ -340,23 +303,16 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     }
 }
 
-#ifndef R3N_ABLATE
-#define R3N_ABLATE 0  // diagnostics only (tools/variants.py): 1 no scan steps, 2 no atomics, 3 no block test / scan
-#endif
-#ifndef R3N_BIG_LEAN
-#define R3N_BIG_LEAN 2  // the work-item kernel's scan step without intermediate branches: 1 = one predicate in C++ (shade_pixel_lean),
-                        // 2 = the predicate as a v_cmpx chain (shade_pixel_cmpx); 0 = the early-out form of rounds 1-3.  Stand-alone the
-                        // three run the same (85.3 / 85.3 / 85.1 us per shadow launch: the kernel waits for its atomics); in the frame,
-                        // beside the resolve, fewer scalar instructions are worth 1.2 % (1.0504 -> 1.0378 ms)
-#endif
 // One scan step of the work-item kernel at one sample per pixel, opaque key: the same coverage / depth-clip / target arithmetic as
 // shade_pixel, as STRAIGHT-LINE code -- every lane evaluates everything, the tests are combined into one predicate and only the
 // atomic is predicated.  Why: the kernel is bound by instruction ISSUE, and more by the scalar unit than by the vector units
 // (profiles/r04_summary.md: 31 M scalar against 27 M vector instructions per shadow launch, 78 % of a SIMD's scalar issue slots):
 // every early-out `if` costs a mask AND, an exec update and a branch on the scalar unit and saves vector work only when ALL 64
 // lanes fail, which the block rejection test in front of the step has already made rare.
-// R3N_BIG_LEAN == 2: the predicate as a chain of v_cmpx (each narrows EXEC on the vector unit: no mask ANDs, no exec update
-// and no branch on the scalar unit), the atomic under the narrowed mask, EXEC restored -- one asm statement.
+// The predicate is a chain of v_cmpx (each narrows EXEC on the vector unit: no mask ANDs, no exec update and no branch on the
+// scalar unit), the atomic under the narrowed mask, EXEC restored -- one asm statement.  (Stand-alone the early-out form of rounds
+// 1-3, a one-predicate C++ form and this one run the same, 85.3 / 85.3 / 85.1 us per shadow launch: the kernel waits for its
+// atomics; in the frame, beside the resolve, fewer scalar instructions are worth 1.2 %, 1.0504 -> 1.0378 ms.)
 // fine: the step's lanes hold block index `b` (0xFFFFFFFF: none); coarse: b is not tested.
 template <bool DEPTH_ONLY, bool FINE>
 R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int y, uint32_t b, int rx0, int rx1, int ry1) {
@@ -364,7 +320,7 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
 #pragma unroll
     for (int i = 0; i < 3; ++i) E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
     const float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
-    const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;  // accepted: [0, 1] or -0 (see shade_pixel_lean)
+    const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;  // an accepted z is in [0, 1] or -0: clearing the sign bit canonicalises -0 and changes nothing else
     const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
     unsigned long long save;
     typedef __attribute__((address_space(1))) void *gv_t;
@@ -422,30 +378,6 @@ R3N_DEV void shade_pixel_cmpx(const RasterArgs &a, const TriWork &tw, int x, int
 #undef R3N_CMPX_CHAIN
 }
 
-template <bool DEPTH_ONLY>
-R3N_DEV void shade_pixel_lean(const RasterArgs &a, const TriWork &tw, int x, int y, bool active) {
-    float E[3];
-    bool ok = active;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        E[i] = (tw.ts.e[i][0] * ((float)x + 0.5f) + tw.ts.e[i][1] * ((float)y + 0.5f)) + tw.ts.e[i][2];
-        ok = ok & (E[i] >= tw.thr[i]);
-    }
-    float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
-    ok = ok & (z >= 0.0f) & (z <= 1.0f);  // depth clip (unclipped_depth: false, forward.rs:343)
-    // an accepted z is in [0, 1] or -0: clearing the sign bit canonicalises -0 and changes nothing else
-    const uint32_t zb = __float_as_uint(z) & 0x7FFFFFFFu;
-    const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
-#if R3N_ABLATE == 2
-    asm volatile("" : : "v"(zb), "v"(pix), "v"(ok ? 1u : 0u));
-    return;
-#endif
-    if (ok) {
-        if (DEPTH_ONLY) global_max_u32_at(a.depth, pix << 2, zb);
-        else global_max_u64_at(a.vis, pix << 3, ((unsigned long long)zb << 32) | (unsigned long long)tw.slot1);
-    }
-}
-
 // The three edge thresholds of a work item travel in the top bits of its `material` word (bit 29 + i set: edge i is NOT a
 // top / left edge, threshold = the smallest subnormal): the producer has them in registers, the consumer would spend two dozen
 // scalar instructions per item deriving them from the coefficients' bits.
@@ -455,56 +387,27 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
     return ((thr[0] != 0.0f ? 1u : 0u) | (thr[1] != 0.0f ? 2u : 0u) | (thr[2] != 0.0f ? 4u : 0u)) << R3N_BIG_THR_SHIFT;
 }
 
-#ifndef R3N_SMALL_MAX
-#define R3N_SMALL_MAX 8
-#endif
+// The rasterisers' constants.  They are NOT build options: each was fixed by a measurement (quoted beside it, details in
+// profiles/r0N_summary.md); an experiment with another value is a patch against this file (profiles/patches/).
+#define R3N_SMALL_MAX 8      // triangles up to 8 x 8 px are scanned in place by their thread
 // Work items cover at most R3N_TILE x R3N_TILE px.  Measured on the bench scene (us per frame, shadow big / viewport
 // big): tile 64 coarse-only 478 / 218, tile 32 coarse-only 475 / 204, tile 32 + fine 423 / 185, tile 16 + fine 482 / 191.
-#ifndef R3N_TILE
 #define R3N_TILE 32
-#endif
-#ifndef R3N_SMALL_OCC
-#define R3N_SMALL_OCC 1  // min waves per SIMD asked of k_raster_small (launch bound)
-#endif
-#ifndef R3N_BIG_XCD
-#define R3N_BIG_XCD 0
-#endif
-#ifndef R3N_BIG_TOUCH
-#define R3N_BIG_TOUCH 0  // the work-item kernel pulls the record after the next one into the local L2 with an unwaited vector load --
-                         // measured: no effect (shadow 81.6 -> 81.3 us per launch stand-alone, frame 1.017 -> 1.024 ms): the record's latency is
-                         // not what a wave's progress waits for once enough waves are resident; off
-#endif
-#ifndef R3N_SMALL_WATERFALL
-#define R3N_SMALL_WATERFALL 0  // per-triangle pass: object record + baked matrix through scalar loads, one round per distinct object of a wave -- measured SLOWER (viewport 22.9 -> 37.6 us, shadow 43.8 -> 45.9 us per launch): a wave's 64 entries span several objects often enough that the repeated setup rounds cost more than the gathers they replace
-#endif
-#ifndef R3N_ITEM_ALIGN
-#define R3N_ITEM_ALIGN 16  // (a power of two <= R3N_TILE; measured: viewport work items 84.7 -> 73.2 us, shadow 85.0 -> 80.8 us per launch)
-#endif
-#ifndef R3N_FINE_LW_DEPTH
+#define R3N_SMALL_OCC 1      // min waves per SIMD asked of k_raster_small (launch bound)
+#define R3N_ITEM_ALIGN 16    // (a power of two <= R3N_TILE; measured: viewport work items 84.7 -> 73.2 us, shadow 85.0 -> 80.8 us per launch)
 #define R3N_FINE_LW_DEPTH 3  // log2 of the fine block's width on a depth target (2: 4x4, 3: 8x2, 4: 16x1 texels).  Measured (shadow work items
                              // per launch stand-alone / frame): 4x4 81.5 us / 1.025 ms, 8x2 74.0 / 1.003, 16x1 76.4 / 1.033 (fewest lines per
                              // step, but more steps: partly covered blocks along every edge)
-#endif
-#ifndef R3N_FINE_LW_VIS
 #define R3N_FINE_LW_VIS 3    // the same on the key target (a line is 8 keys): 4x4 72.6 us / 1.025 ms, 8x2 66.4 / 1.001; both 8x2: 1.003
-#endif
-#ifndef R3N_FINE
-#define R3N_FINE 1    // regions of the tile size are scanned four 4x4 blocks per step instead of one 8x8 block
-#endif
+// Measured and NOT kept (round 4, profiles/r04_summary.md sections 2 and 6c; the code is in the history, commit 79bedf3): the
+// per-triangle pass with the object record + baked matrix through scalar loads in a waterfall over the wave's distinct objects
+// (viewport 22.9 -> 37.6 us, shadow 43.8 -> 45.9 us per launch); an XCD-affine walk of the work queue (shadow 81.7 -> 87.1 us);
+// the record after the next one pulled into the local L2 by an unwaited vector load (81.6 -> 81.3 us, frame 1.017 -> 1.024 ms).
 
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
-#ifdef R3N_WAVE_TRACE
-// diagnostics build only (tools/wave_trace.py): per wave of the shadow views' per-triangle launches {start, after the setup
-// of the last round, end (100 MHz ticks), triangles set up, largest in-place box (texels), work items emitted}
-__device__ uint32_t g_small_trace[4][8192][6];
-#endif
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false>
 R3N_DEV void raster_small_body(const RasterArgs &a) {
-#ifdef R3N_WAVE_TRACE
-    const uint32_t st_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    uint32_t st_prep = st_t0, st_tris = 0, st_box = 0, st_items = 0;
-#endif
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
     const uint32_t n = a.sub_counts[a.key * R3N_SUBQ + q];
@@ -515,40 +418,11 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
     const uint32_t bq = __builtin_amdgcn_readfirstlane((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % R3N_BIGQ);
     const bool positive_visible = (a.hdr->flags & R3N_PCU_POSITIVE_AREA_VISIBLE) != 0u;
     const uint32_t stride = (gridDim.x / R3N_SUBQ) * blockDim.x;
-#if R3N_SMALL_WATERFALL
-    // every lane of the workgroup walks the same number of rounds (the waterfall below needs whole waves); lanes past the end idle
-    for (uint32_t i0 = (blockIdx.x / R3N_SUBQ) * blockDim.x; i0 < n; i0 += stride) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool live = i < n;
-        r3n_tri_ref ref;
-        ref.object = 0u; ref.triangle = 0u;
-        if (live) ref = list[i];
-        TriWork tw;
-        bool ok = false;
-        // a wave's 64 list entries come from one or two objects (the cull appends an object's triangles together): one round
-        // of the setup per DISTINCT object, with that object's record and matrix in scalar registers
-        unsigned long long todo = __ballot(live);
-        while (todo) {
-            const uint32_t obj_u = (uint32_t)__builtin_amdgcn_readlane((int)ref.object, (int)__builtin_ctzll(todo));
-            const bool mine = live && ref.object == obj_u;
-            if (mine) ok = prepare_triangle<DEPTH_ONLY, TEX, true, NOCUT>(a, obj_u, ref.triangle, positive_visible, tw);
-            todo &= ~__ballot(mine);
-        }
-        if (!ok) continue;
-        const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
-#else
     for (uint32_t i = (blockIdx.x / R3N_SUBQ) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const r3n_tri_ref ref = list[i];
         TriWork tw;
-        if (!prepare_triangle<DEPTH_ONLY, TEX, false, NOCUT>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
+        if (!prepare_triangle<DEPTH_ONLY, TEX, NOCUT>(a, ref.object, ref.triangle, positive_visible, tw)) continue;
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
-#endif
-#ifdef R3N_WAVE_TRACE
-        st_prep = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        ++st_tris;
-        if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) st_box = max(st_box, (uint32_t)(bw * bh));
-        else st_items += (uint32_t)(((tw.x1 - (tw.x0 & ~(R3N_ITEM_ALIGN - 1)) + R3N_TILE) / R3N_TILE) * ((bh + (R3N_TILE - 1)) / R3N_TILE));
-#endif
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
                 for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
@@ -597,22 +471,6 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
             }
         }
     }
-#ifdef R3N_WAVE_TRACE
-    if (DEPTH_ONLY) {
-        // wave totals through the lanes: triangles and items summed, the box and the setup time as maxima
-        uint32_t tris = st_tris, box = st_box, items = st_items, prep = st_prep - st_t0;
-        for (int d = 32; d > 0; d >>= 1) {
-            tris += __shfl_xor(tris, d); items += __shfl_xor(items, d);
-            box = max(box, (uint32_t)__shfl_xor(box, d)); prep = max(prep, (uint32_t)__shfl_xor(prep, d));
-        }
-        const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63u) == 0u && wv < 8192u) {
-            const uint32_t quad = (a.vp_x ? 1u : 0u) + (a.vp_y ? 2u : 0u);
-            uint32_t *t = g_small_trace[quad][wv];
-            t[0] = st_t0; t[1] = st_t0 + prep; t[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); t[3] = tris; t[4] = box; t[5] = items;
-        }
-    }
-#endif
 }
 
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false>
@@ -727,43 +585,22 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 // the next item's record is in flight while the current one is scanned.  Waves walk the concatenation of the
 // R3N_BIGQ producer sub-queues with a stride of the wave count, which spreads neighbouring (similar-cost) items
 // over different waves.
-#ifdef R3N_WAVE_TRACE
-// diagnostics build only (tools/wave_trace.py): per wave of the shadow-view launches {start, end (s_memrealtime, 100 MHz
-// ticks, low 32 bits), items, scan steps}, indexed by the cascade's atlas quadrant
-__device__ uint32_t g_wave_trace[4][32768][4];
-#endif
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool NOCUT = false>
 R3N_DEV void raster_big_body(RasterArgs a) {
-#ifdef R3N_WAVE_TRACE
-    const uint32_t trace_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    uint32_t trace_items = 0, trace_steps = 0;
-#endif
     // Pin the kernel arguments the scan uses into SGPRs here: hipcc otherwise sinks the wait for their s_load
     // into the scan loop, and an `s_waitcnt lgkmcnt(0)` there would also wait for the record prefetch below.
     asm volatile("" : "+s"(a.target_pitch), "+s"(a.vp_x), "+s"(a.vp_y), "+s"(a.depth), "+s"(a.vis), "+s"(a.key),
                  "+s"(a.materials), "+s"(a.big_items), "+s"(a.big_count), "+s"(a.big_capacity));
     const uint32_t lane = threadIdx.x & 63u;
-#if R3N_BIG_XCD
-    // XCD affinity (speed only, never correctness): workgroup b is observed to run on XCD b mod 8, and the producers' waves of
-    // workgroup b append to sub-queues (4 b + wave) mod 32 -- so sub-queues 4 x .. 4 x + 3 were written on XCD x, and plain stores
-    // stay in that XCD's L2.  A consumer workgroup walks ONLY the four sub-queues of its own residue: the record loads then hit
-    // the local L2 instead of going to the memory side (35 % of this kernel is the latency of those loads).  Every sub-queue
-    // is consumed whatever the placement is; only the hit rate depends on it.
-    static_assert(R3N_BIGQ == 32u, "four sub-queues per XCD residue");
-    const uint32_t qgroup = (blockIdx.x & 7u) * 4u;
-    const uint32_t wave_global = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
-    const uint32_t nwaves = ((gridDim.x + 7u - (blockIdx.x & 7u)) >> 3) * 4u;  // workgroups of this residue x 4 waves
-#else
     const uint32_t qgroup = 0u;
     const uint32_t wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-#endif
     const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
     const uint32_t cap = a.big_capacity;
     // Sub-queue bounds live in registers: lane q < R3N_BIGQ holds [excl, incl), the flat indices of sub-queue q in the
     // concatenation (one vector load + a wave scan at kernel start, before any atomic is in flight).  Locating an item
     // is then a ballot + readlane, with no memory access in the item loop.
-    const uint32_t qcnt_l = lane < (R3N_BIG_XCD ? 4u : R3N_BIGQ) ? min(a.big_count[qgroup + lane], cap) : 0u;
+    const uint32_t qcnt_l = lane < R3N_BIGQ ? min(a.big_count[qgroup + lane], cap) : 0u;
     uint32_t incl = qcnt_l;
 #pragma unroll
     for (uint32_t d = 1; d < R3N_BIGQ; d <<= 1) {
@@ -791,31 +628,14 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         sptr_t sp = (sptr_t)(unsigned long long)rec;
         da = *reinterpret_cast<__attribute__((address_space(4))) const u32x16 *>(sp);
     }
-#if R3N_BIG_TOUCH
-    // The record of the item AFTER the next one is pulled into this XCD's L2 by a vector load nobody waits for (its result is
-    // never read): the records were written by the previous kernel on other XCDs, so a scalar load of one goes all the way to
-    // the memory side (~1.4 us, and scalar loads return out of order: only one can usefully be in flight); behind the touch it
-    // is an L2 hit.  A second scalar prefetch cannot do this: 64 SGPRs of records make the compiler spill the destinations of
-    // loads that are still in flight.  `touch` is an in/out operand of every statement, which keeps its register out of the
-    // allocator's hands for the whole loop (the load writes it whenever it returns).
-    uint32_t touch = 0u;
-    const uint32_t touch_off = (lane & 15u) << 2;
-    const uint32_t *nrec = rec ? locate(flat + nwaves) : nullptr;
-#endif
     while (rec) {
         // The next record's scalar loads stay in flight while this item is scanned (the records come from HBM /
         // Infinity Cache: without the overlap every item costs a full memory latency per wave).  hipcc sinks a
         // plain load to its first use, so the prefetch is an asm load it does not track; the matching wait
         // statement at the end of the iteration names both destinations (cdna_hip_programming.md section 5.7 (ii)).
         flat += nwaves;
-#if R3N_BIG_TOUCH
-        const uint32_t *trec = nrec ? locate(flat + nwaves) : nullptr;
-        if (nrec) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(na) : "s"(nrec) : "memory");
-        if (trec) asm volatile("global_load_dword %0, %1, %2" : "+v"(touch) : "v"(touch_off), "s"(trec) : "memory");
-#else
         const uint32_t *nrec = locate(flat);
         if (nrec) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(na) : "s"(nrec) : "memory");
-#endif
         uint32_t d[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = da[j];
@@ -865,12 +685,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
         const int rx0 = (int)(kxy0 & 0xFFFFu), ry0 = (int)(kxy0 >> 16);
         const int rx1 = (int)(kxy1 & 0xFFFFu), ry1 = (int)(kxy1 >> 16);
         const int gx0 = rx0 & ~(R3N_ITEM_ALIGN - 1);  // origin of the block grid: blocks sit on the target's cache lines
-#if R3N_ABLATE == 3
-        asm volatile("" : : "s"(rx0), "s"(ry0), "s"(rx1), "s"(ry1), "s"(w.ts.e[0][0]), "s"(w.ts.z[2]));
-        if (false) {
-#else
-        if (R3N_FINE && rx1 - gx0 < 32 && ry1 - ry0 < 32) {
-#endif
+        if (rx1 - gx0 < 32 && ry1 - ry0 < 32) {
             // fine mode (regions up to 32x32 px): lane = 16-pixel block for the rejection test; every step then scans
             // FOUR surviving blocks, 16 lanes each -- small triangles fill the wave far better than with 8x8 blocks.
             // The block is FW x FH pixels (FW * FH = 16): the shape decides how many of the target's 64-byte lines one
@@ -880,17 +695,10 @@ R3N_DEV void raster_big_body(RasterArgs a) {
             const int cbx = gx0 + (int)(lane & ((1u << LC) - 1u)) * FW, cby = ry0 + (int)(lane >> LC) * FH;
             const bool cand = cbx <= rx1 && cbx + (FW - 1) >= rx0 && cby <= ry1 && block_may_cover<FW, (S > 1), FH>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
-#if R3N_ABLATE == 1
-            asm volatile("" : : "s"(blocks));
-            blocks = 0ull;
-#endif
             const uint32_t grp = lane >> 4;
             const int px = (int)(lane & (uint32_t)(FW - 1)), py = (int)((lane & 15u) >> LW);
-            if (R3N_BIG_LEAN && S == 1 && !BLEND && !w.cutout) {
+            if (S == 1 && !BLEND && !w.cutout) {
                 while (blocks) {
-#ifdef R3N_WAVE_TRACE
-                    ++trace_steps;
-#endif
                     // four find-first / clear-bit pairs (an empty mask yields -1: no block, and clearing bit 63 of zero is harmless)
                     // (one statement: between separate asm statements the compiler pads every scalar write with a hazard s_nop)
                     uint32_t bsel[4];
@@ -903,17 +711,10 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                     int x, y;
                     asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(x) : "v"(b & ((1u << LC) - 1u)), "v"(gx0 + px), "n"(LW));
                     asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(y) : "v"(b >> LC), "v"(ry0 + py), "n"(4 - LW));
-#if R3N_BIG_LEAN >= 2
                     shade_pixel_cmpx<DEPTH_ONLY, true>(a, w, x, y, b, rx0, rx1, ry1);
-#else
-                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (b < 64u) & (x >= rx0) & (x <= rx1) & (y <= ry1));
-#endif
                 }
             } else
             while (blocks) {
-#ifdef R3N_WAVE_TRACE
-                ++trace_steps;
-#endif
                 int bsel[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -928,56 +729,29 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(y) : "v"(b >> LC), "v"(ry0 + py), "n"(4 - LW));
                 if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
-        } else if (R3N_ABLATE != 3) {
+        } else {
             const int cbx = gx0 + lx * 8, cby = ry0 + ly * 8;
             const bool cand = cbx <= rx1 && cbx + 7 >= rx0 && cby <= ry1 && block_may_cover<8, (S > 1)>(w.ts, cbx, cby, rx1, ry1);
             unsigned long long blocks = __ballot(cand);
-            if (R3N_BIG_LEAN && S == 1 && !BLEND && !w.cutout) {
+            if (S == 1 && !BLEND && !w.cutout) {
                 while (blocks) {
-#ifdef R3N_WAVE_TRACE
-                    ++trace_steps;
-#endif
                     int b;
                     asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(b), "+s"(blocks));
                     const int x = gx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-#if R3N_BIG_LEAN >= 2
                     shade_pixel_cmpx<DEPTH_ONLY, false>(a, w, x, y, 0u, rx0, rx1, ry1);
-#else
-                    shade_pixel_lean<DEPTH_ONLY>(a, w, x, y, (x >= rx0) & (x <= rx1) & (y <= ry1));
-#endif
                 }
             } else
             while (blocks) {
-#ifdef R3N_WAVE_TRACE
-                ++trace_steps;
-#endif
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = gx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
                 if (x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
             }
         }
-#ifdef R3N_WAVE_TRACE
-        ++trace_items;
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na) : : "memory");
         rec = nrec;
         da = na;
-#if R3N_BIG_TOUCH
-        nrec = trec;
-        asm volatile("" : "+v"(touch));
-#endif
     }
-#if R3N_BIG_TOUCH
-    asm volatile("" : : "v"(touch));
-#endif
-#ifdef R3N_WAVE_TRACE
-    if (DEPTH_ONLY && lane == 0u && wave_global < 32768u) {
-        const uint32_t quad = (a.vp_x ? 1u : 0u) + (a.vp_y ? 2u : 0u);
-        uint32_t *t = g_wave_trace[quad][wave_global];
-        t[0] = trace_t0; t[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); t[2] = trace_items; t[3] = trace_steps;
-    }
-#endif
 }
 
 template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool NOCUT = false>
@@ -1126,10 +900,8 @@ __global__ __launch_bounds__(256) void k_hiz_head(const unsigned long long *__re
     hiz_head_body(vis, pyr, d, levels, samples, t);
 }
 
-#ifndef R3N_HIZ_PRIO
 #define R3N_HIZ_PRIO 3  // wave priority of the single-workgroup tail: it sits on the frame's serial chain while the CU it lands on is
                         // shared with the shadow lanes' and the previous frame's resolve waves (85 us average in flight against 21 alone)
-#endif
 __global__ __launch_bounds__(1024) void k_hiz_tail(float *__restrict__ pyr, r3n_hiz_desc d, uint32_t first) {
     __shared__ float lds_a[R3N_HIZ_LDS_A];
     __shared__ float lds_b[R3N_HIZ_LDS_B];

@@ -12,25 +12,14 @@
 #include "device_math.h"
 #include "texture.h"
 
-#ifndef R3N_XCD_REMAP
-#define R3N_XCD_REMAP 0  // resolve tiles in contiguous per-XCD bands: measured, no gain (shade 595 -> 593 us, frame 1.184 -> 1.193 ms)
-#endif
-#ifndef R3N_MS_OCC
-#define R3N_MS_OCC 5   // the same for the multisampled record-based resolve (lean split pass: 0.86 ms at 5, 0.92 at 4)
-#endif
-#ifndef R3N_TEX_OCC
+// The resolve's constants -- fixed by measurement, NOT build options (an experiment is a patch: profiles/patches/).
 #define R3N_TEX_OCC 5  // min waves per SIMD asked of the textured record-based resolve (launch bound)
-#endif
-#ifndef R3N_PCF_WIDE
-#define R3N_PCF_WIDE 1
-#endif
-#ifndef R3N_SKIP_OCCLUDED
-#define R3N_SKIP_OCCLUDED 1
-#endif
-#ifndef R3N_SHADE_ABLATE
-#define R3N_SHADE_ABLATE 0  // diagnostics only (tools/variants.py): bit 0 textures return a constant, bit 1 no texture coordinates /
-                            // derivatives, bit 2 no shadow lookup, bit 3 no lights, bit 4 no tangent frame -- cost of each part
-#endif
+#define R3N_MS_OCC 5   // the same for the multisampled record-based resolve (lean split pass: 0.86 ms at 5, 0.92 at 4)
+// Measured and NOT kept (code in the history, commit 79bedf3; numbers in profiles/r0N_summary.md): resolve tiles in contiguous
+// per-XCD bands (shade 595 -> 593 us, frame 1.184 -> 1.193 ms); the directional lights in groups of two / four whose shadow
+// texels are in flight together (461.0 vs 460.6 us; four: 624 us at three waves per SIMD); round 5: the lookups of every light
+// issued in front of the texture chain (460.8 -> 474.0 / 493.6 us, profiles/patches/r05_resolve_early_shadow_lookups.patch);
+// the parts of the fragment stage compiled out one by one to cost them (profiles/r04_summary.md section 6b).
 
 // ------------------------------------------------------------------------------------------------ K6 resolve
 struct TriRecord;
@@ -95,9 +84,7 @@ struct ShadeArgs {
 #define R3N_FEAT_TEX_GENERAL  0x1000u // binds a texture outside the sampler's short path (set by the host's census, r3n.hip:
                                       // extent not a power of two, float pool texels, pool beyond 2^30 texels, id out of range)
 #define R3N_FEAT_ALL          0x1FFFu
-#ifndef R3N_BATCH_OCC
 #define R3N_BATCH_OCC 4  // waves per SIMD asked of the PBR class's kernel: its batched sampler holds 24 texels in flight (128 VGPRs)
-#endif
 #define R3N_CLS_PLAIN  0u
 #define R3N_CLS_ALBEDO (R3N_FEAT_TEX_ALBEDO)
 #define R3N_CLS_PBR3   (R3N_FEAT_TEX_ALBEDO | R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR)
@@ -254,7 +241,6 @@ R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t
     const uint32_t row = aw << 2;
     const uint32_t base = (__umul24((uint32_t)(int)f0y - 1u, aw) + ((uint32_t)(int)f0x - 1u)) << 2;  // byte offset of texel (cx - 1, cy - 1)
     const char *ap = reinterpret_cast<const char *>(atlas);
-#if R3N_PCF_WIDE
     // the 12 texels as FOUR loads (2 + 4 + 4 + 2 texels: the block's rows are contiguous; dword-aligned multi-dword loads) instead of
     // twelve: a third of the vector-memory instructions of the whole fragment stage were these
     struct __attribute__((packed, aligned(4))) T2 { float v[2]; };
@@ -284,76 +270,6 @@ R3N_DEV float shadow_pcf5(const float *__restrict__ atlas, uint32_t aw, uint32_t
         r = r + tapb(c10, c11, c20, c21, fxm, fy0);  // (-1,  0)
         return r * 0.2f;
     }
-#else
-    auto cmp = [&](uint32_t dy, uint32_t dx) { return ref >= *reinterpret_cast<const float *>(ap + (base + dy * row + (dx << 2))) ? 1.0f : 0.0f; };
-    const float c01 = cmp(0, 1), c02 = cmp(0, 2);
-    const float c10 = cmp(1, 0), c11 = cmp(1, 1), c12 = cmp(1, 2), c13 = cmp(1, 3);
-    const float c20 = cmp(2, 0), c21 = cmp(2, 1), c22 = cmp(2, 2), c23 = cmp(2, 3);
-    const float c31 = cmp(3, 1), c32 = cmp(3, 2);
-    // tap(a, b, c, d, fx, fy) = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy, (top, bot) as a packed pair
-    auto tap = [&](float a, float b, float c, float d, float fx, float fy) {
-        const f2 tb = M::mad((f2){b, d}, splat2(fx), (f2){a, c} * splat2(1.0f - fx));
-        return M::mad(tb.y, fy, tb.x * (1.0f - fy));
-    };
-    float r = 0.0f;
-    r = r + tap(c11, c12, c21, c22, fx0, fy0);  // ( 0,  0)
-    r = r + tap(c21, c22, c31, c32, fx0, fyp);  // ( 0, +1)
-    r = r + tap(c01, c02, c11, c12, fx0, fym);  // ( 0, -1)
-    r = r + tap(c12, c13, c22, c23, fxp, fy0);  // (+1,  0)
-    r = r + tap(c10, c11, c20, c21, fxm, fy0);  // (-1,  0)
-    return r * 0.2f;
-#endif
-}
-
-// The same lookup in two halves, for the light loop that issues the texel loads of several lights before it consumes any
-// (fragment_stage, R3N_LIGHT_GROUP): pcf5_issue derives what shadow_pcf5 derives in front of its loads and issues them,
-// pcf5_finish is what follows them.  Same expressions, same order.
-struct Pcf5Texels {
-    struct __attribute__((packed, aligned(4))) T2 { float v[2]; };
-    struct __attribute__((packed, aligned(4))) T4 { float v[4]; };
-    T2 r0, r3;
-    T4 r1, r2;
-    float fx0, fxp, fxm, fy0, fyp, fym;
-    bool regular;
-};
-R3N_DEV void pcf5_issue(const float *__restrict__ atlas, uint32_t aw, uint32_t ah, float u, float v, Pcf5Texels &p) {
-    const float tx0 = u * (float)aw - 0.5f, ty0 = v * (float)ah - 0.5f;
-    const float txp = tx0 + 1.0f, txm = tx0 + -1.0f, typ = ty0 + 1.0f, tym = ty0 + -1.0f;
-    const float f0x = floorf(tx0), fpx = floorf(txp), fmx = floorf(txm);
-    const float f0y = floorf(ty0), fpy = floorf(typ), fmy = floorf(tym);
-    p.regular = fpx == f0x + 1.0f && fmx == f0x - 1.0f && fpy == f0y + 1.0f && fmy == f0y - 1.0f &&
-                f0x >= 1.0f && f0x <= (float)aw - 3.0f && f0y >= 1.0f && f0y <= (float)ah - 3.0f &&
-                ((unsigned long long)aw * ah <= (1ull << 30));
-    p.fx0 = tx0 - f0x; p.fxp = txp - fpx; p.fxm = txm - fmx;
-    p.fy0 = ty0 - f0y; p.fyp = typ - fpy; p.fym = tym - fmy;
-    if (p.regular) {
-        const uint32_t row = aw << 2;
-        const uint32_t base = (__umul24((uint32_t)(int)f0y - 1u, aw) + ((uint32_t)(int)f0x - 1u)) << 2;
-        const char *ap = reinterpret_cast<const char *>(atlas);
-        p.r0 = *reinterpret_cast<const Pcf5Texels::T2 *>(ap + (base + 4u));
-        p.r1 = *reinterpret_cast<const Pcf5Texels::T4 *>(ap + (base + row));
-        p.r2 = *reinterpret_cast<const Pcf5Texels::T4 *>(ap + (base + 2u * row));
-        p.r3 = *reinterpret_cast<const Pcf5Texels::T2 *>(ap + (base + 3u * row + 4u));
-    }
-}
-template <class M>
-R3N_DEV float pcf5_finish(const Pcf5Texels &p, float ref) {  // (p.regular)
-    const bool c01 = ref >= p.r0.v[0], c02 = ref >= p.r0.v[1];
-    const bool c10 = ref >= p.r1.v[0], c11 = ref >= p.r1.v[1], c12 = ref >= p.r1.v[2], c13 = ref >= p.r1.v[3];
-    const bool c20 = ref >= p.r2.v[0], c21 = ref >= p.r2.v[1], c22 = ref >= p.r2.v[2], c23 = ref >= p.r2.v[3];
-    const bool c31 = ref >= p.r3.v[0], c32 = ref >= p.r3.v[1];
-    auto tapb = [&](bool a, bool b, bool c, bool d, float fx, float fy) {
-        const float omx = 1.0f - fx;
-        const f2 tb = (f2){b ? fx : 0.0f, d ? fx : 0.0f} + (f2){a ? omx : 0.0f, c ? omx : 0.0f};
-        return M::mad(tb.y, fy, tb.x * (1.0f - fy));
-    };
-    float r = 0.0f;
-    r = r + tapb(c11, c12, c21, c22, p.fx0, p.fy0);  // ( 0,  0)
-    r = r + tapb(c21, c22, c31, c32, p.fx0, p.fyp);  // ( 0, +1)
-    r = r + tapb(c01, c02, c11, c12, p.fx0, p.fym);  // ( 0, -1)
-    r = r + tapb(c12, c13, c22, c23, p.fxp, p.fy0);  // (+1,  0)
-    r = r + tapb(c10, c11, c20, c21, p.fxm, p.fy0);  // (-1,  0)
-    return r * 0.2f;
 }
 
 struct PixelData {
@@ -362,16 +278,6 @@ struct PixelData {
 
 #define R3N_PI 3.14159265359f
 
-#ifndef R3N_LIGHT_GROUP_ALL
-#define R3N_LIGHT_GROUP_ALL 0  // 1: every record-based single-sample kernel groups its lights (and asks for four waves per SIMD), not only the PBR class's
-#endif
-#ifndef R3N_LIGHT_GROUP
-#define R3N_LIGHT_GROUP 1  // directional lights whose shadow texel loads are in flight together (1: one by one).  Measured: 2 -- resolve
-                           // 461.0 vs 460.6 us stand-alone, frame 1.007-1.017 vs 0.986-0.998 ms; 4 -- 624 us (three waves per SIMD): off
-#endif
-#ifndef R3N_BRDF_HOIST
-#define R3N_BRDF_HOIST 1
-#endif
 // The terms of surface_shading that do not depend on the light, evaluated once per pixel instead of once per light (same
 // expressions, same values: a square root, two dot products and a handful of multiplies per further light).
 struct BrdfPixel {
@@ -649,28 +555,23 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
     }
     float coords[2] = {0.0f, 0.0f}, ddx[2] = {0.0f, 0.0f}, ddy[2] = {0.0f, 0.0f};
     const bool nearest = kNearest && (mflags & R3N_FLAGS_NEAREST) != 0u;
-    if (kAnyTex && any_tex && !(R3N_SHADE_ABLATE & 2)) {  // opaque.wgsl:207-209
+    if (kAnyTex && any_tex) {  // opaque.wgsl:207-209
         const f2 sr = interp2<M>(lam, (f2){r.uv[0][0], r.uv[0][1]}, (f2){r.uv[1][0], r.uv[1][1]}, (f2){r.uv[2][0], r.uv[2][1]});
         const float self_raw[2] = {sr.x, sr.y};
         frag_coords<M>(ts, r.uv, mat.uv_transform0, (int)x, (int)y, coords, ddx, ddy, self_raw);
     }
     // tex4: all four channels; tex3: the callers that read r, g, b only (alpha neither decoded nor filtered)
-#if R3N_SHADE_ABLATE & 1
-    auto tex4 = [&](int slot, float dst[4]) { dst[0] = coords[0]; dst[1] = coords[1]; dst[2] = ddx[0] + ddy[0]; dst[3] = ddx[1] + ddy[1] + (float)slot; };
-    auto tex3 = tex4;
-#else
     // (a class without TEX_GENERAL / NEAREST: every bound texture is on the sampler's short path -- the host's census says so)
     constexpr bool kShortOnly = (CLS & (R3N_FEAT_TEX_GENERAL | R3N_FEAT_NEAREST)) == 0u;
     // classes that can bind more than one map: the maps share level of detail and footprints where their extents allow (texture.h TexShare)
-    constexpr bool kShare = R3N_TEX_SHARE && kShortOnly && (CLS & (R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR)) != 0u;
+    constexpr bool kShare = kShortOnly && (CLS & (R3N_FEAT_TEX_NORMAL | R3N_FEAT_TEX_AOMR)) != 0u;
     TexShare tshare;
     tshare.width = 0u; tshare.height = 0u; tshare.mips = 0u; tshare.level = 0u; tshare.frac = 0.0f;
     auto tex4 = [&](int slot, float dst[4]) { tex_sample_grad<M, true, kShortOnly, kShare>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst, &tshare); };
     auto tex3 = [&](int slot, float dst[4]) { tex_sample_grad<M, false, kShortOnly, kShare>(a.tex, mat.textures[slot], nearest, coords[0], coords[1], ddx, ddy, dst, &tshare); };
-#endif
     auto has = [&](int slot) { return TEX && (CLS & kSlotFeat[slot]) != 0u && mat.textures[slot] != 0u; };
     // the PBR class (base colour + normal + AO / roughness / metallic maps, nothing else): its three maps in one batched pass
-    constexpr bool kBatch = R3N_TEX_BATCH && TEX && kShortOnly && CLS == R3N_CLS_PBR3 && (R3N_SHADE_ABLATE == 0);
+    constexpr bool kBatch = TEX && kShortOnly && CLS == R3N_CLS_PBR3;
     float tb3[3][4];
     bool batched = false;
     if (kBatch && any_tex) {
@@ -713,7 +614,7 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
         for (int c = 0; c < 4; ++c) out[c] = px.albedo[c];
     } else {
         // --- normal (opaque.wgsl:246-273)
-        if (has(1) && !(R3N_SHADE_ABLATE & 16)) {
+        if (has(1)) {
             float t[4], n[3];
             tex_slot012(1, t, true);
             if (kNormalFlags && (mflags & R3N_FLAGS_BICOMPONENT_NORMAL)) {
@@ -815,7 +716,6 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) vv[c] = -vv[c];
         float color[3] = {px.emissive[0], px.emissive[1], px.emissive[2]};
-#if R3N_SKIP_OCCLUDED
         // A fully occluded light (shadow * ao == 0) adds (finite) * 0 = +-0 when every factor of surface_shading is
         // finite: skip its BRDF.  Finite is guaranteed by: all pixel inputs finite (the sum of magnitudes is finite;
         // NaN fails the comparison), roughness^2 >= 1e-9 (D <= 1/(pi a^2) <= 3.2e17 without underflow of f^2,
@@ -824,76 +724,9 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
                            ((fabsf(vv[1]) + fabsf(vv[2])) + (fabsf(px.f0[0]) + fabsf(px.f0[1])))) +
                           (((fabsf(px.f0[2]) + fabsf(px.diffuse[0])) + (fabsf(px.diffuse[1]) + fabsf(px.diffuse[2]))) + fabsf(px.ao));
         const bool skip_ok = px.roughness >= 1e-9f && px.roughness <= 1e9f && mag < 1e30f;
-#endif
-#if R3N_BRDF_HOIST
         const BrdfPixel pre_v = brdf_pixel<M>(px, vv);
         const BrdfPixel *pre = &pre_v;
-#else
-        const BrdfPixel *pre = nullptr;
-#endif
-#if R3N_LIGHT_GROUP > 1 && R3N_PCF_WIDE && !R3N_SHADE_ABLATE
-        // (the kernels that hold a group's texels need the register budget of four waves per SIMD: k_resolve_opaque's launch bound)
-        if constexpr (SL && (CLS == R3N_CLS_PBR3 || R3N_LIGHT_GROUP_ALL)) {
-            // The directional lights in groups of R3N_LIGHT_GROUP: first every light of the group gets as far as its shadow texel
-            // loads (all of them in flight together), then each is finished and shaded in order -- the same values summed in the same
-            // order as the one-by-one loop below; what changes is that a group costs one round trip to the atlas instead of one per
-            // light (the resolve is bound by the length of its chain of dependent memory round trips).
-            for (uint32_t i0 = 0; i0 < n_dir; i0 += R3N_LIGHT_GROUP) {
-                Pcf5Texels pt[R3N_LIGHT_GROUP];
-                float pref[R3N_LIGHT_GROUP], pu[R3N_LIGHT_GROUP], pv[R3N_LIGHT_GROUP];
-                bool lit[R3N_LIGHT_GROUP], sampled[R3N_LIGHT_GROUP];
-#pragma unroll
-                for (uint32_t j = 0; j < R3N_LIGHT_GROUP; ++j) {
-                    lit[j] = false; sampled[j] = false; pref[j] = 0.0f; pu[j] = 0.0f; pv[j] = 0.0f; pt[j].regular = false;
-                    if (i0 + j >= n_dir) continue;  // (wave-uniform)
-                    const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i0 + j);
-                    const float nl_raw = dot3m<M>(px.normal, L.l);
-                    if (px.roughness > 0.0f && nl_raw == nl_raw && sat(nl_raw) == 0.0f) continue;
-                    lit[j] = true;
-                    float sn[4];
-                    mul_vec4m<MathExact>(L.m, vpos[0], vpos[1], vpos[2], vpos[3], sn);
-                    const float fl[2] = {sn[0] * 0.5f + 0.5f, sn[1] * 0.5f + 0.5f};
-                    const float local[2] = {fl[0], 1.0f - fl[1]};
-                    float tl[2] = {L.offset[0], L.offset[1]};
-                    float tr[2] = {tl[0] + L.size[0], tl[1] + L.size[1]};
-                    const float coords[2] = {tl[0] * (1.0f - local[0]) + tr[0] * local[0],
-                                             tl[1] * (1.0f - local[1]) + tr[1] * local[1]};
-                    const float border[2] = {L.inv_res[0] * 1.5f, L.inv_res[1] * 1.5f};
-                    tl[0] += border[0]; tl[1] += border[1];
-                    tr[0] -= border[0]; tr[1] -= border[1];
-                    pref[j] = sn[2]; pu[j] = coords[0]; pv[j] = coords[1];
-                    if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f) {
-                        sampled[j] = true;
-                        pcf5_issue(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], pt[j]);
-                    }
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < R3N_LIGHT_GROUP; ++j) {
-                    if (i0 + j >= n_dir) continue;
-                    if (!lit[j]) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) color[c] += 0.0f;
-                        continue;
-                    }
-                    const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i0 + j);
-                    float shadow = 1.0f;
-                    if (sampled[j]) shadow = pt[j].regular ? pcf5_finish<M>(pt[j], pref[j]) : shadow_pcf5_general<M>(a.atlas, a.atlas_w, a.atlas_h, pu[j], pv[j], pref[j]);
-#if R3N_SKIP_OCCLUDED
-                    if (skip_ok && L.sane != 0.0f && shadow * px.ao == 0.0f) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) color[c] += 0.0f;
-                        continue;
-                    }
-#endif
-                    float res[3];
-                    surface_shading<M>(L.l, L.color, px, vv, shadow * px.ao, res, pre);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) color[c] += res[c];
-                }
-            }
-        } else
-#endif
-        for (uint32_t i = 0; i < ((R3N_SHADE_ABLATE & 8) ? 0u : n_dir); ++i) {
+        for (uint32_t i = 0; i < n_dir; ++i) {
             const LdsDirLight L = load_light<LdsDirLight, SL>(s_dir + i);
             // surface_shading scales by k = nol * occlusion.  With nol == 0 and roughness > 0 every factor is finite
             // (D <= 1/(pi a^2), V <= 0.5/(nov a), nov >= 1e-5), so the light adds exactly +0: skip the shadow lookup
@@ -918,15 +751,13 @@ R3N_DEV void fragment_stage(const ShadeArgs &a, const LdsDirLight *s_dir, const 
             tr[0] -= border[0]; tr[1] -= border[1];
             float shadow = 1.0f;
             // opaque.wgsl:509-514 (quirk: `any`, un-atlased coords vs atlas-space bounds -- reproduced)
-            if (!(R3N_SHADE_ABLATE & 4) && (fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f)
+            if ((fl[0] >= tl[0] || fl[1] >= tl[1]) && (fl[0] <= tr[0] || fl[1] <= tr[1]) && sn[2] >= 0.0f && sn[2] <= 1.0f)
                 shadow = shadow_pcf5<M>(a.atlas, a.atlas_w, a.atlas_h, coords[0], coords[1], sn[2]);
-#if R3N_SKIP_OCCLUDED
             if (skip_ok && L.sane != 0.0f && shadow * px.ao == 0.0f) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) color[c] += 0.0f;
                 continue;
             }
-#endif
             float res[3];
             surface_shading<M>(L.l, L.color, px, vv, shadow * px.ao, res, pre);
 #pragma unroll
@@ -1044,7 +875,7 @@ static __global__ __launch_bounds__(256) void k_stage_view_lights(ShadeArgs a, V
 // (R3N_CLS_*).  With more than one variant in flight (a.variants) a workgroup first ORs its pixels' features and leaves
 // unless the tile is its own: the smallest launched variant that covers the tile.
 template <int S, bool TEX, bool REC = false, bool SPLIT = false, bool FAST = false, uint32_t CLS = R3N_CLS_ALL, uint32_t VARIANT = 3u>
-__global__ __launch_bounds__(256, (S == 1 && REC && R3N_LIGHT_GROUP > 1 && R3N_LIGHT_GROUP_ALL) ? R3N_BATCH_OCC : ((S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? ((R3N_TEX_BATCH && CLS == R3N_CLS_PBR3) ? R3N_BATCH_OCC : R3N_TEX_OCC) : R3N_MS_OCC) : 1))) void k_resolve_opaque(ShadeArgs a) {
+__global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? (CLS == R3N_CLS_PBR3 ? R3N_BATCH_OCC : R3N_TEX_OCC) : R3N_MS_OCC) : 1)) void k_resolve_opaque(ShadeArgs a) {
     typedef typename std::conditional<FAST, MathFast, MathExact>::type M;
     static_assert(CLS == R3N_CLS_ALL || (S == 1 && REC), "material classes exist for the single-sample record-based resolve");
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
@@ -1053,29 +884,12 @@ __global__ __launch_bounds__(256, (S == 1 && REC && R3N_LIGHT_GROUP > 1 && R3N_L
     // each wavefront shades an 8x8 pixel quad of the 16x16 tile (fewer distinct triangles / atlas texels per wave
     // than a 16x4 strip; measured 3 % faster)
     const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
-#if R3N_XCD_REMAP
-    // Workgroups are dealt to the 8 XCDs round-robin by linear id; remap so that every XCD shades a contiguous band of
-    // tiles (its L2 then holds one band's triangle records, texels and shadow texels instead of a slice of all of them).
-    const uint32_t nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t per = (nb + 7u) / 8u;
-    uint32_t tile = (lin & 7u) * per + (lin >> 3);
-    if (tile >= nb) tile = lin;  // (only when nb is not a multiple of 8: the tail keeps its place)
-    const uint32_t bx = tile % gridDim.x, by = tile / gridDim.x;
-#else
     const uint32_t bx = blockIdx.x, by = blockIdx.y;
-#endif
     const uint32_t x = bx * 16u + (ln & 7u) + 8u * (wv & 1u);
     const uint32_t y = a.row_begin + by * 16u + (ln >> 3) + 8u * (wv >> 1);
     const bool inside = x < a.width && y < a.row_end;
     const size_t pix = inside ? (size_t)y * a.width + x : 0u;
     uint32_t id1 = 0u;  // S == 1: the pixel's triangle (canonical slot + 1), 0 = background
-#ifdef R3N_RESOLVE_VGPR_PAD
-    // experiment: naming a high vector register as clobbered raises the kernel's register count, i.e. lowers its waves per SIMD,
-    // without touching its code (-DR3N_RESOLVE_VGPR_PAD=v135: 136 registers = three waves)
-#define R3N_STR2(x) #x
-#define R3N_STR(x) R3N_STR2(x)
-    if (S == 1 && REC) asm volatile("" : : : R3N_STR(R3N_RESOLVE_VGPR_PAD));
-#endif
     if (S == 1) {
         id1 = inside ? (uint32_t)(a.vis[pix] & 0xFFFFFFFFull) : 0u;
         if (REC && (a.variants & (a.variants - 1u)) != 0u) {  // (launch-uniform) several variants run: is this tile mine?

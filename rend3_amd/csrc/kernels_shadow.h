@@ -25,10 +25,8 @@
 
 #define R3N_STILE 64u            // shadow tile edge in texels
 #define R3N_STILE_CAP 8192u      // triangle references per tile list
-#ifndef R3N_STILE_THREADS
 #define R3N_STILE_THREADS 256u  // threads of the workgroup that owns a tile: busy tiles (thousands of triangles) set the duration of
                                  // the kernel, and a tile's work is only as parallel as its workgroup is wide
-#endif
 
 // 64 bytes: everything the scan of one triangle needs.
 struct r3n_shadow_tri {

@@ -129,13 +129,9 @@ static_assert(sizeof(r3n_big_uv) == 48, "big item cutout record is 12 dwords");
 // Output lists and work queues are split into sub-queues so that appends do not serialise on one counter: a
 // returning atomic on a single address retires at only ~88 per microsecond on MI355X (MI355X_MICROARCH.md,
 // "dequeue" row), which was the bound of the cull kernel with a single counter per list.
-#ifndef R3N_SUBQ
 #define R3N_SUBQ 32   // sub-lists per (list, material key) of the cull output
-#endif
-#ifndef R3N_BIGQ
 #define R3N_BIGQ 32   // sub-queues of the rasteriser's large-triangle work queue; the consumers index their
                       // concatenation, so the split only spreads the producers' counter traffic
-#endif
 struct r3n_sub_counts {
     uint32_t n[2][3][R3N_SUBQ];  // [predicted|residual][material key][sub-list] = triangles appended
 };

@@ -58,9 +58,7 @@ std::string g_create_error;
 }  // namespace
 
 #define R3N_QLANES 4  // shadow views drawn concurrently at most (batched path: two per lane)
-#ifndef R3N_AUX_STREAMS
 #define R3N_AUX_STREAMS 2  // main + shade + these = the four hardware queues the runtime uses by default; 3 / 4 streams measured no faster (profiles/r02_summary.md section 9)
-#endif
 
 // Dynamic LDS bytes asked by the work-item rasteriser's launches.  The kernel uses no LDS: the allocation caps its workgroups per CU.
 // Shadow views at 32 KB (4 workgroups = 4 waves per SIMD instead of 8): the four launches take 444 instead of 466 us and the frame
@@ -71,12 +69,8 @@ std::string g_create_error;
 // Round 4, with the resolve at four waves per SIMD and the slimmer per-triangle pass beside them: the cap pays on the viewport's
 // launches too, and three workgroups per CU beat four -- frame (same box, two runs each): shadow 32 KB / viewport none 0.982-0.993 ms;
 // 32 / 32 0.968-0.972; 48 / 32 0.961 (0.935 on another box against 0.968); 48 / 48 0.940; 64 / 48 (two workgroups) 1.061; no cap 1.049.
-#ifndef R3N_BIG_LDS
-#define R3N_BIG_LDS 49152       // shadow views
-#endif
-#ifndef R3N_VIEWPORT_BIG_LDS
+#define R3N_BIG_LDS 49152           // shadow views
 #define R3N_VIEWPORT_BIG_LDS 49152  // viewport
-#endif
 static_assert(R3N_AUX_STREAMS >= 1 && R3N_AUX_STREAMS <= R3N_QLANES, "every auxiliary stream (shadow lane) needs a work queue of its own: big_items / big_count / big_uv hold 1 + R3N_QLANES");
 
 struct r3n_ctx {
@@ -173,7 +167,6 @@ struct r3n_ctx {
     std::vector<uint32_t> h_blend_order;
     uint32_t n_blend = 0, blend_tris = 0;
     uint32_t frag_capacity = 32u << 20;  // fragment nodes (12 B each), allocated on first use
-    DevBuf tex_texels_f;  // R3N_TEXEL_FLOAT: the RGBA8 pool decoded to float4 at upload
     DevBuf tex_descs, tex_texels, tex_level_off, srgb8_decode;  // bindless texture array (row N2): descriptors, RGBA8 texel pool, decode tables  // bindless texture array (row N2) + sRGB8 -> linear table
     uint32_t n_textures = 0;
     uint64_t n_texels = 0;
@@ -800,7 +793,7 @@ void r3n_destroy(r3n_ctx *c) {
                       &c->frag_count, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
                       &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
                       &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1], &c->material_feat, &c->view_lights[0],
-                      &c->view_lights[1], &c->tex_texels_f};
+                      &c->view_lights[1]};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     free_cam(c->canon);
@@ -965,21 +958,10 @@ static TextureArgs texture_args(r3n_ctx *c) {
     t.texels = c->tex_texels.as<uint32_t>();
     t.decode = c->srgb8_decode.as<float>();
     t.level_off = c->tex_level_off.as<uint32_t>();
-    t.small_pool = c->n_texels <= (1ull << (R3N_TEXEL_FLOAT ? 28 : 30)) ? 1u : 0u;  // byte offsets into the pool fit 32 bits: the sampler's short path
-    t.texels_f = c->tex_texels_f.as<float4>();
+    t.small_pool = c->n_texels <= (1ull << 30) ? 1u : 0u;  // byte offsets into the pool fit 32 bits: the sampler's short path
     return t;
 }
 
-#if R3N_TEXEL_FLOAT
-__global__ __launch_bounds__(256) static void k_decode_pool(const uint32_t *__restrict__ texels, float4 *__restrict__ out, size_t n,
-                                                            const float *__restrict__ decode, uint32_t srgb) {
-    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = texels[i];
-    const float *rgb = decode + (srgb ? 256 : 0);
-    out[i] = make_float4(rgb[v & 0xFFu], rgb[(v >> 8) & 0xFFu], rgb[(v >> 16) & 0xFFu], decode[v >> 24]);
-}
-#endif
 // First word (pool index) of every level of every texture: R3N_TEX_LEVELS entries per texture, so that the sampler does not
 // walk the chain.  `descs` = the descriptors as the device holds them (offsets in pool words; a texel is one word, or four
 // for R3N_POOL_FLOAT textures).
@@ -999,18 +981,6 @@ static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uin
         c->h_tex_short[i] = (w && h && ((w & (w - 1u)) | (h & (h - 1u))) == 0u && descs[i].format < R3N_POOL_FLOAT) ? 1 : 0;
     }
     c->classes_dirty = true;
-#if R3N_TEXEL_FLOAT
-    if (n_texels && n_texels <= (1ull << 28)) {
-        TRY(ensure(c, c->tex_texels_f, (size_t)n_texels * 16, false, -1));
-        for (uint32_t i = 0; i < n; ++i) {
-            if (descs[i].format >= R3N_POOL_FLOAT) continue;
-            uint64_t cnt = 0;
-            for (uint32_t k = 0; k < descs[i].mips; ++k) cnt += (uint64_t)std::max(1u, descs[i].width >> k) * std::max(1u, descs[i].height >> k);
-            hipLaunchKernelGGL(k_decode_pool, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->tex_texels.as<uint32_t>() + descs[i].offset,
-                               c->tex_texels_f.as<float4>() + descs[i].offset, (size_t)cnt, c->srgb8_decode.as<float>(), descs[i].format == 1u ? 1u : 0u);
-        }
-    }
-#endif
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->tex_level_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
@@ -1432,26 +1402,13 @@ int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t 
     return R3N_OK;
 }
 
-#ifndef R3N_MSAA_SPLIT
-#define R3N_MSAA_SPLIT 1  // MSAA resolve in three passes (first triangle per pixel / queued edge triangles / edge pixel average)
-#endif
-#ifndef R3N_BIG_GRID
+// (constants fixed by measurement, not build options)
 #define R3N_BIG_GRID 8192  // 4x the resident wave count (8 waves per SIMD at < 64 VGPRs): the hardware dispatcher
                            // then balances the uneven item costs (measured on the bench scene, shadow views:
                            // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
-#endif
-// Workgroup sizes of the two rasteriser kernels (neither uses LDS or barriers: a workgroup is only the unit in which wave slots are
-// handed back to the dispatcher -- a 4-wave workgroup holds all four until its slowest wave is done).  The grids below are quoted in
-// 256-thread workgroups and scaled at the launch.
-#ifndef R3N_SMALL_BLOCK
-#define R3N_SMALL_BLOCK 256
-#endif
-#ifndef R3N_BIG_BLOCK
-#define R3N_BIG_BLOCK 256
-#endif
-#ifndef R3N_SMALL_GRID
+// Workgroups of the two rasteriser kernels: 256 threads (neither uses LDS or barriers: a workgroup is only the unit in which wave
+// slots are handed back to the dispatcher; 64- and 128-thread workgroups measured the same, profiles/r04_summary.md section 6a).
 #define R3N_SMALL_GRID 2048
-#endif
 #define R3N_FB_SMALL_GRID 1024  // the shadow views' fallback lists are short: smaller grids (x views)
 #define R3N_FB_BIG_GRID 2048
 
@@ -1777,10 +1734,7 @@ int r3n_hi_z(r3n_ctx *c) {
                        c->vis.as<unsigned long long>(), c->hiz.as<float>(), c->hizd, levels, c->hiz_plane_ready ? 0u : c->samples);
     c->hiz_plane_ready = false;
     uint32_t first = levels + 1u;
-#ifndef R3N_HIZ_SPLIT
-#define R3N_HIZ_SPLIT 1
-#endif
-    if (R3N_HIZ_SPLIT && first < c->hizd.mips) {
+    if (first < c->hizd.mips) {
         // the first level behind the head is still thousands of texels (120 x 67 at 4K): a grid of workgroups builds it, so the
         // single-workgroup tail -- which shares its CU with whatever else is resident -- starts from a level a quarter the size
         const uint32_t dw = std::max(1u, c->width >> first), dh = std::max(1u, c->height >> first);
@@ -1894,8 +1848,8 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         // textured variant only where it can matter: cutout key and a non-empty texture array
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         auto launch = [&](auto small, auto big) {
-            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_VIEWPORT_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), R3N_VIEWPORT_BIG_LDS, stream, a); }
         };
         const bool nocut = key != R3N_KEY_CUTOUT;  // the opaque key's instantiations carry nothing of the cutout test (kernels_raster.h NOCUT)
         if (c->samples == 4) {
@@ -1914,14 +1868,14 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         a.depth = c->atlas.as<uint32_t>();
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         if (tex) {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
         } else if (key != R3N_KEY_CUTOUT) {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false, true>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false, false, true>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false, true>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false, false, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
         } else {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid * (256 / R3N_SMALL_BLOCK)), dim3(R3N_SMALL_BLOCK), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID * (256 / R3N_BIG_BLOCK)), dim3(R3N_BIG_BLOCK), R3N_BIG_LDS / (256 / R3N_BIG_BLOCK), stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
         }
     }
     return check_launch(c, "raster");
@@ -1936,7 +1890,7 @@ static int refresh_material_classes(r3n_ctx *c) {
     const uint32_t n = c->n_materials;
     c->h_materials.resize(n, r3n_material208{});
     std::vector<uint32_t> feat(std::max(n, 1u), R3N_FEAT_ALL);
-    const bool small_pool = c->n_texels <= (1ull << (R3N_TEXEL_FLOAT ? 28 : 30));
+    const bool small_pool = c->n_texels <= (1ull << 30);
     uint32_t variants = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const r3n_material208 &m = c->h_materials[i];
@@ -2005,7 +1959,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     const bool use_records = c->total_tris > 0 && (uint64_t)c->total_tris * sizeof(TriRecord) <= (8ull << 30);
     const uint64_t npix_all = (uint64_t)c->width * c->height;
     const bool blend_samples = c->samples == 4 && c->blend_tris > 0;  // a transparent pass will blend into the individual samples
-    const bool split = c->samples == 4 && use_records && !blend_samples && npix_all < (1ull << 29) && R3N_MSAA_SPLIT;
+    const bool split = c->samples == 4 && use_records && !blend_samples && npix_all < (1ull << 29);  // MSAA resolve in three passes (first triangle per pixel / queued edge triangles / edge pixel average)
     uint32_t edge_cap = 0;
     // single-sample record-based resolve of a textured world: one kernel per material class present (R3N_RESOLVE_CLASSES=0: the general kernel)
     const bool classes = use_records && c->samples == 1 && c->n_textures > 0 && c->n_materials > 0 && c->resolve_classes;
@@ -2850,19 +2804,6 @@ int r3n_readback_output(r3n_ctx *c, uint8_t *rgba8, float *rgba_f32) {
 }
 
 // ------------------------------------------------------------------------------------------------ timing
-#ifdef R3N_WAVE_TRACE
-extern "C" int r3n_debug_wave_trace(r3n_ctx *c, uint32_t *dst) {  // diagnostics build only; dst: [4][32768][4]
-    TRY(sync_all(c));
-    HIP_TRY(c, hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), sizeof(uint32_t) * 4 * 32768 * 4));
-    return R3N_OK;
-}
-extern "C" int r3n_debug_small_trace(r3n_ctx *c, uint32_t *dst) {  // dst: [4][8192][6]
-    TRY(sync_all(c));
-    HIP_TRY(c, hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_small_trace), sizeof(uint32_t) * 4 * 8192 * 6));
-    return R3N_OK;
-}
-#endif
-
 __global__ static void k_empty() {}
 int r3n_timing_enable(r3n_ctx *c, int enable) {
     if (!c) return R3N_ERR_INVALID_ARG;

@@ -5,25 +5,21 @@
 
 #include "kernels_shade.h"
 
-#ifndef R3N_RESOLVE_LDS
-#define R3N_RESOLVE_LDS 0  // experiment: dynamic LDS asked per workgroup (unused) = a cap on the resident workgroups per CU
-#endif
-
 extern "C" int r3n_internal_resolve_class(const ShadeArgs *ap, uint32_t variant, int fast, hipStream_t stream) {
     const ShadeArgs &a = *ap;
     const dim3 rgrid((a.width + 15u) / 16u, (a.row_end - a.row_begin + 15u) / 16u);
     switch (variant) {
     case 0u:
-        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), R3N_RESOLVE_LDS, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), R3N_RESOLVE_LDS, stream, a);
+        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), 0, stream, a);
         break;
     case 1u:
-        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), R3N_RESOLVE_LDS, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), R3N_RESOLVE_LDS, stream, a);
+        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), 0, stream, a);
         break;
     case 2u:
-        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), R3N_RESOLVE_LDS, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), R3N_RESOLVE_LDS, stream, a);
+        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), 0, stream, a);
         break;
     default:
         return (int)hipErrorInvalidValue;

@@ -16,9 +16,9 @@
 #pragma once
 #include "device_math.h"
 
-#ifndef R3N_TEX_SRGB_BRANCH
-#define R3N_TEX_SRGB_BRANCH 0  // (measured: resolve 439 vs 436 us with the branch off -- the divergent branch costs what the shorter addressing saves) short-path-only samplers (the resolve's material classes) branch on the texture's encoding: see tex_texel_at
-#endif
+// Measured and NOT kept (round 4, profiles/r04_summary.md section 1; code in the history, commit 79bedf3): short-path samplers that
+// branch on the texture's encoding to fold the decode table's offset into the LDS read (resolve 439 vs 436 us without the branch);
+// RGBA8 texels decoded ONCE at upload into a float4 pool (4x the memory, -10 % vector instructions, 437.8 vs 438.2 us).
 
 struct TextureArgs {
     const r3n_texture_desc32 *descs;
@@ -31,15 +31,7 @@ struct TextureArgs {
                                   // same speed -- the kernel is bound by VALU work, not by the decode.)
     const uint32_t *level_off;    // R3N_TEX_LEVELS entries per texture: pool index of the first texel of each level
     uint32_t small_pool;          // 1: the pool holds <= 2^30 texels, so a texel's BYTE offset fits 32 bits
-    const float4 *texels_f;       // R3N_TEXEL_FLOAT: the RGBA8 texels of the pool decoded once, at upload (same index: texel i of the
-                                  // pool = texels_f[i]; the same values the tables give), or null
 };
-#ifndef R3N_TEX_SHARE
-#define R3N_TEX_SHARE 1  // the maps of a material share level of detail and footprints when their levels have the same extents (TexShare)
-#endif
-#ifndef R3N_TEXEL_FLOAT
-#define R3N_TEXEL_FLOAT 0  // experiment: the short-path samplers of the resolve's material classes read pre-decoded float4 texels
-#endif
 
 R3N_DEV uint32_t tex_mip_dim(uint32_t d, uint32_t k) {
     const uint32_t v = d >> k;
@@ -226,12 +218,6 @@ struct TexShare {
 // -1 = per-lane table pointer `rgb` (an extract and a shift-or per channel).
 template <bool NEED_A, int SRGB_SEL = -1>
 R3N_DEV Texel4 tex_texel_at(const TextureArgs &t, const float *__restrict__ rgb, uint32_t byte_off) {
-#if R3N_TEXEL_FLOAT
-    if (SRGB_SEL == 2) {  // pre-decoded pool: one 16-byte load, no decode (byte_off * 4 < 2^32: the pool holds < 2^28 texels then)
-        const float4 f = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(t.texels_f) + (byte_off << 2));
-        return Texel4{(f2){f.x, f.y}, (f2){f.z, NEED_A ? f.w : 0.0f}};
-    }
-#endif
     const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t.texels) + byte_off);  // uniform base + 32-bit offset
     const float *tab = SRGB_SEL < 0 ? rgb : t.decode + (SRGB_SEL == 1 ? 256 : 0);
     Texel4 o;
@@ -271,7 +257,6 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
                              const float ddy[2], float o[4], TexShare *share = nullptr) {
     if (id == 0u || (!SHORT_ONLY && id > t.count)) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const r3n_texture_desc32 d = t.descs[id - 1u];
-#if R3N_TEX_SHARE
     if (SHORT_ONLY && SHARE) {
         // 0: same extents and mip count as the entry; 1: half the extents, one level less, and the entry's level >= 1
         const bool same = share->width == d.width && share->height == d.height && share->mips == d.mips;
@@ -318,7 +303,6 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         o[0] = r.rg.x; o[1] = r.rg.y; o[2] = r.ba.x; o[3] = r.ba.y;
         return;
     }
-#endif
     const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
     if (SHORT_ONLY || (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT)) {
         // level of detail exactly as tex_footprint derives it
@@ -343,24 +327,8 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             Texel4 r, hi;
-#if R3N_TEXEL_FLOAT
-            if (SHORT_ONLY) {
-                r = tex_bilinear_fast<M, NEED_A, 2>(t, rgb, l0);
-                if (two) hi = tex_bilinear_fast<M, NEED_A, 2>(t, rgb, l1);
-            } else
-#elif R3N_TEX_SRGB_BRANCH
-            if (SHORT_ONLY && d.format == 1u) {  // (a material set's maps of one slot share their encoding: the branch is wave-uniform in practice)
-                r = tex_bilinear_fast<M, NEED_A, 1>(t, rgb, l0);
-                if (two) hi = tex_bilinear_fast<M, NEED_A, 1>(t, rgb, l1);
-            } else if (SHORT_ONLY) {
-                r = tex_bilinear_fast<M, NEED_A, 0>(t, rgb, l0);
-                if (two) hi = tex_bilinear_fast<M, NEED_A, 0>(t, rgb, l1);
-            } else
-#endif
-            {
-                r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
-                if (two) hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
-            }
+            r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
+            if (two) hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
             if (two) {
                 const float omf = 1.0f - frac;
                 r.rg = mix2<M>(r.rg, hi.rg, frac, omf);
@@ -387,9 +355,6 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
 // one level less (TexShare: the level of detail is then the largest map's, shifted by one).  Returns false -- for the whole
 // wavefront, having done nothing -- when some lane binds a map that is neither; the caller samples one by one then.
 // Every bound id is on the sampler's short path (SHORT_ONLY's contract).  out[k] of an unbound slot (id 0) is zero.
-#ifndef R3N_TEX_BATCH
-#define R3N_TEX_BATCH 1
-#endif
 template <class M>
 R3N_DEV bool tex_sample3_batched(const TextureArgs &t, const uint32_t id[3], float u, float v, const float ddx[2], const float ddy[2],
                                  float out[3][4]) {

@@ -23,13 +23,13 @@ def _free_port():
     return p
 
 
-def _run(extra):
+def _run(extra, n=2, size=("1280x720", 1280 * 720)):
     sys.path.insert(0, HERE)
     import rccl_shim
     env = dict(os.environ, R3N_BENCH_SHARE_GPU="1", R3N_RCCL_LIB=rccl_shim.build(), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--objects", "300", "--tris", "150000", "--resolution", "1280x720", "--no-cpu-baseline"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2",
+           "--objects", "300", "--tris", "150000", "--resolution", size[0], "--no-cpu-baseline"] + extra
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -57,3 +57,16 @@ def test_bench_two_ranks_one_line(partition):
     assert ex is not None and set(ex) >= {"shadow", "pass1", "pass2", "rows"}, ex
     assert d["exchange_bytes_per_frame"]["pass2"] == (8 * 1280 * 720 if partition == "objects" else 0)
     assert d["roofline"]["traffic"] is None and "cpu_baseline" not in d  # N = 1 only, as the contract says
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["objects", "rows"])
+def test_bench_eight_ranks_one_line(partition):
+    """the driver's N = 8 launch line on a small target (eight ranks time-share the one GPU: plumbing, not a
+    number).  Four shadow views on eight ranks: four ranks own none; 360 rows = eight equal bands of 45."""
+    d = _run(["--partition", partition], n=8, size=("640x360", 640 * 360))
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["value"] > 0 and d["ms_per_step"] > 0
+    par = d["config"]["parallelism"]
+    assert ("object-range split issued by the library" in par) if partition == "objects" else ("sort-first" in par), par
+    assert d["exchange_note"] is None, d["exchange_note"]
+    assert d["exchange_bytes_per_frame"]["pass2"] == (8 * 640 * 360 if partition == "objects" else 0)
