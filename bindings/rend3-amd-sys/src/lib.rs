@@ -386,7 +386,6 @@ extern "C" {
     pub fn r3n_readback_triangle_sets(ctx: *mut r3n_ctx, camera: u32, pass: *mut u8, residual: *mut u8, n: u64) -> c_int;
     pub fn r3n_readback_draw_calls(ctx: *mut r3n_ctx, camera: u32, calls: *mut r3n_indirect_call) -> c_int;
     pub fn r3n_readback_raster_stats(ctx: *mut r3n_ctx, big_items: *mut u32) -> c_int;
-    pub fn r3n_readback_shadow_tile_counts(ctx: *mut r3n_ctx, shadow_view: u32, counts: *mut u32, n: u32, tiles_x: *mut u32) -> c_int;
     pub fn r3n_readback_baked(ctx: *mut r3n_ctx, camera: u32, model_view_and_mvp: *mut f32, capacity: u32) -> c_int;
     pub fn r3n_readback_mesh(ctx: *mut r3n_ctx, byte_offset: u64, dst: *mut c_void, bytes: u64) -> c_int;
     pub fn r3n_readback_joint_matrices(ctx: *mut r3n_ctx, first_matrix: u32, dst: *mut f32, n_matrices: u32) -> c_int;

@@ -497,9 +497,6 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 /* work-queue occupancy of the rasteriser: big_items[i] = number of >8x8 px work items the i-th r3n_forward call of
  * the last frame produced (performance diagnostics only) */
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
-/* triangle references binned into each 64 x 64 texel tile of a shadow view by the last frame (row-major, tiles_x per row;
- * performance diagnostics only) */
-int r3n_readback_shadow_tile_counts(r3n_ctx *ctx, r3n_camera shadow_view, uint32_t *counts, uint32_t n, uint32_t *tiles_x);
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
 int r3n_readback_joint_matrices(r3n_ctx *ctx, uint32_t first_matrix, float *dst, uint32_t n_matrices); /* what the last r3n_skinning read */

@@ -74,7 +74,6 @@ SIGNATURES = {
     "r3n_readback_triangle_sets": (cint, [vp, u32, vp, vp, u64]),
     "r3n_readback_draw_calls": (cint, [vp, u32, vp]),
     "r3n_readback_raster_stats": (cint, [vp, vp]),
-    "r3n_readback_shadow_tile_counts": (cint, [vp, u32, vp, u32, vp]),
     "r3n_readback_baked": (cint, [vp, u32, vp, u32]),
     "r3n_readback_mesh": (cint, [vp, u64, vp, u64]),
     "r3n_readback_texels": (cint, [vp, u64, vp, u64]),

@@ -21,7 +21,7 @@ SO = os.path.join(HERE, "librend3_amd.so")
 COMMON = ["layouts.h", "device_math.h", "../../include/r3n.h"]
 # translation unit -> the headers it includes (besides COMMON)
 UNITS = {
-    "r3n.hip": ["texture.h", "kernels_cull.h", "kernels_raster.h", "kernels_shadow.h", "kernels_shade.h", "comm.h"],
+    "r3n.hip": ["texture.h", "kernels_cull.h", "kernels_raster.h", "kernels_shade.h", "comm.h"],
     "shade.hip": ["texture.h", "kernels_shade.h"],
     "shade_cls.hip": ["texture.h", "kernels_shade.h"],
     "shade_ms.hip": ["texture.h", "kernels_shade.h"],

@@ -477,28 +477,6 @@ template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false>
 __global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs a) {
     raster_small_body<DEPTH_ONLY, S, TEX, NOCUT>(a);
 }
-// The same over several targets at once: blockIdx.y picks the view's argument block (kernels_shadow.h: the shadow views'
-// fallback lists, one launch for all views).
-// A pointer read from memory is a FLAT pointer as far as the compiler can prove (a kernel argument is known to be global): the
-// work-queue append became a flat_atomic_add, measured 10x slower for the launch.  The append goes through global_add_u32
-// (explicit address space); readfirstlane keeps the pointers in scalar registers like kernel arguments.
-template <class T> R3N_DEV T *uniform_global(T *p) {
-    const unsigned long long v = (unsigned long long)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (T *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
-}
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
-__global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small_views(const RasterArgs *__restrict__ views) {
-    RasterArgs a = views[blockIdx.y];
-    a.big_count = uniform_global(a.big_count);
-    a.big_items = uniform_global(a.big_items);
-    a.big_uv = uniform_global(a.big_uv);
-    a.depth = uniform_global(a.depth);
-    a.list = uniform_global(a.list);
-    a.sub_counts = uniform_global(a.sub_counts);
-    raster_small_body<DEPTH_ONLY, S, TEX>(a);
-}
-
 // Transparent pass, stage 1 (row N3): one thread per triangle of the blend-key objects, in DRAW ORDER -- objects back
 // to front (blend_order, sorted on the host like batching.rs:146-176), triangles in index order; g is therefore
 // the triangle's draw order.  Triangles that passed this frame's cull (cull.wgsl:372-378 writes exactly those into
@@ -758,11 +736,6 @@ template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
     raster_big_body<DEPTH_ONLY, S, TEX, BLEND, NOCUT>(a);
 }
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false>
-__global__ __launch_bounds__(256) void k_raster_big_views(const RasterArgs *__restrict__ views) {
-    raster_big_body<DEPTH_ONLY, S, TEX, false>(views[blockIdx.y]);
-}
-
 // ------------------------------------------------------------------------------------------------ clears
 __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long *__restrict__ p, unsigned long long v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) p[i] = v;

@@ -13,7 +13,6 @@
 #include "comm.h"
 #include "kernels_cull.h"
 #include "kernels_raster.h"
-#include "kernels_shadow.h"
 #define R3N_SHADE_DECL_ONLY
 #include "kernels_shade.h"
 
@@ -45,10 +44,6 @@ struct CamState {
     DevBuf slot_base[2], mask[2], predicted[2], sub_counts[2], counts[2];
     uint32_t subcap[2] = {0, 0};  // list entries reserved per (material key, sub-list)
     DevBuf residual;
-    // shadow views (kernels_shadow.h): triangle records, tile lists and the fallback list's counters; the stages the host
-    // has asked for since the last flush (they are issued batched over all views, flush_shadows)
-    DevBuf recs, tile_count, tile_list, fb_counts;
-    bool pend_bake = false, pend_cull = false, pend_draw[2] = {false, false};
     bool range_set = false;      // r3n_set_camera_object_range: this camera's own object range (multi-GPU: shadow views owned whole)
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
 };
@@ -57,7 +52,6 @@ std::string g_create_error;
 
 }  // namespace
 
-#define R3N_QLANES 4  // shadow views drawn concurrently at most (batched path: two per lane)
 #define R3N_AUX_STREAMS 2  // main + shade + these = the four hardware queues the runtime uses by default; 3 / 4 streams measured no faster (profiles/r02_summary.md section 9)
 
 // Dynamic LDS bytes asked by the work-item rasteriser's launches.  The kernel uses no LDS: the allocation caps its workgroups per CU.
@@ -71,7 +65,8 @@ std::string g_create_error;
 // 32 / 32 0.968-0.972; 48 / 32 0.961 (0.935 on another box against 0.968); 48 / 48 0.940; 64 / 48 (two workgroups) 1.061; no cap 1.049.
 #define R3N_BIG_LDS 49152           // shadow views
 #define R3N_VIEWPORT_BIG_LDS 49152  // viewport
-static_assert(R3N_AUX_STREAMS >= 1 && R3N_AUX_STREAMS <= R3N_QLANES, "every auxiliary stream (shadow lane) needs a work queue of its own: big_items / big_count / big_uv hold 1 + R3N_QLANES");
+#define R3N_QLANES R3N_AUX_STREAMS  // work queues beside the viewport's: one per auxiliary stream (a shadow view draws on lane 1 + view mod R3N_AUX_STREAMS)
+static_assert(R3N_AUX_STREAMS >= 1, "the shadow views draw on auxiliary streams");
 
 struct r3n_ctx {
     int device = 0;
@@ -187,10 +182,6 @@ struct r3n_ctx {
     uint32_t big_capacity = (2u << 20) / R3N_BIGQ;  // entries (64 B) per work sub-queue (R3N_BIGQ of them)
     CamState viewport;
     std::map<uint32_t, CamState> shadows;
-    DevBuf shadow_views[3], shadow_rargs[2];  // device arrays of the batched shadow stages: ShadowView per stage, RasterArgs per key
-    bool shadow_pending = false;
-    bool shadow_tiles = false;  // R3N_SHADOW_TILES=1: the batched tile-owned shadow path (kernels_shadow.h) instead of the per-view one
-    bool shadow_bin = true;     // R3N_SHADOW_TILES=2: the batched path WITHOUT the tile pass (every view in one launch per stage, general rasteriser)
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
     uint32_t row_begin = 0, row_end = 0xFFFFFFFFu;
     bool shard_rows = false;  // R3N_SHARD_ROWS: the viewport camera rasterises its row band only
@@ -432,7 +423,7 @@ CamState *find_cam(r3n_ctx *c, r3n_camera cam, bool create) {
 void free_cam(CamState &s) {
     DevBuf *bufs[] = {&s.own_hdr, &s.chain, &s.baked, &s.vis_flags, &s.vis_list, &s.first_entry, &s.block_sums, &s.block_off, &s.slot_base[0],
                       &s.slot_base[1], &s.mask[0], &s.mask[1], &s.predicted[0], &s.predicted[1], &s.sub_counts[0],
-                      &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual, &s.recs, &s.tile_count, &s.tile_list, &s.fb_counts};
+                      &s.sub_counts[1], &s.counts[0], &s.counts[1], &s.residual};
     for (DevBuf *b : bufs)
         if (b->p) { (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
 }
@@ -673,7 +664,6 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');
     if (const char *e6 = std::getenv("R3N_ALWAYS_FORK")) c->always_fork = e6[0] == '1';
-    if (const char *e4 = std::getenv("R3N_SHADOW_TILES")) { c->shadow_tiles = e4[0] == '1' || e4[0] == '2'; c->shadow_bin = e4[0] != '2'; }
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
     if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
@@ -791,8 +781,7 @@ void r3n_destroy(r3n_ctx *c) {
                       &c->skin_wave_first, &c->skin_joint_counts, &c->vis, &c->hdr16, &c->out8, &c->out_f32, &c->atlas, &c->hiz, &c->alt_vis, &c->alt_atlas, &c->alt_vp_baked, &c->srgb_lut, &c->srgb_thr, &c->tex_descs, &c->tex_texels, &c->tex_level_off, &c->srgb8_decode,
                       &c->tri_rec, &c->tri_seen, &c->blend_order, &c->blend_rank_base, &c->frag_keys, &c->frag_vals, &c->frag_head,
                       &c->frag_count, &c->samples16, &c->anim_rigs, &c->anim_joints, &c->anim_clips, &c->anim_tracks,
-                      &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->shadow_views[0],
-                      &c->shadow_views[1], &c->shadow_views[2], &c->shadow_rargs[0], &c->shadow_rargs[1], &c->material_feat, &c->view_lights[0],
+                      &c->anim_times, &c->anim_values, &c->pose_requests, &c->edge_list, &c->edge_count, &c->material_feat, &c->view_lights[0],
                       &c->view_lights[1]};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1409,190 +1398,6 @@ int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t 
 // Workgroups of the two rasteriser kernels: 256 threads (neither uses LDS or barriers: a workgroup is only the unit in which wave
 // slots are handed back to the dispatcher; 64- and 128-thread workgroups measured the same, profiles/r04_summary.md section 6a).
 #define R3N_SMALL_GRID 2048
-#define R3N_FB_SMALL_GRID 1024  // the shadow views' fallback lists are short: smaller grids (x views)
-#define R3N_FB_BIG_GRID 2048
-
-// Issues the shadow views' pending stages, every stage ONE launch over all views (kernels_shadow.h).  Called where the reference's
-// node order moves on from the shadow nodes (the viewport's uniform bake, base.rs:156) and wherever their results are needed.
-static TextureArgs texture_args(r3n_ctx *c);
-static int flush_shadows(r3n_ctx *c) {
-    if (!c->shadow_pending) return R3N_OK;
-    c->shadow_pending = false;
-    std::vector<std::pair<uint32_t, CamState *>> batch;
-    for (auto &kv : c->shadows)
-        if (kv.second.pend_bake || kv.second.pend_cull || kv.second.pend_draw[0] || kv.second.pend_draw[1]) batch.push_back({kv.first, &kv.second});
-    if (batch.empty() || c->capacity == 0) {
-        for (auto &b : batch) b.second->pend_bake = b.second->pend_cull = b.second->pend_draw[0] = b.second->pend_draw[1] = false;
-        return R3N_OK;
-    }
-    const uint32_t cap = c->capacity, nblocks = (cap + 255u) / 256u;
-    const uint32_t mw = max_waves(c);
-    const uint32_t chunks = (mw + R3N_CHUNK_WAVES - 1u) / R3N_CHUNK_WAVES;
-    const uint32_t subcap = ((chunks + R3N_SUBQ - 1u) / R3N_SUBQ) * (R3N_CHUNK_WAVES * 64u);
-    const size_t list_bytes = (size_t)3 * R3N_SUBQ * subcap * sizeof(r3n_tri_ref);
-    // Groups: the tile pass needs every view in one launch (one group, lane 1).  Without it (R3N_SHADOW_TILES=2) the views are
-    // split over the lanes -- view v in group v mod lanes -- and each lane issues ONE launch per stage for its views, concurrently
-    // with the other lane.  A view drawn concurrently with others has a work queue of its own (queues 1 .. R3N_QLANES).
-    const int ngroups = (!c->shadow_bin && c->multi_stream) ? R3N_AUX_STREAMS : 1;
-    const uint32_t per_launch = (uint32_t)std::max(1, R3N_QLANES / ngroups);  // views per raster launch of a group
-    // ---- sizes first (allocations run on the main stream), then the descriptors
-    std::vector<ShadowView> hv[R3N_AUX_STREAMS][3];  // per group: [bake | cull | draw]
-    std::vector<RasterArgs> hr[R3N_AUX_STREAMS][2];  // per group: general-rasteriser draws per key
-    uint32_t max_tiles = 1;
-    for (auto &b : batch) {
-        CamState &s = *b.second;
-        const int cur = s.cur;
-        const int g = ngroups > 1 ? (int)(b.first % (uint32_t)ngroups) : 0;
-        TRY(ensure(c, s.vis_flags, cap, true, 0));
-        TRY(ensure(c, s.vis_list, (size_t)(cap + 1u) * sizeof(r3n_vis_entry), false, -1));
-        TRY(ensure(c, s.block_sums, (size_t)nblocks * sizeof(ObjBlockSums), false, -1));
-        TRY(ensure(c, s.block_off, (size_t)nblocks * sizeof(ObjBlockOffsets), false, -1));
-        TRY(ensure(c, s.slot_base[cur], (size_t)cap * 4u, true, 0xFF));
-        TRY(ensure(c, s.sub_counts[cur], sizeof(r3n_sub_counts), false, 0));
-        TRY(ensure(c, s.counts[cur], sizeof(r3n_cull_counts), false, 0));
-        TRY(ensure(c, s.mask[cur], (size_t)mw * 8u, false, -1));
-        TRY(ensure(c, s.predicted[cur], list_bytes, false, -1));
-        const uint32_t tiles_x = std::max(1u, (s.vp_size + R3N_STILE - 1u) / R3N_STILE);
-        if (c->shadow_bin) TRY(ensure(c, s.recs, (size_t)mw * 64u * sizeof(r3n_shadow_tri), false, -1));
-        TRY(ensure(c, s.tile_count, (size_t)tiles_x * tiles_x * 4u, false, 0));
-        if (c->shadow_bin) TRY(ensure(c, s.tile_list, (size_t)tiles_x * tiles_x * R3N_STILE_CAP * 4u, false, -1));
-        TRY(ensure(c, s.fb_counts, 3u * R3N_SUBQ * 4u, false, 0));
-        s.subcap[cur] = subcap;
-        max_tiles = std::max(max_tiles, tiles_x * tiles_x);
-        ShadowView v{};
-        v.hdr = s.d_hdr.as<r3n_camera_header240>();
-        v.baked = s.baked.as<r3n_baked128>();
-        v.vis_flags = s.vis_flags.as<uint8_t>();
-        v.block_sums = s.block_sums.as<ObjBlockSums>();
-        v.block_off = s.block_off.as<ObjBlockOffsets>();
-        v.vis_list = s.vis_list.as<r3n_vis_entry>();
-        v.slot_base = s.slot_base[cur].as<uint32_t>();
-        v.counts = s.counts[cur].as<r3n_cull_counts>();
-        v.sub_counts = s.sub_counts[cur].as<r3n_sub_counts>();
-        v.mask = s.mask[cur].as<unsigned long long>();
-        v.recs = s.recs.as<r3n_shadow_tri>();
-        v.tile_count = s.tile_count.as<uint32_t>();
-        v.tile_list = s.tile_list.as<uint32_t>();
-        v.fallback = s.predicted[cur].as<r3n_tri_ref>();
-        v.fb_counts = s.fb_counts.as<uint32_t>();
-        v.subcap = subcap;
-        v.vp_x = s.vp_x; v.vp_y = s.vp_y; v.vp_size = s.vp_size; v.tiles_x = tiles_x;
-        v.own = camera_own(c, s);
-        if (s.pend_bake) hv[g][0].push_back(v);
-        if (s.pend_cull) hv[g][1].push_back(v);
-        if (s.pend_draw[0]) hv[g][2].push_back(v);
-        for (uint32_t key = 0; key < 2u; ++key) {
-            if (!s.pend_draw[key]) continue;
-            // its own work queue among the views drawn at the same time: `per_launch` views per raster launch of the group
-            const uint32_t slot = (uint32_t)hr[g][key].size();
-            const int qlane = 1 + g * (int)per_launch + (int)(slot % per_launch);
-            RasterArgs a{};
-            a.hdr = v.hdr;
-            a.objects = c->objects.as<r3n_object128>();
-            a.mesh = c->mesh.as<uint32_t>();
-            a.baked = v.baked;
-            a.materials = c->materials.as<r3n_material208>();
-            a.material_keys = c->material_keys.as<uint8_t>();
-            a.n_materials = c->n_materials;
-            a.tri_base = c->tri_base.as<uint32_t>();
-            a.list = v.fallback;
-            a.sub_counts = v.fb_counts;
-            a.subcap = subcap;
-            a.key = key;
-            a.big_items = c->big_items[qlane].as<r3n_big_item>();
-            const uint32_t fwd = std::min(c->forward_index_lane[qlane]++, 63u);
-            a.big_count = c->big_count[qlane].as<uint32_t>() + (size_t)fwd * R3N_BIGQ;
-            a.big_capacity = c->big_capacity;
-            a.big_uv = c->big_uv[qlane].as<r3n_big_uv>();
-            a.tex = texture_args(c);
-            a.vp_x = s.vp_x; a.vp_y = s.vp_y; a.vp_w = s.vp_size; a.vp_h = s.vp_size; a.target_pitch = c->atlas_w;
-            a.depth = c->atlas.as<uint32_t>();
-            a.row_begin = 0; a.row_end = 0xFFFFFFFFu;
-            hr[g][key].push_back(a);
-        }
-        s.pend_bake = s.pend_cull = s.pend_draw[0] = s.pend_draw[1] = false;
-    }
-    // the descriptor arrays of all groups go up in one piece per kind (main stream); a group's launches index its own range
-    auto upload = [&](DevBuf &dst, const void *src, size_t bytes) -> int {
-        TRY(ensure(c, dst, std::max<size_t>(bytes, 256), false, -1));
-        for (size_t off = 0; off < bytes; off += r3n_ctx::kStageSlotBytes)
-            TRY(upload_small(c, static_cast<char *>(dst.p) + off, static_cast<const char *>(src) + off, std::min<size_t>(r3n_ctx::kStageSlotBytes, bytes - off)));
-        return R3N_OK;
-    };
-    size_t v_first[R3N_AUX_STREAMS][3] = {}, r_first[R3N_AUX_STREAMS][2] = {};
-    for (int st = 0; st < 3; ++st) {
-        std::vector<ShadowView> all;
-        for (int g = 0; g < ngroups; ++g) { v_first[g][st] = all.size(); all.insert(all.end(), hv[g][st].begin(), hv[g][st].end()); }
-        if (!all.empty()) TRY(upload(c->shadow_views[st], all.data(), all.size() * sizeof(ShadowView)));
-    }
-    for (int key = 0; key < 2; ++key) {
-        std::vector<RasterArgs> all;
-        for (int g = 0; g < ngroups; ++g) { r_first[g][key] = all.size(); all.insert(all.end(), hr[g][key].begin(), hr[g][key].end()); }
-        if (!all.empty()) TRY(upload(c->shadow_rargs[key], all.data(), all.size() * sizeof(RasterArgs)));
-    }
-    for (int g = 0; g < ngroups; ++g) {
-        if (hv[g][0].empty() && hv[g][1].empty() && hv[g][2].empty() && hr[g][0].empty() && hr[g][1].empty()) continue;
-        const int lane = c->multi_stream ? 1 + g : 0;
-        hipStream_t stream = lane_stream(c, lane);
-        TRY(fork_lane(c, lane));  // after the header / descriptor uploads and the frame's clears (main stream)
-        ShadowBatchArgs a{};
-        a.objects = c->objects.as<r3n_object128>();
-        a.soa = obj_soa(c);
-        a.mesh = c->mesh.as<uint32_t>();
-        a.material_keys = c->material_keys.as<uint8_t>();
-        a.n_materials = c->n_materials;
-        a.atlas = c->atlas.as<uint32_t>();
-        a.atlas_pitch = c->atlas_w;
-        a.bin_tiles = c->shadow_bin ? 1u : 0u;
-        if (!hv[g][0].empty()) {
-            a.views = c->shadow_views[0].as<ShadowView>() + v_first[g][0];
-            Timed t(c, R3N_STAGE_BAKE, stream);
-            hipLaunchKernelGGL(k_shadow_bake, dim3((cap * 4u + 255u) / 256u, (unsigned)hv[g][0].size()), dim3(256), 0, stream, a);
-        }
-        if (!hv[g][1].empty()) {
-            a.views = c->shadow_views[1].as<ShadowView>() + v_first[g][1];
-            const unsigned nv = (unsigned)hv[g][1].size();
-            {
-                Timed t(c, R3N_STAGE_OBJECT_CULL, stream);
-                hipLaunchKernelGGL(k_shadow_object_count, dim3(nblocks, nv), dim3(256), 0, stream, a);
-                hipLaunchKernelGGL(k_shadow_object_scan, dim3(1, nv), dim3(nblocks <= 64u ? 64 : 1024), 0, stream, a, nblocks);
-                hipLaunchKernelGGL(k_shadow_object_scatter, dim3(nblocks, nv), dim3(256), 0, stream, a);
-            }
-            {
-                Timed t(c, R3N_STAGE_TRIANGLE_CULL, stream);
-                hipLaunchKernelGGL(k_shadow_cull_bin, dim3(std::max(1u, std::min(chunks, 4096u)), nv), dim3(256), 0, stream, a);
-            }
-        }
-        if (!hv[g][2].empty() && c->shadow_bin) {
-            a.views = c->shadow_views[2].as<ShadowView>() + v_first[g][2];
-            Timed t(c, R3N_STAGE_SHADOW_RASTER, stream);
-            hipLaunchKernelGGL(k_shadow_tiles, dim3(max_tiles, (unsigned)hv[g][2].size()), dim3(R3N_STILE_THREADS), 0, stream, a);
-        }
-        TRY(check_launch(c, "shadow batch"));
-        // what the tiles declined (opaque key) and the cutout key -- or, without the tile pass, everything: the general rasteriser
-        // over the per-view lists, AFTER the tile stores
-        for (uint32_t key = 0; key < 2u; ++key) {
-            const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
-            for (size_t first = 0; first < hr[g][key].size(); first += per_launch) {
-                const unsigned nv = (unsigned)std::min<size_t>(per_launch, hr[g][key].size() - first);
-                const RasterArgs *views = c->shadow_rargs[key].as<RasterArgs>() + r_first[g][key] + first;
-                for (unsigned k = 0; k < nv; ++k)  // counters past the ones zeroed at frame begin
-                    if (hr[g][key][first + k].big_count == c->big_count[1 + g * (int)per_launch + (int)((first + k) % per_launch)].as<uint32_t>() + (size_t)63 * R3N_BIGQ)
-                        HIP_TRY(c, hipMemsetAsync(hr[g][key][first + k].big_count, 0, R3N_BIGQ * 4, stream));
-                Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream);
-                const unsigned gs = c->shadow_bin ? R3N_FB_SMALL_GRID : R3N_SMALL_GRID, gb = c->shadow_bin ? R3N_FB_BIG_GRID : R3N_BIG_GRID;
-                if (tex) {
-                    hipLaunchKernelGGL((k_raster_small_views<true, 1, true>), dim3(gs, nv), dim3(256), 0, stream, views);
-                    hipLaunchKernelGGL((k_raster_big_views<true, 1, true>), dim3(gb, nv), dim3(256), 0, stream, views);
-                } else {
-                    hipLaunchKernelGGL((k_raster_small_views<true, 1, false>), dim3(gs, nv), dim3(256), 0, stream, views);
-                    hipLaunchKernelGGL((k_raster_big_views<true, 1, false>), dim3(gb, nv), dim3(256), 0, stream, views);
-                }
-            }
-        }
-    }
-    return check_launch(c, "shadow fallback raster");
-}
 
 int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr) {
     if (!c || !hdr) return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: null");
@@ -1613,12 +1418,6 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     if (s->hdr_frame != c->frame_no) TRY(upload_small(c, s->d_hdr.p, hdr, sizeof *hdr));  // else: it went up with the frame's constants
     // per-camera buffer regrow preserves old matrices (disabled slots keep stale data, App. D.2)
     TRY(ensure(c, s->baked, (size_t)c->capacity * sizeof(r3n_baked128), true, 0));
-    if (cam != R3N_CAMERA_VIEWPORT && c->shadow_tiles) {  // shadow views: issued batched over all views (flush_shadows)
-        s->pend_bake = true;
-        c->shadow_pending = true;
-        return R3N_OK;
-    }
-    if (cam == R3N_CAMERA_VIEWPORT) TRY(flush_shadows(c));  // reference order (base.rs:148-156): the shadow nodes precede the viewport's
     const int lane = cam_lane(c, cam);
     if (c->fused_frame && c->in_frame && chained_pass_fits(c)) {
         // r3n_render_frame: this camera's r3n_cull follows in the same frame with the same header and ranges, and its object pass
@@ -1657,13 +1456,6 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     if (s->baked_frame != c->frame_no) return fail(c, R3N_ERR_STATE, "cull: r3n_uniform_bake has not run for this camera in this frame");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
-    if (!viewport && c->shadow_tiles) {  // shadow views: issued batched over all views (flush_shadows)
-        s->pend_cull = true;
-        c->shadow_pending = true;
-        s->culled = true;
-        s->last = s->cur;
-        return R3N_OK;
-    }
     const int cur = s->cur, prev = 1 - cur;
     const int lane = cam_lane(c, cam);
     hipStream_t stream = lane_stream(c, lane);
@@ -1789,17 +1581,6 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         return forward_blend(c);
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!viewport && c->shadow_tiles) {
-        // shadow views (base.rs:366-396: opaque_depth and cutout_depth over CullingSource::Residual): issued batched over all
-        // views by flush_shadows -- tile rasteriser for the opaque key, the general one for cutouts and what the tiles decline
-        if (source != R3N_SOURCE_RESIDUAL) return fail(c, R3N_ERR_UNSUPPORTED, "forward: shadow views draw the residual source (base.rs:366-396)");
-        if (!s->culled) return R3N_OK;
-        if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
-            return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
-        s->pend_draw[key] = true;
-        c->shadow_pending = true;
-        return R3N_OK;
-    }
     int idx;
     const r3n_tri_ref *list;
     const uint32_t *sub_counts;
@@ -1952,7 +1733,6 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     if (r1 <= r0) return R3N_OK;
     CamState &s = c->viewport;
     if (!s.has_hdr && c->capacity) return fail(c, R3N_ERR_STATE, "resolve_opaque: viewport uniforms not baked");
-    TRY(flush_shadows(c));  // the resolve reads the shadow atlas
     // (Re)allocations FIRST: ensure() fills and copies on the MAIN stream, and the event that orders the shade stream behind the
     // main stream is recorded below -- a buffer zeroed after that event would race with the resolve's kernels (first frame /
     // after the world grew: k_mark_visible's flags wiped by the late fill).
@@ -2232,7 +2012,6 @@ int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
 // (r3n_render_frame's Closer) must not consume the report of an earlier frame's overflow.
 static int close_frame(r3n_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
-    TRY(flush_shadows(c));
     TRY(join_lanes(c));  // the next frame's clears (main stream) must not overtake this frame's shadow work
     auto flip = [](CamState &s) {
         if (s.culled) { s.cur = 1 - s.cur; s.has_prev = true; }
@@ -2556,7 +2335,6 @@ int r3n_exchange_depth(r3n_ctx *c, void **depth_f32, uint64_t *count) {
 }
 int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atlas, uint64_t *atlas_count) {
     if (!c || !c->vis.p) return fail(c, R3N_ERR_STATE, "exchange_buffers: no frame targets yet");
-    TRY(flush_shadows(c));
     TRY(join_lanes(c));  // collectives are ordered on the main stream
     if (vis) *vis = c->vis.p;
     if (vis_count) *vis_count = (uint64_t)c->width * c->height * c->samples;
@@ -2566,7 +2344,6 @@ int r3n_exchange_buffers(r3n_ctx *c, void **vis, uint64_t *vis_count, void **atl
 }
 int r3n_exchange_shadow_stream(r3n_ctx *c, void **atlas, uint64_t *atlas_count, void **stream) {
     if (!c || !c->atlas.p) return fail(c, R3N_ERR_STATE, "exchange_shadow_stream: no shadow atlas yet");
-    TRY(flush_shadows(c));
     hipStream_t on = c->stream;
     if (c->multi_stream) {
         // lane 1 carries the exchange: behind the main stream's clears / uploads of this frame, and behind the other lanes' views
@@ -2624,7 +2401,6 @@ int r3n_output_work_enqueued(r3n_ctx *c) {
 // ------------------------------------------------------------------------------------------------ readbacks
 static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     HIP_TRY(c, hipSetDevice(c->device));
-    TRY(flush_shadows(c));
     TRY(join_lanes(c));
     TRY(join_shade(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -2712,15 +2488,6 @@ int r3n_readback_raster_stats(r3n_ctx *c, uint32_t big_items[64]) {
             for (int q = 0; q < R3N_BIGQ; ++q) big_items[base + f] += raw[f * R3N_BIGQ + q];
     }
     return R3N_OK;
-}
-
-int r3n_readback_shadow_tile_counts(r3n_ctx *c, r3n_camera cam, uint32_t *counts, uint32_t n, uint32_t *tiles_x) {
-    CamState *s = c ? find_cam(c, cam, false) : nullptr;
-    if (!s || cam == R3N_CAMERA_VIEWPORT || !s->tile_count.p || !counts) return fail(c, R3N_ERR_STATE, "readback_shadow_tile_counts: shadow view never drawn");
-    const uint32_t tx = std::max(1u, (s->vp_size + R3N_STILE - 1u) / R3N_STILE);
-    if (n < tx * tx) return fail(c, R3N_ERR_INVALID_ARG, "readback_shadow_tile_counts: buffer too small");
-    if (tiles_x) *tiles_x = tx;
-    return d2h(c, counts, s->tile_count.p, (size_t)tx * tx * 4u);
 }
 
 int r3n_readback_baked(r3n_ctx *c, r3n_camera cam, float *out, uint32_t capacity) {

@@ -1244,8 +1244,6 @@ def _scenario_frames(r3, name, make_renderer):
 
 RUNTIME_SWITCHES = [
     {},                              # the defaults (reference for the others: same scenarios, same oracle frames)
-    {"R3N_SHADOW_TILES": "1"},       # batched shadow views with the tile-owned LDS rasteriser (kernels_shadow.h)
-    {"R3N_SHADOW_TILES": "2"},       # batched shadow views, general rasteriser (k_raster_*_views)
     {"R3N_PIPELINE": "0"},           # no frames in flight: the resolve on the main stream
     {"R3N_SINGLE_STREAM": "1"},      # every camera on the main stream
     {"R3N_FRAME_NODES": "1"},        # the host mirror issues the frame node by node (one C call per reference node) instead of r3n_render_frame

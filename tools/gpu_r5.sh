@@ -48,6 +48,18 @@ for w in "$@"; do
         echo "== $name"; stats $out/ser_$name 14
       done
       cd $root;;
+    envab)  # A/B of a run-time switch inside one call: ENVAB="R3N_X=0 R3N_X=1" (each setting: two frame runs + the stand-alone kernel durations)
+      for setting in ${ENVAB:-R3N_SHADOW_TILE_LDS=0 R3N_SHADOW_TILE_LDS=1}; do
+        for rep in 1 2; do
+          env $setting python bench.py --steps 100 --warmup 10 --no-cpu-baseline ${ENVAB_FLAGS:-} > "$out/bench_${setting}_$rep.json" 2> "$out/bench_${setting}_$rep.err"; line "$out/bench_${setting}_$rep.json"
+        done
+      done
+      cd /tmp
+      for setting in ${ENVAB:-R3N_SHADOW_TILE_LDS=0 R3N_SHADOW_TILE_LDS=1}; do
+        env $setting R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ser_$setting -o k -- python $root/bench.py --no-cpu-baseline --steps 30 --warmup 5 ${ENVAB_FLAGS:-} > $out/ser_$setting.json 2> $out/ser_$setting.err
+        echo "== $setting, single stream"; stats $out/ser_$setting 14 | grep -v "k_copy\|copyBuffer"
+      done
+      cd $root;;
     *) echo "unknown action $w";;
   esac
 done
