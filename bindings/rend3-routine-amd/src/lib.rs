@@ -4,7 +4,7 @@
 //! tests/test_rust_bindings.py diffs the constructor and `add_*_to_graph` signatures against the reference's, pinned in
 //! tests/golden/rust_signatures.json): `BaseRenderGraph::new(&renderer, &spp)`, `PbrRoutine::new(...)`,
 //! `TonemappingRoutine::new(...)` are called exactly as in the reference's examples -- the `AmdContext` is found from the
-//! renderer (`AmdContext::of`, kept alive in `Renderer::add_graph_data` storage).  Only the closures registered with the render
+//! renderer (`AmdContext::of` = `Renderer::amd`: bindings/rend3-hooks.patch makes `Renderer::new` create it and the managers feed it).  Only the closures registered with the render
 //! graph differ: where the reference records wgpu passes, these call `r3n_*`.  The graph
 //! machinery, the managers and the user-facing `Renderer` API stay rend3's.  Source only in this repository (no Rust toolchain
 //! in the build image): the same call sequence runs from Python in `rend3_amd/renderer.py`, which the GPU tests drive.
@@ -18,6 +18,5 @@ pub mod hi_z;
 pub mod skinning;
 pub mod tonemapping;
 pub mod uniforms;
-pub mod upload;
 
 pub use amd::AmdContext;

@@ -68,9 +68,11 @@ def test_sys_crate_spells_every_type_in_rust():
 def test_adaptor_crate_calls_only_declared_symbols_and_covers_the_frame():
     declared = set(re.findall(r"pub fn (r3n_\w+)\(", _sys_rs()))
     src_dir = os.path.join(ROOT, "bindings", "rend3-routine-amd", "src")
+    # the adaptor crate's node bodies + the file bindings/rend3-hooks.patch installs as rend3/src/util/amd.rs (context, uploads)
+    sources = [os.path.join(src_dir, f) for f in sorted(os.listdir(src_dir))] + [os.path.join(ROOT, "bindings", "rend3-hooks", "amd.rs")]
     used = set()
-    for f in sorted(os.listdir(src_dir)):
-        used |= set(re.findall(r"sys::(r3n_\w+)\(", open(os.path.join(src_dir, f)).read()))
+    for f in sources:
+        used |= set(re.findall(r"sys::(r3n_\w+)\(", open(f).read()))
     assert used <= declared, sorted(used - declared)
     frame = {"r3n_frame_begin", "r3n_shadow_viewport", "r3n_skinning", "r3n_uniform_bake", "r3n_cull", "r3n_forward", "r3n_hi_z",
              "r3n_resolve_opaque", "r3n_tonemap", "r3n_frame_end", "r3n_set_output_format", "r3n_mesh_buffer_write", "r3n_objects_write",
@@ -79,8 +81,8 @@ def test_adaptor_crate_calls_only_declared_symbols_and_covers_the_frame():
     # constants too, and the texture-format map covers every format id of the header
     consts = set(re.findall(r"pub const (R3N_\w+):", _sys_rs()))
     used_consts = set()
-    for f in sorted(os.listdir(src_dir)):
-        used_consts |= set(re.findall(r"sys::(R3N_\w+)", open(os.path.join(src_dir, f)).read()))
+    for f in sources:
+        used_consts |= set(re.findall(r"sys::(R3N_\w+)", open(f).read()))
     assert used_consts <= consts, sorted(used_consts - consts)
     formats = {c for c in consts if c.startswith("R3N_TEXTURE_") and c != "R3N_TEXTURE_FORMAT_COUNT"}
     assert len(formats) == 34 and formats <= used_consts, sorted(formats - used_consts)

@@ -19,6 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ADAPTOR = os.path.join(ROOT, "bindings", "rend3-routine-amd", "src")
+HOOKS = os.path.join(ROOT, "bindings", "rend3-hooks", "amd.rs")  # installed as rend3/src/util/amd.rs by bindings/rend3-hooks.patch
 FIXTURE = os.path.join(ROOT, "tests", "golden", "rust_visibility.json")
 CRATES = {"rend3": "rend3/src", "rend3_routine": "rend3-routine/src", "rend3_types": "rend3-types/src"}
 ITEM = r"pub\s+(?:unsafe\s+)?(?:struct|enum|trait|fn|type|const|static|union)\s+{name}\b"
@@ -249,7 +250,34 @@ def field_checks(ref):
     return res
 
 
+def patched_reference(ref):
+    """A copy of the reference's three crates with bindings/rend3-hooks.patch applied (tools/make_hooks_patch.py's edits, written
+    out directly): the tree the adaptor is written against -- `rend3::util::amd::AmdContext`, `Renderer::amd` exist only there."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_hooks_patch
+    dst = tempfile.mkdtemp(prefix="rend3_patched_")
+    for crate_dir in ("rend3", "rend3-routine", "rend3-types"):
+        shutil.copytree(os.path.join(ref, crate_dir), os.path.join(dst, crate_dir))
+    shutil.copy(os.path.join(ref, "Cargo.toml"), os.path.join(dst, "Cargo.toml"))
+    for rel, (_old, new) in make_hooks_patch.patched_files(ref).items():
+        os.makedirs(os.path.dirname(os.path.join(dst, rel)), exist_ok=True)
+        open(os.path.join(dst, rel), "w").write(new)
+    return dst
+
+
 def survey(ref):
+    """`ref`: the reference checkout; the survey runs on its PATCHED copy (patched_reference)."""
+    import shutil
+    patched = patched_reference(ref)
+    try:
+        return survey_tree(patched)
+    finally:
+        shutil.rmtree(patched, ignore_errors=True)
+
+
+def survey_tree(ref):
     paths = {}
     for path, files in sorted(adaptor_paths().items()):
         ok, why = resolve_public(path, ref)

@@ -51,7 +51,7 @@ def run(steps):
         if not f.endswith(".so"):
             continue
         env = dict(os.environ, R3N_LIB=os.path.join(VDIR, f))
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline"],
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline"] + os.environ.get("VARIANT_FLAGS", "").split(),
                              env=env, capture_output=True, text=True)
         try:
             d = json.loads(res.stdout.strip().splitlines()[-1])
