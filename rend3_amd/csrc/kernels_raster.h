@@ -78,6 +78,15 @@ struct TriWork {
     uint32_t slot1;  // canonical slot + 1 (forward)
     float uv[3][2];                     // cutout key + albedo texture only
     bool alpha_tex;                     // the cutout alpha samples the albedo texture
+    // ... then, in the WORK-ITEM kernel (HOIST): what that sample needs of the material and of the texture array, fetched once
+    // per item through scalar loads instead of per fragment behind the material record: texture id, sampler choice, coordinate
+    // transform, descriptor.  A fragment's chain is then level offset -> texels instead of material -> descriptor -> level offset
+    // -> texels.  (The per-triangle pass keeps the per-fragment loads: its triangles are per THREAD, and twenty more vector
+    // registers there cost an occupancy step.)
+    uint32_t tex0;
+    bool nearest;
+    float uvt[12];                      // material.uv_transform0 (forward only)
+    r3n_texture_desc32 tdesc;           // descriptor of tex0 (zero when the id is outside the array)
     bool cutout;
     float thr[3];    // device_math.h::edge_threshold of the three edges
     int x0, y0, x1, y1;
@@ -156,19 +165,28 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 // Alpha of the albedo texture at pixel (x, y) for the cutout test.  Forward (opaque.wgsl:207-215): coordinates through
 // uv_transform0, sampler chosen by FLAGS_NEAREST.  Depth-only (depth.wgsl:108-118, quirks reproduced): raw coords0,
 // always the primary sampler, and uvdy = dpdx(coords).
-template <bool DEPTH_ONLY, bool TEX>
+template <bool DEPTH_ONLY, bool TEX, bool HOIST = false>
 R3N_DEV float cutout_texture_alpha(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (!TEX || !tw.alpha_tex) return 1.0f;
+    float coords[2], ddx[2], ddy[2];
+    if (HOIST) {
+        if (DEPTH_ONLY) {
+            frag_coords(tw.ts, tw.uv, nullptr, x, y, coords, ddx, ddy);
+            return tex_sample_alpha(a.tex, tw.tex0, tw.tdesc, false, coords[0], coords[1], ddx, ddx);
+        }
+        frag_coords(tw.ts, tw.uv, tw.uvt, x, y, coords, ddx, ddy);
+        return tex_sample_alpha(a.tex, tw.tex0, tw.tdesc, tw.nearest, coords[0], coords[1], ddx, ddy);
+    }
     const r3n_material208 &m = a.materials[tw.material];
-    float coords[2], ddx[2], ddy[2], texel[4];
+    const uint32_t id = m.textures[0];
+    r3n_texture_desc32 d{};
+    if (id - 1u < a.tex.count) d = a.tex.descs[id - 1u];
     if (DEPTH_ONLY) {
         frag_coords(tw.ts, tw.uv, nullptr, x, y, coords, ddx, ddy);
-        tex_sample_grad(a.tex, m.textures[0], false, coords[0], coords[1], ddx, ddx, texel);
-    } else {
-        frag_coords(tw.ts, tw.uv, m.uv_transform0, x, y, coords, ddx, ddy);
-        tex_sample_grad(a.tex, m.textures[0], (m.flags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy, texel);
+        return tex_sample_alpha(a.tex, id, d, false, coords[0], coords[1], ddx, ddx);
     }
-    return texel[3];
+    frag_coords(tw.ts, tw.uv, m.uv_transform0, x, y, coords, ddx, ddy);
+    return tex_sample_alpha(a.tex, id, d, (m.flags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy);
 }
 
 // Multisampling (row N4; forward.rs:358 MultisampleState{count}): coverage and depth at the standard 4x sample
@@ -214,7 +232,7 @@ R3N_DEV uint32_t target_pixel(const RasterArgs &a, uint32_t x, uint32_t y) {
     return __umul24(a.vp_y + y, a.target_pitch) + (a.vp_x + x);
 }
 
-template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false>
+template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false, bool HOIST = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (BLEND) {
         // Transparent pass: depth test GreaterEqual against the final opaque depth, depth write off (pbr/routine.rs:
@@ -248,14 +266,21 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
         float z = frag_depth(tw.ts, (float)x + 0.5f, (float)y + 0.5f);
         if (!(z >= 0.0f && z <= 1.0f)) return;  // depth clip (unclipped_depth: false, forward.rs:343)
         if (z == 0.0f) z = 0.0f;                // canonicalise -0
-        if (tw.cutout) {
-            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
-            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
-        }
         // rows and pitch are below 2^16 (r3n_frame_begin), the target below 2^29 samples: 24-bit multiply, 32-bit byte offsets
         const uint32_t pix = target_pixel<DEPTH_ONLY>(a, (uint32_t)x, (uint32_t)y);
         const uint32_t zb = __float_as_uint(z);
+        if (tw.cutout) {
+            // The cutout test is the expensive part of this fragment (two more attribute interpolations for the derivatives and
+            // a trilinear sample of the albedo map: the Bistro-like scene's foliage cards, profiles/r05_summary.md) and decides
+            // nothing for a fragment the target already beats: the target only grows (MAX), so a key that loses against the value
+            // read here loses against the final one -- skip the test and the atomic.  The opaque key of the same pass was drawn by
+            // the launches in front of this one, so foliage behind walls ends here.
+            if (DEPTH_ONLY) { if (!(zb > a.depth[pix])) return; }
+            else if (!((((unsigned long long)zb << 32) | (unsigned long long)tw.slot1) > a.vis[pix])) return;
+            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
+        }
         if (DEPTH_ONLY) {
             if (!PREREAD || zb > a.depth[pix]) global_max_u32_at(a.depth, pix << 2, zb);
         } else {
@@ -277,29 +302,34 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             mask |= 1u << sm;
         }
         if (!mask) return;
-        if (tw.cutout) {
-            float E[3];
-            (void)edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E);
-            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
-            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX>(a, tw, x, y), al) < tw.mat_cutoff) return;
-        }
         const size_t pix = ((size_t)(a.vp_y + (uint32_t)y) * a.target_pitch + a.vp_x + (uint32_t)x) * (size_t)S;
         // PREREAD (the work-item kernel under MSAA): the pixel's four keys are 32 contiguous bytes; read them once and
         // skip the atomics that cannot win.  Memory-side atomics are 65 % of that kernel at 4 samples (ablation,
         // bench scene: 1.43 ms -> 0.50 ms without them); the read removes the overdrawn ones: 1.43 -> 1.04 ms.  Keys only
         // grow, so a key that loses against a stale read loses against the current value too.
+        // The cutout key reads them whatever PREREAD says, IN FRONT of its alpha test (see the single-sample branch): a pixel
+        // none of whose covered samples can still win skips the texture sample.
+        const bool preread = PREREAD || tw.cutout;
         unsigned long long cur[S];
-        if (PREREAD) {
+        if (preread) {
 #pragma unroll
             for (int sm = 0; sm < S; ++sm) cur[sm] = a.vis[pix + (size_t)sm];
+#pragma unroll
+            for (int sm = 0; sm < S; ++sm)
+                if ((mask & (1u << sm)) && !((((unsigned long long)__float_as_uint(zs[sm]) << 32) | (unsigned long long)tw.slot1) > cur[sm])) mask &= ~(1u << sm);
+            if (!mask) return;
+        }
+        if (tw.cutout) {
+            float E[3];
+            (void)edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E);
+            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST>(a, tw, x, y), al) < tw.mat_cutoff) return;
         }
 #pragma unroll
         for (int sm = 0; sm < S; ++sm)
-            if (mask & (1u << sm)) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(zs[sm]) << 32) | (unsigned long long)tw.slot1;
-                if (!PREREAD || key > cur[sm]) global_max_u64(&a.vis[pix + (size_t)sm], key);
-            }
+            if (mask & (1u << sm))
+                global_max_u64(&a.vis[pix + (size_t)sm], ((unsigned long long)__float_as_uint(zs[sm]) << 32) | (unsigned long long)tw.slot1);
     }
 }
 
@@ -656,6 +686,16 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 if (TEX && w.alpha_tex) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { w.uv[k][0] = __uint_as_float(up[2 * k]); w.uv[k][1] = __uint_as_float(up[2 * k + 1]); }
+                    // the material's sampling state and the texture's descriptor: wave-uniform, through scalar loads
+                    w.tex0 = mp[0];
+                    w.nearest = (w.mat_flags & R3N_FLAGS_NEAREST) != 0u;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) w.uvt[k] = __uint_as_float(mp[offsetof(r3n_material208, uv_transform0) / 4 + k]);
+                    w.tdesc = r3n_texture_desc32{};
+                    if (w.tex0 - 1u < a.tex.count) {
+                        sptr_t dp = (sptr_t)(unsigned long long)(a.tex.descs + (w.tex0 - 1u));
+                        w.tdesc.offset = dp[0]; w.tdesc.width = dp[1]; w.tdesc.height = dp[2]; w.tdesc.mips = dp[3]; w.tdesc.format = dp[4];
+                    }
                 }
             }
         }
@@ -705,7 +745,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 int x, y;
                 asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(x) : "v"(b & ((1 << LC) - 1)), "v"(gx0 + px), "n"(LW));
                 asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(y) : "v"(b >> LC), "v"(ry0 + py), "n"(4 - LW));
-                if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
+                if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND, true>(a, w, x, y);
             }
         } else {
             const int cbx = gx0 + lx * 8, cby = ry0 + ly * 8;
@@ -723,7 +763,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = gx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND>(a, w, x, y);
+                if (x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND, true>(a, w, x, y);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na) : : "memory");

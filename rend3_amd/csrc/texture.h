@@ -346,6 +346,54 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
     o[0] = r.rg.x; o[1] = r.rg.y; o[2] = r.ba.x; o[3] = r.ba.y;
 }
 
+// ALPHA of textureSampleGrad alone: what the rasterisers' cutout test reads (opaque.wgsl:231-235, depth.wgsl:100-127).  On the short
+// path a texel costs one word and one division -- decode[c] IS c / 255 as an f32 division (r3n_create builds the table that way), so
+// no table load -- instead of four table loads out of global memory per texel (the rasterisers do not stage the tables in LDS): 8
+// texels x 4 channels per fragment before.  The alpha channel of tex_sample_grad runs through exactly these operations (a packed
+// pair rounds each lane like the scalar form), so the value is the same bit for bit; every other case calls tex_sample_grad.
+// `d` = t.descs[id - 1], fetched by the caller once per triangle / work item (the fragments of one share it).
+template <class M = MathExact>
+R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_texture_desc32 &d, bool nearest, float u, float v, const float ddx[2], const float ddy[2]) {
+    if (id == 0u || id > t.count) return 0.0f;
+    const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
+    if (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT) {
+        const float W = (float)d.width, H = (float)d.height;
+        const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
+        const float rho = exact_math::sqrt(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
+        uint32_t level = 0;
+        float frac = 0.0f;
+        if (rho > 1.0f && rho < INFINITY) {
+            const uint32_t bits = __float_as_uint(rho);
+            level = (bits >> 23) - 127u;
+            frac = (float)(bits & 0x7FFFFFu) / 8388608.0f;
+        } else if (rho == INFINITY) {
+            level = d.mips;
+        }
+        if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
+        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
+        TexLvlFast l0, l1;
+        bool tame = tex_level_fast<false>(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
+        const bool two = frac > 0.0f;
+        if (two) tame = tex_level_fast<false>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
+        if (tame) {
+            const char *pool = reinterpret_cast<const char *>(t.texels);
+            auto alpha_at = [&](uint32_t byte_off) { return (float)(*reinterpret_cast<const uint32_t *>(pool + byte_off) >> 24) / 255.0f; };
+            auto bilinear = [&](const TexLvlFast &l) {
+                const float a00 = alpha_at(l.o00), a10 = alpha_at(l.o10), a01 = alpha_at(l.o01), a11 = alpha_at(l.o11);
+                const float omx = 1.0f - l.fx, omy = 1.0f - l.fy;
+                const float top = M::mad(a10, l.fx, a00 * omx), bot = M::mad(a11, l.fx, a01 * omx);
+                return M::mad(bot, l.fy, top * omy);
+            };
+            float r = bilinear(l0);
+            if (two) r = M::mad(bilinear(l1), frac, r * (1.0f - frac));
+            return r;
+        }
+    }
+    float o[4];
+    tex_sample_grad<M, true>(t, id, nearest, u, v, ddx, ddy, o);
+    return o[3];
+}
+
 // The three maps of a material (albedo, normal, AO / roughness / metallic: opaque.wgsl:207-351 samples them at the same coordinates
 // with the same gradients) in ONE pass whose memory operations go out in three batches -- the descriptors; the level offsets; the
 // (up to 24) texels -- instead of three dependent chains of descriptor -> level offset -> texels, one behind the other: the resolve is

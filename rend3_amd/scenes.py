@@ -4,6 +4,7 @@ is no network here).  Parameters follow SURVEY.md section 8(d).  Generators only
 transforms, materials, lights, camera); they use the product host mirror for matrix maths.
 """
 import math
+import os
 
 import numpy as np
 
@@ -202,8 +203,106 @@ def procedural_textures(n_albedo=16, n_normal=8, n_orm=8, size=1024, seed=0x7E57
     return out
 
 
+_V2_TEXTURES = {}  # tex_size -> the BC7 chains of bistro_like's v2 texture sets
+_BC7_W4 = np.array([0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64], dtype=np.float32)
+
+
+def bc7_encode(rgba8):
+    """(H, W, 4) u8, H and W multiples of 4 -> BC7 blocks (bytes), every block in MODE 6 (one subset, 7-bit RGBA endpoints + a
+    p-bit each, 4-bit indices): endpoints = the block's per-channel bounding box, indices by projection on its diagonal.  A
+    plain encoder for synthetic assets -- the product and the oracle DECODE the blocks (texture_decode.hip / oracle/bcn.c, both
+    pinned on Pillow's decoder), so whatever it writes reads back the same on both sides.  Vectorised over the image's blocks."""
+    h, w = rgba8.shape[:2]
+    assert h % 4 == 0 and w % 4 == 0 and rgba8.shape[2] == 4
+    px = rgba8.reshape(h // 4, 4, w // 4, 4, 4).transpose(0, 2, 1, 3, 4).reshape(-1, 16, 4).astype(np.float32)  # blocks x pixels x channels
+    lo8, hi8 = px.min(axis=1), px.max(axis=1)
+    # the bounding box's diagonal that follows the data: a channel that falls while the widest channel rises swaps its ends
+    dev = px - px.mean(axis=1, keepdims=True)
+    major = np.take_along_axis(dev, (hi8 - lo8).argmax(axis=1)[:, None, None].repeat(16, 1), axis=2)
+    anti = (dev * major).sum(axis=1) < 0.0
+    lo8, hi8 = np.where(anti, hi8, lo8), np.where(anti, lo8, hi8)
+
+    def quant(e):  # 8-bit value -> 7 bits + a p-bit shared by the endpoint's four channels
+        e = e.astype(np.uint32)
+        p = ((e & 1).sum(axis=1) >= 2).astype(np.uint32)
+        q = np.clip((e.astype(np.int32) - p[:, None].astype(np.int32) + 1) >> 1, 0, 127).astype(np.uint32)
+        return q, p, ((q << 1) | p[:, None]).astype(np.float32)
+
+    q0, p0, e0 = quant(lo8)
+    q1, p1, e1 = quant(hi8)
+    d = e1 - e0
+    den = (d * d).sum(axis=1)
+    t = ((px - e0[:, None, :]) * d[:, None, :]).sum(axis=2) / np.maximum(den, 1.0)[:, None]
+    idx = np.abs(np.clip(t, 0.0, 1.0)[:, :, None] * 64.0 - _BC7_W4[None, None, :]).argmin(axis=2).astype(np.uint64)
+    swap = idx[:, 0] >= 8  # the anchor index (pixel 0) stores three bits: its top bit must be clear
+    idx[swap] = 15 - idx[swap]
+    q0s, q1s = np.where(swap[:, None], q1, q0).astype(np.uint64), np.where(swap[:, None], q0, q1).astype(np.uint64)
+    p0s, p1s = np.where(swap, p1, p0).astype(np.uint64), np.where(swap, p0, p1).astype(np.uint64)
+    lo = np.full(len(px), 1 << 6, dtype=np.uint64)  # mode 6: six zero bits, then a one
+    for c in range(4):
+        lo |= (q0s[:, c] << np.uint64(7 + 14 * c)) | (q1s[:, c] << np.uint64(14 + 14 * c))
+    lo |= p0s << np.uint64(63)
+    hi = p1s | (idx[:, 0] << np.uint64(1))
+    for k in range(1, 16):
+        hi |= idx[:, k] << np.uint64(4 * k)
+    return np.stack([lo, hi], axis=1).astype("<u8").tobytes()
+
+
+def bc7_mip_chain(rgba8):
+    """BC7 levels of an image (power-of-two extents >= 4), largest first, down to 4 x 4: box-filtered levels, each encoded."""
+    levels, img = [], rgba8
+    while True:
+        levels.append(bc7_encode(img))
+        if min(img.shape[:2]) <= 4:
+            return levels
+        img = ((img[0::2, 0::2].astype(np.uint16) + img[1::2, 0::2] + img[0::2, 1::2] + img[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+
+def foliage_cards(n_cards, rng_np):
+    """A clump of `n_cards` crossed, double-sided quads inside the unit cube (two triangles per side: 4 per card), with texture
+    coordinates over the whole leaf atlas: the alpha-tested foliage of a scanned city asset.  Returns positions, indices, normals,
+    uv, tangents (LH-front-facing winding like the other generators; both windings are present)."""
+    c = rng_np.uniform(-0.8, 0.8, (n_cards, 3)).astype(f32)
+    ang = rng_np.uniform(0.0, math.pi, n_cards).astype(f32)
+    half = rng_np.uniform(0.12, 0.3, n_cards).astype(f32)
+    ux = np.stack([np.cos(ang), np.zeros(n_cards, f32), np.sin(ang)], axis=1) * half[:, None]
+    uy = np.stack([np.zeros(n_cards, f32), np.ones(n_cards, f32), np.zeros(n_cards, f32)], axis=1) * half[:, None]
+    corners = np.stack([c - ux - uy, c + ux - uy, c + ux + uy, c - ux + uy], axis=1)  # (n, 4, 3)
+    nrm = np.cross(ux, uy)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tan = ux / half[:, None]
+    # front and back copies own their vertices (opposite normals)
+    pos = np.concatenate([corners, corners], axis=1).reshape(-1, 3).astype(f32)
+    normals = np.concatenate([np.repeat(nrm[:, None], 4, 1), np.repeat(-nrm[:, None], 4, 1)], axis=1).reshape(-1, 3).astype(f32)
+    tangents = np.concatenate([np.repeat(tan[:, None], 4, 1), np.repeat(-tan[:, None], 4, 1)], axis=1).reshape(-1, 3).astype(f32)
+    uv1 = np.array([[0, 1], [1, 1], [1, 0], [0, 0]], dtype=f32)
+    uv = np.tile(np.concatenate([uv1, uv1]), (n_cards, 1)).astype(f32)
+    base = (np.arange(n_cards, dtype=np.uint32) * 8)[:, None]
+    idx = np.concatenate([base + np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32), base + np.array([4, 6, 5, 4, 7, 6], dtype=np.uint32)], axis=1).reshape(-1)
+    return pos, idx.astype(np.uint32), normals, uv, tangents
+
+
+def leaf_atlas(size, seed):
+    """RGBA8 leaf texture: green blades on a transparent ground (alpha 0 / 255 with a soft edge): what an alpha cutout tests."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    a = np.zeros((size, size), dtype=np.float32)
+    for _ in range(40):
+        cx, cy, ang, ln, wd = rng.uniform(0.1, 0.9), rng.uniform(0.1, 0.9), rng.uniform(0, math.pi), rng.uniform(0.08, 0.22), rng.uniform(0.015, 0.05)
+        dx, dy = xx - cx, yy - cy
+        u, v = dx * math.cos(ang) + dy * math.sin(ang), -dx * math.sin(ang) + dy * math.cos(ang)
+        a = np.maximum(a, np.clip(1.5 - np.sqrt((u / ln) ** 2 + (v / wd) ** 2) * 1.5, 0.0, 1.0))
+    img = np.empty((size, size, 4), dtype=np.uint8)
+    shade = 0.6 + 0.4 * rng.random((size, size)).astype(np.float32)
+    img[..., 0] = 60 * shade
+    img[..., 1] = 170 * shade
+    img[..., 2] = 50 * shade
+    img[..., 3] = np.clip(a * 255.0, 0, 255)
+    return img
+
+
 def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=130, seed=0xB157, shadow_res=2048,
-                n_lights=4, textured=False, unique=True, tex_size=1024):
+                n_lights=4, textured=False, unique=True, tex_size=1024, v2=False, v2_tex_size=2048):
     """BASELINE.json configs[2] stand-in (SURVEY.md section 8d cfg 3): street canyon with real occlusion, ~3 000 objects,
     ~2.8 M triangles (log-normal per object), 130 PBR materials (roughness U[0.2,0.9], metallic in {0,1} p=0.2),
     4 directional lights with 2048^2 shadow views, distance 100, ambient 0.1 (applied by the caller),
@@ -217,8 +316,15 @@ def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=13
     textured: every material gets a base colour, a normal and a packed AO / roughness / metallic map (tex_size^2 /
     (tex_size/2)^2 RGBA8 with full mip chains, trilinear) from a pool of 32 procedural textures, like the scanned material
     set of the real asset; meshes then carry box-projected texture coordinates and tangents.
+    v2 (closer to the Lumberyard asset than the default): the maps are 2048^2 (AO / roughness / metallic 1024^2)
+    and arrive BLOCK-COMPRESSED -- BC7 with stored mip chains, decoded at upload like any `Bc7RgbaUnorm[Srgb]` texture of
+    rend3-gltf's loader -- in 24 texture sets (a texel pool of ~1.2 GB instead of 145 MB); a fifth of the triangles are
+    alpha-tested FOLIAGE: clumps of crossed double-sided cards on the CUTOUT key whose alpha comes from a leaf atlas
+    (opaque.wgsl:231-235, depth.wgsl:100-127); and a third of the props are INSTANCES of shared meshes.
     Returns dict(objects, triangles, camera=(view, projection), mesh_bytes, unique_triangles)."""
     rng = Pcg32(seed)
+    if v2:
+        textured, tex_size = True, v2_tex_size  # (tests pass a smaller size)
     rh = r.handedness == RIGHT
     fix = (lambda i: _flip(i)) if rh else (lambda i: i)  # generators emit LH-front-facing winding
 
@@ -267,7 +373,35 @@ def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=13
     spheres = [m for m in lib if m[0] == "sphere"]
 
     tex = None
-    if textured:
+    if textured and v2:
+        from . import containers
+        # six distinct images per kind, encoded once; 24 texture sets cycle over them (every set owns its texels in the pool: the
+        # working set is that of 24 distinct sets)
+        if tex_size not in _V2_TEXTURES:  # (the oracle's and the product's renderer build the same scene: encode once per process,
+            # and keep the encoded chains in the temporary directory for the next process of the same session: ~100 s at 2048^2)
+            import pickle
+            import tempfile
+            cache = os.path.join(tempfile.gettempdir(), f"rend3_amd_bistro_v2_textures_{tex_size}.pkl")
+            try:
+                with open(cache, "rb") as fh:
+                    _V2_TEXTURES[tex_size] = pickle.load(fh)
+            except (OSError, ValueError, EOFError, pickle.UnpicklingError):
+                imgs = procedural_textures(n_albedo=6, n_normal=6, n_orm=6, size=tex_size)
+                _V2_TEXTURES[tex_size] = ({k: [bc7_mip_chain(im) for im in v] for k, v in imgs.items()},
+                                          [bc7_mip_chain(leaf_atlas(tex_size // 2, 0x1EAF + k)) for k in range(4)])
+                try:
+                    with open(cache + ".tmp", "wb") as fh:
+                        pickle.dump(_V2_TEXTURES[tex_size], fh)
+                    os.replace(cache + ".tmp", cache)
+                except OSError:
+                    pass
+        enc, leaf_enc = _V2_TEXTURES[tex_size]
+        n_sets = 24
+        tex = {"albedo": [r.add_texture_2d_encoded(containers.BC7_SRGB, tex_size, tex_size, enc["albedo"][k % 6]) for k in range(n_sets)],
+               "normal": [r.add_texture_2d_encoded(containers.BC7, tex_size, tex_size, enc["normal"][k % 6]) for k in range(n_sets)],
+               "orm": [r.add_texture_2d_encoded(containers.BC7, tex_size // 2, tex_size // 2, enc["orm"][k % 6]) for k in range(n_sets)]}
+        leaf = [r.add_texture_2d_encoded(containers.BC7_SRGB, tex_size // 2, tex_size // 2, leaf_enc[k]) for k in range(4)]
+    elif textured:
         imgs = procedural_textures(size=tex_size)
         tex = {"albedo": [r.add_texture_2d(im, srgb=True, mip_count="maximum", mip_source="generated") for im in imgs["albedo"]],
                "normal": [r.add_texture_2d(im, srgb=False, mip_count="maximum", mip_source="generated") for im in imgs["normal"]],
@@ -349,9 +483,41 @@ def bistro_like(r, hm, mk, n_objects=3000, target_tris=2_800_000, n_materials=13
         objs.append((mesh, xf(place(along, side, up), (s, s, s), rng.uniform(0.0, 2 * math.pi))))
 
     total = 0
-    for mesh, m in objs:
-        r.add_object(instance_mesh(mesh), mats[rng.randint(len(mats))], m)
+    shared = {}  # v2: library entry -> the mesh its instanced props share
+    for k, (mesh, m) in enumerate(objs):
+        if v2 and k >= n_fixed and k % 3 == 0:  # a third of the props are instances of shared meshes
+            if id(mesh) not in shared:
+                shared[id(mesh)] = instance_mesh(mesh)
+            handle = shared[id(mesh)]
+        else:
+            handle = instance_mesh(mesh)
+        r.add_object(handle, mats[rng.randint(len(mats))], m)
         total += mesh[1]
+    if v2:
+        # ---- foliage: clumps of alpha-tested cards (cutout key) in planters along the pavements and on the facades, until a
+        # fifth of the scene's triangles are theirs; 8 clump meshes, instanced
+        frng = np.random.default_rng(seed ^ 0xF011A6E)
+        leaf_mats = [r.add_material(mk(albedo=(1.0, 1.0, 1.0, 1.0), albedo_mode="texture", albedo_texture=leaf[k % 4], roughness=0.8,
+                                       metallic=0.0, cutout=0.5), CUTOUT) for k in range(8)]
+        clumps = []
+        for k in range(8):
+            p, i, nr, uv, tan = foliage_cards(350, frng)
+            clumps.append((upload(p, fix(i), nr, uv, tan), len(i) // 3))
+        want = int(0.25 * total)  # of the opaque triangles = a fifth of the whole
+        placed = 0
+        while placed < want:
+            k = int(frng.integers(0, 8))
+            along = float(frng.uniform(-6.0, length))
+            if frng.random() < 0.7:   # trees / planters on the pavements
+                side = float((1.0 if frng.random() < 0.5 else -1.0) * frng.uniform(street_half - 1.5, street_half + 2.0))
+                s, up = float(frng.uniform(0.8, 2.2)), float(frng.uniform(1.0, 5.0))
+            else:                     # creepers on the facades
+                side = float((1.0 if frng.random() < 0.5 else -1.0) * (street_half + 5.4))
+                s, up = float(frng.uniform(0.6, 1.5)), float(frng.uniform(2.0, 12.0))
+            r.add_object(clumps[k][0], leaf_mats[int(frng.integers(0, 8))], xf(place(along, side, up), (s, s, s), float(frng.uniform(0.0, 2 * math.pi))))
+            objs.append((None, None))
+            placed += clumps[k][1]
+        total += placed
 
     # ---- lights (scene_viewer/mod.rs:736-737 + 3 rotated copies), shadow distance 100, resolution 2048
     d0 = np.array([1.0, -5.0, -1.0])

@@ -1170,6 +1170,38 @@ def test_config3_bistro_like(r3):
     assert (fo["vis"] != 0).mean() > 0.9
 
 
+def test_config3_bistro_v2(r3):
+    """The Bistro-faithful variant of the bench scene (bench.py --bistro-v2) at a size the oracle finishes in
+    seconds: the maps arrive as BC7 with stored mip chains (decoded at upload on both sides), a fifth of the triangles are
+    alpha-tested foliage cards on the CUTOUT key whose alpha comes from a leaf atlas (opaque.wgsl:231-235 in the viewport,
+    depth.wgsl:100-127 in the four shadow views), a third of the props are instances of shared meshes; two resolve classes
+    (base colour only / the three PBR maps) share the frame.  Three frames of the camera dolly, bit-exact like the other scenes."""
+    import bench
+    import rend3_amd.scenes as S
+    w, h = 1280, 720
+    o, p = both(r3, oh.RIGHT, f32(w) / f32(h))
+    kw = dict(n_objects=900, target_tris=200_000, unique=True, v2=True, v2_tex_size=256, shadow_res=1024)
+    io = S.bistro_like(o, oh, omk, **kw)
+    ip = S.bistro_like(p, r3.host, r3.material_record, **kw)
+    assert io["triangles"] == ip["triangles"] and io["objects"] == ip["objects"]
+    assert io["unique_triangles"] < io["triangles"]  # instanced props and foliage clumps
+    view0, proj = io["camera"]
+    for k in range(3):
+        o.set_camera_data(bench.camera_path(oh, view0, k), proj)
+        p.set_camera_data(bench.camera_path(r3.host, view0, k), proj)
+        fo = o.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+        fp = p.render(w, h, ambient=bench.AMBIENT, clear_color=bench.CLEAR)
+        compare_frames(fo, fp, f"bistro v2 frame {k}")
+    keys = fo["material_keys"][fo["objects"][:, 22]]
+    ntri = (fo["objects"][:, 21] // 3) * (fo["objects"][:, 29] != 0)
+    assert ntri[keys == 1].sum() >= 0.19 * ntri.sum(), "a fifth of the triangles on the cutout key"
+    # the cutout key drew in the viewport and in every shadow view
+    tri_obj = np.searchsorted(fo["tri_base"], np.arange(len(fo["pass"])), side="right") - 1
+    cut = keys[tri_obj] == 1
+    assert (fo["pass"].astype(bool) & cut).sum() > 1000 and all((s["pass"][: len(cut)].astype(bool) & cut).sum() > 1000 for s in fo["shadows"])
+    assert fo["residual"].sum() > 0 and (fo["vis"] != 0).mean() > 0.9
+
+
 def test_config3_4k_frame(r3):
     """bench.py's workload at its full size -- 3840x2160, ~3 000 objects / ~2.8 M unique triangles, 4 shadow views of
     2048^2 -- with factor-only materials (the textured fragment stage is covered above at 1080p; at 4K it would only

@@ -19,10 +19,12 @@ run() {  # name, counters...
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+if [ "${PMC_TRAFFIC_ONLY:-0}" != 1 ]; then   # (the other workload variants: the two traffic counters only)
 R3N_SINGLE_STREAM=1 run sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
 R3N_SINGLE_STREAM=1 run ic SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES
 R3N_SINGLE_STREAM=1 run mix SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_INSTS_VMEM_RD
 R3N_SINGLE_STREAM=1 run mix2 SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VSKIPPED SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_IOPS
+fi
 cd "$root"
 python tools/make_traffic.py "$out" $extra
 find "$out" -name "*.csv" -size +20M -delete

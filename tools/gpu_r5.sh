@@ -60,6 +60,13 @@ for w in "$@"; do
         echo "== $setting, single stream"; stats $out/ser_$setting 14 | grep -v "k_copy\|copyBuffer"
       done
       cd $root;;
+    v2)  # the Bistro-faithful stand-in: its parity test, its bench line with the oracle's parity block, its stand-alone kernel durations
+      timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "bistro_v2" > "$out/pytest_v2.log" 2>&1; echo "pytest v2 rc=$?"; tail -3 "$out/pytest_v2.log"; grep -E '^E ' "$out/pytest_v2.log" | head -8
+      python bench.py --bistro-v2 --steps 60 --warmup 8 --cpu-sample-frames 1 > "$out/bench_bistro_v2.json" 2> "$out/bench_bistro_v2.err"; line "$out/bench_bistro_v2.json"; tail -2 "$out/bench_bistro_v2.err" | grep -v amdgpu.ids
+      cd /tmp
+      R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ser_v2 -o k -- python $root/bench.py --bistro-v2 --no-cpu-baseline --steps 30 --warmup 5 > $out/ser_v2.json 2> $out/ser_v2.err
+      echo "== bistro v2, single stream"; stats $out/ser_v2 20 | grep -v "k_copy\|copyBuffer"
+      cd $root;;
     *) echo "unknown action $w";;
   esac
 done

@@ -61,7 +61,8 @@ def main():
         table[short(k)] = row
     variant = ("instanced" if "--instanced" in args else "unique") + ("-untextured" if "--untextured" in args else "-textured") + \
               ("-s4" if "--samples" in args and args[args.index("--samples") + 1] == "4" else "-s1") + \
-              ("-fast" if "--shade-mode" in args and args[args.index("--shade-mode") + 1] == "fast" else "")
+              ("-fast" if "--shade-mode" in args and args[args.index("--shade-mode") + 1] == "fast" else "") + \
+              ("-cfg4" if "--config" in args and args[args.index("--config") + 1] == "4" else "") + ("-v2" if "--bistro-v2" in args else "")
     import bench
     pick = {"k_resolve_opaque": [k for k in table if k.startswith("k_resolve_opaque")],
             "k_triangle_cull": [k for k in table if k.startswith("k_triangle_cull")],
@@ -83,6 +84,19 @@ def main():
             # integer / address work and conversions are NOT flops
             t = table[names[0]]
             doc["useful_flops_per_launch"][key] = int(64 * (t["sq_insts_valu_add_f32"] + t["sq_insts_valu_mul_f32"] + 2 * t["sq_insts_valu_fma_f32"] + t.get("sq_insts_valu_trans_f32", 0.0)))
+    # one entry per workload variant (bench.py quotes the entry of the variant it runs): merged into the file the previous
+    # variants of THIS build left in the same directory tree (gpurun_out/<tag>/traffic.json), or into profiles/traffic.json
+    merged = {"source": doc["source"], "kernel_sources_sha": doc["kernel_sources_sha"], "variants": {}}
+    for prior in (os.path.join(os.path.dirname(out.rstrip("/")), "traffic.json"), os.path.join(ROOT, "profiles", "traffic.json")):
+        try:
+            old = json.load(open(prior))
+            if old.get("kernel_sources_sha") == doc["kernel_sources_sha"] and "variants" in old:
+                merged["variants"].update(old["variants"])
+                break
+        except (OSError, ValueError):
+            pass
+    merged["variants"][variant] = {k: doc[k] for k in ("taken", "bytes_per_launch", "valu_busy", "valu_insts_per_launch", "useful_flops_per_launch", "kernels")}
+    json.dump(merged, open(os.path.join(os.path.dirname(out.rstrip("/")), "traffic.json"), "w"), indent=1)
     json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     for k, row in table.items():
         print(k[:60], {a: (round(b, 3) if isinstance(b, float) else b) for a, b in row.items()})
