@@ -165,17 +165,19 @@ R3N_DEV bool prepare_triangle(const RasterArgs &a, uint32_t obj, uint32_t tri, b
 // Alpha of the albedo texture at pixel (x, y) for the cutout test.  Forward (opaque.wgsl:207-215): coordinates through
 // uv_transform0, sampler chosen by FLAGS_NEAREST.  Depth-only (depth.wgsl:108-118, quirks reproduced): raw coords0,
 // always the primary sampler, and uvdy = dpdx(coords).
-template <bool DEPTH_ONLY, bool TEX, bool HOIST = false>
+// SHORTA: every albedo map a cutout material of the world binds is on the sampler's short path (the host's census, r3n.hip
+// refresh_material_classes): the general sampler is not instantiated -- it is most of these kernels' vector registers.
+template <bool DEPTH_ONLY, bool TEX, bool HOIST = false, bool SHORTA = false>
 R3N_DEV float cutout_texture_alpha(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (!TEX || !tw.alpha_tex) return 1.0f;
     float coords[2], ddx[2], ddy[2];
     if (HOIST) {
         if (DEPTH_ONLY) {
             frag_coords(tw.ts, tw.uv, nullptr, x, y, coords, ddx, ddy);
-            return tex_sample_alpha(a.tex, tw.tex0, tw.tdesc, false, coords[0], coords[1], ddx, ddx);
+            return tex_sample_alpha<MathExact, SHORTA>(a.tex, tw.tex0, tw.tdesc, false, coords[0], coords[1], ddx, ddx);
         }
         frag_coords(tw.ts, tw.uv, tw.uvt, x, y, coords, ddx, ddy);
-        return tex_sample_alpha(a.tex, tw.tex0, tw.tdesc, tw.nearest, coords[0], coords[1], ddx, ddy);
+        return tex_sample_alpha<MathExact, SHORTA>(a.tex, tw.tex0, tw.tdesc, tw.nearest, coords[0], coords[1], ddx, ddy);
     }
     const r3n_material208 &m = a.materials[tw.material];
     const uint32_t id = m.textures[0];
@@ -183,10 +185,10 @@ R3N_DEV float cutout_texture_alpha(const RasterArgs &a, const TriWork &tw, int x
     if (id - 1u < a.tex.count) d = a.tex.descs[id - 1u];
     if (DEPTH_ONLY) {
         frag_coords(tw.ts, tw.uv, nullptr, x, y, coords, ddx, ddy);
-        return tex_sample_alpha(a.tex, id, d, false, coords[0], coords[1], ddx, ddx);
+        return tex_sample_alpha<MathExact, SHORTA>(a.tex, id, d, false, coords[0], coords[1], ddx, ddx);
     }
     frag_coords(tw.ts, tw.uv, m.uv_transform0, x, y, coords, ddx, ddy);
-    return tex_sample_alpha(a.tex, id, d, (m.flags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy);
+    return tex_sample_alpha<MathExact, SHORTA>(a.tex, id, d, (m.flags & R3N_FLAGS_NEAREST) != 0u, coords[0], coords[1], ddx, ddy);
 }
 
 // Multisampling (row N4; forward.rs:358 MultisampleState{count}): coverage and depth at the standard 4x sample
@@ -232,7 +234,7 @@ R3N_DEV uint32_t target_pixel(const RasterArgs &a, uint32_t x, uint32_t y) {
     return __umul24(a.vp_y + y, a.target_pitch) + (a.vp_x + x);
 }
 
-template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false, bool HOIST = false>
+template <bool DEPTH_ONLY, bool PREREAD, int S = 1, bool TEX = false, bool BLEND = false, bool HOIST = false, bool SHORTA = false>
 R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
     if (BLEND) {
         // Transparent pass: depth test GreaterEqual against the final opaque depth, depth write off (pbr/routine.rs:
@@ -279,7 +281,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             else if (!((((unsigned long long)zb << 32) | (unsigned long long)tw.slot1) > a.vis[pix])) return;
             const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
             const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST, SHORTA>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
         }
         if (DEPTH_ONLY) {
             if (!PREREAD || zb > a.depth[pix]) global_max_u32_at(a.depth, pix << 2, zb);
@@ -324,7 +326,7 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             (void)edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E);
             const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
             const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
-            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST>(a, tw, x, y), al) < tw.mat_cutoff) return;
+            if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST, SHORTA>(a, tw, x, y), al) < tw.mat_cutoff) return;
         }
 #pragma unroll
         for (int sm = 0; sm < S; ++sm)
@@ -436,7 +438,7 @@ R3N_DEV uint32_t pack_thresholds(const float thr[3]) {
 
 // Stage 1: one thread per list entry.  Small triangles are scanned in place; larger ones are split into
 // <=64x64 px items for stage 2.
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false, bool SHORTA = false>
 R3N_DEV void raster_small_body(const RasterArgs &a) {
     // block b walks sub-list (b % R3N_SUBQ) of the region, and appends to work sub-queue (b % R3N_BIGQ)
     const uint32_t q = blockIdx.x % R3N_SUBQ;
@@ -455,7 +457,7 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
         const int bw = tw.x1 - tw.x0 + 1, bh = tw.y1 - tw.y0 + 1;
         if (bw <= R3N_SMALL_MAX && bh <= R3N_SMALL_MAX) {
             for (int y = tw.y0; y <= tw.y1; ++y)
-                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
+                for (int x = tw.x0; x <= tw.x1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX, false, false, SHORTA>(a, tw, x, y);
         } else {
             // Work items start on a multiple of R3N_ITEM_ALIGN pixels in x: the scan's blocks then sit on the target's
             // 64-byte lines (16 depth texels, 8 keys) instead of straddling them, and one atomic instruction touches fewer lines --
@@ -496,16 +498,16 @@ R3N_DEV void raster_small_body(const RasterArgs &a) {
                 } else {
                     // queue full: never drop work -- scan the region here (slow path)
                     for (int y = ry0; y <= ry1; ++y)
-                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX>(a, tw, x, y);
+                        for (int x = rx0; x <= rx1; ++x) shade_pixel<DEPTH_ONLY, R3N_PREREAD_SMALL != 0, S, TEX, false, false, SHORTA>(a, tw, x, y);
                 }
             }
         }
     }
 }
 
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool NOCUT = false, bool SHORTA = false>
 __global__ __launch_bounds__(256, R3N_SMALL_OCC) void k_raster_small(RasterArgs a) {
-    raster_small_body<DEPTH_ONLY, S, TEX, NOCUT>(a);
+    raster_small_body<DEPTH_ONLY, S, TEX, NOCUT, SHORTA>(a);
 }
 // Transparent pass, stage 1 (row N3): one thread per triangle of the blend-key objects, in DRAW ORDER -- objects back
 // to front (blend_order, sorted on the host like batching.rs:146-176), triangles in index order; g is therefore
@@ -593,7 +595,7 @@ R3N_DEV bool block_may_cover(const TriSetup &ts, int bx, int by, int rx1, int ry
 // the next item's record is in flight while the current one is scanned.  Waves walk the concatenation of the
 // R3N_BIGQ producer sub-queues with a stride of the wave count, which spreads neighbouring (similar-cost) items
 // over different waves.
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool NOCUT = false>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool NOCUT = false, bool SHORTA = false>
 R3N_DEV void raster_big_body(RasterArgs a) {
     // Pin the kernel arguments the scan uses into SGPRs here: hipcc otherwise sinks the wait for their s_load
     // into the scan loop, and an `s_waitcnt lgkmcnt(0)` there would also wait for the record prefetch below.
@@ -745,7 +747,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 int x, y;
                 asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(x) : "v"(b & ((1 << LC) - 1)), "v"(gx0 + px), "n"(LW));
                 asm("v_lshl_add_u32 %0, %1, %3, %2" : "=v"(y) : "v"(b >> LC), "v"(ry0 + py), "n"(4 - LW));
-                if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND, true>(a, w, x, y);
+                if (b < 64 && x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND, true, SHORTA>(a, w, x, y);
             }
         } else {
             const int cbx = gx0 + lx * 8, cby = ry0 + ly * 8;
@@ -763,7 +765,7 @@ R3N_DEV void raster_big_body(RasterArgs a) {
                 const int b = __builtin_ctzll(blocks);
                 blocks &= blocks - 1ull;
                 const int x = gx0 + (b & 7) * 8 + lx, y = ry0 + (b >> 3) * 8 + ly;
-                if (x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND, true>(a, w, x, y);
+                if (x >= rx0 && x <= rx1 && y <= ry1) shade_pixel<DEPTH_ONLY, (R3N_PREREAD_BIG != 0) || (!DEPTH_ONLY && (S > 1 ? R3N_PREREAD_MS != 0 : R3N_PREREAD_VIEWPORT != 0)), S, TEX, BLEND, true, SHORTA>(a, w, x, y);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na) : : "memory");
@@ -772,9 +774,9 @@ R3N_DEV void raster_big_body(RasterArgs a) {
     }
 }
 
-template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool NOCUT = false>
+template <bool DEPTH_ONLY, int S = 1, bool TEX = false, bool BLEND = false, bool NOCUT = false, bool SHORTA = false>
 __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a) {
-    raster_big_body<DEPTH_ONLY, S, TEX, BLEND, NOCUT>(a);
+    raster_big_body<DEPTH_ONLY, S, TEX, BLEND, NOCUT, SHORTA>(a);
 }
 // ------------------------------------------------------------------------------------------------ clears
 __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long *__restrict__ p, unsigned long long v, size_t n) {

@@ -134,6 +134,7 @@ struct r3n_ctx {
     DevBuf view_lights[2];  // ViewLights of the frame set (k_stage_view_lights writes it in front of the single-sample resolve)
     uint32_t resolve_variants = 0;
     bool classes_dirty = true;
+    bool cutout_short_dirty = true, cutout_short = false;  // cutout_alpha_short(): census of the cutout materials' albedo maps
     bool key_census_dirty = true;
     uint64_t key_objects[3] = {0, 0, 0};  // enabled objects per material key
     uint64_t total_tris = 0;
@@ -930,7 +931,7 @@ int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208
     c->key_census_dirty = true;
     c->h_materials.resize(need, r3n_material208{});
     for (uint32_t i = 0; i < n; ++i) c->h_materials[slots[i]] = records[i];
-    c->classes_dirty = true;
+    c->classes_dirty = true; c->cutout_short_dirty = true;
     for (uint32_t i = 0; i < n; ++i) {
         HIP_TRY(c, hipMemcpyAsync(c->materials.as<r3n_material208>() + slots[i], records + i, sizeof(r3n_material208),
                                   hipMemcpyHostToDevice, c->stream));
@@ -969,7 +970,7 @@ static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uin
         const uint32_t w = descs[i].width, h = descs[i].height;
         c->h_tex_short[i] = (w && h && ((w & (w - 1u)) | (h & (h - 1u))) == 0u && descs[i].format < R3N_POOL_FLOAT) ? 1 : 0;
     }
-    c->classes_dirty = true;
+    c->classes_dirty = true; c->cutout_short_dirty = true;
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->tex_level_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
@@ -1554,6 +1555,24 @@ int r3n_shadow_viewport(r3n_ctx *c, r3n_camera cam, uint32_t x, uint32_t y, uint
 
 static int forward_blend(r3n_ctx *c);
 
+// Every albedo map a CUTOUT-key material samples for its alpha test (opaque.wgsl:231-235, depth.wgsl:100-127) is on the sampler's
+// short path -- power-of-two extents, RGBA8 pool texels, a pool below 2^30 texels, the linear sampler: the rasterisers' textured
+// instantiations then carry no general sampler (kernels_raster.h SHORTA: most of their vector registers).  Host mirrors only.
+static bool cutout_alpha_short(r3n_ctx *c) {
+    if (!c->cutout_short_dirty) return c->cutout_short;
+    bool ok = c->n_texels <= (1ull << 30);
+    for (uint32_t i = 0; ok && i < c->n_materials && i < c->h_materials.size(); ++i) {
+        const r3n_material208 &m = c->h_materials[i];
+        if (i >= c->h_material_key.size() || c->h_material_key[i] != R3N_KEY_CUTOUT) continue;
+        if (!(m.flags & R3N_FLAGS_ALBEDO_ACTIVE) || m.textures[0] == 0u) continue;
+        const uint32_t id = m.textures[0];
+        ok = id <= c->n_textures && id <= c->h_tex_short.size() && c->h_tex_short[id - 1u] != 0 && !(m.flags & R3N_FLAGS_NEAREST);
+    }
+    c->cutout_short = ok;
+    c->cutout_short_dirty = false;
+    return ok;
+}
+
 int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint32_t key) {
     if (!c || pass > R3N_PASS_FORWARD || source > R3N_SOURCE_RESIDUAL || key > R3N_KEY_BLEND)
         return fail(c, R3N_ERR_INVALID_ARG, "forward: bad args");
@@ -1633,12 +1652,15 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
             { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), R3N_VIEWPORT_BIG_LDS, stream, a); }
         };
         const bool nocut = key != R3N_KEY_CUTOUT;  // the opaque key's instantiations carry nothing of the cutout test (kernels_raster.h NOCUT)
+        const bool shorta = tex && cutout_alpha_short(c);
         if (c->samples == 4) {
-            if (tex) launch(k_raster_small<false, 4, true>, k_raster_big<false, 4, true>);
+            if (shorta) launch(k_raster_small<false, 4, true, false, true>, k_raster_big<false, 4, true, false, false, true>);
+            else if (tex) launch(k_raster_small<false, 4, true>, k_raster_big<false, 4, true>);
             else if (nocut) launch(k_raster_small<false, 4, false, true>, k_raster_big<false, 4, false, false, true>);
             else launch(k_raster_small<false, 4, false>, k_raster_big<false, 4, false>);
         } else {
-            if (tex) launch(k_raster_small<false, 1, true>, k_raster_big<false, 1, true>);
+            if (shorta) launch(k_raster_small<false, 1, true, false, true>, k_raster_big<false, 1, true, false, false, true>);
+            else if (tex) launch(k_raster_small<false, 1, true>, k_raster_big<false, 1, true>);
             else if (nocut) launch(k_raster_small<false, 1, false, true>, k_raster_big<false, 1, false, false, true>);
             else launch(k_raster_small<false, 1, false>, k_raster_big<false, 1, false>);
         }
@@ -1648,7 +1670,10 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
         a.depth = c->atlas.as<uint32_t>();
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
-        if (tex) {
+        if (tex && cutout_alpha_short(c)) {
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true, false, true>), dim3(small_grid), dim3(256), 0, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true, false, false, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+        } else if (tex) {
             { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), 0, stream, a); }
             { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
         } else if (key != R3N_KEY_CUTOUT) {

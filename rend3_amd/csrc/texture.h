@@ -352,11 +352,13 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
 // texels x 4 channels per fragment before.  The alpha channel of tex_sample_grad runs through exactly these operations (a packed
 // pair rounds each lane like the scalar form), so the value is the same bit for bit; every other case calls tex_sample_grad.
 // `d` = t.descs[id - 1], fetched by the caller once per triangle / work item (the fragments of one share it).
-template <class M = MathExact>
+// SHORT_ONLY: the caller knows the short path's conditions hold (and the linear sampler is asked for): no general path behind it,
+// wild coordinates handled inside (tex_level_fast<true>).
+template <class M = MathExact, bool SHORT_ONLY = false>
 R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_texture_desc32 &d, bool nearest, float u, float v, const float ddx[2], const float ddy[2]) {
     if (id == 0u || id > t.count) return 0.0f;
     const bool pow2 = (((d.width & (d.width - 1u)) | (d.height & (d.height - 1u))) == 0u);
-    if (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT) {
+    if (SHORT_ONLY || (!nearest && pow2 && t.small_pool != 0u && d.format < R3N_POOL_FLOAT)) {
         const float W = (float)d.width, H = (float)d.height;
         const float ax = ddx[0] * W, ay = ddx[1] * H, bx = ddy[0] * W, by = ddy[1] * H;
         const float rho = exact_math::sqrt(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
@@ -372,10 +374,10 @@ R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_text
         if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
         const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
         TexLvlFast l0, l1;
-        bool tame = tex_level_fast<false>(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
+        bool tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
         const bool two = frac > 0.0f;
-        if (two) tame = tex_level_fast<false>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
-        if (tame) {
+        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
+        if (SHORT_ONLY || tame) {
             const char *pool = reinterpret_cast<const char *>(t.texels);
             auto alpha_at = [&](uint32_t byte_off) { return (float)(*reinterpret_cast<const uint32_t *>(pool + byte_off) >> 24) / 255.0f; };
             auto bilinear = [&](const TexLvlFast &l) {
@@ -389,6 +391,7 @@ R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_text
             return r;
         }
     }
+    if (SHORT_ONLY) return 0.0f;  // (not reached)
     float o[4];
     tex_sample_grad<M, true>(t, id, nearest, u, v, ddx, ddy, o);
     return o[3];
