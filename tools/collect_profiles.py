@@ -11,22 +11,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-for name in ("bench", "bench_fast", "bench_instanced", "bench_untextured", "bench_msaa4", "bench_shadow_tiles", "bench_cfg4", "bench_scene",
+for name in ("bench", "bench_fast", "bench_instanced", "bench_untextured", "bench_msaa4", "bench_cfg4", "bench_cfg4_traffic", "bench_bistro_v2", "bench_scene",
              "bench_exchange_rows", "bench_exchange_objects", "bench_exchange_rows_python", "bench_exchange_spatial", "bench_exchange_slots", "bench_under_rocprof", "bench_under_rocprof_serial", "bench_under_rocprof_single"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p):
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
         json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
-for sub, out in (("kt", "kernel_stats"), ("kts", "kernel_stats_serial"), ("kt1", "kernel_stats_single_stream")):
+for sub, out in (("kt", "kernel_stats"), ("kts", "kernel_stats_serial"), ("kt1", "kernel_stats_single_stream"),
+                 ("kt1_cfg4", "cfg4_kernel_stats_single_stream"), ("kt1_v2", "bistro_v2_kernel_stats_single_stream")):
     f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, f"{tag}_bench_{out}.csv"))
-for sub, out in (("pmc", "pmc_kernels"), ("pmc_fast", "pmc_kernels_fast")):
+for sub, out in (("pmc", "pmc_kernels"), ("pmc_cfg4", "pmc_kernels_cfg4"), ("pmc_untextured", "pmc_kernels_untextured")):
     p = os.path.join(src, sub, "traffic.json")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{out}.json"))
-        if sub == "pmc":
-            shutil.copy(p, os.path.join(dst, "traffic.json"))  # what bench.py quotes (stale-checked against the kernel sources)
+p = os.path.join(src, "traffic.json")  # one entry per workload variant (tools/make_traffic.py): what bench.py quotes, stale-checked against the kernel sources
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, "traffic.json"))
 for name in ("host_rate.txt", "host_rate_nodes.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):

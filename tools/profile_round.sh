@@ -15,6 +15,7 @@ $B --steps 100 --warmup 10 --no-cpu-baseline --instanced > "$out/bench_instanced
 $B --steps 100 --warmup 10 --no-cpu-baseline --untextured > "$out/bench_untextured.json" 2>/dev/null
 $B --steps 60 --warmup 10 --no-cpu-baseline --samples 4 > "$out/bench_msaa4.json" 2>/dev/null
 $B --steps 40 --warmup 8 --cpu-sample-frames 1 --config 4 > "$out/bench_cfg4.json" 2>/dev/null   # with the oracle's parity block (one sample frame)
+$B --steps 60 --warmup 8 --cpu-sample-frames 1 --bistro-v2 > "$out/bench_bistro_v2.json" 2>/dev/null   # the Bistro-faithful stand-in, with the oracle's parity block
 $B --steps 60 --warmup 8 --cpu-sample-frames 3 --scene tests/golden/static_gltf-data.glb --directional-light=-1,-4,2 --directional-light-intensity 4 --shadow-distance 20 --camera=3,3,5,-0.55,-0.5 > "$out/bench_scene.json" 2>/dev/null
 for part in rows objects rows_python spatial slots; do
   flags="--partition $part"; [ $part = rows_python ] && flags="--partition rows --python-exchange"
@@ -29,18 +30,26 @@ R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kts
 # everything on ONE stream, no frames in flight: a kernel's average duration here is its stand-alone time -- what the line's
 # rooflines.*.ms_per_launch (HIP events, single stream) must agree with
 R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1" -o kt1 -- $B --no-cpu-baseline --steps 30 --warmup 5 > "$out/bench_under_rocprof_single.json" 2> "$out/kt1.err"
+R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1_cfg4" -o kt1 -- $B --no-cpu-baseline --steps 20 --warmup 5 --config 4 > "$out/bench_cfg4_under_rocprof_single.json" 2> "$out/kt1_cfg4.err"
+R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1_v2" -o kt1 -- $B --no-cpu-baseline --steps 20 --warmup 5 --bistro-v2 > "$out/bench_v2_under_rocprof_single.json" 2> "$out/kt1_v2.err"
 python $root/tools/exact_math_probe.py > "$out/exact_math.txt" 2>&1
 cd "$root"
+# PMC passes: every counter set for the default workload; FETCH_SIZE / WRITE_SIZE alone for the other variants whose lines quote
+# counter traffic (--config 4: VERDICT r4 item 8) and for the factor-only variant (resolve's texel share = textured - untextured).
+# tools/make_traffic.py merges the variants into $out/traffic.json (one entry per workload variant).
 bash tools/gpu_pmc.sh "$tag/pmc" > "$out/pmc_table.txt" 2>&1
-# the headline line LAST, quoting the counter traffic of THIS build (bench.py refuses traffic.json of other kernel sources)
-[ -f "$out/pmc/traffic.json" ] && cp "$out/pmc/traffic.json" "$root/profiles/traffic.json"
+PMC_TRAFFIC_ONLY=1 bash tools/gpu_pmc.sh "$tag/pmc_cfg4" --config 4 > "$out/pmc_table_cfg4.txt" 2>&1
+PMC_TRAFFIC_ONLY=1 bash tools/gpu_pmc.sh "$tag/pmc_untextured" --untextured > "$out/pmc_table_untextured.txt" 2>&1
+# the headline lines LAST, quoting the counter traffic of THIS build (bench.py refuses traffic.json of other kernel sources)
+[ -f "$out/traffic.json" ] && cp "$out/traffic.json" "$root/profiles/traffic.json"
+$B --steps 40 --warmup 8 --no-cpu-baseline --config 4 > "$out/bench_cfg4_traffic.json" 2>/dev/null   # (the same line as bench_cfg4 with its counter traffic)
 $B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"
-# the rasterisers' stall / memory-side counter sets (eleven more passes) after the headline line: the part a short GPU budget may cut
-[ "${SKIP_STALL:-0}" = 1 ] || bash tools/gpu_r4.sh "$tag/stall" pmc_raster > "$out/pmc_raster.txt" 2>&1
+# (round 4's eleven stall / memory-side counter passes of the rasterisers: tools/gpu_r4.sh pmc_raster, not repeated every round)
+[ "${WITH_STALL:-0}" = 1 ] && bash tools/gpu_r4.sh "$tag/stall" pmc_raster > "$out/pmc_raster.txt" 2>&1
 find "$out" -name "*_kernel_trace.csv" -size +8M -delete
 find "$out" -name "*counter_collection.csv" -size +8M -delete
 ls "$out"
-for f in bench bench_fast bench_instanced bench_untextured bench_msaa4 bench_cfg4 bench_scene bench_exchange_rows bench_exchange_objects bench_exchange_rows_python bench_exchange_spatial bench_exchange_slots; do python - "$out/$f.json" <<'PY'
+for f in bench bench_fast bench_instanced bench_untextured bench_msaa4 bench_cfg4 bench_cfg4_traffic bench_bistro_v2 bench_scene bench_exchange_rows bench_exchange_objects bench_exchange_rows_python bench_exchange_spatial bench_exchange_slots; do python - "$out/$f.json" <<'PY'
 import json,sys
 try:
     line=[l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]
