@@ -59,6 +59,7 @@ struct ShadeArgs {
     const ViewLights *view_lights;  // the frame's light lists in view space (k_stage_view_lights), or null: every workgroup stages its own
     const uint32_t *material_feat;  // per material: feature bits, computed by the host when the record is written
     uint32_t variants;              // bit v set: variant v of the resolve runs this frame (more than one bit: tiles are classified)
+    uint32_t resolve_lds;           // dynamic LDS bytes asked by the single-sample resolve launches (unused by the kernel: a cap on its resident workgroups, r3n.hip Tune)
 };
 #define R3N_EDGEQ 32u
 

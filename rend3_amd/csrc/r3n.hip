@@ -63,7 +63,15 @@ std::string g_create_error;
 // Round 4, with the resolve at four waves per SIMD and the slimmer per-triangle pass beside them: the cap pays on the viewport's
 // launches too, and three workgroups per CU beat four -- frame (same box, two runs each): shadow 32 KB / viewport none 0.982-0.993 ms;
 // 32 / 32 0.968-0.972; 48 / 32 0.961 (0.935 on another box against 0.968); 48 / 48 0.940; 64 / 48 (two workgroups) 1.061; no cap 1.049.
-#define R3N_BIG_LDS 49152           // shadow views
+// (constants fixed by measurement, not build options)
+#define R3N_BIG_GRID 8192  // 4x the resident wave count (8 waves per SIMD at < 64 VGPRs): the hardware dispatcher
+                           // then balances the uneven item costs (measured on the bench scene, shadow views:
+                           // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
+// Workgroups of the two rasteriser kernels: 256 threads (neither uses LDS or barriers: a workgroup is only the unit in which wave
+// slots are handed back to the dispatcher; 64- and 128-thread workgroups measured the same, profiles/r04_summary.md section 6a).
+#define R3N_SMALL_GRID 2048
+#define R3N_BIG_LDS 40960           // shadow views (tools/tune_caps.py, round 5: 40960 -- 49152 on the bench scene, 32768 on the million-object one)
+#define R3N_SMALL_LDS 24576         // the shadow views' per-triangle pass: six workgroups per CU (bench scene 0.9285 -> 0.9148 ms, round 5)
 #define R3N_VIEWPORT_BIG_LDS 49152  // viewport
 #define R3N_QLANES R3N_AUX_STREAMS  // work queues beside the viewport's: one per auxiliary stream (a shadow view draws on lane 1 + view mod R3N_AUX_STREAMS)
 static_assert(R3N_AUX_STREAMS >= 1, "the shadow views draw on auxiliary streams");
@@ -134,6 +142,20 @@ struct r3n_ctx {
     DevBuf view_lights[2];  // ViewLights of the frame set (k_stage_view_lights writes it in front of the single-sample resolve)
     uint32_t resolve_variants = 0;
     bool classes_dirty = true;
+    // Launch parameters that decide how the frame's kernels SHARE the chip (profiles/r04_summary.md section 6a: the frame is the sum of
+    // latency-bound kernels on five streams; leaving room for the neighbours moved it more than any kernel's own speed): dynamic LDS
+    // nobody uses = a cap on a kernel's resident workgroups per CU, and the grids of the persistent rasterisers.  The defaults are the
+    // result of tools/tune_caps.py's coordinate search on the bench scene; R3N_TUNE="key=value ..." overrides them at r3n_create.
+    struct Tune {
+        uint32_t big_lds = R3N_BIG_LDS, vp_big_lds = R3N_VIEWPORT_BIG_LDS;  // work-item rasteriser, opaque key: shadow views / viewport
+        uint32_t small_lds = R3N_SMALL_LDS, vp_small_lds = 0;               // per-triangle pass, opaque key
+        uint32_t cut_big_lds = 0, vp_cut_big_lds = 0, cut_small_lds = 0, vp_cut_small_lds = 0;  // the same for the CUTOUT key's launches (their
+                                                                            // alpha test makes them long kernels that want the whole chip: a cap
+                                                                            // of 48 KB cost the Bistro-like scene's frame a quarter)
+        uint32_t cull_lds = 0, vp_cull_lds = 0;                             // triangle cull
+        uint32_t resolve_lds = 0;                                           // single-sample resolve
+        uint32_t big_grid = R3N_BIG_GRID, small_grid = R3N_SMALL_GRID;
+    } tune;
     bool cutout_short_dirty = true, cutout_short = false;  // cutout_alpha_short(): census of the cutout materials' albedo maps
     bool key_census_dirty = true;
     uint64_t key_objects[3] = {0, 0, 0};  // enabled objects per material key
@@ -598,7 +620,44 @@ int drain_timing(r3n_ctx *c) {
     return R3N_OK;
 }
 
+// "key=value key=value ..." -> ctx.tune (unknown keys and out-of-range values are refused: nothing is applied then)
+int apply_tuning(r3n_ctx *c, const char *kv) {
+    r3n_ctx::Tune t = c->tune;
+    std::string text(kv ? kv : "");
+    for (size_t at = 0; at < text.size();) {
+        while (at < text.size() && (text[at] == ' ' || text[at] == ',')) ++at;
+        if (at >= text.size()) break;
+        const size_t end = text.find_first_of(" ,", at), eq = text.find('=', at);
+        if (eq == std::string::npos || (end != std::string::npos && eq > end)) return fail(c, R3N_ERR_INVALID_ARG, "tuning: expected key=value");
+        const std::string key = text.substr(at, eq - at);
+        char *stop = nullptr;
+        const unsigned long val = std::strtoul(text.c_str() + eq + 1, &stop, 10);
+        if (stop == text.c_str() + eq + 1 || (*stop && *stop != ' ' && *stop != ',')) return fail(c, R3N_ERR_INVALID_ARG, "tuning: " + key + " wants an unsigned number");
+        struct { const char *name; uint32_t *p; unsigned long lo, hi, step; } keys[] = {
+            {"big_lds", &t.big_lds, 0, 65536, 1}, {"vp_big_lds", &t.vp_big_lds, 0, 65536, 1}, {"small_lds", &t.small_lds, 0, 65536, 1},
+            {"vp_small_lds", &t.vp_small_lds, 0, 65536, 1}, {"cut_big_lds", &t.cut_big_lds, 0, 65536, 1}, {"vp_cut_big_lds", &t.vp_cut_big_lds, 0, 65536, 1},
+            {"cut_small_lds", &t.cut_small_lds, 0, 65536, 1}, {"vp_cut_small_lds", &t.vp_cut_small_lds, 0, 65536, 1}, {"cull_lds", &t.cull_lds, 0, 65000, 1}, {"vp_cull_lds", &t.vp_cull_lds, 0, 65000, 1},
+            {"resolve_lds", &t.resolve_lds, 0, 48000, 1}, {"big_grid", &t.big_grid, 256, 65536, 1},
+            {"small_grid", &t.small_grid, R3N_SUBQ, 32768, R3N_SUBQ}};  // (a multiple of R3N_SUBQ: whole blocks per sub-list)
+        bool known = false;
+        for (auto &k : keys)
+            if (key == k.name) {
+                if (val < k.lo || val > k.hi || val % k.step) return fail(c, R3N_ERR_INVALID_ARG, "tuning: value out of range for " + key);
+                *k.p = (uint32_t)val;
+                known = true;
+            }
+        if (!known) return fail(c, R3N_ERR_INVALID_ARG, "tuning: unknown key " + key);
+        at = end == std::string::npos ? text.size() : end;
+    }
+    c->tune = t;
+    return R3N_OK;
+}
+
 }  // namespace
+
+// tools/tune_caps.py: the launch parameters of ctx.tune between frames of one context (a search over hundreds of settings in one
+// process); R3N_TUNE applies the same string at r3n_create.
+extern "C" int r3n_internal_set_tuning(r3n_ctx *c, const char *kv) { return c ? apply_tuning(c, kv) : R3N_ERR_INVALID_ARG; }
 
 // The frame's clears in one launch: three zero fills (16-byte stores; a buffer's last < 4 words go singly).
 __global__ __launch_bounds__(256) static void k_frame_clear(uint32_t *__restrict__ a, size_t a_words, uint32_t *__restrict__ b, size_t b_words,
@@ -661,6 +720,12 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         return nullptr;
     }
     c->status_host[0] = 0u;
+    if (const char *et = std::getenv("R3N_TUNE"))
+        if (apply_tuning(c, et) != R3N_OK) {
+            g_create_error = "R3N_TUNE: " + c->err;
+            r3n_destroy(c);
+            return nullptr;
+        }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');
@@ -1392,13 +1457,6 @@ int r3n_pose_skeletons(r3n_ctx *c, const r3n_pose_request16 *requests, uint32_t 
     return R3N_OK;
 }
 
-// (constants fixed by measurement, not build options)
-#define R3N_BIG_GRID 8192  // 4x the resident wave count (8 waves per SIMD at < 64 VGPRs): the hardware dispatcher
-                           // then balances the uneven item costs (measured on the bench scene, shadow views:
-                           // 2048 -> 419 us, 4096 -> 387 us, 8192 -> 366 us per frame)
-// Workgroups of the two rasteriser kernels: 256 threads (neither uses LDS or barriers: a workgroup is only the unit in which wave
-// slots are handed back to the dispatcher; 64- and 128-thread workgroups measured the same, profiles/r04_summary.md section 6a).
-#define R3N_SMALL_GRID 2048
 
 int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr) {
     if (!c || !hdr) return fail(c, R3N_ERR_INVALID_ARG, "uniform_bake: null");
@@ -1506,7 +1564,7 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     const uint32_t grid = std::max(1u, std::min(chunks, 4096u));
     {
         Timed t(c, R3N_STAGE_TRIANGLE_CULL, stream);
-        hipLaunchKernelGGL(k_triangle_cull, dim3(grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_triangle_cull, dim3(grid), dim3(256), viewport ? c->tune.vp_cull_lds : c->tune.cull_lds, stream, a);
     }
     TRY(check_launch(c, "k_triangle_cull"));
     s->culled = true;
@@ -1637,7 +1695,7 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     a.big_capacity = c->big_capacity;
     a.big_uv = c->big_uv[lane].as<r3n_big_uv>();
     a.tex = texture_args(c);
-    const uint32_t small_grid = R3N_SMALL_GRID;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
+    const uint32_t small_grid = c->tune.small_grid;  // multiple of R3N_SUBQ and R3N_BIGQ: 64 blocks per sub-list
     TRY(fork_lane(c, lane));
     if (fwd == 63u) HIP_TRY(c, hipMemsetAsync(a.big_count, 0, R3N_BIGQ * 4, stream));  // the first 63 calls of a lane have counters zeroed at frame begin
     a.row_begin = 0; a.row_end = 0xFFFFFFFFu;
@@ -1647,11 +1705,11 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         if (c->shard_rows) { a.row_begin = std::min(c->row_begin, c->height); a.row_end = std::min(c->row_end, c->height); }
         // textured variant only where it can matter: cutout key and a non-empty texture array
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
-        auto launch = [&](auto small, auto big) {
-            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(R3N_BIG_GRID), dim3(256), R3N_VIEWPORT_BIG_LDS, stream, a); }
-        };
         const bool nocut = key != R3N_KEY_CUTOUT;  // the opaque key's instantiations carry nothing of the cutout test (kernels_raster.h NOCUT)
+        auto launch = [&](auto small, auto big) {
+            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), nocut ? c->tune.vp_small_lds : c->tune.vp_cut_small_lds, stream, a); }
+            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(c->tune.big_grid), dim3(256), nocut ? c->tune.vp_big_lds : c->tune.vp_cut_big_lds, stream, a); }
+        };
         const bool shorta = tex && cutout_alpha_short(c);
         if (c->samples == 4) {
             if (shorta) launch(k_raster_small<false, 4, true, false, true>, k_raster_big<false, 4, true, false, false, true>);
@@ -1671,17 +1729,17 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         a.depth = c->atlas.as<uint32_t>();
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         if (tex && cutout_alpha_short(c)) {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true, false, true>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true, false, false, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true, false, true>), dim3(small_grid), dim3(256), c->tune.cut_small_lds, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true, false, false, true>), dim3(c->tune.big_grid), dim3(256), c->tune.cut_big_lds, stream, a); }
         } else if (tex) {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, true>), dim3(small_grid), dim3(256), c->tune.cut_small_lds, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, true>), dim3(c->tune.big_grid), dim3(256), c->tune.cut_big_lds, stream, a); }
         } else if (key != R3N_KEY_CUTOUT) {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false, true>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false, false, true>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false, true>), dim3(small_grid), dim3(256), c->tune.small_lds, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false, false, true>), dim3(c->tune.big_grid), dim3(256), c->tune.big_lds, stream, a); }
         } else {
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid), dim3(256), 0, stream, a); }
-            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(R3N_BIG_GRID), dim3(256), R3N_BIG_LDS, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER, stream); hipLaunchKernelGGL((k_raster_small<true, 1, false>), dim3(small_grid), dim3(256), c->tune.cut_small_lds, stream, a); }
+            { Timed t(c, R3N_STAGE_SHADOW_RASTER_BIG, stream); hipLaunchKernelGGL((k_raster_big<true, 1, false>), dim3(c->tune.big_grid), dim3(256), c->tune.cut_big_lds, stream, a); }
         }
     }
     return check_launch(c, "raster");

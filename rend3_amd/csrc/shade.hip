@@ -43,20 +43,20 @@ int r3n_internal_resolve(const ShadeArgs *ap, uint32_t samples, int tex, int rec
                 const int rc = r3n_internal_resolve_class(ap, v, fast, stream);
                 if (rc) return rc;
             } else if (fast) {
-                hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), a.resolve_lds, stream, a);
             } else {
-                hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), 0, stream, a);
+                hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), a.resolve_lds, stream, a);
             }
         }
     } else if (rec && fast) {
-        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, false, true, false, true>), rgrid, dim3(256), 0, stream, a);
+        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true>), rgrid, dim3(256), a.resolve_lds, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, false, true, false, true>), rgrid, dim3(256), a.resolve_lds, stream, a);
     } else if (rec) {
-        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, false, true>), rgrid, dim3(256), 0, stream, a);
+        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, true>), rgrid, dim3(256), a.resolve_lds, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, false, true>), rgrid, dim3(256), a.resolve_lds, stream, a);
     } else {
-        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, false>), rgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, false, false>), rgrid, dim3(256), 0, stream, a);
+        if (tex) hipLaunchKernelGGL((k_resolve_opaque<1, true, false>), rgrid, dim3(256), a.resolve_lds, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, false, false>), rgrid, dim3(256), a.resolve_lds, stream, a);
     }
     return launch_status();
 }

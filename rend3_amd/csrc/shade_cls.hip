@@ -10,16 +10,16 @@ extern "C" int r3n_internal_resolve_class(const ShadeArgs *ap, uint32_t variant,
     const dim3 rgrid((a.width + 15u) / 16u, (a.row_end - a.row_begin + 15u) / 16u);
     switch (variant) {
     case 0u:
-        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), 0, stream, a);
+        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), a.resolve_lds, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PLAIN, 0u>), rgrid, dim3(256), a.resolve_lds, stream, a);
         break;
     case 1u:
-        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), 0, stream, a);
+        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), a.resolve_lds, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_ALBEDO, 1u>), rgrid, dim3(256), a.resolve_lds, stream, a);
         break;
     case 2u:
-        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), 0, stream, a);
+        if (fast) hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, true, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), a.resolve_lds, stream, a);
+        else hipLaunchKernelGGL((k_resolve_opaque<1, true, true, false, false, R3N_CLS_PBR3, 2u>), rgrid, dim3(256), a.resolve_lds, stream, a);
         break;
     default:
         return (int)hipErrorInvalidValue;

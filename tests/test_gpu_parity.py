@@ -1281,6 +1281,9 @@ RUNTIME_SWITCHES = [
     {"R3N_FRAME_NODES": "1"},        # the host mirror issues the frame node by node (one C call per reference node) instead of r3n_render_frame
     {"R3N_ALWAYS_FORK": "1"},        # the shadow lanes wait for the main stream at every fork (no epoch gate): a main-stream producer that forgot its epoch bump would differ from the default run
     {"R3N_RESOLVE_CLASSES": "0"},    # the general resolve kernel for every tile instead of one kernel per material class (kernels_shade.h R3N_CLS_*)
+    # launch parameters (r3n.hip Tune: dynamic-LDS occupancy caps and grid sizes; tools/tune_caps.py searches them): results never depend on them
+    {"R3N_TUNE": "big_lds=16384 vp_big_lds=0 small_lds=0 vp_small_lds=32768 cut_big_lds=49152 vp_cut_big_lds=32768 cut_small_lds=8192 "
+                 "vp_cut_small_lds=16384 cull_lds=32768 vp_cull_lds=16384 resolve_lds=8192 big_grid=1024 small_grid=512"},
 ]
 
 
@@ -1295,6 +1298,18 @@ def test_runtime_switches(r3, monkeypatch, env, scenario):
         compare_frames(fo, fp, f"{scenario} {env} frame {f}")
     if scenario == "bistro":
         assert len(fo["shadows"]) == 4 and all(s["pass"].sum() > 200 for s in fo["shadows"]) and (fo["atlas"] != 0).mean() > 0.05
+
+
+def test_tuning_rejects_what_it_does_not_know(r3):
+    """r3n_internal_set_tuning: an unknown key, a value out of range or a malformed pair fails with R3N_ERR_ARG and changes nothing."""
+    import ctypes
+    p = r3.Renderer(oh.LEFT, f32(1.0))
+    fn = p.lib.r3n_internal_set_tuning
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]
+    assert fn(p.ctx, b"big_lds=32768 small_grid=1024") == 0
+    for bad in (b"big_ldz=1", b"big_lds=1000000", b"big_grid=0", b"big_lds", b"big_lds=abc"):
+        assert fn(p.ctx, bad) != 0, bad
+    p.close()
 
 
 def compare_frames_fast(o, p, tag=""):
