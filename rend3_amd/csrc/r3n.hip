@@ -152,6 +152,8 @@ struct r3n_ctx {
         uint32_t cut_big_lds = 0, vp_cut_big_lds = 0, cut_small_lds = 0, vp_cut_small_lds = 0;  // the same for the CUTOUT key's launches (their
                                                                             // alpha test makes them long kernels that want the whole chip: a cap
                                                                             // of 48 KB cost the Bistro-like scene's frame a quarter)
+        uint32_t prio_main = 1, prio_shade = 1, prio_aux = 1;  // stream priorities (0 high, 1 normal, 2 low), applied when the streams are created (R3N_TUNE)
+        uint32_t timed_pipeline = 0;  // tools/frame_timeline.py: keep the frames in flight while the timing taps are on (the stage figures then overlap)
         uint32_t cull_lds = 0, vp_cull_lds = 0;                             // triangle cull
         uint32_t resolve_lds = 0;                                           // single-sample resolve
         uint32_t big_grid = R3N_BIG_GRID, small_grid = R3N_SMALL_GRID;
@@ -231,7 +233,7 @@ struct r3n_ctx {
     uint32_t bulk_next = 0;
     // timing taps
     bool timing = false;
-    struct Span { hipEvent_t a, b; int stage; };
+    struct Span { hipEvent_t a, b; int stage; hipStream_t stream; };
     std::vector<Span> spans;
     double span_overhead_ms = 0.0;  // two events around an empty launch (median of 32), measured when timing is switched on
     bool span_calibrated = false;
@@ -375,7 +377,7 @@ struct Timed {
     ~Timed() {
         if (!a) return;
         (void)hipEventRecord(b, stream);
-        c->spans.push_back({a, b, stage});
+        c->spans.push_back({a, b, stage, stream});
     }
 };
 
@@ -620,6 +622,29 @@ int drain_timing(r3n_ctx *c) {
     return R3N_OK;
 }
 
+// tools/frame_timeline.py: the pending spans as (stage, stream index in order of first use, start, end) in milliseconds from the first
+// span's start -- the schedule the streams actually ran, which rocprofv3's kernel trace cannot show (it serialises the dispatches).
+// Consumes the spans like drain_timing.  Returns the number of entries written (<= max) or a negative error.
+int read_timeline(r3n_ctx *c, float *out, int max) {
+    if (c->spans.empty()) return 0;
+    if (sync_all(c) != R3N_OK) return -1;
+    std::vector<hipStream_t> streams;
+    int n = 0;
+    for (auto &s : c->spans) {
+        float t0 = 0.f, t1 = 0.f;
+        size_t si = std::find(streams.begin(), streams.end(), s.stream) - streams.begin();
+        if (si == streams.size()) streams.push_back(s.stream);
+        if (n < max && hipEventElapsedTime(&t0, c->spans[0].a, s.a) == hipSuccess && hipEventElapsedTime(&t1, c->spans[0].a, s.b) == hipSuccess) {
+            out[4 * n + 0] = (float)s.stage; out[4 * n + 1] = (float)si; out[4 * n + 2] = t0; out[4 * n + 3] = t1;
+            ++n;
+        }
+        c->event_pool.push_back(s.a);
+        c->event_pool.push_back(s.b);
+    }
+    c->spans.clear();
+    return n;
+}
+
 // "key=value key=value ..." -> ctx.tune (unknown keys and out-of-range values are refused: nothing is applied then)
 int apply_tuning(r3n_ctx *c, const char *kv) {
     r3n_ctx::Tune t = c->tune;
@@ -637,8 +662,9 @@ int apply_tuning(r3n_ctx *c, const char *kv) {
             {"big_lds", &t.big_lds, 0, 65536, 1}, {"vp_big_lds", &t.vp_big_lds, 0, 65536, 1}, {"small_lds", &t.small_lds, 0, 65536, 1},
             {"vp_small_lds", &t.vp_small_lds, 0, 65536, 1}, {"cut_big_lds", &t.cut_big_lds, 0, 65536, 1}, {"vp_cut_big_lds", &t.vp_cut_big_lds, 0, 65536, 1},
             {"cut_small_lds", &t.cut_small_lds, 0, 65536, 1}, {"vp_cut_small_lds", &t.vp_cut_small_lds, 0, 65536, 1}, {"cull_lds", &t.cull_lds, 0, 65000, 1}, {"vp_cull_lds", &t.vp_cull_lds, 0, 65000, 1},
-            {"resolve_lds", &t.resolve_lds, 0, 48000, 1}, {"big_grid", &t.big_grid, 256, 65536, 1},
-            {"small_grid", &t.small_grid, R3N_SUBQ, 32768, R3N_SUBQ}};  // (a multiple of R3N_SUBQ: whole blocks per sub-list)
+            {"resolve_lds", &t.resolve_lds, 0, 61440, 1}, {"big_grid", &t.big_grid, 256, 65536, 1},
+            {"small_grid", &t.small_grid, R3N_SUBQ, 32768, R3N_SUBQ}, {"timed_pipeline", &t.timed_pipeline, 0, 1, 1},
+            {"prio_main", &t.prio_main, 0, 2, 1}, {"prio_shade", &t.prio_shade, 0, 2, 1}, {"prio_aux", &t.prio_aux, 0, 2, 1}};  // (read at r3n_create only)  // (a multiple of R3N_SUBQ: whole blocks per sub-list)
         bool known = false;
         for (auto &k : keys)
             if (key == k.name) {
@@ -658,6 +684,7 @@ int apply_tuning(r3n_ctx *c, const char *kv) {
 // tools/tune_caps.py: the launch parameters of ctx.tune between frames of one context (a search over hundreds of settings in one
 // process); R3N_TUNE applies the same string at r3n_create.
 extern "C" int r3n_internal_set_tuning(r3n_ctx *c, const char *kv) { return c ? apply_tuning(c, kv) : R3N_ERR_INVALID_ARG; }
+extern "C" int r3n_internal_read_timeline(r3n_ctx *c, float *out, int max) { return c && out ? read_timeline(c, out, max) : -1; }
 
 // The frame's clears in one launch: three zero fills (16-byte stores; a buffer's last < 4 words go singly).
 __global__ __launch_bounds__(256) static void k_frame_clear(uint32_t *__restrict__ a, size_t a_words, uint32_t *__restrict__ b, size_t b_words,
@@ -700,7 +727,14 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
     if (config && config->struct_size >= sizeof(r3n_config) && config->max_big_items)
         c->big_capacity = std::max(1024u, config->max_big_items / R3N_BIGQ);
     if (config && config->struct_size >= sizeof(r3n_config) && config->shade_mode <= R3N_SHADE_FAST) c->shade_mode = config->shade_mode;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (const char *et = std::getenv("R3N_TUNE"))
+        if (apply_tuning(c, et) != R3N_OK) {
+            g_create_error = "R3N_TUNE: " + c->err;
+            delete c;
+            return nullptr;
+        }
+    // (stream priorities, ctx.tune.prio_*: 0 high, 1 normal, 2 low -- the runtime's range is [-1, 1])
+    e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, (int)c->tune.prio_main - 1);
     if (e != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete c;
@@ -720,18 +754,12 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         return nullptr;
     }
     c->status_host[0] = 0u;
-    if (const char *et = std::getenv("R3N_TUNE"))
-        if (apply_tuning(c, et) != R3N_OK) {
-            g_create_error = "R3N_TUNE: " + c->err;
-            r3n_destroy(c);
-            return nullptr;
-        }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');
     if (const char *e6 = std::getenv("R3N_ALWAYS_FORK")) c->always_fork = e6[0] == '1';
     if (const char *e3 = std::getenv("R3N_EDGE_CAPACITY")) c->edge_capacity_override = (uint32_t)std::strtoul(e3, nullptr, 10);
-    if (hipStreamCreateWithFlags(&c->shade, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&c->shade, hipStreamNonBlocking, (int)c->tune.prio_shade - 1) != hipSuccess ||
         hipEventCreateWithFlags(&c->vp_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->shade_done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->shade_done[1], hipEventDisableTiming) != hipSuccess) {
@@ -740,7 +768,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         return nullptr;
     }
     for (int k = 0; k < R3N_AUX_STREAMS; ++k)
-        if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess ||
+        if (hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, (int)c->tune.prio_aux - 1) != hipSuccess ||
             hipEventCreateWithFlags(&c->fork_ev[k], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->join_ev[k], hipEventDisableTiming) != hipSuccess) {
             g_create_error = "auxiliary stream creation failed";
@@ -1842,7 +1870,7 @@ int r3n_resolve_opaque(r3n_ctx *c) {
     // frames in flight: the resolve goes to the shade stream, ordered after this frame's viewport chain (main stream up
     // to here) and shadow views (lanes); the main stream is free to start the next frame.  Not when a transparent pass
     // follows (it continues on the main stream with the HDR target) or while stage timing is on.
-    const bool on_shade = c->overlap && c->multi_stream && !c->timing && c->blend_tris == 0;
+    const bool on_shade = c->overlap && c->multi_stream && (!c->timing || c->tune.timed_pipeline != 0u) && c->blend_tris == 0;
     hipStream_t stream = on_shade ? c->shade : c->stream;
     if (on_shade) {
         HIP_TRY(c, hipEventRecord(c->vp_ev, c->stream));

@@ -35,7 +35,7 @@ KNOBS = {
     "vp_cut_small_lds": [0, 32768],
     "cull_lds": [0, 16384],
     "vp_cull_lds": [0, 16384],
-    "resolve_lds": [0, 8192, 16384],
+    "resolve_lds": [0, 36864, 49152],   # four / three workgroups per CU (160 KB): below ~36 KB the cap does not bind
     "big_grid": [4096, 8192],
     "small_grid": [1024, 2048, 4096],
 }
@@ -57,7 +57,9 @@ def main():
     ap.add_argument("--scenes", default="default,cfg4,v2")
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--knobs", default="", help="comma-separated subset of the knobs to search (default: all)")
     a = ap.parse_args()
+    knobs = {k: v for k, v in KNOBS.items() if not a.knobs or k in a.knobs.split(",")}
     set_tuning = None
     results = {}
     for name in a.scenes.split(","):
@@ -94,7 +96,7 @@ def main():
         improved, sweeps = True, 0
         while improved and sweeps < 3:
             improved, sweeps = False, sweeps + 1
-            for knob, values in KNOBS.items():
+            for knob, values in knobs.items():
                 row = {}
                 for v in values:
                     row[v] = best_ms if v == best[knob] else measure({**best, knob: v})
