@@ -22,6 +22,7 @@ for part in rows objects rows_python spatial slots; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-exchange $flags --steps 60 --warmup 8 2>/dev/null | grep '^{' > "$out/bench_exchange_$part.json"
 done
 python tools/host_rate.py > "$out/host_rate.txt" 2>&1
+for sc in default cfg4 v2; do python tools/frame_timeline.py --scene $sc 2>&1 | grep -v amdgpu > "$out/frame_timeline_$sc.txt"; done   # the schedule of the pipelined multi-stream frame (the library's own timing taps)
 R3N_FRAME_NODES=1 python tools/host_rate.py > "$out/host_rate_nodes.txt" 2>&1
 python tools/run_config.py cfg2 cfg4 cfg5 cfg5anim cfg5asset > "$out/configs.jsonl" 2> "$out/configs.err"
 cd /tmp
