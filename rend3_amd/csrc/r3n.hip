@@ -1087,7 +1087,7 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(sync_all(c));  // no frame may still sample the old array
     TRY(ensure(c, c->tex_descs, std::max<size_t>(n, 1) * sizeof(r3n_texture_desc32), false, -1));
-    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4, false, -1));
+    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4 + 16, false, -1));  // (+16: the sampler reads a footprint row as one 8-byte load -- the pool's last texel has a word behind it)
     if (n) {
         HIP_TRY(c, hipMemcpyAsync(c->tex_descs.p, descs, (size_t)n * sizeof(r3n_texture_desc32), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->tex_texels.p, texels, n_texels * 4, hipMemcpyHostToDevice, c->stream));
@@ -1153,7 +1153,7 @@ int r3n_textures_write_encoded(r3n_ctx *c, const r3n_texture_desc32 *descs, uint
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(sync_all(c));  // no frame may still sample the old array
     TRY(ensure(c, c->tex_descs, std::max<size_t>(n, 1) * sizeof(r3n_texture_desc32), false, -1));
-    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4, false, -1));
+    TRY(ensure(c, c->tex_texels, std::max<uint64_t>(n_texels, 1) * 4 + 16, false, -1));  // (+16: the sampler reads a footprint row as one 8-byte load -- the pool's last texel has a word behind it)
     if (n) {
         void *staged = nullptr;
         HIP_TRY(c, hipMalloc(&staged, std::max<uint64_t>(payload_bytes, 4)));

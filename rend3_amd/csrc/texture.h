@@ -47,6 +47,26 @@ R3N_DEV uint32_t tex_wrap(float f, uint32_t n) {  // f = floor(coordinate); Repe
     const int m = i % (int)n;
     return (uint32_t)(m < 0 ? m + (int)n : m);
 }
+// First texel of level L of a POWER-OF-TWO texture's contiguous chain, relative to the texture's first texel:
+// sum over k < L of max(W >> k, 1) * max(H >> k, 1) -- what r3n.hip's level-offset table holds (minus the texture's offset), in closed
+// form: the geometric part (both extents still halving) is (4 W H - 4 W H / 4^L1) / 3, an exact division done as a multiplication by
+// 3's inverse modulo 2^32; a non-square texture's tail (one extent stuck at 1) and the 1x1 levels behind it are added on a rarely
+// taken path.  A dozen integer instructions instead of a dependent load: on the short path of the sampler the level offsets were one
+// of the round trips in a chain of them (descriptor -> level offset -> texels).  W * H * 4 / 3 < 2^31 (the short path's pool holds at
+// most 2^30 texels), L <= 15.
+R3N_DEV uint32_t tex_level_start_pow2(uint32_t W, uint32_t H, uint32_t L) {
+    const uint32_t a = 31u - (uint32_t)__builtin_clz(W | 1u), b = 31u - (uint32_t)__builtin_clz(H | 1u);  // (an extent of 0 counts as 1, like tex_mip_dim)
+    const uint32_t m = a < b ? a : b, M = a < b ? b : a;
+    const uint32_t L1 = L < m + 1u ? L : m + 1u;
+    const uint32_t top = a + b + 2u;
+    uint32_t off = ((1u << top) - (1u << (top - 2u * L1))) * 0xAAAAAAABu;
+    if (L > m + 1u) {
+        const uint32_t L2 = L < M + 1u ? L : M + 1u;
+        off += (1u << (M - m)) - (1u << (M + 1u - L2));
+        if (L > M + 1u) off += L - (M + 1u);
+    }
+    return off;
+}
 // Everything about one sample that depends only on the texture's extent / mip count, the coordinates and the gradients
 // -- not on its texels: the level(s), the blend fraction and the bilinear footprints.
 struct TexFootprint {
@@ -282,16 +302,15 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         }
         const uint32_t level = share->level - ((!same && half) ? 1u : 0u);
         const float frac = share->frac;
-        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
         const float *rgb = t.decode + (d.format == 1u ? 256 : 0);
         const bool two = frac > 0.0f;
-        const uint32_t b0 = lo[level];
+        const uint32_t b0 = d.offset + tex_level_start_pow2(d.width, d.height, level);
         TexLvlFast l0, l1;
         l0.o00 = (b0 + share->l0.r00) << 2; l0.o10 = (b0 + share->l0.r10) << 2; l0.o01 = (b0 + share->l0.r01) << 2; l0.o11 = (b0 + share->l0.r11) << 2;
         l0.fx = share->l0.fx; l0.fy = share->l0.fy;
         Texel4 r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
         if (two) {
-            const uint32_t b1 = lo[level + 1u];
+            const uint32_t b1 = b0 + __umul24(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level));
             l1.o00 = (b1 + share->l1.r00) << 2; l1.o10 = (b1 + share->l1.r10) << 2; l1.o01 = (b1 + share->l1.r01) << 2; l1.o11 = (b1 + share->l1.r11) << 2;
             l1.fx = share->l1.fx; l1.fy = share->l1.fy;
             const Texel4 hi = tex_bilinear_fast<M, NEED_A>(t, rgb, l1);
@@ -319,12 +338,13 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
             level = d.mips;
         }
         if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
-        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
         const float *rgb = t.decode + (d.format == 1u ? 256 : 0);
+        const uint32_t w0 = tex_mip_dim(d.width, level), h0 = tex_mip_dim(d.height, level);
+        const uint32_t b0 = d.offset + tex_level_start_pow2(d.width, d.height, level);  // (closed form: no load between the level of detail and the texels)
         TexLvlFast l0, l1;
-        bool tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
+        bool tame = tex_level_fast<SHORT_ONLY>(w0, h0, b0, u, v, l0);
         const bool two = frac > 0.0f;  // then level + 1 <= mips - 1
-        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
+        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), b0 + __umul24(w0, h0), u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             Texel4 r, hi;
             r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
@@ -372,11 +392,13 @@ R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_text
             level = d.mips;
         }
         if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
-        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
+        // (the levels' first texels in closed form: no load between the level of detail and the texels)
+        const uint32_t w0 = tex_mip_dim(d.width, level), h0 = tex_mip_dim(d.height, level);
+        const uint32_t b0 = d.offset + tex_level_start_pow2(d.width, d.height, level);
         TexLvlFast l0, l1;
-        bool tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level), tex_mip_dim(d.height, level), lo[level], u, v, l0);
+        bool tame = tex_level_fast<SHORT_ONLY>(w0, h0, b0, u, v, l0);
         const bool two = frac > 0.0f;
-        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), lo[level + 1u], u, v, l1) && tame;
+        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), b0 + __umul24(w0, h0), u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             const char *pool = reinterpret_cast<const char *>(t.texels);
             auto alpha_at = [&](uint32_t byte_off) { return (float)(*reinterpret_cast<const uint32_t *>(pool + byte_off) >> 24) / 255.0f; };
@@ -398,7 +420,7 @@ R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_text
 }
 
 // The three maps of a material (albedo, normal, AO / roughness / metallic: opaque.wgsl:207-351 samples them at the same coordinates
-// with the same gradients) in ONE pass whose memory operations go out in three batches -- the descriptors; the level offsets; the
+// with the same gradients) in ONE pass whose memory operations go out in batches -- the descriptors; (the level offsets until round 5: closed form now); the
 // (up to 24) texels -- instead of three dependent chains of descriptor -> level offset -> texels, one behind the other: the resolve is
 // bound by the LENGTH of its chain of dependent memory round trips at five waves per SIMD, not by instruction issue
 // (profiles/r04_summary.md: 8 % fewer vector instructions moved its time by 1 %).
@@ -410,16 +432,14 @@ template <class M>
 R3N_DEV bool tex_sample3_batched(const TextureArgs &t, const uint32_t id[3], float u, float v, const float ddx[2], const float ddy[2],
                                  float out[3][4]) {
     bool present[3];
-    uint32_t w[3], h[3], mips[3], fmt[3];
-    const uint32_t *lo[3];
+    uint32_t w[3], h[3], mips[3], fmt[3], base[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         present[k] = id[k] != 0u;
         const uint32_t idx = present[k] ? id[k] - 1u : 0u;   // (an unbound slot reads descriptor 0: valid memory; its texel addresses are forced into the pool below)
         const uint4 dw = *reinterpret_cast<const uint4 *>(&t.descs[idx]);  // offset, width, height, mips
-        w[k] = dw.y; h[k] = dw.z; mips[k] = dw.w;
+        base[k] = dw.x; w[k] = dw.y; h[k] = dw.z; mips[k] = dw.w;
         fmt[k] = t.descs[idx].format;
-        lo[k] = t.level_off + (size_t)idx * R3N_TEX_LEVELS;
     }
     // the reference map: the widest bound one
     uint32_t W = 0u, H = 0u, MI = 0u;
@@ -467,49 +487,74 @@ R3N_DEV bool tex_sample3_batched(const TextureArgs &t, const uint32_t id[3], flo
         la[k] = half[k] ? (level == 0u ? 0u : level - 1u) : level;
         two[k] = frac > 0.0f && !first_is_f1[k];
     }
-    // batch 2: the level offsets
+    // the levels' first texels in closed form (tex_level_start_pow2; a load of two table entries per map before round 5: one of the
+    // three round trips of this function)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        // both offsets with ONE 8-byte load (dword-aligned) whether or not a second level is blended: fetched only where needed, the
-        // second one is a round trip of its own in front of the second level's texels (the compiler sinks a separate load under the
-        // condition).  The pair starts at the first level, or one before it at the table's last entry.
-        struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
-        const uint32_t pb = la[k] + 1u < R3N_TEX_LEVELS ? la[k] : la[k] - 1u;
-        const Pair pr = *reinterpret_cast<const Pair *>(lo[k] + pb);
-        ba[k] = pb == la[k] ? pr.a : pr.b;
-        bb[k] = two[k] ? pr.b : ba[k];  // (two[k]: la + 1 <= mips - 1 < R3N_TEX_LEVELS, so pb == la)
+        ba[k] = base[k] + tex_level_start_pow2(w[k], h[k], la[k]);
+        bb[k] = two[k] ? ba[k] + __umul24(tex_mip_dim(w[k], la[k]), tex_mip_dim(h[k], la[k])) : ba[k];
         // An unbound slot still issues its texel loads (results discarded): they go to the START of the pool plus the reference
         // map's footprint offsets, which are smaller than that map's level `level` and therefore than the pool that holds the map --
-        // provably inside the allocation wherever the caller placed its textures (entry 0's level offsets plus another map's
-        // footprint could point past the pool's end when texture 1 sits last in it).
+        // provably inside the allocation wherever the caller placed its textures.
         if (!present[k]) { ba[k] = 0u; bb[k] = 0u; }
     }
     // batch 3: the texels (byte offsets from the uniform pool pointer: the pool holds < 2^30 texels on the short path)
+    // A footprint row's two texels are neighbours in memory unless the row wraps (Repeat at the right edge; a 1-texel level): ONE 8-byte
+    // load per row (dword-aligned) instead of two 4-byte loads -- the vector L1 works per instruction and line, and this kernel's texel
+    // fetches were 48 of its 76 vector-memory instructions; the lanes of a wrapping row fetch their second texel separately (rare,
+    // behind a wave-uniform test).  The word behind the pool's last texel exists (r3n.hip pads the pool).
+    struct __attribute__((packed, aligned(4))) W2 { uint32_t v[2]; };
     uint32_t ta[3][4], tb[3][4];
     const char *pool = reinterpret_cast<const char *>(t.texels);
     const bool any_two = __any(frac > 0.0f);
+    const bool pair0 = f0.r10 == f0.r00 + 1u, pair1 = f1.r10 == f1.r00 + 1u;
+    bool wrap_a = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const TexLvlRel &fa = first_is_f1[k] ? f1 : f0;
-        ta[k][0] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r00) << 2));
-        ta[k][1] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r10) << 2));
-        ta[k][2] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r01) << 2));
-        ta[k][3] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r11) << 2));
+        const W2 top = *reinterpret_cast<const W2 *>(pool + ((ba[k] + fa.r00) << 2));
+        const W2 bot = *reinterpret_cast<const W2 *>(pool + ((ba[k] + fa.r01) << 2));
+        ta[k][0] = top.v[0]; ta[k][1] = top.v[1]; ta[k][2] = bot.v[0]; ta[k][3] = bot.v[1];
+        wrap_a = wrap_a || !(first_is_f1[k] ? pair1 : pair0);
+    }
+    if (__any(wrap_a)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const TexLvlRel &fa = first_is_f1[k] ? f1 : f0;
+            if (!(first_is_f1[k] ? pair1 : pair0)) {
+                ta[k][1] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r10) << 2));
+                ta[k][3] = *reinterpret_cast<const uint32_t *>(pool + ((ba[k] + fa.r11) << 2));
+            }
+        }
     }
     // (the second level's byte offsets are formed out here, in front of the wave-uniform branch: that is what puts the loads of their
     // level offsets into batch 2 instead of a round trip of their own inside the branch)
     uint32_t ob[3][4];
+    bool pair_b[3], wrap_b = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {  // (lanes without a second level read their first level's texels again)
-        const TexLvlRel &fb = two[k] ? f1 : (first_is_f1[k] ? f1 : f0);
+        const bool use1 = two[k] || first_is_f1[k];
+        const TexLvlRel &fb = use1 ? f1 : f0;
         ob[k][0] = (bb[k] + fb.r00) << 2; ob[k][1] = (bb[k] + fb.r10) << 2; ob[k][2] = (bb[k] + fb.r01) << 2; ob[k][3] = (bb[k] + fb.r11) << 2;
+        pair_b[k] = use1 ? pair1 : pair0;
+        wrap_b = wrap_b || !pair_b[k];
     }
     asm volatile("" : : "v"(ob[0][0]), "v"(ob[1][0]), "v"(ob[2][0]));
     if (any_two) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k) {
+            const W2 top = *reinterpret_cast<const W2 *>(pool + ob[k][0]);
+            const W2 bot = *reinterpret_cast<const W2 *>(pool + ob[k][2]);
+            tb[k][0] = top.v[0]; tb[k][1] = top.v[1]; tb[k][2] = bot.v[0]; tb[k][3] = bot.v[1];
+        }
+        if (__any(wrap_b)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tb[k][j] = *reinterpret_cast<const uint32_t *>(pool + ob[k][j]);
+            for (int k = 0; k < 3; ++k)
+                if (!pair_b[k]) {
+                    tb[k][1] = *reinterpret_cast<const uint32_t *>(pool + ob[k][1]);
+                    tb[k][3] = *reinterpret_cast<const uint32_t *>(pool + ob[k][3]);
+                }
+        }
     }
     // decode + filter: the expressions of tex_texel_at / tex_bilinear_fast / tex_sample_grad
     auto decode = [&](uint32_t word, const float *tab, bool need_a) {
