@@ -340,11 +340,13 @@ R3N_DEV void tex_sample_grad(const TextureArgs &t, uint32_t id, bool nearest, fl
         if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
         const float *rgb = t.decode + (d.format == 1u ? 256 : 0);
         const uint32_t w0 = tex_mip_dim(d.width, level), h0 = tex_mip_dim(d.height, level);
-        const uint32_t b0 = d.offset + tex_level_start_pow2(d.width, d.height, level);  // (closed form: no load between the level of detail and the texels)
+        // (closed form in the SHORT_ONLY instantiations: no load between the level of detail and the texels; tex_sample_alpha has the note)
+        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
+        const uint32_t b0 = SHORT_ONLY ? d.offset + tex_level_start_pow2(d.width, d.height, level) : lo[level];
         TexLvlFast l0, l1;
         bool tame = tex_level_fast<SHORT_ONLY>(w0, h0, b0, u, v, l0);
         const bool two = frac > 0.0f;  // then level + 1 <= mips - 1
-        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), b0 + __umul24(w0, h0), u, v, l1) && tame;
+        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), SHORT_ONLY ? b0 + __umul24(w0, h0) : lo[level + 1u], u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             Texel4 r, hi;
             r = tex_bilinear_fast<M, NEED_A>(t, rgb, l0);
@@ -394,11 +396,15 @@ R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_text
         if (level >= d.mips - 1u) { level = d.mips - 1u; frac = 0.0f; }
         // (the levels' first texels in closed form: no load between the level of detail and the texels)
         const uint32_t w0 = tex_mip_dim(d.width, level), h0 = tex_mip_dim(d.height, level);
-        const uint32_t b0 = d.offset + tex_level_start_pow2(d.width, d.height, level);
+        // (SHORT_ONLY instantiations only: the ones with the general sampler behind them have no scalar registers to spare for the
+        // closed form's intermediates -- tests/test_kernel_isa.py caught the allocator spilling the in-flight destination of the
+        // work-item kernels' record prefetch -- and read the table as before)
+        const uint32_t *lo = t.level_off + (size_t)(id - 1u) * R3N_TEX_LEVELS;
+        const uint32_t b0 = SHORT_ONLY ? d.offset + tex_level_start_pow2(d.width, d.height, level) : lo[level];
         TexLvlFast l0, l1;
         bool tame = tex_level_fast<SHORT_ONLY>(w0, h0, b0, u, v, l0);
         const bool two = frac > 0.0f;
-        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), b0 + __umul24(w0, h0), u, v, l1) && tame;
+        if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), SHORT_ONLY ? b0 + __umul24(w0, h0) : lo[level + 1u], u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             const char *pool = reinterpret_cast<const char *>(t.texels);
             auto alpha_at = [&](uint32_t byte_off) { return (float)(*reinterpret_cast<const uint32_t *>(pool + byte_off) >> 24) / 255.0f; };
