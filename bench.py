@@ -515,9 +515,11 @@ def main():
                        "frac": rs["valu"]["useful_frac_of_vector_peak"],
                        "frac_note": "useful f32 flops / vector peak; every vector instruction counted as one lane-op gives valu.issue_frac_of_vector_peak "
                                     "(0.25 is the ceiling of unpacked, unfused f32 code), the ALUs are busy valu.busy of the launch",
-                       "limiter": "measured (profiles/r04_summary.md section 6b): neither roofline binds -- 8 % fewer vector instructions moved "
-                                  "the launch by 1 %; its time is the length of a wave's chain of dependent memory round trips (key -> "
-                                  "record -> material -> descriptors -> level offsets -> texels -> one shadow lookup per light) at four "
+                       "limiter": "measured (profiles/r04_summary.md section 6b, profiles/r05_paired_texel_loads.txt): neither roofline binds.  "
+                                  "10 % fewer vector instructions, one round trip less in the chain key -> record -> material -> descriptors -> "
+                                  "texels -> shadow lookups, or an occupancy cap move the launch by <= 1 %; a third fewer vector-MEMORY "
+                                  "instructions (footprint rows as one 8-byte load, round 5) moved it by 7 %, as the PCF's twelve loads -> four "
+                                  "had in round 3: the kernel is short of the rate at which the vector L1 takes memory instructions, at four "
                                   "waves per SIMD.  `bound` keeps the label of the nearer roofline (the HBM figure is `frac_hbm`)"})
         else:
             rs["bound_note"] = "VALU-bound kernel (no PMC pass of these sources on record: only the HBM figure can be quoted)"
