@@ -129,21 +129,26 @@ def split_model(stage_ms, launches, world, width, height, samples, n_views, setu
     (every peer pair has its own link: a rank receives (N - 1) shares concurrently).
       rows    (sort-first): the viewport's cull and per-triangle setup are REPLICATED, pixel work / N; depth bands all-gathered.
       objects (north_star): the viewport's cull, setup and pixel work / N; depth plane MAX all-reduce + key MAX reduce-scatter.
-    Both: shadow views by view (ceil(V / N) per rank) + broadcast, resolve / N, row gather.  setup_frac: share of the per-triangle
-    pass that is per-triangle work (fetch + setup + work-item emission) rather than pixels -- an assumption, stated in the line."""
+    Both: shadow views by view (ceil(V / N) per rank; with N > V a view's rows are split into N // V bands, one rank each: the
+    view's culls and per-triangle setup replicated, its pixel work / bands -- r3n.hip shadow_parts) + broadcast, resolve / N, row
+    gather.  setup_frac: share of the per-triangle pass that is per-triangle work (fetch + setup + work-item emission) rather than
+    pixels -- an assumption, stated in the line."""
     per = lambda st: stage_ms[st] / max(launches.get(st, 0) or 1, 1)  # noqa: E731
     cams = 1 + n_views
     # the stage table sums every camera's launches: a camera's share = the per-launch average (2 viewport draws: predicted + residual)
     cull_vp = per("bake") * (1 if launches.get("bake") else 0) + per("object_cull") + per("triangle_cull")
     small_vp, big_vp = stage_ms["raster"], stage_ms["raster_big"]
-    shadow = stage_ms["shadow_raster"] + stage_ms["shadow_raster_big"] + (cams - 1) * (per("object_cull") + per("triangle_cull"))
+    shadow_cull = (cams - 1) * (per("object_cull") + per("triangle_cull"))
+    shadow = stage_ms["shadow_raster"] + stage_ms["shadow_raster_big"] + shadow_cull
     views_here = -(-n_views // world) if n_views else 0
+    bands = world // n_views if n_views and world > n_views else 1  # rows of a view split over the ranks that would own none
+    shadow_banded = shadow_cull + stage_ms["shadow_raster"] * (setup_frac + (1.0 - setup_frac) / bands) + stage_ms["shadow_raster_big"] / bands
     px = width * height
     link = XGMI_LINK_GBS * 1e9 * XGMI_EFFICIENCY
     share = lambda bytes_total: 1e3 * (bytes_total / world) / link + COLLECTIVE_LATENCY_MS  # noqa: E731  one band / shard per link, all links at once
     depth_bytes = px * (4 if samples == 1 else 8 * samples)
-    common = (shadow * views_here / n_views if n_views else 0.0) + (stage_ms["shade"] + stage_ms["vertex"]) / world + stage_ms["clear"] + stage_ms["hiz"] \
-        + ((1e3 * views_here * 4.0 * 2048 * 2048 / link + COLLECTIVE_LATENCY_MS) if n_views and world > 1 else 0.0) + (share(4.0 * px) if world > 1 else 0.0)
+    common = (shadow_banded * views_here / n_views if n_views else 0.0) + (stage_ms["shade"] + stage_ms["vertex"]) / world + stage_ms["clear"] + stage_ms["hiz"] \
+        + ((1e3 * views_here * 4.0 * 2048 * 2048 / bands / link + COLLECTIVE_LATENCY_MS) if n_views and world > 1 else 0.0) + (share(4.0 * px) if world > 1 else 0.0)
     rows = common + cull_vp + small_vp * (setup_frac + (1.0 - setup_frac) / world) + big_vp / world + (share(depth_bytes) if world > 1 else 0.0)
     objects = common + (cull_vp + small_vp + big_vp) / world + ((2.0 * share(depth_bytes) + share(8.0 * samples * px)) if world > 1 else 0.0)
     single = stage_ms["shade"] + stage_ms["vertex"] + stage_ms["clear"] + stage_ms["hiz"] + shadow + cull_vp + small_vp + big_vp
@@ -151,7 +156,7 @@ def split_model(stage_ms, launches, world, width, height, samples, n_views, setu
             "predicted_speedup": {"rows": round(single / rows, 2), "objects": round(single / objects, 2)},
             "choice": "rows" if rows <= objects else "objects",
             "inputs_ms": {"viewport_cull": round(cull_vp, 4), "viewport_per_triangle_pass": round(small_vp, 4), "viewport_work_items": round(big_vp, 4),
-                          "shadow_views_total": round(shadow, 4), "resolve": round(stage_ms["shade"] + stage_ms["vertex"], 4)},
+                          "shadow_views_total": round(shadow, 4), "shadow_bands_per_view": bands, "resolve": round(stage_ms["shade"] + stage_ms["vertex"], 4)},
             "assumptions": f"stand-alone stage sums (no overlap between streams or frames), xGMI {XGMI_LINK_GBS:.0f} GB/s per link x {XGMI_EFFICIENCY} efficiency, "
                            f"direct exchange (one share per peer link), {COLLECTIVE_LATENCY_MS} ms per collective, setup_frac {setup_frac}; "
                            "nothing here was measured on more than one GPU"}

@@ -63,7 +63,7 @@ def test_bench_two_ranks_one_line(partition):
 @pytest.mark.parametrize("partition", ["objects", "rows"])
 def test_bench_eight_ranks_one_line(partition):
     """the driver's N = 8 launch line on a small target (eight ranks time-share the one GPU: plumbing, not a
-    number).  Four shadow views on eight ranks: four ranks own none; 360 rows = eight equal bands of 45."""
+    number).  Four shadow views on eight ranks: every view's rows in two bands, one rank each; 360 rows = eight equal bands of 45."""
     d = _run(["--partition", partition], n=8, size=("640x360", 640 * 360))
     assert d["n_gpus"] == 8 and d["steps"] == 4 and d["value"] > 0 and d["ms_per_step"] > 0
     par = d["config"]["parallelism"]

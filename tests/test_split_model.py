@@ -47,3 +47,21 @@ def test_model_is_monotone_in_the_work_it_divides():
         if prev is not None and world > 2:  # (from 1 to 2 ranks the exchange terms appear)
             assert m["objects_ms"] < prev["objects_ms"] and m["rows_ms"] < prev["rows_ms"]
         prev = m
+
+
+def test_round5_lines_and_the_shadow_band_split():
+    """Round 5: with more ranks than shadow views a view's rows are split into N // V bands (r3n.hip shadow_parts; the model's
+    `shadow_bands_per_view`).  On the round's own lines: configs[3] still comes out as north_star's object-range split at eight ranks
+    -- past the 3.5x of north_star on the model -- and, its object pass being six times cheaper than in round 4, as rows at four."""
+    m8 = _model(_line("r05_bench_cfg4.json"), 8)
+    assert m8["inputs_ms"]["shadow_bands_per_view"] == 2 and m8["choice"] == "objects" and m8["predicted_speedup"]["objects"] >= 3.5, m8
+    m4 = _model(_line("r05_bench_cfg4.json"), 4)
+    assert m4["inputs_ms"]["shadow_bands_per_view"] == 1 and m4["choice"] == "rows", m4
+    for world in (2, 4, 8):
+        assert _model(_line("r05_bench.json"), world)["choice"] == "rows"
+    # the band split only ever removes work from a rank
+    line = _line("r05_bench.json")
+    import bench
+    banded = _model(line, 8)
+    whole = bench.split_model(line["stage_ms_per_frame"], line["stage_launches_per_frame"], 4, 3840, 2160, 1, 4)  # (four ranks: one whole view each)
+    assert banded["rows_ms"] < whole["rows_ms"]

@@ -180,15 +180,17 @@ def test_two_processes_exchange_matches_unsharded(mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,mode,n_objects", [
     (4, "native-ragged", 200),            # sort-first rows, 190 rows over 4 ranks: bands of 48 / 48 / 47 / 47, one broadcast per band
-    (4, "native-objects-ragged", 200),    # object ranges + MAX all-reduces; two shadow views on four ranks: ranks 2 and 3 own none
+    (4, "native-objects-ragged", 200),    # object ranges + MAX all-reduces; two shadow views on four ranks: each view's rows split in two bands
     (4, "native-objects-msaa", 200),      # equal bands (192 rows), four samples: reduce-scatter of the keys' bands
     (8, "native-ragged", 200),            # 190 rows over 8 ranks: seven peers in the ragged band broadcasts
-    (8, "native-objects-ragged", 6),      # six objects on eight ranks: EMPTY object ranges, six ranks without a shadow view
+    (8, "native-objects-ragged", 6),      # six objects on eight ranks: EMPTY object ranges; two shadow views in four bands of 64 rows each
     (8, "native-objects", 200),           # equal bands at eight ranks: in-place reduce-scatter onto the row owners
 ])
 def test_many_processes_exchange_matches_unsharded(world, mode, n_objects):
-    """the library's own exchange with MORE than two ranks -- states two ranks cannot reach (ranks that own no
-    shadow view: view v belongs to rank v mod world; empty object ranges; seven peers in comm_gather_bands' ragged broadcasts).
+    """the library's own exchange with MORE than two ranks -- states two ranks cannot reach (more ranks than
+    shadow views: a view's rows are split into world / views bands, band p of view v drawn by rank v + p * views and broadcast from
+    there -- the atlas every rank ends up with is compared bit for bit; empty object ranges; seven peers in comm_gather_bands'
+    ragged broadcasts).
     One GPU per rank over RCCL where the box has them, else every rank on the one GPU through tests/rccl_shim.cpp (it takes any
     rank count).  Each rank compares its rows / its objects' sets with its own unsharded render, bit for bit, over four frames."""
     import torch
