@@ -461,8 +461,10 @@ def main():
                 lane_ops = vi * 64.0 / (ms * 1e-3) / 1e12
                 d["valu"] = {"insts_per_launch": int(vi), "lane_ops_T_per_s": round(lane_ops, 2), "peak_tflops": VALU_PEAK_TFLOPS,
                              "issue_frac_of_vector_peak": round(lane_ops / VALU_PEAK_TFLOPS, 4), "busy": valu_busy.get(traffic_key),
-                             "note": "issue_frac counts EVERY vector instruction (moves, selects, address math) as one lane-op; useful_* counts f32 "
-                                     "add + mul + 2 x fma + transcendental only"}
+                             "note": "issue_frac counts EVERY vector instruction (moves, selects, address math) as one lane-op; useful_* = 64 x "
+                                     "SQ_INSTS_VALU_FLOPS_FP32: f32 add / sub / mul / transcendental 1, fma 2, packed forms twice that, everything else "
+                                     "(min / max, floor, compares, division fix-ups, moves, integer, conversions) 0 -- weights calibrated per "
+                                     "instruction on the box (profiles/r05_valu_counter_probe.txt)"}
                 uf = useful_flops.get(traffic_key)
                 if uf:
                     d["valu"]["useful_tflops"] = round(uf / (ms * 1e-3) / 1e12, 2)
@@ -511,8 +513,8 @@ def main():
         roofline_of("k_resolve_opaque", "shade", 20.0 * WIDTH * HEIGHT / world, "k_resolve_opaque",
                     f"8 B key + 8 B HDR + 4 B sRGB per pixel, texels / triangle records / shadow texels excluded; per pixel: {cameras - 1} lights x "
                     "(5-tap PCF + GGX)" + ("" if args.untextured else ", 3 trilinear maps, tangent frame"))
-        # the resolve is bound by vector issue, not by HBM: its roofline is the f32 vector peak, `frac` = useful flops (add + mul +
-        # 2 x fma + transcendental lane-ops, SQ_INSTS_VALU_*_F32 passes) / launch time / 157.3 TFLOP/s; the HBM figure stays beside it
+        # the resolve is bound by vector issue, not by HBM: its roofline is the f32 vector peak, `frac` = useful flops (64 x SQ_INSTS_VALU_FLOPS_FP32:
+        # add / mul / transcendental 1, fma 2, packed forms twice that; calibrated by tools/valu_counter_probe.hip) / launch time / 157.3 TFLOP/s; the HBM figure stays beside it
         rs = rooflines["shade"]
         if rs.get("valu", {}).get("useful_tflops"):
             rs.update({"bound": "valu", "frac_hbm": rs["frac"], "achieved_hbm_GBps": rs["achieved"], "peak_hbm_GBps": rs["peak"],

@@ -71,7 +71,7 @@ def main():
             "k_shadow_tiles": [k for k in table if k.startswith("k_shadow_tiles")]}
     doc = {"source": "tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter set per run; FETCH_SIZE x2 (gfx950 wide-load correction) + WRITE_SIZE",
            "taken": datetime.date.today().isoformat(), "variant": variant, "kernel_sources_sha": bench.kernel_sources_sha(),
-           "bytes_per_launch": {}, "valu_busy": {}, "valu_insts_per_launch": {}, "useful_flops_per_launch": {}, "kernels": table}
+           "bytes_per_launch": {}, "valu_busy": {}, "valu_insts_per_launch": {}, "useful_flops_per_launch": {}, "useful_flops_unpacked_count": {}, "kernels": table}
     for key, names in pick.items():
         if names and "hbm_bytes" in table[names[0]]:
             doc["bytes_per_launch"][key] = table[names[0]]["hbm_bytes"]
@@ -80,10 +80,16 @@ def main():
         if names and "sq_insts_valu" in table[names[0]]:
             doc["valu_insts_per_launch"][key] = int(table[names[0]]["sq_insts_valu"])
         if names and "sq_insts_valu_add_f32" in table[names[0]]:
-            # f32 arithmetic only: 64 lanes x (add + mul + 2 x fma + transcendental) wave-instructions -- moves, selects, compares,
-            # integer / address work and conversions are NOT flops
+            # f32 arithmetic only -- moves, selects, compares, min / max, floor, division fix-ups, integer / address work and
+            # conversions are NOT flops.  SQ_INSTS_VALU_FLOPS_FP32 weighs an instruction by its flops per lane: add / sub / mul /
+            # transcendental 1, fma 2, the PACKED forms twice that (calibrated per instruction on the box: tools/valu_counter_probe.hip,
+            # profiles/r05_valu_counter_probe.txt).  The per-class counters count a packed instruction ONCE, so the sum
+            # add + mul + 2 x fma + transcendental (rounds 4-5) missed half of every v_pk_mul_f32 / v_pk_add_f32 -- half of the
+            # resolve's f32 arithmetic instructions are packed; it is kept beside the counter as `..._unpacked_count`.
             t = table[names[0]]
-            doc["useful_flops_per_launch"][key] = int(64 * (t["sq_insts_valu_add_f32"] + t["sq_insts_valu_mul_f32"] + 2 * t["sq_insts_valu_fma_f32"] + t.get("sq_insts_valu_trans_f32", 0.0)))
+            by_class = int(64 * (t["sq_insts_valu_add_f32"] + t["sq_insts_valu_mul_f32"] + 2 * t["sq_insts_valu_fma_f32"] + t.get("sq_insts_valu_trans_f32", 0.0)))
+            doc["useful_flops_unpacked_count"][key] = by_class
+            doc["useful_flops_per_launch"][key] = int(64 * t["sq_insts_valu_flops_fp32"]) if t.get("sq_insts_valu_flops_fp32") else by_class
     # one entry per workload variant (bench.py quotes the entry of the variant it runs): merged into the file the previous
     # variants of THIS build left in the same directory tree (gpurun_out/<tag>/traffic.json), or into profiles/traffic.json
     merged = {"source": doc["source"], "kernel_sources_sha": doc["kernel_sources_sha"], "variants": {}}
@@ -95,7 +101,7 @@ def main():
                 break
         except (OSError, ValueError):
             pass
-    merged["variants"][variant] = {k: doc[k] for k in ("taken", "bytes_per_launch", "valu_busy", "valu_insts_per_launch", "useful_flops_per_launch", "kernels")}
+    merged["variants"][variant] = {k: doc[k] for k in ("taken", "bytes_per_launch", "valu_busy", "valu_insts_per_launch", "useful_flops_per_launch", "useful_flops_unpacked_count", "kernels")}
     json.dump(merged, open(os.path.join(os.path.dirname(out.rstrip("/")), "traffic.json"), "w"), indent=1)
     json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     for k, row in table.items():
