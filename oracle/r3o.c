@@ -1430,7 +1430,13 @@ void r3o_shade(const uint64_t *vis, uint32_t w, uint32_t h, uint32_t samples, co
             int x0, y0, x1, y1;
             tri_bounds(baked[o].model_view_proj, v, half_w, half_h, (int)w, (int)h, &x0, &y0, &x1, &y1);
             uint32_t id = tri_base[o] + t + 1u;
-#pragma omp parallel for schedule(dynamic, 4)
+            /* one parallel region PER TRIANGLE (draw order is serial): a team as large as the box has hardware threads costs tens
+             * of milliseconds to fork and join, a few thousand times per frame (tools/fuzz_parity.py: 67 s for a 226 x 220 frame on
+             * the GPU box's 256 threads, 1 s on 8) -- the team is sized by the triangle's rows, small triangles run serially.
+             * Scheduling only: every pixel is written by one iteration. */
+            const int blend_rows = y1 - y0 + 1;
+            const int blend_team = blend_rows / 16 < 1 ? 1 : (blend_rows / 16 > 16 ? 16 : blend_rows / 16);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(blend_team) if (blend_rows >= 32)
             for (int y = y0; y <= y1; ++y)
                 for (int x = x0; x <= x1; ++x) {
                     const uint64_t pix = (uint64_t)y * w + (uint64_t)x;
