@@ -1555,6 +1555,11 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
         TRY(ensure(c, s->block_sums, (size_t)nblocks0 * sizeof(ObjBlockSums), false, -1));
         TRY(ensure(c, s->block_off, (size_t)nblocks0 * sizeof(ObjBlockOffsets), false, -1));
         TRY(ensure(c, s->slot_base[cur], (size_t)cap0 * 4u, true, 0xFF));
+        // LAST frame's table too: the triangle cull reads prev_slot_base[object] for every object of THIS frame's work list, and an
+        // object added since the last frame may sit beyond last frame's capacity (the buffer doubled: handle = old capacity).  The
+        // new entries read INVALID = "not batched last frame" (batching.rs:226): all of its passing triangles are residual.
+        // (Found by tools/fuzz_parity.py: the read ran past the allocation, the object's first frame was drawn by neither pass.)
+        if (viewport && s->has_prev) TRY(ensure(c, s->slot_base[prev], (size_t)cap0 * 4u, true, 0xFF));
         TRY(ensure(c, s->sub_counts[cur], sizeof(r3n_sub_counts), false, 0));
         TRY(ensure(c, s->counts[cur], sizeof(r3n_cull_counts), false, 0));
         TRY(ensure(c, s->first_entry, first_entry_bytes(c), false, -1));

@@ -263,6 +263,32 @@ def test_random_scene_multi_frame(r3, handedness):
     assert fo["residual"].sum() < fo["pass"].sum()
 
 
+@pytest.mark.parametrize("n_objects", [16, 32, 128])
+def test_object_added_past_a_full_buffer(r3, n_objects):
+    """The object buffer is exactly full (a power of two: freelist/buffer.rs:48-52), two frames of history exist, then an object is
+    added: its handle is the old capacity, the buffer doubles, and the triangle cull looks the new object up in LAST frame's table
+    of result-bit bases, which was sized for the old capacity.  It must read 'not batched last frame' (batching.rs:226) -- every
+    passing triangle residual, drawn by pass 2 in its first frame.  (tools/fuzz_parity.py found the read running past the
+    allocation: the object's first frame was drawn by neither pass.)"""
+    o, p = both(r3, oh.LEFT, f32(200) / f32(120))
+    ho = scenes.build_random_scene(o, oh, omk, n_objects, 11, lights=1, shadow_res=128)
+    hp = scenes.build_random_scene(p, oh, r3.material_record, n_objects, 11, lights=1, shadow_res=128)
+    assert ho == hp and max(ho) == n_objects - 1
+    for r in (o, p):
+        r.set_camera_data(oh.look_at_lh((0, 2, -8), (0, 0, 0), (0, 1, 0)), ("perspective", 70.0, 0.1))
+    for f in range(2):
+        compare_frames(o.render(200, 120), p.render(200, 120), f"frame {f}")
+    added = [r.add_object(scenes.cube_mesh(r), scenes.lit(r, mk, (0.8, 0.7, 0.2, 1.0)), oh.translation((0.0, 1.0, -3.0)))
+             for r, mk in ((o, omk), (p, r3.material_record))]
+    assert added == [n_objects, n_objects]
+    fo, fp = o.render(200, 120), p.render(200, 120)
+    assert fo["capacity"] == 2 * n_objects
+    first = int(fo["tri_base"][n_objects])
+    assert fo["residual"][first:first + 12].sum() > 0, "the new cube is in view: its front faces are newly visible"
+    compare_frames(fo, fp, "the frame the buffer grew in")
+    compare_frames(o.render(200, 120), p.render(200, 120), "the frame after")
+
+
 def test_hiz_pyramid_matches_oracle(r3):
     """hi_z.wgsl: non-power-of-two target (odd mip dimensions take the 3-wide path)."""
     o, p = both(r3, oh.LEFT, f32(200) / f32(120))
