@@ -8,6 +8,11 @@ of view / near plane) or orthographic projection, a random eye and target; then 
 moved, one removed and one added in between, so the temporal two-pass culling, Hi-Z and the growth / removal paths engage.  The
 comparison is tests/test_gpu_parity.py::compare_frames (sets, keys, atlas, HDR bit-exact; framebuffer within 1e-3).
 
+--mutate: five frames and, between them, up to four world edits drawn from the case's seed -- objects moved / removed / added
+one by one or in bulk (the object buffer doubles, freed handles are reused), a material rewritten or moved to another transparency
+key, directional lights turned / resized / added (the shadow atlas is laid out again), point lights moved / added, the target
+resized, the sample count switched.
+
     python tools/fuzz_parity.py --seconds 240 --first-seed 1000        # prints one line per case, a summary, exit code 1 on a mismatch
 """
 import argparse
@@ -89,6 +94,122 @@ def camera(c, f):
     return view, proj
 
 
+def mutate(rng, c, st, pair, f):
+    """Apply up to four random world edits to BOTH renderers (pair = ((renderer, host module, material_record), ...));
+    st: the case's mutable state (live handles, own material / mesh handles, target size, samples).  Returns what it did."""
+    done = []
+    for _ in range(rng.randint(5)):
+        kind = rng.randint(12)
+        live = st["live"]
+        if kind == 0 and live:  # move
+            h = live[rng.randint(len(live))]
+            pos = (rng.uniform(-10, 10), rng.uniform(-2, 4), rng.uniform(-10, 10))
+            sc = math.exp(rng.uniform(math.log(0.3), math.log(3.0)))
+            ang = rng.uniform(0, 6.28)
+            for r, hm, _mk in pair:
+                r.set_object_transform(h, hm.mat4_mul(hm.mat4_mul(hm.translation(pos), hm.rotation_y(ang)), hm.scale((sc, sc, sc))))
+            done.append(f"move {h}")
+        elif kind == 1 and len(live) > 4:  # remove
+            h = live.pop(rng.randint(len(live)))
+            for r, _hm, _mk in pair:
+                r.remove_object(h)
+            done.append(f"remove {h}")
+        elif kind in (2, 3):  # add one (near the target, so it is usually in view)
+            pos = tuple(0.5 * t + rng.uniform(-3, 3) for t in c["target"])
+            sc = rng.uniform(0.3, 2.5)
+            hs = [r.add_object(st["mesh"][i][kind - 2], st["mat"][i][0],
+                               hm.mat4_mul(hm.translation(pos), hm.scale((sc, sc, sc)))) for i, (r, hm, _mk) in enumerate(pair)]
+            assert hs[0] == hs[1], f"handles diverge: {hs}"
+            live.append(hs[0])
+            done.append(f"add {hs[0]}")
+        elif kind == 4:  # add in bulk: the object buffer grows, freed handles are reused first
+            n = 1 + rng.randint(max(len(live), 1) + 40)
+            xs = np.zeros((n, 16), dtype=f32)
+            for k in range(n):
+                pos = (rng.uniform(-14, 14), rng.uniform(-3, 5), rng.uniform(-14, 14))
+                sc = rng.uniform(0.2, 1.5)
+                xs[k] = np.asarray(oh.mat4_mul(oh.translation(pos), oh.scale((sc, sc, sc))), dtype=f32).reshape(16)
+            which = rng.randint(2)
+            hs = [r.add_objects_bulk([st["mesh"][i][which]] * n, [st["mat"][i][k % 2] for k in range(n)], xs) for i, (r, _hm, _mk) in enumerate(pair)]
+            assert list(hs[0]) == list(hs[1]), "handles diverge (bulk)"
+            live.extend(int(h) for h in hs[0])
+            done.append(f"bulk +{n}")
+        elif kind == 5:  # rewrite a material (colour, roughness), sometimes moving it to another transparency key
+            key = (scenes.OPAQUE, scenes.CUTOUT, scenes.BLEND)[rng.randint(3)] if rng.uniform() < 0.4 else None
+            col = (rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.3, 1.0))
+            rough = rng.uniform(0.2, 0.9)
+            for i, (r, _hm, mk) in enumerate(pair):
+                r.update_material(st["mat"][i][1], mk(albedo=col, albedo_mode="value", roughness=rough, cutout=0.5 if key == scenes.CUTOUT else None), key)
+            done.append(f"material key {key}")
+        elif kind == 6 and st["dir"] > 0:  # turn / resize a directional light
+            h = rng.randint(st["dir"])
+            ch = dict(direction=(rng.uniform(-1, 1), -rng.uniform(0.5, 3.0), rng.uniform(-1, 1)))
+            if rng.uniform() < 0.5:
+                ch["resolution"] = (64, 128, 256, 512)[rng.randint(4)]
+            if rng.uniform() < 0.3:
+                ch["distance"] = rng.uniform(10.0, 90.0)
+            for r, _hm, _mk in pair:
+                r.update_directional_light(h, **ch)
+            done.append(f"light {h} {sorted(ch)}")
+        elif kind == 7 and st["dir"] < 4:  # one more shadow view: the atlas is laid out again
+            ch = dict(color=(1, 1, 1), intensity=rng.uniform(0.5, 4.0), direction=(rng.uniform(-1, 1), -rng.uniform(0.5, 3.0), rng.uniform(-1, 1)),
+                      distance=rng.uniform(15.0, 70.0), resolution=(64, 128, 256, 512)[rng.randint(4)])
+            for r, _hm, _mk in pair:
+                r.add_directional_light(**ch)
+            st["dir"] += 1
+            done.append("light added")
+        elif kind == 8:  # point lights
+            pos = (rng.uniform(-8, 8), rng.uniform(0, 4), rng.uniform(-8, 8))
+            if st["point"] and rng.uniform() < 0.5:
+                h = rng.randint(st["point"])
+                for r, _hm, _mk in pair:
+                    r.update_point_light(h, position=pos)
+            else:
+                for r, _hm, _mk in pair:
+                    r.add_point_light(pos, (1.0, 0.8, 0.6), rng.uniform(1.0, 6.0), rng.uniform(2.0, 10.0))
+                st["point"] += 1
+            done.append("point light")
+        elif kind == 9:  # resize the target
+            st["w"], st["h"] = 48 + rng.randint(340), 40 + rng.randint(220)
+            done.append(f"resize {st['w']}x{st['h']}")
+        elif kind == 10 and rng.uniform() < 0.5:
+            st["samples"] = 5 - st["samples"]  # 1 <-> 4
+            done.append(f"samples {st['samples']}")
+    return done
+
+
+def run_mutating_case(r3, c):
+    o = OracleRenderer(c["handedness"], f32(c["w"]) / f32(c["h"]))
+    p = r3.Renderer(c["handedness"], f32(c["w"]) / f32(c["h"]))
+    log = []
+    try:
+        ho = build(o, oh, omk, c)
+        hp = build(p, r3.host, r3.material_record, c)
+        assert ho == hp
+        pair = ((o, oh, omk), (p, r3.host, r3.material_record))
+        st = dict(live=list(ho), w=c["w"], h=c["h"], samples=c["samples"], dir=c["lights"], point=c["point_lights"], mesh=[], mat=[])
+        for r, hm, mk in pair:
+            pos, idx, nrm = scenes.icosphere(1)
+            if c["handedness"] == oh.LEFT:
+                idx = idx.reshape(-1, 3)[:, ::-1].reshape(-1)
+            st["mesh"].append((scenes.cube_mesh(r), r.add_mesh(pos, idx, normals=nrm)))
+            st["mat"].append((scenes.lit(r, mk, (0.8, 0.7, 0.2, 1.0)), scenes.lit(r, mk, (0.3, 0.6, 0.9, 1.0))))
+        rng = scenes.Pcg32(c["seed"] * 7919 + 13)
+        for f in range(5):
+            view, proj = camera(c, f)
+            for r in (o, p):
+                r.set_camera_data(view, proj)
+            if f:
+                log.append((f, mutate(rng, c, st, pair, f)))
+            kw = dict(samples=st["samples"], ambient=c["ambient"], clear_color=(0.02, 0.03, 0.05, 1.0))
+            fo = o.render(st["w"], st["h"], **kw)
+            fp = p.render(st["w"], st["h"], **kw)
+            compare_frames(fo, fp, f"frame {f} after {log}")
+        return int(fo["visible"].sum()), int(fo["pass"].sum()), int((fo["vis"] != 0).sum())
+    finally:
+        p.close()
+
+
 def run_case(r3, c):
     o = OracleRenderer(c["handedness"], f32(c["w"]) / f32(c["h"]))
     p = r3.Renderer(c["handedness"], f32(c["w"]) / f32(c["h"]))
@@ -124,6 +245,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--first-seed", type=int, default=1000)
     ap.add_argument("--max-cases", type=int, default=10000)
+    ap.add_argument("--mutate", action="store_true", help="five frames with random world edits in between (see the module docstring)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a drawn parameter (bisecting a case), e.g. --set blend=0 --set lights=1")
     a = ap.parse_args()
     import rend3_amd as r3
@@ -139,7 +261,7 @@ def main():
               f"points {c['point_lights']} blend {int(c['blend'])} {'ortho' if c['ortho'] else 'vfov %.0f near %g' % (c['vfov'], c['near'])}"
         t1 = time.time()
         try:
-            vis, tris, px = run_case(r3, c)
+            vis, tris, px = (run_mutating_case if a.mutate else run_case)(r3, c)
             ok += 1
             covered[c["builder"]] = covered.get(c["builder"], 0) + 1
             print(f"ok   {tag}: visible objects {vis}, pass triangles {tris}, covered samples {px} ({time.time() - t1:.1f} s)", flush=True)
