@@ -1234,10 +1234,10 @@ static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t
     HIP_TRY(c, hipSetDevice(c->device));
     // (an overflow an earlier frame raised is reported by r3n_frame_end / r3n_sync / a read-back, never by refusing THIS frame:
     // the frame that overflowed has been presented already, the next one must still render)
-    if (w != c->width || h != c->height) {
-        // resolution change invalidates the temporal history exactly like a new CullingBufferMap entry would
-        c->viewport.has_prev = false;
-    }
+    // (a resolution change keeps the temporal history, like the reference: CullingBufferMap is keyed by the camera alone,
+    // culler.rs:53-80 -- last frame's predicted triangles are drawn into the new target, Hi-Z is built at the new size, the cull's
+    // residual test reads last frame's bits.  Rounds 1-5 dropped the history here; tools/fuzz_parity.py --mutate found the
+    // difference against the oracle, which keeps it.)
     c->width = w; c->height = h; c->samples = samples; c->atlas_w = atlas_w; c->atlas_h = atlas_h;
     std::memcpy(c->clear, clear_color, 16);
     // frames in flight: this frame renders into the other set of targets / per-frame inputs

@@ -289,6 +289,26 @@ def test_object_added_past_a_full_buffer(r3, n_objects):
     compare_frames(o.render(200, 120), p.render(200, 120), "the frame after")
 
 
+def test_target_resize_keeps_the_temporal_history(r3):
+    """The target changes size (and sample count) between frames.  The reference keeps a camera's culling buffers across that --
+    CullingBufferMap is keyed by the camera alone (culler.rs:53-80) -- so the frame after the change still draws last frame's
+    predicted triangles first and only the newly visible ones are residual.  (Rounds 1-5 reset the history on a size change;
+    tools/fuzz_parity.py --mutate found the difference against the oracle.)"""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    scenes.build_random_scene(o, oh, omk, 200, 0xC0FFEE, lights=1, with_cutout=True)
+    scenes.build_random_scene(p, oh, r3.material_record, 200, 0xC0FFEE, lights=1, with_cutout=True)
+    for f, (w, h, s) in enumerate(((320, 192, 1), (320, 192, 1), (211, 140, 1), (211, 140, 4), (400, 90, 4), (64, 64, 1))):
+        ang = 0.2 * f
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh((3.0 * math.sin(ang), 1.0, -3.0 * math.cos(ang)), (10 * math.sin(ang + 0.3), 0, 10 * math.cos(ang + 0.3)), (0, 1, 0)),
+                              ("perspective", 60.0, 0.1))
+        fo = o.render(w, h, samples=s, ambient=(0.1, 0.1, 0.1, 1.0))
+        fp = p.render(w, h, samples=s, ambient=(0.1, 0.1, 0.1, 1.0))
+        compare_frames(fo, fp, f"frame {f} at {w}x{h} s{s}")
+        if f >= 1:
+            assert 0 < fo["residual"].sum() < fo["pass"].sum(), "history engaged: most passing triangles were predicted"
+
+
 def test_hiz_pyramid_matches_oracle(r3):
     """hi_z.wgsl: non-power-of-two target (odd mip dimensions take the 3-wide path)."""
     o, p = both(r3, oh.LEFT, f32(200) / f32(120))

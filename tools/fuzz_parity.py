@@ -9,8 +9,7 @@ moved, one removed and one added in between, so the temporal two-pass culling, H
 comparison is tests/test_gpu_parity.py::compare_frames (sets, keys, atlas, HDR bit-exact; framebuffer within 1e-3).
 
 --mutate: five frames and, between them, up to four world edits drawn from the case's seed -- objects moved / removed / added
-one by one or in bulk (the object buffer doubles, freed handles are reused), a material rewritten or moved to another transparency
-key, directional lights turned / resized / added (the shadow atlas is laid out again), point lights moved / added, the target
+one by one or in bulk (the object buffer doubles, freed handles are reused), a material rewritten, directional lights turned / resized / added (the shadow atlas is laid out again), point lights moved / added, the target
 resized, the sample count switched.
 
     python tools/fuzz_parity.py --seconds 240 --first-seed 1000        # prints one line per case, a summary, exit code 1 on a mismatch
@@ -134,13 +133,14 @@ def mutate(rng, c, st, pair, f):
             assert list(hs[0]) == list(hs[1]), "handles diverge (bulk)"
             live.extend(int(h) for h in hs[0])
             done.append(f"bulk +{n}")
-        elif kind == 5:  # rewrite a material (colour, roughness), sometimes moving it to another transparency key
-            key = (scenes.OPAQUE, scenes.CUTOUT, scenes.BLEND)[rng.randint(3)] if rng.uniform() < 0.4 else None
-            col = (rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.3, 1.0))
+        elif kind == 5:  # rewrite a material (colour, roughness) in place.  Its transparency key stays: the frame in which a key changes
+            # is outside the reference's domain (last frame's predicted triangles sit in the draw range of the OLD key,
+            # forward.rs:286; tests/test_gpu_parity.py::test_material_key_flip_between_frames compares the converged state)
+            col = (rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), 1.0)
             rough = rng.uniform(0.2, 0.9)
             for i, (r, _hm, mk) in enumerate(pair):
-                r.update_material(st["mat"][i][1], mk(albedo=col, albedo_mode="value", roughness=rough, cutout=0.5 if key == scenes.CUTOUT else None), key)
-            done.append(f"material key {key}")
+                r.update_material(st["mat"][i][1], mk(albedo=col, albedo_mode="value", roughness=rough))
+            done.append("material rewritten")
         elif kind == 6 and st["dir"] > 0:  # turn / resize a directional light
             h = rng.randint(st["dir"])
             ch = dict(direction=(rng.uniform(-1, 1), -rng.uniform(0.5, 3.0), rng.uniform(-1, 1)))
@@ -165,8 +165,9 @@ def mutate(rng, c, st, pair, f):
                 for r, _hm, _mk in pair:
                     r.update_point_light(h, position=pos)
             else:
+                intensity, radius = rng.uniform(1.0, 6.0), rng.uniform(2.0, 10.0)
                 for r, _hm, _mk in pair:
-                    r.add_point_light(pos, (1.0, 0.8, 0.6), rng.uniform(1.0, 6.0), rng.uniform(2.0, 10.0))
+                    r.add_point_light(pos, (1.0, 0.8, 0.6), intensity, radius)
                 st["point"] += 1
             done.append("point light")
         elif kind == 9:  # resize the target
