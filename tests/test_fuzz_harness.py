@@ -29,7 +29,7 @@ def test_case_parameters_are_a_function_of_the_seed():
 
 def test_edit_schedule_reaches_both_renderers_alike():
     kinds = set()
-    for seed in range(5000, 5012):
+    for seed in range(5000, 5016):
         c = F.draw_case(seed)
         o = OracleRenderer(c["handedness"], f32(c["w"]) / f32(c["h"]))
         p = OracleRenderer(c["handedness"], f32(c["w"]) / f32(c["h"]))
@@ -54,4 +54,4 @@ def test_edit_schedule_reaches_both_renderers_alike():
             fo, fp = o.render(st["w"], st["h"], **kw), p.render(st["w"], st["h"], **kw)
             for k in ("vis", "hdr16", "pass", "residual", "visible", "point_buf", "dir_buf", "objects", "materials"):
                 assert np.array_equal(np.asarray(fo[k]), np.asarray(fp[k])), f"seed {seed} frame {f}: {k}"
-    assert {"move", "remove", "add", "bulk", "material", "light", "point", "resize"} <= kinds
+    assert {"move", "remove", "add", "bulk", "material", "light", "point", "resize", "mesh", "newmat", "texture"} <= kinds

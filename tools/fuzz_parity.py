@@ -10,7 +10,7 @@ comparison is tests/test_gpu_parity.py::compare_frames (sets, keys, atlas, HDR b
 
 --mutate: five frames and, between them, up to four world edits drawn from the case's seed -- objects moved / removed / added
 one by one or in bulk (the object buffer doubles, freed handles are reused), a material rewritten, directional lights turned / resized / added (the shadow atlas is laid out again), point lights moved / added, the target
-resized, the sample count switched.
+resized, the sample count switched, new meshes / materials / textures created between frames.
 
     python tools/fuzz_parity.py --seconds 240 --first-seed 1000        # prints one line per case, a summary, exit code 1 on a mismatch
 """
@@ -98,7 +98,7 @@ def mutate(rng, c, st, pair, f):
     st: the case's mutable state (live handles, own material / mesh handles, target size, samples).  Returns what it did."""
     done = []
     for _ in range(rng.randint(5)):
-        kind = rng.randint(12)
+        kind = rng.randint(15)
         live = st["live"]
         if kind == 0 and live:  # move
             h = live[rng.randint(len(live))]
@@ -176,6 +176,32 @@ def mutate(rng, c, st, pair, f):
         elif kind == 10 and rng.uniform() < 0.5:
             st["samples"] = 5 - st["samples"]  # 1 <-> 4
             done.append(f"samples {st['samples']}")
+        elif kind in (11, 12, 13):  # a NEW mesh / material / texture between frames (the mesh buffer, the material table and the texel
+            # pool grow while the previous frame's resolve may still be reading them) and an object that uses it
+            pos = tuple(0.5 * t + rng.uniform(-3, 3) for t in c["target"])
+            sc = rng.uniform(0.4, 2.0)
+            col = (rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), 1.0)
+            sub = rng.randint(3)
+            tex_seed = c["seed"] * 31 + f * 7 + len(done)
+            hs = []
+            for i, (r, hm, mk) in enumerate(pair):
+                mesh, mat = st["mesh"][i][0], st["mat"][i][0]
+                if kind in (11, 13):
+                    mp, mi, mn = scenes.icosphere(sub)
+                    if c["handedness"] == oh.LEFT:
+                        mi = mi.reshape(-1, 3)[:, ::-1].reshape(-1)
+                    uv = (mp[:, :2] * np.float32(1.5) + np.float32(0.5)).astype(np.float32)
+                    mesh = r.add_mesh(mp, mi, normals=mn, uv0=uv)
+                if kind == 12:
+                    mat = scenes.lit(r, mk, col)
+                if kind == 13:
+                    img = np.random.default_rng(tex_seed).integers(0, 256, (16 << sub, 16, 4), dtype=np.uint8)
+                    t = r.add_texture_2d(img, srgb=True, mip_count="maximum", mip_source="generated")
+                    mat = r.add_material(mk(albedo_mode="texture_value", albedo_texture=t, albedo=col, roughness=0.5), scenes.OPAQUE)
+                hs.append(r.add_object(mesh, mat, hm.mat4_mul(hm.translation(pos), hm.scale((sc, sc, sc)))))
+            assert hs[0] == hs[1], f"handles diverge: {hs}"
+            live.append(hs[0])
+            done.append(("mesh", "newmat", "texture")[kind - 11] + f" {hs[0]}")
     return done
 
 
