@@ -55,3 +55,12 @@ def test_edit_schedule_reaches_both_renderers_alike():
             for k in ("vis", "hdr16", "pass", "residual", "visible", "point_buf", "dir_buf", "objects", "materials"):
                 assert np.array_equal(np.asarray(fo[k]), np.asarray(fp[k])), f"seed {seed} frame {f}: {k}"
     assert {"move", "remove", "add", "bulk", "material", "light", "point", "resize", "mesh", "newmat", "texture"} <= kinds
+
+
+def test_oracle_thread_limit_is_scoped():
+    import ctypes
+    omp = ctypes.CDLL("libgomp.so.1")
+    before = omp.omp_get_max_threads()
+    with F.oracle_threads(2):
+        assert omp.omp_get_max_threads() == min(2, before)
+    assert omp.omp_get_max_threads() == before

@@ -39,6 +39,31 @@ from test_gpu_parity import compare_frames  # noqa: E402
 f32 = np.float32
 
 
+class oracle_threads:
+    """`with oracle_threads(32):` -- the oracle's OpenMP team for the block.  OMP_NUM_THREADS only counts when it is set before the
+    OpenMP runtime loads (inside a pytest session torch has loaded it long before); omp_set_num_threads works at any time.  The
+    cases here are a few hundred rows: on the GPU box's 256 hardware threads a team per loop costs more in fork / join than it
+    saves (0.25 s per case instead of 0.05)."""
+
+    def __init__(self, n):
+        self.n, self.old, self.omp = n, None, None
+
+    def __enter__(self):
+        import ctypes
+        try:
+            self.omp = ctypes.CDLL("libgomp.so.1")
+            self.old = self.omp.omp_get_max_threads()
+            self.omp.omp_set_num_threads(min(self.n, self.old))
+        except OSError:
+            self.omp = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.omp is not None and self.old:
+            self.omp.omp_set_num_threads(self.old)
+        return False
+
+
 def draw_case(seed):
     rng = scenes.Pcg32(seed ^ 0x5EED5EED)
     c = {"seed": seed}
