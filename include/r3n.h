@@ -309,7 +309,10 @@ int r3n_set_shade_mode(r3n_ctx *ctx, uint32_t mode);
  * clear_shadow_buffers (clear.rs:4-20).  Clears colour to `clear_color`, depth and the shadow atlas to 0.0.
  * `samples` is SampleCount::One (1) or ::Four (4): the colour / depth targets of the viewport then hold 4 samples per pixel
  * (forward.rs:358, base.rs:236-258), Hi-Z starts from their depth-min resolve (resolve_depth_min.wgsl) and the HDR target
- * the tonemapper reads is the render pass's box resolve.  Shadow views are always single-sampled (base.rs:230). */
+ * the tonemapper reads is the render pass's box resolve.  Shadow views are always single-sampled (base.rs:230).
+ * width / height / samples may change from one frame to the next: the targets are re-created, the cameras' culling history (last
+ * frame's result bits and predicted triangles) is KEPT, as the reference keeps a camera's culling buffers whatever the target's
+ * size (CullingBufferMap is keyed by the CameraSpecifier alone, culler.rs:53-80). */
 int r3n_frame_begin(r3n_ctx *ctx, const r3n_frame_uniforms496 *uniforms, uint32_t width, uint32_t height,
                     uint32_t samples, const float clear_color[4], uint32_t shadow_atlas_width,
                     uint32_t shadow_atlas_height);
