@@ -17,7 +17,7 @@ from rend3_amd import parallel
 WORLDS = st.integers(min_value=1, max_value=16)
 
 
-@settings(max_examples=300, deadline=None)
+@settings(max_examples=300, deadline=None, derandomize=True, database=None)
 @given(st.lists(st.integers(min_value=0, max_value=5000), min_size=0, max_size=300), WORLDS)
 def test_object_ranges_tile_the_slots_and_balance_the_load(counts, world):
     ranges = parallel.partition_objects(counts, world)
@@ -31,7 +31,7 @@ def test_object_ranges_tile_the_slots_and_balance_the_load(counts, world):
         assert max(loads) <= math.ceil(cost.sum() / world) + int(cost.max())
 
 
-@settings(max_examples=300, deadline=None)
+@settings(max_examples=300, deadline=None, derandomize=True, database=None)
 @given(st.integers(min_value=1, max_value=5000), WORLDS)
 def test_row_bands_tile_the_target_like_the_library_does(height, world):
     rows = parallel.row_ranges(height, world)
@@ -44,7 +44,7 @@ def test_row_bands_tile_the_target_like_the_library_does(height, world):
         assert b == r * base + min(r, rem) and e == b + base + (1 if r < rem else 0)
 
 
-@settings(max_examples=120, deadline=None)
+@settings(max_examples=120, deadline=None, derandomize=True, database=None)
 @given(st.integers(min_value=0, max_value=2 ** 31 - 1), st.integers(min_value=0, max_value=400), WORLDS)
 def test_spatial_partition_assigns_every_live_slot_once(seed, n, world):
     rng = np.random.default_rng(seed)
@@ -80,7 +80,7 @@ def _rows_of_points(points, view_proj, height):
     return ((1.0 - y[ok] / w[ok]) * 0.5 * height)
 
 
-@settings(max_examples=80, deadline=None)
+@settings(max_examples=80, deadline=None, derandomize=True, database=None)
 @given(st.integers(min_value=0, max_value=2 ** 31 - 1), st.integers(min_value=2, max_value=8), st.booleans(), st.booleans())
 def test_row_extents_of_the_spatial_split_are_conservative(seed, world, left_handed, orthographic):
     rng = np.random.default_rng(seed)
