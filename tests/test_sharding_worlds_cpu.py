@@ -4,8 +4,8 @@ tests/test_multi_rank_gloo.py runs one fixed scene with 2 and 4 processes over g
 each with its own sharded oracle renderer, and the exchange steps are the collectives' definitions applied to the ranks' arrays
 between two barriers (element-wise MAX of the depth plane / of the 64-bit keys; a shadow view's rectangle copied from its owner):
 no process group, so seven or eight ranks cost nothing, and the scenes come from tools/fuzz_parity.py's generator.  What is checked
-is what the native exchanges (r3n_comm_*) and rend3_amd/parallel.py implement: with the viewport split by object ranges, or by
-rows, and the shadow views split by view, every rank ends every frame with the unsharded frame's keys (its own rows under the row
+is what the native exchanges (r3n_comm_*) and rend3_amd/parallel.py implement: with the viewport split by object ranges, by owner
+bytes (the spatial partition) or by rows, and the shadow views split by view, every rank ends every frame with the unsharded frame's keys (its own rows under the row
 split), atlas, Hi-Z pyramid and image, and its triangle sets are the unsharded ones restricted to what it owns."""
 import os
 import sys
@@ -46,7 +46,7 @@ class Ranks:
                 for v, sh in enumerate(shadows):
                     x, y, s = int(sh["offset"][0]), int(sh["offset"][1]), int(sh["size"])
                     merged[y:y + s, x:x + s] = self.slot[parallel.shadow_view_owner(v, self.world)][y:y + s, x:x + s]
-            elif what == "pass2" and rows_mode:
+            elif what == "pass2" and rows_mode is True:
                 merged = None  # sort-first: nothing is exchanged after pass 2
             elif arr.dtype == np.uint64:  # keys: depth bits << 32 | triangle, depth >= 0: unsigned MAX
                 merged = np.maximum.reduce([self.slot[k] for k in range(self.world)])
@@ -74,8 +74,12 @@ def _run(world, rows_mode, seed):
     counts = (full.objects[:, 21] // 3) * (full.objects[:, 29] != 0)
     ranges = parallel.partition_objects(counts, world)
     rows = parallel.row_ranges(h, world)
+    spheres = full.objects[:, 16:20].view(np.float32)
+    owners = parallel.partition_objects_spatial(spheres[:, :3], counts, world)
     for rank, s in enumerate(shards):
-        if rows_mode:
+        if rows_mode == "spatial":
+            s.object_owners = (owners, rank)  # owner bytes (Morton-order partition) instead of a slot range
+        elif rows_mode:
             s.row_band = rows[rank]
         else:
             s.object_range = ranges[rank]
@@ -106,11 +110,11 @@ def _run(world, rows_mode, seed):
         tri_obj = np.searchsorted(ref["tri_base"], np.arange(len(ref["pass"])), side="right") - 1
         union = np.zeros(len(ref["pass"]), dtype=bool)
         for rank in range(world):
-            g, tag = got[rank], f"seed {seed} world {world} {'rows' if rows_mode else 'objects'} frame {f} rank {rank}"
+            g, tag = got[rank], f"seed {seed} world {world} {'rows' if rows_mode is True else (rows_mode or 'objects')} frame {f} rank {rank}"
             assert np.array_equal(ref["atlas"].view(np.uint32), g["atlas"].view(np.uint32)), tag + ": atlas"
             assert np.array_equal(ref["hiz"].view(np.uint32), g["hiz"].view(np.uint32)), tag + ": Hi-Z"
             r0, r1 = rows[rank]
-            if rows_mode:
+            if rows_mode is True:
                 assert np.array_equal(ref["vis"][r0:r1], g["vis"][r0:r1]), tag + ": own rows of the keys"
                 assert np.array_equal(ref["rgba8"][r0:r1], g["rgba8"][r0:r1]), tag + ": own rows of the image"
                 for k in ("visible", "pass", "residual"):
@@ -120,19 +124,22 @@ def _run(world, rows_mode, seed):
                 assert np.array_equal(ref["rgba8"], g["rgba8"]), tag + ": image"
                 b, e = ranges[rank]
                 mine = is_blend.copy()  # translucent objects are culled and drawn by EVERY rank (ordered blending is not a MAX merge)
-                mine[b:e] = True
+                if rows_mode == "spatial":
+                    mine |= owners == rank
+                else:
+                    mine[b:e] = True
                 assert np.array_equal(g["visible"].astype(bool), ref["visible"].astype(bool) & mine), tag + ": L1"
                 assert np.array_equal(g["pass"].astype(bool), ref["pass"].astype(bool) & mine[tri_obj]), tag + ": L2 pass"
                 assert np.array_equal(g["residual"].astype(bool), ref["residual"].astype(bool) & mine[tri_obj]), tag + ": L2 residual"
                 union |= g["pass"].astype(bool)
-        if not rows_mode:
+        if rows_mode is not True:
             assert np.array_equal(union, ref["pass"].astype(bool)), f"seed {seed} frame {f}: the ranks' pass sets tile the unsharded one"
     assert {"shadow", "pass2"} <= ranks.sites and ({"pass1_depth", "pass1"} & ranks.sites), ranks.sites
     return int(ref["pass"].sum())
 
 
 @pytest.mark.parametrize("world", [3, 5, 7, 8])
-@pytest.mark.parametrize("rows_mode", [False, True], ids=["objects", "rows"])
+@pytest.mark.parametrize("rows_mode", [False, True, "spatial"], ids=["objects", "rows", "spatial"])
 def test_every_rank_ends_with_the_unsharded_frame(world, rows_mode):
     ran, drawn = 0, 0
     with F.oracle_threads(4):  # N renderers run side by side
