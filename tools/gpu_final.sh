@@ -43,7 +43,7 @@ for w in "$@"; do
       cd /tmp
       R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1" -o kt1 -- $B --no-cpu-baseline --steps 30 --warmup 5 > "$out/bench_under_rocprof_single.json" 2> "$out/kt1.err"
       echo "== default, single stream"; stats "$out/kt1" 18
-      for v in ${SERIAL_MORE:-cfg4 v2}; do
+      for v in ${SERIAL_MORE-cfg4 v2}; do  # SERIAL_MORE="" : the default workload only
         flag="--config 4"; [ $v = v2 ] && flag="--bistro-v2"
         R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt1_$v" -o kt1 -- $B --no-cpu-baseline --steps 20 --warmup 5 $flag > "$out/bench_${v}_under_rocprof_single.json" 2> "$out/kt1_$v.err"
         echo "== $v, single stream"; stats "$out/kt1_$v" 14
