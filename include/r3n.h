@@ -414,7 +414,10 @@ typedef struct r3n_frame_desc {
 int r3n_render_frame(r3n_ctx *ctx, const r3n_frame_desc *desc);
 
 /* ---- multi-GPU support: object-range sharding (not in the reference).
- * Only objects with slot in [begin, end) are culled/drawn by this context; buffers stay replicated. */
+ * Only objects with slot in [begin, end) are culled/drawn by this context; buffers stay replicated.  The ranges are the CALLER's
+ * partition of the slots that exist when it is made: a slot beyond every rank's `end` (objects added after the object buffer grew) is
+ * drawn by NO rank until the ranges are set again -- re-partition after world edits that add slots, or give the last rank
+ * end = 0xFFFFFFFF. */
 int r3n_set_object_range(r3n_ctx *ctx, uint32_t begin, uint32_t end);
 /* The same sharding by OWNER BYTE instead of slot range: this context culls / draws the opaque and cutout objects whose
  * owners[slot] == rank (a spatial partition -- Morton order of the bounding-sphere centres -- gives every rank a compact region
