@@ -2,7 +2,7 @@
 
 Every case draws its scene, target and (in the mutating mode) its world edits from its seed and compares every frame of the HIP path
 with the oracle like the hand-written tests do (compare_frames: sets, keys, atlas, HDR bit-exact).  The campaign proper runs for
-minutes with fresh seeds (profiles/r05_fuzz_parity*.txt: 5 600 cases after the two defects it found were fixed); the seeds below
+minutes with fresh seeds (profiles/r05_fuzz_parity*.txt: 6 377 cases after the two defects it found were fixed); the seeds below
 are the ranges in which those defects first showed -- an object added to an exactly full object buffer (static mode, third frame),
 a target resized between frames (mutating mode) -- so that a regression fails here by seed.
 (The file sorts last on purpose: the drawn cases run after the hand-written ones.)"""
