@@ -227,7 +227,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    # R3N_BENCH_SHARE_GPU=1 (tests/test_bench_two_ranks.py on the one-GPU boxes): every rank on cuda:0, torch's collectives over gloo
+    # R3N_BENCH_SHARE_GPU=1 (tests/test_zzz_bench_ranks_gpu.py on the one-GPU boxes): every rank on cuda:0, torch's collectives over gloo
     # and the library's over the library R3N_RCCL_LIB names (RCCL refuses two ranks on one device) -- exercises this file's N > 1
     # branches (cost-model probe, split choice, native exchanges, max-over-ranks timing); its numbers mean nothing
     share_gpu = os.environ.get("R3N_BENCH_SHARE_GPU") == "1"

@@ -1,8 +1,12 @@
 // r3n.hip -- context, device-memory management and the extern "C" entry points of include/r3n.h.
 // All device work is enqueued on the context's stream; nothing on the frame path reads back to the host.
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -232,6 +236,9 @@ struct r3n_ctx {
     // of the call and the frame path must not wait for the GPU; a buffer is reused once the copy issued from it has executed
     struct Bulk { uint8_t *p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; } bulk[4];
     uint32_t bulk_next = 0;
+    // R3N_BREADCRUMBS=<prefix>: one line per stage / collective into <prefix>.pid<pid>.ctx<n> as it is ENQUEUED (write(2), no
+    // buffering) -- where a rank that stopped answering was last seen (tests/mp_harness.py, tools/soak_native.py); -1: off
+    int crumb_fd = -1;
     // timing taps
     bool timing = false;
     struct Span { hipEvent_t a, b; int stage; hipStream_t stream; };
@@ -251,6 +258,14 @@ int fail(r3n_ctx *c, int code, const std::string &msg) {
     return code;
 }
 
+static void crumb(const r3n_ctx *c, const char *what, long long a = -1, long long b = -1);
+// a host wait on the device (where a rank that hangs is found): breadcrumb with the line in front and behind
+#define HIP_WAIT(c, expr)                                    \
+    do {                                                     \
+        crumb((c), "wait " #expr, __LINE__);                 \
+        HIP_TRY((c), expr);                                  \
+        crumb((c), "wait done", __LINE__);                   \
+    } while (0)
 #define HIP_TRY(c, expr)                                                                          \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
@@ -294,7 +309,7 @@ int ensure(r3n_ctx *c, DevBuf &b, size_t bytes, bool preserve, int fill) {
 int upload_small(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     if (bytes > r3n_ctx::kStageSlotBytes || !c->stage) {
         HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));
         return R3N_OK;
     }
     const uint32_t half_slots = r3n_ctx::kStageSlots / 2;
@@ -302,7 +317,7 @@ int upload_small(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     const uint32_t half = slot / half_slots;
     if (slot % half_slots == 0 && c->stage_half_pending[half]) {
         // entering a half of the ring: every copy previously issued from it must have executed
-        HIP_TRY(c, hipEventSynchronize(c->stage_half_done[half]));
+        HIP_WAIT(c, hipEventSynchronize(c->stage_half_done[half]));
         c->stage_half_pending[half] = false;
     }
     uint8_t *h = c->stage + (size_t)slot * r3n_ctx::kStageSlotBytes;
@@ -323,7 +338,7 @@ int upload_bulk(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     r3n_ctx::Bulk &b = c->bulk[c->bulk_next];
     c->bulk_next = (c->bulk_next + 1u) % 4u;
     if (b.pending) {
-        HIP_TRY(c, hipEventSynchronize(b.ev));
+        HIP_WAIT(c, hipEventSynchronize(b.ev));
         b.pending = false;
     }
     if (b.bytes < bytes) {
@@ -358,6 +373,19 @@ int check_async_status(r3n_ctx *c) {
         if (_r != R3N_OK) return _r;   \
     } while (0)
 
+static const char *const kStageNames[R3N_STAGE_COUNT] = {"bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear",
+    "raster_big", "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth",
+    "exchange_rows", "exchange_keys"};
+static void crumb(const r3n_ctx *c, const char *what, long long a, long long b) {
+    if (c->crumb_fd < 0) return;
+    char line[160];
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const int n = std::snprintf(line, sizeof line, "%lld.%06ld frame %llu %s %lld %lld\n", (long long)ts.tv_sec, ts.tv_nsec / 1000,
+                                (unsigned long long)c->frame_no, what, a, b);
+    if (n > 0) (void)!write(c->crumb_fd, line, (size_t)n);
+}
+
 struct Timed {
     r3n_ctx *c;
     int stage;
@@ -365,6 +393,7 @@ struct Timed {
     hipEvent_t a = nullptr, b = nullptr;
     Timed(r3n_ctx *ctx, int st, hipStream_t on = nullptr) : c(ctx), stage(st), stream(on ? on : ctx->stream) {
         c->stage_launches[stage]++;
+        crumb(c, kStageNames[stage]);
         if (!c->timing) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -422,12 +451,14 @@ int join_shade(r3n_ctx *c) {
     return R3N_OK;
 }
 int sync_all(r3n_ctx *c) {
+    crumb(c, "sync_all");
     int r = join_lanes(c);
     if (r != R3N_OK) return r;
     r = join_shade(c);
     if (r != R3N_OK) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->shade) HIP_TRY(c, hipStreamSynchronize(c->shade));
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));
+    if (c->shade) HIP_WAIT(c, hipStreamSynchronize(c->shade));
+    crumb(c, "sync_all done");
     return R3N_OK;
 }
 
@@ -484,7 +515,7 @@ int refresh_obj_meta(r3n_ctx *c) {
     TRY(join_lanes(c));  // the lanes' object passes of the previous frame read the old words
     ++c->main_epoch;
     HIP_TRY(c, hipMemcpyAsync(c->obj_meta.p, meta.data(), (size_t)c->capacity * 4u, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `meta` is a temporary
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));  // `meta` is a temporary
     return R3N_OK;
 }
 
@@ -580,7 +611,7 @@ int refresh_tri_base(r3n_ctx *c) {
     c->canon.d_hdr = c->canon.own_hdr;
     ++c->main_epoch;  // tri_base / slot_table are rebuilt on the main stream: the lanes' rasterisers read them
     HIP_TRY(c, hipMemcpyAsync(c->canon.d_hdr.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));  // h is a stack temporary
     TRY(run_object_pass(c, c->canon, 0, ObjOwn{0u, 0u, nullptr, 0u}, c->tri_base.as<uint32_t>(), c->stream));
     c->slot_table_size = (uint32_t)(c->total_tris >> R3N_SLOT_TABLE_SHIFT) + 1u;
     TRY(ensure(c, c->slot_table, (size_t)c->slot_table_size * 4u, false, -1));
@@ -755,6 +786,12 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         return nullptr;
     }
     c->status_host[0] = 0u;
+    if (const char *eb = std::getenv("R3N_BREADCRUMBS")) {
+        static std::atomic<int> n_ctx{0};
+        const std::string path = std::string(eb) + ".pid" + std::to_string((long long)getpid()) + ".ctx" + std::to_string(n_ctx.fetch_add(1));
+        c->crumb_fd = open(path.c_str(), O_CREAT | O_WRONLY | O_APPEND, 0644);
+        crumb(c, "created");
+    }
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');
@@ -858,6 +895,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
 
 void r3n_destroy(r3n_ctx *c) {
     if (!c) return;
+    crumb(c, "destroy");
     (void)hipSetDevice(c->device);
     (void)r3n_comm_destroy(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -924,7 +962,7 @@ int r3n_mesh_buffer_write(r3n_ctx *c, uint64_t byte_offset, const void *data, ui
     TRY(ensure(c, c->mesh, byte_offset + bytes, true, 0));
     if (bytes) {
         HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(c->mesh.p) + byte_offset, data, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns `data` only for the duration of the call
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));  // caller owns `data` only for the duration of the call
     }
     return R3N_OK;
 }
@@ -952,7 +990,7 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
             TRY(ensure(c, c->owners, capacity, true, 0));
             // (the allocation may already have been large enough, its tail never written)
             HIP_TRY(c, hipMemsetAsync(c->owners.as<uint8_t>() + c->owners_n, 0, capacity - c->owners_n, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_WAIT(c, hipStreamSynchronize(c->stream));
             c->owners_n = capacity;
         }
         c->capacity = capacity;
@@ -996,7 +1034,7 @@ int r3n_objects_write(r3n_ctx *c, const uint32_t *slots, const r3n_object128 *re
         i += run;
     }
     if (n) c->tri_base_dirty = true;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));
     return R3N_OK;
 }
 
@@ -1031,7 +1069,7 @@ int r3n_materials_write(r3n_ctx *c, const uint32_t *slots, const r3n_material208
                                   hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->material_keys.as<uint8_t>() + slots[i], keys + i, 1, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));
     return R3N_OK;
 }
 
@@ -1067,7 +1105,7 @@ static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uin
     c->classes_dirty = true; c->cutout_short_dirty = true;
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->tex_level_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));  // `off` is a temporary
     c->n_texels = n_texels;
     return R3N_OK;
 }
@@ -1092,7 +1130,7 @@ int r3n_textures_write(r3n_ctx *c, const r3n_texture_desc32 *descs, uint32_t n, 
     if (n) {
         HIP_TRY(c, hipMemcpyAsync(c->tex_descs.p, descs, (size_t)n * sizeof(r3n_texture_desc32), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->tex_texels.p, texels, n_texels * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the sources only for the duration of the call
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));  // caller owns the sources only for the duration of the call
     }
     TRY(upload_level_offsets(c, descs, n, n_texels));
     c->n_textures = n;
@@ -1258,7 +1296,7 @@ static int frame_begin_impl(r3n_ctx *c, const r3n_frame_uniforms496 *u, uint32_t
     }
     // the frame's constants: uniforms + directional lights (they follow the camera: every frame) [+ every camera header], one copy
     if (c->fb_pending[hs]) {  // the copy that last read this pinned image (kFbHost frames ago)
-        HIP_TRY(c, hipEventSynchronize(c->fb_ev[hs]));
+        HIP_WAIT(c, hipEventSynchronize(c->fb_ev[hs]));
         c->fb_pending[hs] = false;
     }
     uint8_t *host = c->fb_host[hs];
@@ -1372,7 +1410,7 @@ int r3n_skinning(r3n_ctx *c, const r3n_skinning_input40 *inputs, uint32_t n, con
         HIP_TRY(c, hipMemcpyAsync(c->skin_inputs.p, inputs, (size_t)n * sizeof *inputs, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->skin_wave_first.p, wave_first.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
         if (w) HIP_TRY(c, hipMemcpyAsync(c->skin_wave_skeleton.p, wave_skel.data(), (size_t)w * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors above are temporaries
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));  // host vectors above are temporaries
     }
     TRY(ensure(c, c->skin_matrices, (size_t)n_joints * 64, true, -1));
     if (joint_matrices) TRY(upload_bulk(c, c->skin_matrices.p, joint_matrices, (size_t)n_joints * 64));  // pinned staging: no wait for the GPU
@@ -1457,7 +1495,7 @@ int r3n_animation_write(r3n_ctx *c, const r3n_anim_rig16 *rigs, uint32_t n_rigs,
     TRY(put(c->anim_tracks, dev_tracks.data(), (size_t)n_tracks * sizeof *tracks));
     TRY(put(c->anim_times, times, (size_t)n_times * 4));
     TRY(put(c->anim_values, values, (size_t)n_values * 4));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller owns the sources only for the duration of the call
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));  // the caller owns the sources only for the duration of the call
     c->h_anim_rigs.assign(rigs, rigs + n_rigs);
     c->anim_max_joints = 1;
     for (uint32_t i = 0; i < n_rigs; ++i) c->anim_max_joints = std::max(c->anim_max_joints, rigs[i].n_joints);
@@ -1803,7 +1841,7 @@ static int refresh_material_classes(r3n_ctx *c) {
     }
     TRY(ensure(c, c->material_feat, feat.size() * 4, false, -1));
     HIP_TRY(c, hipMemcpyAsync(c->material_feat.p, feat.data(), feat.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `feat` is a temporary
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));  // `feat` is a temporary
     c->resolve_variants = variants;
     c->classes_dirty = false;
     return R3N_OK;
@@ -2062,7 +2100,7 @@ int r3n_hdr_write(r3n_ctx *c, const uint16_t *rgba16f, uint64_t first_pixel, uin
     TRY(join_shade(c));
     if (n_pixels) {
         HIP_TRY(c, hipMemcpyAsync(c->hdr16.as<uint16_t>() + first_pixel * 4u, rgba16f, n_pixels * 8u, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller owns the source only for the duration of the call
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));  // caller owns the source only for the duration of the call
     }
     c->resolved_this_frame = false;  // the fused blit no longer matches the HDR target
     return R3N_OK;
@@ -2087,7 +2125,7 @@ int r3n_set_output_format(r3n_ctx *c, uint32_t format) {
             HIP_TRY(c, hipMemcpy(c->srgb_lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice));
         } else {
             HIP_TRY(c, (hipError_t)r3n_internal_build_srgb_lut(c->srgb_lut.as<unsigned char>(), c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_WAIT(c, hipStreamSynchronize(c->stream));
         }
     }
     c->output_format = format;
@@ -2120,7 +2158,7 @@ int r3n_tonemap(r3n_ctx *c, void *host_rgba8, uint64_t pitch) {
         if (pitch < (uint64_t)c->width * 4) return fail(c, R3N_ERR_INVALID_ARG, "tonemap: pitch too small");
         HIP_TRY(c, hipMemcpy2DAsync(host_rgba8, pitch, c->out8.p, (size_t)c->width * 4, (size_t)c->width * 4, c->height,
                                     hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));
     }
     return R3N_OK;
 }
@@ -2152,7 +2190,9 @@ int r3n_frame_end(r3n_ctx *c) {
 // ------------------------------------------------------------------------------------------------ native exchange (r3n_comm_*)
 #define NCCL_TRY(c, expr)                                                                                          \
     do {                                                                                                           \
+        crumb(c, "> " #expr);                                                                                      \
         ncclResult_t _r = (expr);                                                                                  \
+        crumb(c, "< returned", (long long)_r);                                                                     \
         if (_r != ncclSuccess) return fail(c, R3N_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(_r)); \
     } while (0)
 
@@ -2179,6 +2219,7 @@ int r3n_comm_init(r3n_ctx *c, const uint8_t *ids, uint32_t rank, uint32_t world)
     TRY(sync_all(c));
     ncclComm_t *dst[R3N_COMM_IDS] = {&c->comm.main, &c->comm.shadow, &c->comm.rows};
     for (int k = 0; k < R3N_COMM_IDS; ++k) {
+        crumb(c, "comm_init communicator", k, world);
         ncclUniqueId u;
         std::memcpy(u.internal, ids + (size_t)k * R3N_COMM_ID_BYTES, R3N_COMM_ID_BYTES);
         const ncclResult_t rc = rccl().CommInitRank(dst[k], (int)world, u, (int)rank);
@@ -2191,13 +2232,16 @@ int r3n_comm_init(r3n_ctx *c, const uint8_t *ids, uint32_t rank, uint32_t world)
     }
     c->comm.on = true; c->comm.rank = rank; c->comm.world = world;
     c->shard_rows = true;
+    crumb(c, "comm_init done", rank, world);
     return R3N_OK;
 }
 int r3n_comm_destroy(r3n_ctx *c) {
     if (!c) return R3N_ERR_INVALID_ARG;
     if (!c->comm.on) return R3N_OK;
+    crumb(c, "comm_destroy");
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    crumb(c, "comm_destroy synced");
     for (ncclComm_t *k : {&c->comm.main, &c->comm.shadow, &c->comm.rows})
         if (*k) { (void)rccl().CommDestroy(*k); *k = nullptr; }
     for (DevBuf &b : c->comm.stage)
@@ -2351,6 +2395,7 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
         return fail(c, R3N_ERR_INVALID_ARG, "render_frame: null uniforms / headers, or too many shadow views");
     if (c->in_frame) return fail(c, R3N_ERR_STATE, "render_frame: a frame is already open");
     const bool native = c->comm.on;
+    crumb(c, "render_frame", d->width, d->height);
     if (native) {
         if (d->exchange) return fail(c, R3N_ERR_INVALID_ARG, "render_frame: an exchange callback AND r3n_comm_init communicators");
         band_rows(d->height, c->comm.world, c->comm.rank, c->row_begin, c->row_end);
@@ -2434,6 +2479,7 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     TRY(r3n_tonemap(c, nullptr, 0));          // tonemapping (base.rs:184)
     if (native) TRY(comm_gather_rows(c));
     closer.armed = false;
+    crumb(c, "render_frame enqueued");
     return r3n_frame_end(c);
 }
 
@@ -2558,7 +2604,7 @@ static int d2h(r3n_ctx *c, void *dst, const void *src, size_t bytes) {
     TRY(join_lanes(c));
     TRY(join_shade(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_WAIT(c, hipStreamSynchronize(c->stream));
     return check_async_status(c);
 }
 
@@ -2740,7 +2786,7 @@ int r3n_timing_enable(r3n_ctx *c, int enable) {
             hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, c->stream);
             HIP_TRY(c, hipEventRecord(eb[k], c->stream));
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_WAIT(c, hipStreamSynchronize(c->stream));
         std::vector<float> v;
         for (int k = 0; k < 32; ++k) {
             float ms = 0.f;

@@ -720,7 +720,7 @@ def test_native_comm_single_rank(r3, samples, height):
     MSAA) gathered in place in front of Hi-Z, the Rgba8 rows gathered behind the resolve -- with a one-rank communicator set,
     which runs every call of the path except the per-band broadcasts of a ragged row split (one rank always divides the
     height): the frames equal the oracle's, also with frames in flight.
-    World size 2 of the same scheme: tests/test_two_process_gpu.py[rows] and test_two_rank_gloo_rows_exact (Python exchange)."""
+    World size 2 of the same scheme: tests/test_zzz_multi_process_gpu.py[rows] and test_two_rank_gloo_rows_exact (Python exchange)."""
     o, p = both(r3, oh.LEFT, f32(320) / f32(height))
     scenes.build_random_scene(o, oh, omk, 150, 0xE8C5, lights=2, with_cutout=True)
     scenes.build_random_scene(p, oh, r3.material_record, 150, 0xE8C5, lights=2, with_cutout=True)

@@ -5,6 +5,7 @@ probe and the broadcast of rank 0's choice, r3n_comm_init + the split the librar
 region with the max over ranks, the one JSON line of rank 0 -- not a number: two ranks time-share one GPU here."""
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -30,14 +31,23 @@ def _run(extra, n=2, size=("1280x720", 1280 * 720)):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2",
            "--objects", "300", "--tris", "150000", "--resolution", size[0], "--no-cpu-baseline"] + extra
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, f"rank 0 prints ONE JSON line, got {len(lines)}:\n" + res.stdout[-2000:]
+    # its own session: on a time-out the launcher AND every rank are killed (nothing keeps the GPU or the suite)
+    limit = float(os.environ.get("R3N_MP_LIMIT", "150")) + 30.0 * (n > 2)
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        pytest.fail(f"bench.py --gpus {n} gave no line within {limit:.0f} s (ranks killed)\n" + out[-2000:] + err[-6000:], pytrace=False)
+    assert proc.returncode == 0, out[-2000:] + err[-4000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"rank 0 prints ONE JSON line, got {len(lines)}:\n" + out[-2000:]
     return json.loads(lines[0])
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("partition", ["auto", "objects", "rows"])
 def test_bench_two_ranks_one_line(partition):
     d = _run(["--partition", partition])
@@ -60,6 +70,7 @@ def test_bench_two_ranks_one_line(partition):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("partition", ["objects", "rows"])
 def test_bench_eight_ranks_one_line(partition):
     """the driver's N = 8 launch line on a small target (eight ranks time-share the one GPU: plumbing, not a

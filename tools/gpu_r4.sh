@@ -27,7 +27,7 @@ pmc() {  # name, env, counters...
 for w in "$@"; do
   case $w in
     quick) timeout 900 python -m pytest tests -m gpu -x -q -k "textured or bistro or runtime or golden or float_textures or encoded or vertex_colour or material_key or frames_in_flight or shade_mode" > "$out/pytest_quick.log" 2>&1; echo "pytest quick rc=$?"; tail -4 "$out/pytest_quick.log"; grep -E '^E ' "$out/pytest_quick.log" | head -8;;
-    shim) timeout 900 python -m pytest tests/test_two_process_gpu.py -q -x > "$out/pytest_shim.log" 2>&1; echo "pytest two-process rc=$?"; tail -6 "$out/pytest_shim.log"; grep -E '^E |FAIL' "$out/pytest_shim.log" | head -12;;
+    shim) timeout 900 python -m pytest tests/test_zzz_multi_process_gpu.py -q -x > "$out/pytest_shim.log" 2>&1; echo "pytest two-process rc=$?"; tail -6 "$out/pytest_shim.log"; grep -E '^E |FAIL' "$out/pytest_shim.log" | head -12;;
     trace) R3N_LIB=$root/variants/lib_trace.so R3N_SINGLE_STREAM=1 R3N_PIPELINE=0 timeout 400 python tools/wave_trace.py > "$out/wave_trace_single.txt" 2>&1; grep -A12 "per-triangle pass, quadrant [01]" "$out/wave_trace_single.txt" | cut -c1-400
            R3N_LIB=$root/variants/lib_trace.so timeout 400 python tools/wave_trace.py > "$out/wave_trace.txt" 2>&1; grep -A3 "per-triangle pass, quadrant 0" "$out/wave_trace.txt" | cut -c1-400;;
     probe) timeout 300 python tools/exact_math_probe.py > "$out/exact_math.txt" 2>&1; cat "$out/exact_math.txt" | head -80;;

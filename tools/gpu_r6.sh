@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-6 GPU calls.   gpurun --timeout T -- 'bash tools/gpu_r6.sh TAG action...'
+#   suite            the driver's round-end sequence in one call: pytest tests -x -q -m gpu, then __graft_entry__.smoke()
+#   soak:REPEAT      tools/soak_native.py, every two-rank native* mode REPEAT times        
+#   soakmany:REPEAT  the world-4 / world-8 cases REPEAT times
+#   soakmode:MODE:REPEAT   one mode
+set -u
+tag=${1:-r06}
+shift
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+for w in "$@"; do
+  t0=$(date +%s)
+  case $w in
+    suite)
+      timeout 1500 python -m pytest tests -x -q -m gpu --durations=12 > "$out/pytest.log" 2>&1; echo "pytest rc=$?"; tail -22 "$out/pytest.log" | cut -c1-220
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$out/smoke.log" | cut -c1-220;;
+    soak:*) timeout 3000 python tools/soak_native.py --repeat "${w#soak:}" --out "$out/soak" > "$out/soak_stdout.log" 2>&1; echo "soak rc=$?"; tail -4 "$out/soak_stdout.log" | cut -c1-400;;
+    soakmany:*) timeout 3000 python tools/soak_native.py --many --repeat "${w#soakmany:}" --out "$out/soak_many" > "$out/soak_many_stdout.log" 2>&1; echo "soak many rc=$?"; tail -4 "$out/soak_many_stdout.log" | cut -c1-400;;
+    soakmode:*) IFS=: read -r _ mode rep <<< "$w"; timeout 3000 python tools/soak_native.py --modes "$mode" --repeat "$rep" --out "$out/soak_$mode" > "$out/soak_${mode}_stdout.log" 2>&1; echo "soak $mode rc=$?"; tail -4 "$out/soak_${mode}_stdout.log" | cut -c1-400;;
+    *) echo "unknown action $w";;
+  esac
+  echo "-- $w: $(( $(date +%s) - t0 )) s"
+done
