@@ -330,7 +330,9 @@ int r3n_animation_write(r3n_ctx *ctx, const r3n_anim_rig16 *rigs, uint32_t n_rig
                         uint32_t n_joints, const r3n_anim_clip16 *clips, uint32_t n_clips, const r3n_anim_track80 *tracks,
                         uint32_t n_tracks, const float *times, uint32_t n_times, const float *values, uint32_t n_values);
 int r3n_pose_skeletons(r3n_ctx *ctx, const r3n_pose_request16 *requests, uint32_t n);
-/* GpuCuller::object_uniform_upload (culler.rs:427-529) + uniform_prep.wgsl */
+/* GpuCuller::object_uniform_upload (culler.rs:427-529) + uniform_prep.wgsl.  Called on its own it bakes every enabled slot, like
+ * the reference.  Inside r3n_render_frame the bake is fused into the object pass and covers only the slots a kernel reads: those
+ * inside the frustum now or (viewport) in the camera's previous frame -- the others keep what they held. */
 int r3n_uniform_bake(r3n_ctx *ctx, r3n_camera camera, const r3n_camera_header240 *header);
 /* GpuCuller::add_culling_to_graph (culler.rs:682-713) = batch_objects (batching.rs:120-250, frustum cull +
  * slot assignment, done on the GPU here) + GpuCuller::cull (culler.rs:531-659) + cull.wgsl.
@@ -503,6 +505,8 @@ int r3n_readback_draw_calls(r3n_ctx *ctx, r3n_camera camera, r3n_indirect_call c
 /* work-queue occupancy of the rasteriser: big_items[i] = number of >8x8 px work items the i-th r3n_forward call of
  * the last frame produced (performance diagnostics only) */
 int r3n_readback_raster_stats(r3n_ctx *ctx, uint32_t big_items[64]);
+/* The camera's baked matrices, 32 floats per slot.  After r3n_render_frame only the slots inside the frustum this frame or last
+ * frame are defined (see r3n_uniform_bake); after the per-node r3n_uniform_bake every enabled slot is. */
 int r3n_readback_baked(r3n_ctx *ctx, r3n_camera camera, float *model_view_and_mvp, uint32_t capacity);
 int r3n_readback_mesh(r3n_ctx *ctx, uint64_t byte_offset, void *dst, uint64_t bytes); /* e.g. skinned attribute runs */
 int r3n_readback_joint_matrices(r3n_ctx *ctx, uint32_t first_matrix, float *dst, uint32_t n_matrices); /* what the last r3n_skinning read */

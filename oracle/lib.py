@@ -71,7 +71,7 @@ class OracleLib:
             "r3o_hiz_build": [vp, ctypes.c_uint32, ctypes.c_uint32],
             "r3o_cull_triangles": [vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp],
             "r3o_raster_visibility": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32,
-                                      ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp],
+                                      ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint32, vp, vp, vp],
             "r3o_raster_depth": [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint32,
                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint32, vp],
             "r3o_vis_to_depth": [vp, ctypes.c_uint64, ctypes.c_uint32, vp],

@@ -838,6 +838,13 @@ static float fetch_color_alpha(const r3o_object *ob, const uint32_t *mesh, uint3
  * key = depth_bits << 32 | (canonical slot + 1); larger key wins (reverse-Z GreaterEqual,
  * forward.rs:347-351).  material_keys[material] : 0 opaque, 1 cutout, 2 blend (pbr/material.rs:497-499);
  * blend objects are skipped here (drawn by the transparent pass, base.rs:451-465).
+ *
+ * entry_keys (NULL or one byte per list entry): the key of the DRAW RANGE the entry sits in.  The pipeline -- with or without
+ * the cutout discard, pbr/routine.rs:61-83 -- belongs to the range (forward.rs:286-313), and last frame's predicted triangles
+ * sit in the ranges batch_objects made LAST frame (forward.rs:224-232: the cached DrawCallSet), from Material::key() as it was then
+ * (batching.rs:153).  After Renderer::update_material changed a material's transparency (renderer/mod.rs:256-266,
+ * managers/material.rs:163-188: only the TYPE is fixed) the two differ for one frame: the record read here is the current one
+ * (forward.rs:257: the archetype buffer), the discard is the old key's.  NULL: every entry is drawn under its material's current key.
  */
 /*
  * Multisampling (row N4; forward.rs:358 MultisampleState{count}, base.rs:236-258): `samples` = 1 or 4.  The
@@ -865,7 +872,7 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
                            const r3o_baked *baked, const r3o_material *materials, const uint8_t *material_keys,
                            const uint32_t *tri_base, const uint32_t *list_obj, const uint32_t *list_tri,
                            uint64_t n, uint32_t w, uint32_t h, uint32_t samples, const r3o_texture_desc *tdescs,
-                           uint32_t ntex, const uint32_t *texels, uint64_t *vis) {
+                           uint32_t ntex, const uint32_t *texels, uint64_t *vis, const uint8_t *entry_keys) {
     const float(*spos)[2] = samples == 4u ? SAMPLE_POS_4 : SAMPLE_POS_1;
     r3o_textures tt = {tdescs, ntex, texels};
     init_srgb8();
@@ -877,7 +884,7 @@ void r3o_raster_visibility(const r3o_camera_header *hdr, const r3o_object *objec
         const r3o_object *ob = &objects[o];
         if (ob->enabled == 0u) continue; /* opaque.wgsl:104-112 */
         const r3o_material *mat = &materials[ob->material_index];
-        uint8_t key = material_keys[ob->material_index];
+        uint8_t key = entry_keys ? entry_keys[i] : material_keys[ob->material_index];
         if (key > 1) continue;
         uint32_t idx[3];
         float v[3][3];

@@ -570,22 +570,25 @@ class OracleRenderer:
         vis = np.zeros((height, width) if samples == 1 else (height, width, samples), dtype=np.uint64)
         tri_base_now, _ = self.tri_base()
 
-        def draw(lo, lt):
+        def draw(lo, lt, entry_keys=None):
             if len(lo):
                 with _Span("forward_raster"):
                     lib.r3o_raster_visibility(lib.ptr(hdr), lib.ptr(self.objects), lib.ptr(self.mesh_words),
                                               lib.ptr(baked), lib.ptr(mats), lib.ptr(mat_keys), lib.ptr(tri_base_now),
-                                              lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, *self._tex_args(), lib.ptr(vis))
+                                              lib.ptr(lo), lib.ptr(lt), len(lo), width, height, samples, *self._tex_args(), lib.ptr(vis),
+                                              None if entry_keys is None else lib.ptr(entry_keys))
             if self.row_band is not None:  # a rank sharded by rows rasterises its band only: elsewhere the keys stay clear
                 vis[: self.row_band[0]] = 0
                 vis[self.row_band[1]:] = 0
 
-        # 8. pass 1: last frame's predicted triangles (forward.rs:224-232)
+        # 8. pass 1: last frame's predicted triangles, in LAST frame's draw ranges (forward.rs:224-232: the cached DrawCallSet --
+        # material_key_ranges as batch_objects made them then, forward.rs:286): an entry is drawn by the pipeline of the key its
+        # material had at that cull (opaque: no discard, cutout: discard), with the material record as it is now
         predicted = self.cam_state.get("predicted_list")
         if predicted is not None:
-            lo, lt = predicted
+            lo, lt, lk = predicted
             keep = lo < cap
-            draw(np.ascontiguousarray(lo[keep]), np.ascontiguousarray(lt[keep]))
+            draw(np.ascontiguousarray(lo[keep]), np.ascontiguousarray(lt[keep]), np.ascontiguousarray(lk[keep]))
         if exchange is not None and samples != 1:
             exchange("pass1", vis)  # multisampled: the keys (min over samples and max over ranks do not commute)
         # 9. Hi-Z from pass-1 depth (hi_z.rs:161-234)
@@ -602,7 +605,13 @@ class OracleRenderer:
         with _Span("cull"):
             visible, tri_base, pass_bits, residual = self._cull("viewport", hdr, baked, pyr, width, height)
             resid_list = self._list_from_bits(residual, tri_base)
-            self.cam_state["predicted_list"] = self._list_from_bits(pass_bits, tri_base)
+            # next frame's predicted triangles: the passing triangles of the objects batched atomic-capable (cull.wgsl:361-363:
+            # Sorting::OPAQUE, i.e. opaque + cutout keys; a blend object writes residual entries only, cull.wgsl:372-378), each with
+            # the key of the region it was batched under (batching.rs:153,191-204)
+            plo, plt = self._list_from_bits(pass_bits, tri_base)
+            plk = mat_keys[np.minimum(self.objects[plo, 22], len(mat_keys) - 1)].astype(np.uint8)
+            atomic = plk <= CUTOUT
+            self.cam_state["predicted_list"] = (np.ascontiguousarray(plo[atomic]), np.ascontiguousarray(plt[atomic]), np.ascontiguousarray(plk[atomic]))
         assert np.array_equal(tri_base, tri_base_now)
         # 11. pass 2: residual triangles
         draw(*resid_list)

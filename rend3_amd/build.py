@@ -51,12 +51,12 @@ def _obj(unit, obj_dir=OBJ):
     return os.path.join(obj_dir, unit.replace(".", "_") + ".o")
 
 
-def _stale(unit, obj_dir=OBJ):
+def _stale(unit, obj_dir=OBJ, csrc=None):
     o = _obj(unit, obj_dir)
     if not os.path.exists(o):
         return True
     t = os.path.getmtime(o)
-    return any(os.path.getmtime(d) > t for d in _deps(unit))
+    return any(os.path.getmtime(d) > t for d in _deps(unit, csrc))
 
 
 def up_to_date():
@@ -87,7 +87,7 @@ def build(force=False, verbose=False, extra=None, out=SO, obj_dir=OBJ, csrc=None
         if out == SO:
             out = os.path.join(HERE, f"librend3_amd.{tag}.so")
     os.makedirs(obj_dir, exist_ok=True)
-    todo = [u for u in UNITS if force or extra or _stale(u, obj_dir)]
+    todo = [u for u in UNITS if force or extra or _stale(u, obj_dir, csrc)]
 
     def compile_unit(u):
         cmd = [hipcc()] + FLAGS + extra + ["-c", "-o", _obj(u, obj_dir), os.path.join(src, u)]

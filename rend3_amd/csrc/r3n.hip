@@ -47,6 +47,8 @@ struct CamState {
     DevBuf first_entry;          // kernels_cull.h write_first_entries: the work-list entry owning every R3N_CHUNK_ITERS-th wave slot
     DevBuf slot_base[2], mask[2], predicted[2], sub_counts[2], counts[2];
     uint32_t subcap[2] = {0, 0};  // list entries reserved per (material key, sub-list)
+    uint64_t key_objects[2][3] = {};  // enabled objects per material key AS THE CULL OF THAT INDEX SAW THEM: last frame's predicted
+                                      // triangles sit in last frame's draw ranges (forward.rs:224-232,286), whatever the keys are now
     DevBuf residual;
     bool range_set = false;      // r3n_set_camera_object_range: this camera's own object range (multi-GPU: shadow views owned whole)
     uint32_t range_begin = 0, range_end = 0xFFFFFFFFu;
@@ -1100,7 +1102,9 @@ static int upload_level_offsets(r3n_ctx *c, const r3n_texture_desc32 *descs, uin
     c->h_tex_short.assign(n, 0);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t w = descs[i].width, h = descs[i].height;
-        c->h_tex_short[i] = (w && h && ((w & (w - 1u)) | (h & (h - 1u))) == 0u && descs[i].format < R3N_POOL_FLOAT) ? 1 : 0;
+        // (w * h <= 2^29: tex_level_start_pow2 forms 1 << (log2 w + log2 h + 2) in 32 bits -- a single-level 32768^2 texture would
+        // shift by 32; it goes to the general sampler instead)
+        c->h_tex_short[i] = (w && h && ((w & (w - 1u)) | (h & (h - 1u))) == 0u && (uint64_t)w * h <= (1ull << 29) && descs[i].format < R3N_POOL_FLOAT) ? 1 : 0;
     }
     c->classes_dirty = true; c->cutout_short_dirty = true;
     TRY(ensure(c, c->tex_level_off, off.size() * 4, false, -1));
@@ -1571,6 +1575,17 @@ int r3n_uniform_bake(r3n_ctx *c, r3n_camera cam, const r3n_camera_header240 *hdr
     return check_launch(c, "k_uniform_bake");
 }
 
+static void key_census(r3n_ctx *c) {
+    if (!c->key_census_dirty) return;
+    c->key_objects[0] = c->key_objects[1] = c->key_objects[2] = 0;
+    for (uint32_t o = 0; o < c->capacity; ++o)
+        if (c->h_ntri[o]) {
+            const uint32_t mi = c->h_material[o];
+            c->key_objects[mi < c->h_material_key.size() ? std::min<uint32_t>(c->h_material_key[mi], 2) : 0]++;
+        }
+    c->key_census_dirty = false;
+}
+
 int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     if (!c) return R3N_ERR_INVALID_ARG;
     CamState *s = find_cam(c, cam, false);
@@ -1583,6 +1598,8 @@ int r3n_cull(r3n_ctx *c, r3n_camera cam) {
     HIP_TRY(c, hipSetDevice(c->device));
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     const int cur = s->cur, prev = 1 - cur;
+    key_census(c);
+    for (int k = 0; k < 3; ++k) s->key_objects[cur][k] = c->key_objects[k];
     const int lane = cam_lane(c, cam);
     hipStream_t stream = lane_stream(c, lane);
     // (re)allocations below run on the main stream: size everything first, then fork
@@ -1709,18 +1726,11 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
     if (!c->in_frame) return fail(c, R3N_ERR_STATE, "forward: outside a frame");
     CamState *s = find_cam(c, cam, false);
     if (!s || !s->has_hdr || c->capacity == 0) return R3N_OK;  // nothing baked / culled yet: forward.rs:214-242
-    if (c->key_census_dirty) {
-        c->key_objects[0] = c->key_objects[1] = c->key_objects[2] = 0;
-        for (uint32_t o = 0; o < c->capacity; ++o)
-            if (c->h_ntri[o]) {
-                const uint32_t mi = c->h_material[o];
-                c->key_objects[mi < c->h_material_key.size() ? std::min<uint32_t>(c->h_material_key[mi], 2) : 0]++;
-            }
-        c->key_census_dirty = false;
-    }
-    // no object carries this material key: the draw-call range is empty ("no draw calls for this material",
-    // forward.rs:285-288) -- known on the host, so no launch at all
-    if (c->key_objects[key] == 0) return R3N_OK;
+    key_census(c);
+    // no object carried this material key when the draw ranges were made: the range is empty ("no draw calls for this material",
+    // forward.rs:285-288) -- known on the host, so no launch at all.  Last frame's ranges for the predicted source: a material
+    // whose key Renderer::update_material changed since (renderer/mod.rs:256-266) still has its triangles in the OLD key's range
+    if ((source == R3N_SOURCE_PREDICTED ? s->key_objects[1 - s->cur][key] : c->key_objects[key]) == 0) return R3N_OK;
     const bool viewport = cam == R3N_CAMERA_VIEWPORT;
     if ((pass == R3N_PASS_FORWARD) != viewport) return fail(c, R3N_ERR_UNSUPPORTED, "forward: FORWARD needs the viewport, DEPTH a shadow camera");
     if (key == R3N_KEY_BLEND) {
@@ -1798,7 +1808,9 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         if (s->vp_size == 0 || s->vp_x + s->vp_size > c->atlas_w || s->vp_y + s->vp_size > c->atlas_h)
             return fail(c, R3N_ERR_STATE, "forward: shadow viewport not set or outside the atlas");
         a.vp_x = s->vp_x; a.vp_y = s->vp_y; a.vp_w = s->vp_size; a.vp_h = s->vp_size; a.target_pitch = c->atlas_w;
-        a.row_begin = std::min(s->band_begin, s->vp_size); a.row_end = std::min(s->band_end, s->vp_size);  // (whole view unless split over ranks)
+        // whole view unless split over ranks -- and the split is r3n_render_frame's (it also issues the exchange that fills in the other
+        // bands): a caller of the per-node API after a split frame draws the whole view, not a stale band
+        if (c->fused_frame) { a.row_begin = std::min(s->band_begin, s->vp_size); a.row_end = std::min(s->band_end, s->vp_size); }
         a.depth = c->atlas.as<uint32_t>();
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         if (tex && cutout_alpha_short(c)) {
@@ -1875,6 +1887,7 @@ static ShadeArgs make_shade_args(r3n_ctx *c, uint32_t r0, uint32_t r1) {
     a.samples_out = nullptr;
     a.tri_rec = nullptr;
     a.seen = nullptr;
+    a.resolve_lds = c->tune.resolve_lds;  // (the key was parsed and never reached the launches)
     a.total_tris = (uint32_t)c->total_tris;
     a.view_lights = nullptr;
     a.material_feat = nullptr;

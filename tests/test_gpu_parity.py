@@ -1532,3 +1532,26 @@ def test_sharded_two_contexts_multi_frame(r3):
     assert fr["residual"].sum() > 0 and fr["pass"].sum() > 1000
     for r in (ref, a, b):
         r.close()
+
+
+def test_baked_matrices_of_last_frames_visible_slots(r3):
+    """r3n_render_frame bakes the slots inside the frustum now OR in the camera's previous frame (last frame's predicted
+    triangles are drawn with THIS frame's matrices, forward.rs:224-232); compare_frames checks the first set only.  The camera turns
+    away between two frames: the slots that left the frustum must hold this frame's matrices all the same."""
+    o, p = both(r3, oh.LEFT, f32(320) / f32(192))
+    for r, mk in ((o, omk), (p, r3.material_record)):
+        scenes.build_random_scene(r, oh, mk, 300, 0xBA4ED, lights=1)
+    kw = dict(ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.02, 0.03, 0.05, 1.0))
+    prev = None
+    left = 0
+    for f, ang in enumerate((0.0, 0.9, 1.8, 0.4)):
+        for r in (o, p):
+            r.set_camera_data(oh.look_at_lh((0.0, 2.0, -4.0), (12.0 * math.sin(ang), 1.0, 12.0 * math.cos(ang) - 4.0), (0, 1, 0)), ("perspective", 50.0, 0.1))
+        fo, fp = o.render(320, 192, **kw), p.render(320, 192, **kw)
+        compare_frames(fo, fp, f"frame {f}")
+        if prev is not None:
+            gone = prev & ~fo["visible"].astype(bool) & (fo["objects"][:, 29] != 0)
+            left += int(gone.sum())
+            assert np.array_equal(fo["baked"].view(np.uint32)[gone], fp["baked"].view(np.uint32)[gone]), f"frame {f}: slots that left the frustum"
+        prev = fo["visible"].astype(bool)
+    assert left > 20, "the camera turned far enough for objects to leave the frustum"

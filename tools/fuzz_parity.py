@@ -9,7 +9,8 @@ moved, one removed and one added in between, so the temporal two-pass culling, H
 comparison is tests/test_gpu_parity.py::compare_frames (sets, keys, atlas, HDR bit-exact; framebuffer within 1e-3).
 
 --mutate: five frames and, between them, up to four world edits drawn from the case's seed -- objects moved / removed / added
-one by one or in bulk (the object buffer doubles, freed handles are reused), a material rewritten, directional lights turned / resized / added (the shadow atlas is laid out again), point lights moved / added, the target
+one by one or in bulk (the object buffer doubles, freed handles are reused), a material rewritten or moved to ANOTHER TRANSPARENCY
+KEY (the frame after is compared like every other: tests/test_key_flip.py), directional lights turned / resized / added (the shadow atlas is laid out again), point lights moved / added, the target
 resized, the sample count switched, new meshes / materials / textures created between frames.
 
     python tools/fuzz_parity.py --seconds 240 --first-seed 1000        # prints one line per case, a summary, exit code 1 on a mismatch
@@ -158,9 +159,7 @@ def mutate(rng, c, st, pair, f):
             assert list(hs[0]) == list(hs[1]), "handles diverge (bulk)"
             live.extend(int(h) for h in hs[0])
             done.append(f"bulk +{n}")
-        elif kind == 5:  # rewrite a material (colour, roughness) in place.  Its transparency key stays: the frame in which a key changes
-            # is outside the reference's domain (last frame's predicted triangles sit in the draw range of the OLD key,
-            # forward.rs:286; tests/test_gpu_parity.py::test_material_key_flip_between_frames compares the converged state)
+        elif kind == 5:  # rewrite a material (colour, roughness) in place, its transparency key kept (key changes: flip_key below)
             col = (rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), 1.0)
             rough = rng.uniform(0.2, 0.9)
             for i, (r, _hm, mk) in enumerate(pair):
@@ -227,7 +226,28 @@ def mutate(rng, c, st, pair, f):
             assert hs[0] == hs[1], f"handles diverge: {hs}"
             live.append(hs[0])
             done.append(("mesh", "newmat", "texture")[kind - 11] + f" {hs[0]}")
+        elif kind == 14:
+            done.append(flip_key(st, pair))
+    if st["flip_rng"].uniform() < 0.3:
+        done.append(flip_key(st, pair))
     return done
+
+
+def flip_key(st, pair):
+    """Renderer::update_material with another transparency (renderer/mod.rs:256-266; the archetype stays: material.rs:163-188): ANY
+    material of the scene moves to a drawn key, alpha_cutout following it (pbr/material.rs:562-565).  The frame after is the one in
+    which last frame's predicted triangles sit in the OLD key's draw range (tests/test_key_flip.py).  Drawn from a stream of its
+    own, so the schedule of the other edits is what it was before flips joined the campaign."""
+    rng = st["flip_rng"]
+    o = pair[0][0]
+    m = rng.randint(len(o.materials))
+    key = (o.materials[m][1] + 1 + rng.randint(2)) % 3
+    cutout = rng.uniform(0.1, 0.9) if key == scenes.CUTOUT else 0.0
+    for r, _hm, _mk in pair:
+        rec = np.array(r.materials[m][0], dtype=f32, copy=True)
+        rec[50] = f32(cutout)
+        r.update_material(m, rec, key=key)
+    return f"material {m} -> key {key}"
 
 
 def run_mutating_case(r3, c):
@@ -247,6 +267,7 @@ def run_mutating_case(r3, c):
             st["mesh"].append((scenes.cube_mesh(r), r.add_mesh(pos, idx, normals=nrm)))
             st["mat"].append((scenes.lit(r, mk, (0.8, 0.7, 0.2, 1.0)), scenes.lit(r, mk, (0.3, 0.6, 0.9, 1.0))))
         rng = scenes.Pcg32(c["seed"] * 7919 + 13)
+        st["flip_rng"] = scenes.Pcg32(c["seed"] * 104729 + 71)
         for f in range(5):
             view, proj = camera(c, f)
             for r in (o, p):
