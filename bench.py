@@ -97,7 +97,7 @@ def build_workload(args, r, hm, mk):
                             "camera dolly from the given camera")
         return info
     if args.config == 4:
-        info = dict(S.emerald_like(r, hm, mk, n_lights=4))
+        info = dict(S.emerald_like(r, hm, mk, n_lights=4, n_objects=getattr(args, "emerald_objects", 1 << 20)))
         info.update(ambient=AMBIENT, clear=CLEAR, data="synthetic",
                     workload="BASELINE.json configs[3] stand-in: emerald_like (seed 0xE5A0), 1 048 576 objects / 55 M triangles, 3840x2160, full PBR "
                              "opaque + 4 directional shadow views (2048^2), factor-only materials, camera dolly" + (", MSAA x4" if args.samples == 4 else ""))
@@ -137,7 +137,7 @@ def split_model(stage_ms, launches, world, width, height, samples, n_views, setu
     cams = 1 + n_views
     # the stage table sums every camera's launches: a camera's share = the per-launch average (2 viewport draws: predicted + residual)
     cull_vp = per("bake") * (1 if launches.get("bake") else 0) + per("object_cull") + per("triangle_cull")
-    small_vp, big_vp = stage_ms["raster"], stage_ms["raster_big"]
+    small_vp, big_vp = stage_ms["raster"] + stage_ms.get("raster_cut", 0.0), stage_ms["raster_big"] + stage_ms.get("raster_big_cut", 0.0)
     shadow_cull = (cams - 1) * (per("object_cull") + per("triangle_cull"))
     shadow = stage_ms["shadow_raster"] + stage_ms["shadow_raster_big"] + shadow_cull
     views_here = -(-n_views // world) if n_views else 0
@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--objects", type=int, default=3000)
     ap.add_argument("--tris", type=int, default=2_800_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-tally", action="store_true", help="skip the oracle's op tally of the resolve (oracle/tally.h; ~15 s of CPU)")
     ap.add_argument("--untextured", action="store_true",
                     help="factor-only materials (the round-1 workload before textures were built); default: every material "
                          "has base colour + normal + AO/roughness/metallic maps")
@@ -507,6 +508,43 @@ def main():
                     roofline_of(kname, stage, 56.0 * drawn + 4.0 * covered, kname,
                                 "per shadow view: 56 B per drawn triangle + 4 B per covered texel, charged to each of the view's raster launches "
                                 "(both walk the same triangles / texels between them)", {"drawn_triangles": int(drawn), "covered_texels": int(covered)})
+            # viewport rasterisers (opaque.wgsl:91-135 + the depth test; VERDICT r5 missing #3): the two passes of a frame between them
+            # read every drawn triangle once per pass it is drawn in (56 B: list entry + indices + positions + setup hand-over) and
+            # leave one 8-B key per covered sample.  Predicted pass: last frame's passing triangles (this frame's count stands in for
+            # it: the camera moves by a fraction of a pixel per frame), residual pass: the newly visible ones.  Charged per key
+            # (opaque / cutout launches are separate stages) by the key's share of the drawn triangles.
+            tri_obj = np.searchsorted(last["tri_base"], np.arange(len(last["pass"])), side="right") - 1
+            mkeys = np.asarray([k for _rec, k in r.materials], dtype=np.uint8)
+            okeys = np.zeros(r.capacity, dtype=np.uint8)
+            for h, m in r.object_meta.items():
+                okeys[h] = mkeys[m["material"]]
+            tkeys = okeys[np.clip(tri_obj, 0, r.capacity - 1)]
+            covered_samples = float((last["vis"] != 0).sum())
+            drawn_by_key = [float(((last["pass"] != 0) & (tkeys == k)).sum() + ((last["residual"] != 0) & (tkeys == k)).sum()) for k in (0, 1)]
+            drawn_all = max(sum(drawn_by_key), 1.0)
+            for k, (st_small, st_big, tag) in enumerate((("raster", "raster_big", ""), ("raster_cut", "raster_big_cut", ",cutout"))):
+                for stage, kname in ((st_small, f"k_raster_small<vis{tag}>"), (st_big, f"k_raster_big<vis{tag}>")):
+                    if launches.get(stage) and drawn_by_key[k]:
+                        per_frame = 56.0 * drawn_by_key[k] + 8.0 * covered_samples * drawn_by_key[k] / drawn_all
+                        roofline_of(kname, stage, per_frame / launches[stage], kname,
+                                    "viewport, " + ("cutout" if k else "opaque") + " key: 56 B per drawn triangle (predicted + residual passes) + 8 B per covered sample "
+                                    "(this key's share of the drawn triangles), per frame / launches of the stage; both kernels of a pass walk the same "
+                                    "triangles / pixels between them" + ("; the alpha test samples the albedo map per fragment (opaque.wgsl:207-235): texels excluded" if k else ""),
+                                    {"drawn_triangles_per_frame": int(drawn_by_key[k]), "covered_samples": int(covered_samples)})
+            # object pass (uniform_prep.wgsl + batching.rs:144-148 on the GPU): per slot 20 B of the SoA view + 1 B flag + 4 B slot base,
+            # per visible object 8 B list entry, per baked slot 64 B transform in + 128 B matrices out; mean over the cameras
+            if launches.get("object_cull"):
+                vis_mean = float(np.mean([int(c["visible"].astype(bool).sum()) for c in cams]))
+                roofline_of("k_object_pass_chained", "object_cull", 25.0 * r.capacity + (8.0 + 192.0) * vis_mean, "k_object_pass_chained",
+                            "per camera: 25 B per object slot (sphere + meta read, flag + slot base written) + 200 B per frustum-visible object (list entry, "
+                            "transform read, two matrices written); includes the fused uniform bake", {"slots": int(r.capacity), "visible_objects": int(vis_mean)})
+            # Hi-Z (hi_z.rs:161-234): the keys' depth words read (8 B per sample), mip 0 written (4 B per pixel), the chain above it 4/3 B per pixel
+            if launches.get("hiz"):
+                hz = rooflines_hiz = (8.0 * args.samples + 4.0 + 4.0 / 3.0) * WIDTH * HEIGHT
+                d = roofline_of("k_hiz_head + k_hiz_tail", "hiz", hz / launches["hiz"], "k_hiz_head",
+                                "per frame: 8 B per key sample read + 4 B per pixel of mip 0 + 4/3 B per pixel of the levels above, over the stage's launches "
+                                "(head: the first levels in one pass; tail: the last levels in one workgroup, latency-bound by construction)")
+                d["bytes_per_frame"] = int(hz)
         # the deferred PBR resolve (one launch per frame).  HBM floor: 8 B key read + 8 B Rgba16Float write per pixel (BASELINE.md
         # section 5: ">= 16 B / shaded pixel") + 4 B for the Rgba8UnormSrgb blit fused into it.  VALU-bound, not HBM-bound, so its
         # fraction of the HBM roofline is small by construction; `valu` says how close it is to its own bound.
@@ -592,11 +630,65 @@ def main():
         result["cpu_baseline"] = cb
         result["parity"] = parity
         result["vs_cpu_baseline"] = round(result["value"] / cb["value"], 1) if cb["value"] else None
+    # ---------------------------------------------------------------- the oracle's op tally beside the resolve's counter figure (N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_op_tally and not args.scene:
+        try:
+            ot = op_tally(args)
+        except Exception as e:  # noqa: BLE001  (checker-side extra: never costs the line)
+            ot = {"error": repr(e)}
+        rs = result["roofline"] if result["roofline"].get("kernel") == "k_resolve_opaque" else result["rooflines"].get("shade")
+        if rs is not None and ot and "algorithmic_flops_per_shaded_pixel" in ot:
+            ms = rs["ms_per_launch"]
+            px = WIDTH * HEIGHT * (args.samples if args.samples > 1 else 1)
+            tf = ot["algorithmic_flops_per_shaded_pixel"] * px / (ms * 1e-3) / 1e12
+            ot["tflops_at_this_launch"] = round(tf, 2)
+            ot["frac_of_vector_peak"] = round(tf / VALU_PEAK_TFLOPS, 4)
+            ot["note"] = ("fs_main's f32 flops as the ORACLE executes them x every pixel of the target / the resolve's launch time / the vector peak.  An upper "
+                          "estimate of the algorithm's minimum (the oracle recomputes the mip footprint for each of a material's maps and filters every "
+                          "texel in f32; background pixels are charged like shaded ones); the HIP kernel's executed flops are roofline.valu.useful_tflops")
+        if rs is not None:
+            rs["algorithmic"] = ot
     if rank == 0:
         print(json.dumps(result))
     r.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def op_tally(args):
+    """"exact count from the oracle's op tally" -- the ALGORITHMIC f32 flops of the resolve per shaded pixel,
+    counted by the oracle itself (oracle/tally.h: r3o.c compiled with a counting f32, bit-identical frames), on the workload's own
+    materials / lights / texture classes with a cut-down geometry (the count per pixel depends on the material class and the
+    light count, not on how many triangles there are) at 480x270.  Single-threaded: a few seconds.  CHECKER-SIDE code: the figure
+    stands beside the HIP kernel's counter figure in `roofline`, nothing of the product runs through it."""
+    import copy
+    import numpy as np
+    from oracle import host as oh
+    from oracle import lib as olib
+    from oracle.world import OracleRenderer, material_record as omk
+    t0 = time.perf_counter()
+    a2 = copy.copy(args)
+    a2.objects, a2.tris, a2.emerald_objects = min(args.objects, 250), min(args.tris, 80000), 30000
+    w, h = 480, 270
+    o = OracleRenderer(oh.RIGHT, np.float32(w) / np.float32(h), lib=olib.OracleLib(tally=True))
+    info_o = build_workload(a2, o, oh, omk)
+    o.set_camera_data(camera_path(oh, info_o["camera"][0], 1), info_o["camera"][1])
+    fo = o.render(w, h, samples=args.samples, ambient=info_o["ambient"], clear_color=info_o["clear"])
+    shaded = int((fo["vis"] != 0).sum())
+    t = o.stage_tally.get("shade", {})
+    if not shaded or not t:
+        return None
+    fs, vs, ff = t["fs_main"], t["vs_main"], t["fixed_function"]
+    return {"algorithmic_flops_per_shaded_pixel": round(fs["flops"] / shaded, 1),
+            "fs_main_per_shaded_pixel": {k: round(v / shaded, 2) for k, v in fs.items()},
+            "vs_main_flops_per_vertex": round(vs["flops"] / (3.0 * shaded), 1),
+            "fixed_function_flops_per_shaded_pixel": round(ff["flops"] / shaded, 1),
+            "shaded_samples": shaded, "seconds": round(time.perf_counter() - t0, 1),
+            "source": "oracle/tally.h: the oracle's own restatement of opaque.wgsl:203-551 + math/brdf.wgsl + shadow/pcf.wgsl with every f32 operation "
+                      "counted (add / sub / mul / div / sqrt / pow 1, fmaf 2; min / max / floor / compares / conversions 0), on the workload's materials and "
+                      f"lights, geometry cut down to {info_o['objects']} objects, {w}x{h}.  algorithmic_flops_per_shaded_pixel = fs_main only (texture "
+                      "filtering arithmetic included); the oracle redoes vs_main (three vertices) and the triangle setup + attribute interpolation for "
+                      "every pixel: those are counted apart (vs_main per vertex; fixed-function work per pixel) and are NOT in the figure"}
 
 
 def cpu_baseline(args, hip_frame1):

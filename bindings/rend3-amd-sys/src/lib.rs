@@ -91,7 +91,9 @@ pub const R3N_STAGE_EXCHANGE_SHADOW: i32 = 14;
 pub const R3N_STAGE_EXCHANGE_DEPTH: i32 = 15;
 pub const R3N_STAGE_EXCHANGE_ROWS: i32 = 16;
 pub const R3N_STAGE_EXCHANGE_KEYS: i32 = 17;
-pub const R3N_STAGE_COUNT: i32 = 18;
+pub const R3N_STAGE_RASTER_CUT: i32 = 18;
+pub const R3N_STAGE_RASTER_BIG_CUT: i32 = 19;
+pub const R3N_STAGE_COUNT: i32 = 20;
 
 #[repr(C)]
 pub struct r3n_ctx {

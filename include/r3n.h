@@ -540,7 +540,9 @@ int r3n_readback_output(r3n_ctx *ctx, uint8_t *rgba8, float *rgba_f32); /* eithe
 #define R3N_STAGE_EXCHANGE_DEPTH 15  /* depth bands (keys under MSAA) gathered in front of Hi-Z (main stream) */
 #define R3N_STAGE_EXCHANGE_ROWS 16   /* Rgba8 rows gathered behind the resolve (resolve's stream) */
 #define R3N_STAGE_EXCHANGE_KEYS 17   /* object-range split: MAX reduce-scatter of the visibility keys onto the row bands (main stream) */
-#define R3N_STAGE_COUNT 18
+#define R3N_STAGE_RASTER_CUT 18      /* viewport, CUTOUT key: per-triangle pass (alpha test per fragment; the opaque key's launches stay under RASTER) */
+#define R3N_STAGE_RASTER_BIG_CUT 19  /* viewport, CUTOUT key: work-item pass */
+#define R3N_STAGE_COUNT 20
 int r3n_timing_enable(r3n_ctx *ctx, int enable);
 /* What a timed span holds besides its kernels -- two event packets and a launch's dispatch, measured around an empty kernel when
  * timing is first enabled (median of 32) -- and already taken off every span r3n_stage_times reports. */

@@ -32,10 +32,35 @@ def build(force=False):
     return _SO
 
 
+_SO_TALLY = os.path.join(_HERE, "libr3o_tally.so")
+
+
+def build_tally(force=False):
+    """The same restatement with a counting f32 (oracle/tally.h, r3o_tally.cpp): SURVEY.md section 8(d)'s op tally.  C++ (the
+    operators), single-threaded (no -fopenmp: plain counters), the same rounding flags as the oracle proper."""
+    deps = _DEPS + [os.path.join(_HERE, "tally.h"), os.path.join(_HERE, "r3o_tally.cpp")]
+    if not force and os.path.exists(_SO_TALLY) and os.path.getmtime(_SO_TALLY) >= max(os.path.getmtime(d) for d in deps):
+        return _SO_TALLY
+    obj = os.path.join(_HERE, "bcn_tally.o")
+    subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-c", "-ffp-contract=off", "-fno-fast-math", "-o", obj, os.path.join(_HERE, "bcn.c")], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fpermissive", "-w", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas",
+                    "-o", _SO_TALLY, os.path.join(_HERE, "r3o_tally.cpp"), obj, "-lm"], check=True)
+    os.remove(obj)
+    return _SO_TALLY
+
+
 class OracleLib:
-    def __init__(self):
-        build()
-        self.c = ctypes.CDLL(_SO)
+    def __init__(self, tally=False):
+        self.tally = tally
+        if tally:
+            self.c = ctypes.CDLL(build_tally())
+            self.c.r3o_tally_reset.restype = None
+            self.c.r3o_tally_reset.argtypes = []
+            self.c.r3o_tally_read.restype = None
+            self.c.r3o_tally_read.argtypes = [vp]
+        else:
+            build()
+            self.c = ctypes.CDLL(_SO)
         c = self.c
         c.r3o_hiz_mip_count.restype = ctypes.c_uint32
         c.r3o_hiz_mip_count.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
@@ -100,6 +125,26 @@ class OracleLib:
 
     def __getattr__(self, name):
         return getattr(self.c, name)
+
+
+    def tally_reset(self):
+        self.c.r3o_tally_reset()
+
+    def tally_read(self):
+        """{class: count} since the last reset (oracle/tally.h), all scopes together, + "flops" = add + mul + div + sqrt +
+        transcendental + 2 x fma; the same per scope under "fixed_function" / "vs_main" / "fs_main" (r3o.c R3O_SCOPE)"""
+        out = np.zeros((3, 8), dtype=np.uint64)
+        self.c.r3o_tally_read(self.ptr(out))
+        names = ("add", "mul", "div", "sqrt", "transcendental", "fma", "minmax_cmp", "convert")
+
+        def row(v):
+            d = dict(zip(names, (int(x) for x in v)))
+            d["flops"] = d["add"] + d["mul"] + d["div"] + d["sqrt"] + d["transcendental"] + 2 * d["fma"]
+            return d
+        d = row(out.sum(axis=0))
+        for k, scope in enumerate(("fixed_function", "vs_main", "fs_main")):
+            d[scope] = row(out[k])
+        return d
 
 
 _LIB = None

@@ -42,6 +42,13 @@
 #include <string.h>
 #include <math.h>
 
+/* Scopes of the op tally (oracle/tally.h, the counting build): which STAGE of the reference's pipeline the arithmetic that
+ * follows belongs to -- 0 fixed-function work (triangle setup, coverage, attribute interpolation), 1 vs_main, 2 fs_main.
+ * Nothing in the oracle proper: the macro is empty. */
+#ifndef R3O_SCOPE
+#define R3O_SCOPE(n) ((void)0)
+#endif
+
 #define R3O_INVALID 0xFFFFFFFFu
 
 /* ------------------------------------------------------------------ layouts */
@@ -1147,6 +1154,7 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
     int positive_visible = (hdr->flags & PCU_POSITIVE_AREA_VISIBLE) != 0;
     uint32_t nobj = hdr->object_count;
     uint32_t slot = id - 1u;
+    R3O_SCOPE(0);
     /* object = last slot o with tri_base[o] <= slot and a non-empty range */
     uint32_t lo = 0, hi = nobj;
     while (hi - lo > 1u) {
@@ -1167,6 +1175,7 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
     float lam[3] = {E[0] * rs, E[1] * rs, E[2] * rs};
 
     /* vertex stage, opaque.wgsl:114-134 */
+    R3O_SCOPE(1);
     const float *mv = baked[o].model_view;
     float inv_s2[3] = {1.0f / dot3(mv + 0, mv + 0), 1.0f / dot3(mv + 4, mv + 4), 1.0f / dot3(mv + 8, mv + 8)};
     float vpos[4] = {0, 0, 0, 0}, nrm[3] = {0, 0, 0}, col[4] = {0, 0, 0, 0};
@@ -1191,6 +1200,7 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
         } else
             for (int c = 0; c < 4; ++c) vc[k][c] = 1.0f;
     }
+    R3O_SCOPE(0); /* attribute interpolation: the rasteriser's */
     for (int c = 0; c < 4; ++c) vpos[c] = (lam[0] * vp[0][c] + lam[1] * vp[1][c]) + lam[2] * vp[2][c];
     for (int c = 0; c < 3; ++c) nrm[c] = (lam[0] * vn[0][c] + lam[1] * vn[1][c]) + lam[2] * vn[2][c];
     for (int c = 0; c < 3; ++c) tng[c] = (lam[0] * vt[0][c] + lam[1] * vt[1][c]) + lam[2] * vt[2][c];
@@ -1198,6 +1208,7 @@ static void shade_fragment(const shade_ctx *sc, uint32_t id, uint32_t x, uint32_
 
     /* fragment stage, opaque.wgsl:203-424.  Texture slots (managers/material.rs:25-29 order): 0 albedo, 1 normal,
      * 2 roughness, 3 metallic, 4 reflectance, 5 clear coat, 6 clear coat roughness, 7 emissive, 8 anisotropy, 9 AO */
+    R3O_SCOPE(2);
     pixel_data px;
     int any_tex = 0;
     for (int k = 0; k < 10; ++k) any_tex |= mat->tex[k] != 0u;

@@ -159,8 +159,8 @@ class _Mesh:
 
 
 class OracleRenderer:
-    def __init__(self, handedness=host.LEFT, aspect_ratio=None):
-        self.lib = get_lib()
+    def __init__(self, handedness=host.LEFT, aspect_ratio=None, lib=None):
+        self.lib = get_lib() if lib is None else lib  # (lib: oracle.lib.OracleLib(tally=True) -- the op-counting build, stage_tally below)
         self.handedness = handedness
         self.aspect_ratio = aspect_ratio
         self.mesh_words = np.zeros(0, dtype=np.uint32)
@@ -507,6 +507,8 @@ class OracleRenderer:
         lib = self.lib
         # wall-clock per stage of this frame (BASELINE.md section 3 split), read by bench.py's cpu_baseline leg
         stage_s = self.stage_s = {k: 0.0 for k in ("bake", "cull", "hiz", "shadow_depth", "forward_raster", "shade", "tonemap")}
+        tallying = bool(getattr(lib, "tally", False))
+        stage_tally = self.stage_tally = {}
 
         class _Span:
             def __init__(self, name):
@@ -514,9 +516,19 @@ class OracleRenderer:
 
             def __enter__(self):
                 self.t0 = time.perf_counter()
+                if tallying:
+                    lib.tally_reset()
 
             def __exit__(self, *exc):
                 stage_s[self.name] += time.perf_counter() - self.t0
+                if tallying:  # the op-counting build (oracle/tally.h): f32 operations per stage of this frame
+                    def add(dst, src):
+                        for k, v in src.items():
+                            if isinstance(v, dict):
+                                add(dst.setdefault(k, {}), v)
+                            else:
+                                dst[k] = dst.get(k, 0) + v
+                    add(stage_tally.setdefault(self.name, {}), lib.tally_read())
         # Renderer::evaluate_instructions (renderer/eval.rs): last frame's removals become real
         for h in self.pending_free:
             self.objects[h] = 0

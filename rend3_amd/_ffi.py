@@ -18,7 +18,8 @@ PASS_DEPTH, PASS_FORWARD = 0, 1
 SOURCE_PREDICTED, SOURCE_RESIDUAL = 0, 1
 KEY_OPAQUE, KEY_CUTOUT, KEY_BLEND = 0, 1, 2
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big",
-          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth", "exchange_rows", "exchange_keys"]
+          "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth", "exchange_rows", "exchange_keys",
+          "raster_cut", "raster_big_cut"]
 
 COMM_ID_BYTES, COMM_IDS = 128, 3  # R3N_COMM_ID_BYTES, R3N_COMM_IDS
 

@@ -164,6 +164,7 @@ struct r3n_ctx {
         uint32_t cull_lds = 0, vp_cull_lds = 0;                             // triangle cull
         uint32_t resolve_lds = 0;                                           // single-sample resolve
         uint32_t big_grid = R3N_BIG_GRID, small_grid = R3N_SMALL_GRID;
+        uint32_t comm_serial = 1;  // r3n_comm_init: the three communicators' collectives in ONE total order per device (comm_order_*)
     } tune;
     bool cutout_short_dirty = true, cutout_short = false;  // cutout_alpha_short(): census of the cutout materials' albedo maps
     bool key_census_dirty = true;
@@ -224,6 +225,8 @@ struct r3n_ctx {
         uint32_t rank = 0, world = 1;
         ncclComm_t main = nullptr, shadow = nullptr, rows = nullptr;
         DevBuf stage[R3N_MAX_SHADOW_VIEWS];  // contiguous copies of the shadow rectangles (what a broadcast moves)
+        hipEvent_t order_ev = nullptr;       // tune.comm_serial: behind the last collective enqueued, on whichever stream that was
+        bool order_pending = false;
     } comm;
     DevBuf owners;  // r3n_set_object_owners: owner rank per object slot (p == nullptr: slot ranges)
     uint32_t owner_rank = 0, owners_n = 0;
@@ -377,7 +380,7 @@ int check_async_status(r3n_ctx *c) {
 
 static const char *const kStageNames[R3N_STAGE_COUNT] = {"bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear",
     "raster_big", "shadow_raster", "shadow_raster_big", "skinning", "vertex", "pose", "exchange_shadow", "exchange_depth",
-    "exchange_rows", "exchange_keys"};
+    "exchange_rows", "exchange_keys", "raster_cut", "raster_big_cut"};
 static void crumb(const r3n_ctx *c, const char *what, long long a, long long b) {
     if (c->crumb_fd < 0) return;
     char line[160];
@@ -698,7 +701,7 @@ int apply_tuning(r3n_ctx *c, const char *kv) {
             {"cut_small_lds", &t.cut_small_lds, 0, 65536, 1}, {"vp_cut_small_lds", &t.vp_cut_small_lds, 0, 65536, 1}, {"cull_lds", &t.cull_lds, 0, 65000, 1}, {"vp_cull_lds", &t.vp_cull_lds, 0, 65000, 1},
             {"resolve_lds", &t.resolve_lds, 0, 61440, 1}, {"big_grid", &t.big_grid, 256, 65536, 1},
             {"small_grid", &t.small_grid, R3N_SUBQ, 32768, R3N_SUBQ}, {"timed_pipeline", &t.timed_pipeline, 0, 1, 1},
-            {"prio_main", &t.prio_main, 0, 2, 1}, {"prio_shade", &t.prio_shade, 0, 2, 1}, {"prio_aux", &t.prio_aux, 0, 2, 1}};  // (read at r3n_create only)  // (a multiple of R3N_SUBQ: whole blocks per sub-list)
+            {"comm_serial", &t.comm_serial, 0, 1, 1}, {"prio_main", &t.prio_main, 0, 2, 1}, {"prio_shade", &t.prio_shade, 0, 2, 1}, {"prio_aux", &t.prio_aux, 0, 2, 1}};  // (read at r3n_create only)  // (a multiple of R3N_SUBQ: whole blocks per sub-list)
         bool known = false;
         for (auto &k : keys)
             if (key == k.name) {
@@ -1789,8 +1792,8 @@ int r3n_forward(r3n_ctx *c, r3n_camera cam, uint32_t pass, uint32_t source, uint
         const bool tex = key == R3N_KEY_CUTOUT && c->n_textures > 0;
         const bool nocut = key != R3N_KEY_CUTOUT;  // the opaque key's instantiations carry nothing of the cutout test (kernels_raster.h NOCUT)
         auto launch = [&](auto small, auto big) {
-            { Timed t(c, R3N_STAGE_RASTER, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), nocut ? c->tune.vp_small_lds : c->tune.vp_cut_small_lds, stream, a); }
-            { Timed t(c, R3N_STAGE_RASTER_BIG, stream); hipLaunchKernelGGL(big, dim3(c->tune.big_grid), dim3(256), nocut ? c->tune.vp_big_lds : c->tune.vp_cut_big_lds, stream, a); }
+            { Timed t(c, nocut ? R3N_STAGE_RASTER : R3N_STAGE_RASTER_CUT, stream); hipLaunchKernelGGL(small, dim3(small_grid), dim3(256), nocut ? c->tune.vp_small_lds : c->tune.vp_cut_small_lds, stream, a); }
+            { Timed t(c, nocut ? R3N_STAGE_RASTER_BIG : R3N_STAGE_RASTER_BIG_CUT, stream); hipLaunchKernelGGL(big, dim3(c->tune.big_grid), dim3(256), nocut ? c->tune.vp_big_lds : c->tune.vp_cut_big_lds, stream, a); }
         };
         const bool shorta = tex && cutout_alpha_short(c);
         if (c->samples == 4) {
@@ -2259,6 +2262,8 @@ int r3n_comm_destroy(r3n_ctx *c) {
         if (*k) { (void)rccl().CommDestroy(*k); *k = nullptr; }
     for (DevBuf &b : c->comm.stage)
         if (b.p) { (void)hipFree(b.p); b = DevBuf{}; }
+    if (c->comm.order_ev) { (void)hipEventDestroy(c->comm.order_ev); c->comm.order_ev = nullptr; }
+    c->comm.order_pending = false;
     c->comm.on = false; c->comm.by_objects = false; c->comm.world = 1; c->comm.rank = 0;
     c->shard_rows = false; c->row_begin = 0; c->row_end = 0xFFFFFFFFu;
     for (auto &kv : c->shadows) { kv.second.band_begin = 0; kv.second.band_end = 0xFFFFFFFFu; }  // (shadow views split over ranks: whole again)
@@ -2278,6 +2283,28 @@ static int shadow_part_of(uint32_t world, uint32_t n_views, uint32_t rank, uint3
     for (uint32_t p = 0; p < parts; ++p)
         if (shadow_owner(world, n_views, v, p) == rank) return (int)p;
     return -1;
+}
+// ONE total order of the collectives per device (tune.comm_serial, default on).  The three communicators are driven from three streams
+// -- shadow lane, main, resolve -- so that an exchange overlaps the other lanes' kernels; nothing orders their collective KERNELS
+// against each other, and RCCL (like NCCL) promises progress for concurrent communicators only if every rank's device can hold
+// all of their kernels at once: rank A running `shadow` first while rank B runs `main` first, neither with room for the other,
+// would wait for each other for ever.  One GPU per rank with three small communicators has that room today; an 8-GPU node has
+// never run this code, so the default does not lean on it: every collective waits (on its own stream, through one event) for the
+// collective enqueued before it -- whichever stream that was on -- and since every rank enqueues them in the same program order,
+// every device executes them in the same order.  The kernels between the collectives overlap as before.
+// tests: tests/rccl_shim.cpp in its asynchronous mode executes a collective when the stream REACHES it, one at a time per process
+// (the worst case above), so an order dependence between communicators shows up as a time-out there.
+static int comm_order_begin(r3n_ctx *c, hipStream_t on) {
+    if (!c->tune.comm_serial) return R3N_OK;
+    if (!c->comm.order_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->comm.order_ev, hipEventDisableTiming));
+    if (c->comm.order_pending) HIP_TRY(c, hipStreamWaitEvent(on, c->comm.order_ev, 0));
+    return R3N_OK;
+}
+static int comm_order_end(r3n_ctx *c, hipStream_t on) {
+    if (!c->tune.comm_serial) return R3N_OK;
+    HIP_TRY(c, hipEventRecord(c->comm.order_ev, on));
+    c->comm.order_pending = true;
+    return R3N_OK;
 }
 // The owners' atlas rows to every rank, on the shadow lane's stream (r3n_exchange_shadow_stream): one broadcast per (view, band).
 static int comm_exchange_shadows(r3n_ctx *c, const r3n_frame_desc *d) {
@@ -2309,6 +2336,7 @@ static int comm_exchange_shadows(r3n_ctx *c, const r3n_frame_desc *d) {
                 rows_of(sv, p, b, e);
                 if (e > b) HIP_TRY(c, hipMemcpy2DAsync(in_stage(v, sv, b), (size_t)sv.size * 4, in_atlas(sv, b), (size_t)aw * 4, (size_t)sv.size * 4, e - b, hipMemcpyDeviceToDevice, on));
             }
+    TRY(comm_order_begin(c, on));
     NCCL_TRY(c, rccl().GroupStart());  // the broadcasts progress together
     for (uint32_t v = 0; v < nv; ++v)
         for (uint32_t p = 0; p < parts; ++p) {
@@ -2318,6 +2346,7 @@ static int comm_exchange_shadows(r3n_ctx *c, const r3n_frame_desc *d) {
             if (e > b) NCCL_TRY(c, rccl().Broadcast(in_stage(v, sv, b), in_stage(v, sv, b), (size_t)(e - b) * sv.size, ncclFloat, (int)shadow_owner(world, nv, v, p), c->comm.shadow, on));
         }
     NCCL_TRY(c, rccl().GroupEnd());
+    TRY(comm_order_end(c, on));
     for (uint32_t v = 0; v < nv; ++v)
         for (uint32_t p = 0; p < parts; ++p)
             if (shadow_owner(world, nv, v, p) != rank) {
@@ -2332,10 +2361,11 @@ static int comm_exchange_shadows(r3n_ctx *c, const r3n_frame_desc *d) {
 static int comm_gather_bands(r3n_ctx *c, void *base, size_t row_bytes, ncclComm_t comm, hipStream_t on) {
     const uint32_t world = c->comm.world, rank = c->comm.rank, h = c->height;
     char *p = static_cast<char *>(base);
+    TRY(comm_order_begin(c, on));
     if (h % world == 0) {
         const size_t chunk = (size_t)(h / world) * row_bytes;
         NCCL_TRY(c, rccl().AllGather(p + (size_t)rank * chunk, p, chunk, ncclUint8, comm, on));  // in place
-        return R3N_OK;
+        return comm_order_end(c, on);
     }
     NCCL_TRY(c, rccl().GroupStart());  // ragged bands: one broadcast per band
     for (uint32_t r = 0; r < world; ++r) {
@@ -2344,7 +2374,7 @@ static int comm_gather_bands(r3n_ctx *c, void *base, size_t row_bytes, ncclComm_
         if (e > b) NCCL_TRY(c, rccl().Broadcast(p + (size_t)b * row_bytes, p + (size_t)b * row_bytes, (size_t)(e - b) * row_bytes, ncclUint8, (int)r, comm, on));
     }
     NCCL_TRY(c, rccl().GroupEnd());
-    return R3N_OK;
+    return comm_order_end(c, on);
 }
 static int comm_exchange_pass1(r3n_ctx *c) {
     if (c->samples == 1) {
@@ -2368,25 +2398,28 @@ static int comm_reduce_pass1(r3n_ctx *c) {
         uint64_t n = 0;
         TRY(r3n_exchange_depth(c, &plane, &n));
         Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);
+        TRY(comm_order_begin(c, c->stream));
         NCCL_TRY(c, rccl().AllReduce(plane, plane, (size_t)n, ncclFloat32, ncclMax, c->comm.main, c->stream));
-        return R3N_OK;
+        return comm_order_end(c, c->stream);
     }
     Timed t(c, R3N_STAGE_EXCHANGE_DEPTH, c->stream);
+    TRY(comm_order_begin(c, c->stream));
     NCCL_TRY(c, rccl().AllReduce(c->vis.p, c->vis.p, (size_t)c->width * c->height * c->samples, ncclUint64, ncclMax, c->comm.main, c->stream));
-    return R3N_OK;
+    return comm_order_end(c, c->stream);
 }
 static int comm_reduce_pass2(r3n_ctx *c) {
     const uint32_t world = c->comm.world, rank = c->comm.rank, h = c->height;
     const size_t row_keys = (size_t)c->width * c->samples;
     unsigned long long *keys = c->vis.as<unsigned long long>();
     Timed t(c, R3N_STAGE_EXCHANGE_KEYS, c->stream);
+    TRY(comm_order_begin(c, c->stream));
     if (h % world == 0) {
         const size_t chunk = (size_t)(h / world) * row_keys;
         NCCL_TRY(c, rccl().ReduceScatter(keys, keys + (size_t)rank * chunk, chunk, ncclUint64, ncclMax, c->comm.main, c->stream));  // in place
     } else {
         NCCL_TRY(c, rccl().AllReduce(keys, keys, (size_t)h * row_keys, ncclUint64, ncclMax, c->comm.main, c->stream));
     }
-    return R3N_OK;
+    return comm_order_end(c, c->stream);
 }
 static int comm_gather_rows(r3n_ctx *c) {
     void *out = nullptr, *sp = nullptr;

@@ -9,6 +9,15 @@
 // until every rank has made the SAME call on the SAME communicator, a rank that issues its collectives in another order than
 // its peers deadlocks here and trips the barrier's time-out -- which is the property real RCCL needs from the caller.
 //
+// R3N_SHIM_ASYNC=1 -- the asynchronous mode.  The synchronous mode above can never show a dependence on the ORDER
+// in which a device executes the collectives of DIFFERENT communicators: every call completes before the next one is even issued.
+// Here a call only ENQUEUES: device -> host copy of the contribution into the (pinned) segment, a host function on the stream
+// (barrier, gather / reduce into a private pinned buffer, barrier), host -> device copy of the result -- and returns.  The collective
+// runs when its STREAM reaches it, and the runtime runs host functions one at a time per process: the model of a device with room
+// for ONE collective kernel, the worst case RCCL allows itself.  Two ranks whose streams reach the collectives of two communicators
+// in different orders then wait for each other and trip the barrier's time-out (R3N_SHIM_TIMEOUT seconds, default 120): exactly the
+// deadlock the library's comm_serial order (r3n.hip comm_order_begin) exists to exclude.
+//
 // Loaded through R3N_RCCL_LIB (comm.h).  Build: hipcc -shared -fPIC -o librccl_shim.so rccl_shim.cpp -lrt  (tests/rccl_shim.py).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
@@ -26,8 +35,11 @@
 #include <vector>
 
 namespace {
-constexpr size_t kDataBytes = 1ull << 30;  // virtual: pages are touched on use
-constexpr int kTimeoutSeconds = 120;
+constexpr size_t kDataBytesSync = 1ull << 30;   // virtual: pages are touched on use
+constexpr size_t kDataBytesAsync = 128ull << 20;  // pinned (hipHostRegister): the copies must really be asynchronous
+const bool kAsync = [] { const char *e = std::getenv("R3N_SHIM_ASYNC"); return e && e[0] == '1'; }();
+const size_t kDataBytes = kAsync ? kDataBytesAsync : kDataBytesSync;
+const int kTimeoutSeconds = [] { const char *e = std::getenv("R3N_SHIM_TIMEOUT"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 120; }();
 
 struct Header {
     std::atomic<uint32_t> arrived;
@@ -44,6 +56,13 @@ struct ncclComm {
     char *data = nullptr;
     size_t mapped = 0;
     char name[64] = {};
+    // asynchronous mode
+    bool registered = false;
+    char *result = nullptr;       // private pinned buffer: what the host function gathered / reduced, source of the copy back
+    size_t result_bytes = 0;
+    hipStream_t last = nullptr;   // the stream of the previous operation (operations of one communicator are kept in order)
+    hipEvent_t hand_over = nullptr;
+    std::atomic<int> async_failed{0};
 };
 
 namespace {
@@ -115,6 +134,53 @@ bool reduce_typed(void *acc, const void *src, size_t n, ncclDataType_t t, ncclRe
     do {                                                     \
         if (!barrier(c)) return ncclSystemError;             \
     } while (0)
+
+// ---- asynchronous mode: what runs on the stream
+struct Op {
+    ncclComm *c;
+    enum Kind { Gather, Bcast, Reduce } kind;
+    size_t bytes = 0;        // Gather: per rank; Bcast: message; Reduce: bytes of one rank's whole contribution
+    size_t first = 0, n_out = 0;
+    ncclDataType_t t = ncclUint8;
+    ncclRedOp_t op = ncclMax;
+    int root = 0;
+};
+void run_op(void *p) {
+    Op *o = static_cast<Op *>(p);
+    ncclComm *c = o->c;
+    bool ok = barrier(c);  // every rank's contribution is in the segment (its copy is in front of its host function)
+    if (ok) {
+        switch (o->kind) {
+            case Op::Gather: std::memcpy(c->result, c->data, o->bytes * (size_t)c->world); break;
+            case Op::Bcast: if (c->rank != o->root) std::memcpy(c->result, c->data, o->bytes); break;
+            case Op::Reduce: {
+                const size_t tb = type_bytes(o->t);
+                std::memcpy(c->result, c->data + o->first * tb, o->n_out * tb);
+                for (int r = 1; r < c->world; ++r) ok = ok && reduce_typed(c->result, c->data + (size_t)r * o->bytes + o->first * tb, o->n_out, o->t, o->op);
+                break;
+            }
+        }
+    }
+    ok = barrier(c) && ok;  // everybody has read the segment: the next operation may overwrite it
+    if (!ok) c->async_failed.store(1);
+    delete o;
+}
+// operations of ONE communicator stay in order even when the caller moves it to another stream; the result buffer grows here
+ncclResult_t async_begin(ncclComm *c, hipStream_t s, size_t result_bytes) {
+    if (c->async_failed.load() || c->hdr->failed.load()) { g_last_error = "rccl_shim: an earlier asynchronous collective failed (barrier time-out: the ranks' streams reached the communicators' collectives in different orders, or a peer died)"; return ncclSystemError; }
+    if (c->last && c->last != s) {
+        if (hipEventRecord(c->hand_over, c->last) != hipSuccess || hipStreamWaitEvent(s, c->hand_over, 0) != hipSuccess) { g_last_error = "rccl_shim: stream hand-over"; return ncclUnhandledCudaError; }
+    }
+    if (result_bytes > c->result_bytes) {
+        if (c->last && hipStreamSynchronize(c->last) != hipSuccess) { g_last_error = "rccl_shim: sync before growing the result buffer"; return ncclUnhandledCudaError; }
+        (void)hipHostFree(c->result);
+        c->result = nullptr;
+        c->result_bytes = result_bytes + result_bytes / 2;
+        if (hipHostMalloc((void **)&c->result, c->result_bytes, hipHostMallocDefault) != hipSuccess) { g_last_error = "rccl_shim: result buffer"; return ncclUnhandledCudaError; }
+    }
+    c->last = s;
+    return ncclSuccess;
+}
 }  // namespace
 
 extern "C" {
@@ -142,6 +208,14 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     if (p == MAP_FAILED) { g_last_error = "rccl_shim: mmap failed"; delete c; return ncclSystemError; }
     c->hdr = static_cast<Header *>(p);  // a fresh segment is zero-filled: counters start at 0
     c->data = static_cast<char *>(p) + sizeof(Header);
+    if (kAsync) {
+        if (hipHostRegister(p, c->mapped, hipHostRegisterPortable) != hipSuccess) { g_last_error = "rccl_shim: hipHostRegister of the segment failed"; munmap(p, c->mapped); delete c; return ncclUnhandledCudaError; }
+        c->registered = true;
+        c->result_bytes = 32ull << 20;
+        if (hipHostMalloc((void **)&c->result, c->result_bytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c->hand_over, hipEventDisableTiming) != hipSuccess) {
+            g_last_error = "rccl_shim: pinned result buffer"; (void)hipHostUnregister(p); munmap(p, c->mapped); delete c; return ncclUnhandledCudaError;
+        }
+    }
     if (!barrier(c)) { munmap(p, c->mapped); delete c; return ncclSystemError; }  // everybody is attached ...
     if (rank == 0) shm_unlink(c->name);                                         // ... so the name can go: the segment dies with its last user
     *out = c;
@@ -150,6 +224,10 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
 
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
     if (!c) return ncclSuccess;
+    if (c->last) (void)hipStreamSynchronize(c->last);  // (operations still on the stream hold pointers into the communicator)
+    if (c->registered) (void)hipHostUnregister(c->hdr);
+    if (c->result) (void)hipHostFree(c->result);
+    if (c->hand_over) (void)hipEventDestroy(c->hand_over);
     if (c->hdr) munmap(c->hdr, c->mapped);
     delete c;
     return ncclSuccess;
@@ -167,6 +245,19 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t sendcount, ncclD
     const size_t bytes = sendcount * type_bytes(t);
     if (!bytes) return ncclSuccess;
     if (bytes * (size_t)c->world > kDataBytes) { g_last_error = "rccl_shim: message beyond the staging area"; return ncclInvalidArgument; }
+    if (kAsync) {
+        if (ncclResult_t r = async_begin(c, s, bytes * (size_t)c->world)) return r;
+        SHIM_HIP(hipMemcpyAsync(c->data + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost, s));
+        Op *o = new Op{c, Op::Gather};
+        o->bytes = bytes;
+        SHIM_HIP(hipLaunchHostFunc(s, run_op, o));
+        for (int r = 0; r < c->world; ++r) {
+            char *dst = static_cast<char *>(recv) + (size_t)r * bytes;
+            if (r == c->rank && dst == send) continue;
+            SHIM_HIP(hipMemcpyAsync(dst, c->result + (size_t)r * bytes, bytes, hipMemcpyHostToDevice, s));
+        }
+        return ncclSuccess;
+    }
     SHIM_HIP(hipMemcpyAsync(c->data + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToHost, s));
     SHIM_HIP(hipStreamSynchronize(s));
     SHIM_BARRIER();
@@ -184,6 +275,18 @@ ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataT
     const size_t bytes = count * type_bytes(t);
     if (!bytes) return ncclSuccess;
     if (bytes > kDataBytes || root < 0 || root >= c->world) { g_last_error = "rccl_shim: bad broadcast"; return ncclInvalidArgument; }
+    if (kAsync) {
+        if (ncclResult_t r = async_begin(c, s, bytes)) return r;
+        if (c->rank == root) {
+            SHIM_HIP(hipMemcpyAsync(c->data, send, bytes, hipMemcpyDeviceToHost, s));
+            if (recv != send) SHIM_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s));
+        }
+        Op *o = new Op{c, Op::Bcast};
+        o->bytes = bytes; o->root = root;
+        SHIM_HIP(hipLaunchHostFunc(s, run_op, o));
+        if (c->rank != root) SHIM_HIP(hipMemcpyAsync(recv, c->result, bytes, hipMemcpyHostToDevice, s));
+        return ncclSuccess;
+    }
     if (c->rank == root) {
         SHIM_HIP(hipMemcpyAsync(c->data, send, bytes, hipMemcpyDeviceToHost, s));
         if (recv != send) SHIM_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, s));
@@ -204,6 +307,15 @@ static ncclResult_t reduce_common(const void *send, void *recv, size_t first, si
     const size_t tb = type_bytes(t), bytes_all = n_all * tb;
     if (!bytes_all) return ncclSuccess;
     if (!tb || bytes_all * (size_t)c->world > kDataBytes) { g_last_error = "rccl_shim: reduction type / size not supported"; return ncclInvalidArgument; }
+    if (kAsync) {
+        if (ncclResult_t r = async_begin(c, s, n_out * tb)) return r;
+        SHIM_HIP(hipMemcpyAsync(c->data + (size_t)c->rank * bytes_all, send, bytes_all, hipMemcpyDeviceToHost, s));
+        Op *o = new Op{c, Op::Reduce};
+        o->bytes = bytes_all; o->first = first; o->n_out = n_out; o->t = t; o->op = op;
+        SHIM_HIP(hipLaunchHostFunc(s, run_op, o));
+        SHIM_HIP(hipMemcpyAsync(recv, c->result, n_out * tb, hipMemcpyHostToDevice, s));
+        return ncclSuccess;
+    }
     SHIM_HIP(hipMemcpyAsync(c->data + (size_t)c->rank * bytes_all, send, bytes_all, hipMemcpyDeviceToHost, s));
     SHIM_HIP(hipStreamSynchronize(s));
     SHIM_BARRIER();

@@ -474,3 +474,30 @@ def test_depth_interpolation_experiment():
     assert 0.4 <= stats[7][0] <= 0.6 and stats[7][1] <= 0.98, stats   # what rounds 1-3 measured
     assert stats[0][0] <= 0.02 and stats[0][1] >= 0.999, stats         # the contract
     assert stats[3][0] <= 0.05 and stats[3][0] >= stats[0][0], stats   # snapping does not help
+
+
+def test_op_tally_build_is_the_same_oracle_and_counts():
+    """oracle/tally.h ("exact count from the oracle's op tally"): r3o.c compiled with a counting f32 gives
+    bit-identical frames, and the resolve's count per shaded pixel is where the survey's estimate puts it (80 + 130 per light for the
+    untextured formula, a few hundred more with three trilinear maps and the tangent frame)."""
+    import scenes
+    from oracle import host as oh
+    from oracle import lib as olib
+    from oracle.world import OracleRenderer, material_record
+    tally_lib = olib.OracleLib(tally=True)
+    frames = []
+    for lib_ in (None, tally_lib):
+        r = OracleRenderer(oh.LEFT, np.float32(160) / np.float32(96), lib=lib_)
+        scenes.build_textured_scene(r, oh, material_record, 40, 0x7A11, lights=2)
+        r.set_camera_data(oh.look_at_lh((0.0, 2.0, -6.0), (0.0, 0.5, 6.0), (0, 1, 0)), ("perspective", 60.0, 0.1))
+        frames.append((r.render(160, 96, ambient=(0.1, 0.1, 0.1, 1.0), clear_color=(0.0, 0.0, 0.0, 1.0)), r))
+    (a, _), (b, rt) = frames
+    for k in ("vis", "hdr16", "rgba8", "pass", "residual"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["atlas"].view(np.uint32), b["atlas"].view(np.uint32))
+    shaded = int((b["vis"] != 0).sum())
+    t = rt.stage_tally["shade"]
+    per_px = t["fs_main"]["flops"] / max(shaded, 1)
+    assert shaded > 2000 and 300 < per_px < 3000, (shaded, per_px, t)
+    assert t["fs_main"]["sqrt"] > 0 and t["fs_main"]["div"] > 0 and t["vs_main"]["flops"] > 0 and t["fixed_function"]["flops"] > 0
+    assert t["flops"] == t["fs_main"]["flops"] + t["vs_main"]["flops"] + t["fixed_function"]["flops"]

@@ -23,7 +23,7 @@ import rend3_amd as r3  # noqa: E402
 import tune_caps  # noqa: E402
 
 STAGES = ["bake", "object_cull", "triangle_cull", "hiz", "raster", "shade", "tonemap", "clear", "raster_big", "shadow_raster", "shadow_raster_big",
-          "skinning", "vertex", "pose", "x_shadow", "x_depth", "x_rows", "x_keys"]
+          "skinning", "vertex", "pose", "x_shadow", "x_depth", "x_rows", "x_keys", "raster_cut", "raster_big_cut"]
 
 
 def main():

@@ -25,6 +25,13 @@ def per_kernel(path):
     return {k: {c: v[1] / v[0] for c, v in cs.items()} for k, cs in acc.items()}
 
 
+def _targ(name, i):
+    """i-th template argument of a kernel name ('false', '1', 'true', ...), '' when it has fewer"""
+    inner = name[name.find("<") + 1: name.rfind(">")] if "<" in name else ""
+    parts = [x.strip() for x in inner.split(",")]
+    return parts[i] if i < len(parts) else ""
+
+
 def short(name):
     base = name.split("(")[0].replace("void ", "").strip()
     return base
@@ -68,7 +75,15 @@ def main():
             "k_triangle_cull": [k for k in table if k.startswith("k_triangle_cull")],
             "k_raster_small<depth>": [k for k in table if k.startswith("k_raster_small<true")],
             "k_raster_big<depth>": [k for k in table if k.startswith("k_raster_big<true")],
-            "k_shadow_tiles": [k for k in table if k.startswith("k_shadow_tiles")]}
+            "k_shadow_tiles": [k for k in table if k.startswith("k_shadow_tiles")],
+            # viewport rasterisers: <DEPTH_ONLY=false, S, TEX, ...>; the cutout key's launches are the instantiations with TEX (textured
+            # alpha) or without NOCUT -- k_raster_small<false, S, TEX, NOCUT, SHORTA>, k_raster_big<false, S, TEX, BLEND, NOCUT, SHORTA>
+            "k_raster_small<vis>": [k for k in table if k.startswith("k_raster_small<false") and _targ(k, 3) == "true"],
+            "k_raster_big<vis>": [k for k in table if k.startswith("k_raster_big<false") and _targ(k, 4) == "true"],
+            "k_raster_small<vis,cutout>": [k for k in table if k.startswith("k_raster_small<false") and _targ(k, 3) != "true"],
+            "k_raster_big<vis,cutout>": [k for k in table if k.startswith("k_raster_big<false") and _targ(k, 3) != "true" and _targ(k, 4) != "true"],
+            "k_object_pass_chained": [k for k in table if k.startswith("k_object_pass_chained<true")],
+            "k_hiz_head": [k for k in table if k.startswith("k_hiz_head")]}
     doc = {"source": "tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter set per run; FETCH_SIZE x2 (gfx950 wide-load correction) + WRITE_SIZE",
            "taken": datetime.date.today().isoformat(), "variant": variant, "kernel_sources_sha": bench.kernel_sources_sha(),
            "bytes_per_launch": {}, "valu_busy": {}, "valu_insts_per_launch": {}, "useful_flops_per_launch": {}, "useful_flops_unpacked_count": {}, "kernels": table}
