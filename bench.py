@@ -513,7 +513,8 @@ def main():
             # leave one 8-B key per covered sample.  Predicted pass: last frame's passing triangles (this frame's count stands in for
             # it: the camera moves by a fraction of a pixel per frame), residual pass: the newly visible ones.  Charged per key
             # (opaque / cutout launches are separate stages) by the key's share of the drawn triangles.
-            tri_obj = np.searchsorted(last["tri_base"], np.arange(len(last["pass"])), side="right") - 1
+            tri_base = np.concatenate([[0], np.cumsum(counts)])[:-1]  # canonical slot base per object (exclusive scan of the triangle counts)
+            tri_obj = np.searchsorted(tri_base, np.arange(len(last["pass"])), side="right") - 1
             mkeys = np.asarray([k for _rec, k in r.materials], dtype=np.uint8)
             okeys = np.zeros(r.capacity, dtype=np.uint8)
             for h, m in r.object_meta.items():

@@ -17,6 +17,8 @@ for w in "$@"; do
     suite)
       timeout 1500 python -m pytest tests -x -q -m gpu --durations=12 > "$out/pytest.log" 2>&1; echo "pytest rc=$?"; tail -22 "$out/pytest.log" | cut -c1-220
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$out/smoke.log" | cut -c1-220;;
+    suiteall)  # the same without -x: every failure of a development run in one call
+      timeout 1700 python -m pytest tests -q -m gpu --durations=12 > "$out/pytest_all.log" 2>&1; echo "pytest rc=$?"; tail -30 "$out/pytest_all.log" | cut -c1-260;;
     soak:*) timeout 3000 python tools/soak_native.py --repeat "${w#soak:}" --out "$out/soak" > "$out/soak_stdout.log" 2>&1; echo "soak rc=$?"; tail -4 "$out/soak_stdout.log" | cut -c1-400;;
     soakmany:*) timeout 3000 python tools/soak_native.py --many --repeat "${w#soakmany:}" --out "$out/soak_many" > "$out/soak_many_stdout.log" 2>&1; echo "soak many rc=$?"; tail -4 "$out/soak_many_stdout.log" | cut -c1-400;;
     soakmode:*) IFS=: read -r _ mode rep <<< "$w"; timeout 3000 python tools/soak_native.py --modes "$mode" --repeat "$rep" --out "$out/soak_$mode" > "$out/soak_${mode}_stdout.log" 2>&1; echo "soak $mode rc=$?"; tail -4 "$out/soak_${mode}_stdout.log" | cut -c1-400;;
