@@ -19,6 +19,14 @@ for w in "$@"; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$out/smoke.log" | cut -c1-220;;
     suiteall)  # the same without -x: every failure of a development run in one call
       timeout 1700 python -m pytest tests -q -m gpu --durations=12 > "$out/pytest_all.log" 2>&1; echo "pytest rc=$?"; tail -30 "$out/pytest_all.log" | cut -c1-260;;
+    variants:*)  # variants:NAME:BENCH FLAGS... -- every variants/lib_*.so on the bench (tools/variants.py), log under NAME
+      IFS=: read -r _ vname vflags <<< "$w"; VARIANT_FLAGS="$vflags" timeout 1500 python tools/variants.py run --steps 20 > "$out/variants_$vname.txt" 2>&1; cat "$out/variants_$vname.txt" | cut -c1-420;;
+    mutate:*)  # mutate:SECONDS:FIRST_SEED -- the randomised campaign with world edits (material key flips included)
+      IFS=: read -r _ secs first <<< "$w"; timeout $((secs + 120)) python tools/fuzz_parity.py --mutate --seconds "$secs" --first-seed "$first" > "$out/fuzz_mutate_$first.txt" 2>&1; tail -4 "$out/fuzz_mutate_$first.txt" | cut -c1-300;;
+    asyncsoak:*)  # asyncsoak:SERIAL:REPEAT -- the asynchronous shim with comm_serial = SERIAL, two-rank and many-rank cases
+      IFS=: read -r _ ser rep <<< "$w"
+      timeout 1500 python tools/soak_native.py --shim async --serial "$ser" --repeat "$rep" --limit 90 --out "$out/async_serial$ser" > "$out/async_serial${ser}_stdout.log" 2>&1; echo "async serial=$ser rc=$?"; tail -2 "$out/async_serial${ser}_stdout.log" | cut -c1-500
+      timeout 1500 python tools/soak_native.py --shim async --serial "$ser" --many --repeat "$rep" --limit 90 --out "$out/async_many_serial$ser" > "$out/async_many_serial${ser}_stdout.log" 2>&1; echo "async many serial=$ser rc=$?"; tail -2 "$out/async_many_serial${ser}_stdout.log" | cut -c1-500;;
     soak:*) timeout 3000 python tools/soak_native.py --repeat "${w#soak:}" --out "$out/soak" > "$out/soak_stdout.log" 2>&1; echo "soak rc=$?"; tail -4 "$out/soak_stdout.log" | cut -c1-400;;
     soakmany:*) timeout 3000 python tools/soak_native.py --many --repeat "${w#soakmany:}" --out "$out/soak_many" > "$out/soak_many_stdout.log" 2>&1; echo "soak many rc=$?"; tail -4 "$out/soak_many_stdout.log" | cut -c1-400;;
     soakmode:*) IFS=: read -r _ mode rep <<< "$w"; timeout 3000 python tools/soak_native.py --modes "$mode" --repeat "$rep" --out "$out/soak_$mode" > "$out/soak_${mode}_stdout.log" 2>&1; echo "soak $mode rc=$?"; tail -4 "$out/soak_${mode}_stdout.log" | cut -c1-400;;
