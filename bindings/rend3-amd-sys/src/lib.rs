@@ -404,6 +404,7 @@ extern "C" {
     pub fn r3n_stage_times(ctx: *mut r3n_ctx, ms: *mut f64, launches: *mut u64, reset: c_int) -> c_int;
     pub fn r3n_hbm_copy_rate(ctx: *mut r3n_ctx, bytes: u64, repeats: u32, gb_per_s: *mut f64) -> c_int;
     pub fn r3n_selftest_exact_math(hip_device: c_int, hist: *mut u64, guarded: *mut u64) -> c_int;
+    pub fn r3n_selftest_unorm8(hip_device: c_int, n_bad: *mut u32) -> c_int;
     pub fn r3n_host_mat4_mul(a: *const f32, b: *const f32, out: *mut f32);
     pub fn r3n_host_mat4_inverse(m: *const f32, out: *mut f32);
     pub fn r3n_host_look_at(eye: *const f32, center: *const f32, up: *const f32, rh: c_int, out: *mut f32);

@@ -562,6 +562,8 @@ int r3n_hbm_copy_rate(r3n_ctx *ctx, uint64_t bytes, uint32_t repeats, double *gb
  * on which the UNGUARDED sequences differ, by function (rcp, sqrt, rsqrt) and sign + biased exponent; guarded[3]: patterns on
  * which the guarded functions -- what the library evaluates -- differ (must be 0).  Needs no context; returns a hipError_t. */
 int r3n_selftest_exact_math(int hip_device, unsigned long long *hist, unsigned long long *guarded);
+/* exact_math::unorm8 (c / 255 without the division) against the division for all 256 inputs; *n_bad = how many differ (0). */
+int r3n_selftest_unorm8(int hip_device, uint32_t *n_bad);
 
 /* ---- host-side mirror of the reference's CPU math on the path (rend3_amd/csrc/host.cpp).
  * In a real integration these stay in Rust (rend3 core); they exist here so the standalone harness, the

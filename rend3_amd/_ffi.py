@@ -90,6 +90,7 @@ SIGNATURES = {
     "r3n_set_multi_stream": (cint, [vp, cint]),
     "r3n_hbm_copy_rate": (cint, [vp, u64, u32, vp]),
     "r3n_selftest_exact_math": (cint, [cint, vp, vp]),
+    "r3n_selftest_unorm8": (cint, [cint, vp]),
     "r3n_host_mat4_mul": (None, [vp, vp, vp]),
     "r3n_host_mat4_inverse": (None, [vp, vp]),
     "r3n_host_look_at": (None, [vp, vp, vp, cint, vp]),

@@ -63,4 +63,15 @@ __device__ __forceinline__ float half_rcp(float x) {  // 0.5f / x: inside rcp's 
     return 0.5f / x;
 }
 
+// RN((float)c / 255.0f) for an 8-bit c, without the division: q = c * RN(1 / 255) is off by at most an ulp, and one correction with
+// the residual c - 255 q (exact in an fma) lands on the correctly rounded quotient for EVERY c in 0 .. 255 -- a function of 256
+// inputs, compared one by one with the compiler's division on the device (r3n_selftest_unorm8, tests/test_exact_math.py).
+// Three instructions behind the conversion instead of the division's eleven; the rasterisers' cutout test converts eight alphas
+// per fragment.
+__device__ __forceinline__ float unorm8(uint32_t c) {
+    const float x = (float)c, r = 1.0f / 255.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, q, x), r, q);
+}
+
 }  // namespace exact_math

@@ -279,8 +279,13 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             // the launches in front of this one, so foliage behind walls ends here.
             if (DEPTH_ONLY) { if (!(zb > a.depth[pix])) return; }
             else if (!((((unsigned long long)zb << 32) | (unsigned long long)tw.slot1) > a.vis[pix])) return;
-            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
-            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            // (the interpolated vertex alpha enters the test only under ALBEDO_ACTIVE + ALBEDO_BLEND, cutout_alpha: skipped otherwise --
+            // a reciprocal and eight more operations per fragment of a kernel that is bound by vector issue on a foliage scene)
+            float al = 1.0f;
+            if ((tw.mat_flags & (R3N_FLAGS_ALBEDO_ACTIVE | R3N_FLAGS_ALBEDO_BLEND)) == (R3N_FLAGS_ALBEDO_ACTIVE | R3N_FLAGS_ALBEDO_BLEND)) {
+                const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+                al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            }
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST, SHORTA>(a, tw, x, y), al) < tw.mat_cutoff) return;  // opaque.wgsl:231-235 / depth.wgsl:123-125
         }
         if (DEPTH_ONLY) {
@@ -322,10 +327,13 @@ R3N_DEV void shade_pixel(const RasterArgs &a, const TriWork &tw, int x, int y) {
             if (!mask) return;
         }
         if (tw.cutout) {
-            float E[3];
-            (void)edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E);
-            const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
-            const float al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            float al = 1.0f;
+            if ((tw.mat_flags & (R3N_FLAGS_ALBEDO_ACTIVE | R3N_FLAGS_ALBEDO_BLEND)) == (R3N_FLAGS_ALBEDO_ACTIVE | R3N_FLAGS_ALBEDO_BLEND)) {
+                float E[3];
+                (void)edge_eval_thr(tw.ts, tw.thr, (float)x + 0.5f, (float)y + 0.5f, E);
+                const float rs = 1.0f / ((E[0] + E[1]) + E[2]);
+                al = ((E[0] * rs) * tw.va[0] + (E[1] * rs) * tw.va[1]) + (E[2] * rs) * tw.va[2];
+            }
             if (cutout_alpha(tw.mat_flags, tw.mat_alpha, cutout_texture_alpha<DEPTH_ONLY, TEX, HOIST, SHORTA>(a, tw, x, y), al) < tw.mat_cutoff) return;
         }
 #pragma unroll

@@ -42,6 +42,29 @@ __global__ __launch_bounds__(256) void k_exact_probe(unsigned long long *__restr
 }
 }  // namespace
 
+namespace {
+__global__ void k_unorm8_probe(uint32_t *bad) {
+    const uint32_t c = threadIdx.x;  // 256 threads: every 8-bit value
+    const float ref = (float)c / 255.0f;
+    if (__float_as_uint(exact_math::unorm8(c)) != __float_as_uint(ref)) atomicAdd(bad, 1u);
+}
+}  // namespace
+
+// exact_math::unorm8 against the compiler's division for all 256 inputs; *n_bad = how many differ (must be 0).
+extern "C" int r3n_selftest_unorm8(int device, uint32_t *n_bad) {
+    if (!n_bad) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return (int)e;
+    uint32_t *d = nullptr;
+    if ((e = hipMalloc(&d, 4)) != hipSuccess) return (int)e;
+    e = hipMemset(d, 0, 4);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_unorm8_probe, dim3(1), dim3(256), 0, 0, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(n_bad, d, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return (int)e;
+}
+
 // hist: 3 x 512 counters, guarded: 3 counters (host memory).  Returns a hipError_t as int.  Stand-alone: needs no context.
 extern "C" int r3n_selftest_exact_math(int device, unsigned long long *hist, unsigned long long *guarded) {
     if (!hist || !guarded) return (int)hipErrorInvalidValue;

@@ -407,15 +407,28 @@ R3N_DEV float tex_sample_alpha(const TextureArgs &t, uint32_t id, const r3n_text
         if (two) tame = tex_level_fast<SHORT_ONLY>(tex_mip_dim(d.width, level + 1u), tex_mip_dim(d.height, level + 1u), SHORT_ONLY ? b0 + __umul24(w0, h0) : lo[level + 1u], u, v, l1) && tame;
         if (SHORT_ONLY || tame) {
             const char *pool = reinterpret_cast<const char *>(t.texels);
-            auto alpha_at = [&](uint32_t byte_off) { return (float)(*reinterpret_cast<const uint32_t *>(pool + byte_off) >> 24) / 255.0f; };
-            auto bilinear = [&](const TexLvlFast &l) {
-                const float a00 = alpha_at(l.o00), a10 = alpha_at(l.o10), a01 = alpha_at(l.o01), a11 = alpha_at(l.o11);
+            auto byte_at = [&](uint32_t byte_off) { return *reinterpret_cast<const uint32_t *>(pool + byte_off) >> 24; };
+            // every texel's alpha byte first (up to eight loads in flight together)
+            const uint32_t c00 = byte_at(l0.o00), c10 = byte_at(l0.o10), c01 = byte_at(l0.o01), c11 = byte_at(l0.o11);
+            uint32_t d00 = c00, d10 = c10, d01 = c01, d11 = c11;
+            if (two) { d00 = byte_at(l1.o00); d10 = byte_at(l1.o10); d01 = byte_at(l1.o01); d11 = byte_at(l1.o11); }
+            // A footprint of ONE value -- the inside of a leaf (255) or the empty part of its card (0), most fragments of a foliage
+            // scene -- needs no filtering: with every alpha 1.0f the blends are fl(fl(1 - f) + f), which is 1.0f for every f in
+            // [0, 1] (the first rounding errs by at most 2^-25, the sum 1 + e rounds back to 1; ties go to even = 1), and 0 * w + 0 * w'
+            // is +0.  The value is the filtered one bit for bit; the divisions and the seven blends are skipped.  (Other uniform
+            // values are NOT exact this way -- a * (1 - f) + a * f can miss a by an ulp -- and take the arithmetic below.)
+            const uint32_t all_and = (c00 & c10) & (c01 & c11) & (d00 & d10) & (d01 & d11);
+            const uint32_t all_or = (c00 | c10) | (c01 | c11) | (d00 | d10) | (d01 | d11);
+            if (all_and == 255u) return 1.0f;
+            if (all_or == 0u) return 0.0f;
+            auto bilinear = [&](const TexLvlFast &l, uint32_t b00, uint32_t b10, uint32_t b01, uint32_t b11) {
+                const float a00 = exact_math::unorm8(b00), a10 = exact_math::unorm8(b10), a01 = exact_math::unorm8(b01), a11 = exact_math::unorm8(b11);
                 const float omx = 1.0f - l.fx, omy = 1.0f - l.fy;
                 const float top = M::mad(a10, l.fx, a00 * omx), bot = M::mad(a11, l.fx, a01 * omx);
                 return M::mad(bot, l.fy, top * omy);
             };
-            float r = bilinear(l0);
-            if (two) r = M::mad(bilinear(l1), frac, r * (1.0f - frac));
+            float r = bilinear(l0, c00, c10, c01, c11);
+            if (two) r = M::mad(bilinear(l1, d00, d10, d01, d11), frac, r * (1.0f - frac));
             return r;
         }
     }

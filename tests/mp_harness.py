@@ -42,8 +42,9 @@ def init_group(rank, world, run_dir, device=None, seconds=90):
     import datetime
     import torch.distributed as dist
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # the box's hostname may not resolve
-    kw = dict(init_method="file://" + os.path.join(run_dir, "rendezvous"), rank=rank, world_size=world,
-              timeout=datetime.timedelta(seconds=seconds))
+    port = os.environ.get("R3N_MP_TCP_PORT")  # soak only (tools/soak_native.py --rendezvous tcp): the round-5 rendezvous, for comparison
+    method = f"tcp://127.0.0.1:{port}" if port else "file://" + os.path.join(run_dir, "rendezvous")
+    kw = dict(init_method=method, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=seconds))
     if device is not None:
         dist.init_process_group("nccl", device_id=device, **kw)
     else:
@@ -51,10 +52,12 @@ def init_group(rank, world, run_dir, device=None, seconds=90):
     return dist
 
 
-def _entry(target, rank, world, run_dir, q, limit, args):
+def _entry(target, rank, world, run_dir, q, limit, args, tcp_port=None):
     for p in (HERE, os.path.dirname(HERE)):
         if p not in sys.path:
             sys.path.insert(0, p)
+    if tcp_port:
+        os.environ["R3N_MP_TCP_PORT"] = str(tcp_port)
     os.environ["R3N_BREADCRUMBS"] = os.path.join(run_dir, f"lib.rank{rank}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     tb = open(os.path.join(run_dir, f"rank{rank}.traceback"), "w")
@@ -103,7 +106,17 @@ def report(run_dir, world):
     return "\n".join(out)
 
 
-def run_ranks(target, world, args=(), limit=None, keep=None):
+def _closed_port():
+    """What round 5's tests did: bind port 0, read the number, CLOSE the socket, hand the number to the ranks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(target, world, args=(), limit=None, keep=None, rendezvous="file"):
     """-> (results: {rank: "ok" | "FAIL: ..."}, problem: None | str, report: str | None, seconds).  Never raises for a rank's sake,
     never leaves a child behind, never waits longer than `limit` (+ a few seconds of killing)."""
     import torch.multiprocessing as mp
@@ -111,7 +124,8 @@ def run_ranks(target, world, args=(), limit=None, keep=None):
     ctx = mp.get_context("spawn")
     run_dir = tempfile.mkdtemp(prefix="r3n_mp_")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_entry, args=(target, r, world, run_dir, q, limit, tuple(args)), daemon=True) for r in range(world)]
+    tcp_port = _closed_port() if rendezvous == "tcp" else None
+    procs = [ctx.Process(target=_entry, args=(target, r, world, run_dir, q, limit, tuple(args), tcp_port), daemon=True) for r in range(world)]
     t0 = time.monotonic()
     for p in procs:
         p.start()

@@ -27,6 +27,20 @@ for w in "$@"; do
       IFS=: read -r _ ser rep <<< "$w"
       timeout 1500 python tools/soak_native.py --shim async --serial "$ser" --repeat "$rep" --limit 90 --out "$out/async_serial$ser" > "$out/async_serial${ser}_stdout.log" 2>&1; echo "async serial=$ser rc=$?"; tail -2 "$out/async_serial${ser}_stdout.log" | cut -c1-500
       timeout 1500 python tools/soak_native.py --shim async --serial "$ser" --many --repeat "$rep" --limit 90 --out "$out/async_many_serial$ser" > "$out/async_many_serial${ser}_stdout.log" 2>&1; echo "async many serial=$ser rc=$?"; tail -2 "$out/async_many_serial${ser}_stdout.log" | cut -c1-500;;
+    bench:*)  # bench:NAME:FLAGS -- one bench.py line, stage table printed
+      IFS=: read -r _ bname bflags <<< "$w"; timeout 1200 python bench.py $bflags > "$out/bench_$bname.json" 2> "$out/bench_$bname.err"; python - "$out/bench_$bname.json" <<'PY'
+import json,sys
+try:
+    l=[x for x in open(sys.argv[1]).read().splitlines() if x.startswith("{")][-1]
+    d=json.loads(l); r=d.get("roofline") or {}
+    print(sys.argv[1].split('/')[-1], d["ms_per_step"], "parity", (d.get("parity") or {}).get("ok"), "roofline", r.get("kernel"), r.get("bound"), r.get("frac"), "traffic", r.get("traffic"),
+          {k:round(v*1e3,1) for k,v in d["stage_ms_per_frame"].items() if v})
+except Exception as e: print(sys.argv[1], "FAILED", e)
+PY
+      tail -3 "$out/bench_$bname.err" | grep -v amdgpu.ids | cut -c1-300;;
+    pytest:*)  # pytest:NAME:ARGS -- a selection of the GPU tests
+      IFS=: read -r _ pname pargs <<< "$w"; timeout 1500 python -m pytest $pargs -q -m gpu > "$out/pytest_$pname.log" 2>&1; echo "pytest $pname rc=$?"; tail -6 "$out/pytest_$pname.log" | cut -c1-300;;
+    soaktcp:*) timeout 3000 python tools/soak_native.py --rendezvous tcp --repeat "${w#soaktcp:}" --limit 100 --out "$out/soak_tcp" > "$out/soak_tcp_stdout.log" 2>&1; echo "soak tcp rc=$?"; tail -3 "$out/soak_tcp_stdout.log" | cut -c1-500;;
     soak:*) timeout 3000 python tools/soak_native.py --repeat "${w#soak:}" --out "$out/soak" > "$out/soak_stdout.log" 2>&1; echo "soak rc=$?"; tail -4 "$out/soak_stdout.log" | cut -c1-400;;
     soakmany:*) timeout 3000 python tools/soak_native.py --many --repeat "${w#soakmany:}" --out "$out/soak_many" > "$out/soak_many_stdout.log" 2>&1; echo "soak many rc=$?"; tail -4 "$out/soak_many_stdout.log" | cut -c1-400;;
     soakmode:*) IFS=: read -r _ mode rep <<< "$w"; timeout 3000 python tools/soak_native.py --modes "$mode" --repeat "$rep" --out "$out/soak_$mode" > "$out/soak_${mode}_stdout.log" 2>&1; echo "soak $mode rc=$?"; tail -4 "$out/soak_${mode}_stdout.log" | cut -c1-400;;

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "soak"))
     ap.add_argument("--max-failures", type=int, default=6)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop launching after this many seconds (0: no limit)")
+    ap.add_argument("--rendezvous", default="file", choices=("file", "tcp"), help="tcp: round 5's rendezvous (a port number taken from a socket that is closed again), for comparison")
     ap.add_argument("--shim", default="sync", choices=("sync", "async"), help="tests/rccl_shim.cpp's mode (async: collectives run when their stream reaches them)")
     ap.add_argument("--serial", type=int, default=1, choices=(0, 1), help="the library's comm_serial tunable (0: the communicators' collectives unordered against each other)")
     a = ap.parse_args()
@@ -46,7 +47,7 @@ def main():
             if a.seconds and time.monotonic() - t_start > a.seconds:
                 break
             results, problem, rep, s = mp_harness.run_ranks(T.worker, world, T.worker_args(mode, world, n_objects, a.shim, a.serial), limit=a.limit,
-                                                            keep=os.path.join(a.out, "failed"))
+                                                            keep=os.path.join(a.out, "failed"), rendezvous=a.rendezvous)
             ok = problem is None and len(results) == world and all(m == "ok" for m in results.values())
             n += 1
             secs.append(s)
@@ -65,7 +66,7 @@ def main():
         break
     summary = {"launches": n, "failed": len(failures), "failures": failures, "seconds_total": round(time.monotonic() - t_start, 1),
                "seconds_per_launch_mean": round(sum(secs) / max(1, len(secs)), 2), "seconds_per_launch_max": round(max(secs or [0]), 2),
-               "cases": [f"{w}:{m}" for w, m, _ in cases], "limit_s": a.limit, "shim": a.shim, "comm_serial": a.serial}
+               "cases": [f"{w}:{m}" for w, m, _ in cases], "limit_s": a.limit, "shim": a.shim, "comm_serial": a.serial, "rendezvous": a.rendezvous}
     print(json.dumps(summary))
     with open(os.path.join(a.out, "soak_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
