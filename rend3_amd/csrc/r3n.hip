@@ -244,6 +244,7 @@ struct r3n_ctx {
     // R3N_BREADCRUMBS=<prefix>: one line per stage / collective into <prefix>.pid<pid>.ctx<n> as it is ENQUEUED (write(2), no
     // buffering) -- where a rank that stopped answering was last seen (tests/mp_harness.py, tools/soak_native.py); -1: off
     int crumb_fd = -1;
+    bool sync_stages = false;  // R3N_SYNC_STAGES=1: every stage is waited for where it is enqueued (diagnosis of a kernel that does not return)
     // timing taps
     bool timing = false;
     struct Span { hipEvent_t a, b; int stage; hipStream_t stream; };
@@ -410,6 +411,10 @@ struct Timed {
         (void)hipEventRecord(a, stream);
     }
     ~Timed() {
+        if (c->sync_stages) {  // R3N_SYNC_STAGES=1 (diagnosis): wait for the stage here, so that the last breadcrumb names the kernel that does not return
+            (void)hipStreamSynchronize(stream);
+            crumb(c, "stage done", stage);
+        }
         if (!a) return;
         (void)hipEventRecord(b, stream);
         c->spans.push_back({a, b, stage, stream});
@@ -797,6 +802,7 @@ r3n_ctx *r3n_create(int hip_device, const r3n_config *config) {
         c->crumb_fd = open(path.c_str(), O_CREAT | O_WRONLY | O_APPEND, 0644);
         crumb(c, "created");
     }
+    if (const char *es = std::getenv("R3N_SYNC_STAGES")) c->sync_stages = es[0] == '1';
     if (const char *e1 = std::getenv("R3N_SINGLE_STREAM")) c->multi_stream = !(e1[0] == '1');
     if (const char *e2 = std::getenv("R3N_PIPELINE")) c->overlap = !(e2[0] == '0');
     if (const char *e5 = std::getenv("R3N_RESOLVE_CLASSES")) c->resolve_classes = !(e5[0] == '0');

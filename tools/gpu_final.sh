@@ -31,7 +31,9 @@ for w in "$@"; do
     pmc) bash tools/gpu_pmc.sh "$tag/pmc" > "$out/pmc_table.txt" 2>&1; tail -3 "$out/pmc_table.txt" | cut -c1-200
       [ -f "$out/traffic.json" ] && cp "$out/traffic.json" "$root/profiles/traffic.json";;
     pmc_more)
-      PMC_TRAFFIC_ONLY=1 bash tools/gpu_pmc.sh "$tag/pmc_cfg4" --config 4 > "$out/pmc_table_cfg4.txt" 2>&1
+      # every counter set for configs[3] and the Bistro-faithful scene too (round 6: a VALU figure for every variant's dominant kernel)
+      bash tools/gpu_pmc.sh "$tag/pmc_cfg4" --config 4 > "$out/pmc_table_cfg4.txt" 2>&1
+      bash tools/gpu_pmc.sh "$tag/pmc_v2" --bistro-v2 > "$out/pmc_table_v2.txt" 2>&1
       PMC_TRAFFIC_ONLY=1 bash tools/gpu_pmc.sh "$tag/pmc_untextured" --untextured > "$out/pmc_table_untextured.txt" 2>&1
       [ -f "$out/traffic.json" ] && cp "$out/traffic.json" "$root/profiles/traffic.json";;
     bench) $B --steps 100 --warmup 10 > "$out/bench.json" 2> "$out/bench.err"; line "$out/bench.json"; tail -2 "$out/bench.err" | grep -v amdgpu.ids;;
