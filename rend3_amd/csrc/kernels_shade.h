@@ -14,7 +14,11 @@
 
 // The resolve's constants -- fixed by measurement, NOT build options (an experiment is a patch: profiles/patches/).
 #define R3N_TEX_OCC 5  // min waves per SIMD asked of the textured record-based resolve (launch bound)
-#define R3N_MS_OCC 5   // the same for the multisampled record-based resolve (lean split pass: 0.86 ms at 5, 0.92 at 4)
+#define R3N_MS_OCC 4   // the same for the multisampled record-based resolve and its edge pass.  5 is 9 % faster (shade 857 vs 935 us on
+                       // the bench scene at four samples) but costs the textured instantiations 480 spilled vector registers, 80 spilled
+                       // scalar ones and 1.1 KB of scratch per lane (4: 100 B) -- and round 6 met a build of exactly these kernels that
+                       // never returned at 5 and ran at 4 with the same source (profiles/r06_native_hang.md): spill code at the
+                       // register limit is not worth 9 % of a non-headline mode
 // Measured and NOT kept (code in the history, commit 79bedf3; numbers in profiles/r0N_summary.md): resolve tiles in contiguous
 // per-XCD bands (shade 595 -> 593 us, frame 1.184 -> 1.193 ms); the directional lights in groups of two / four whose shadow
 // texels are in flight together (461.0 vs 460.6 us; four: 624 us at three waves per SIMD); round 5: the lookups of every light
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? (CLS =
 // park the half-rounded colour in every sample it owns.  Pass C (k_resolve_edge_pixels): the entry flagged as its
 // pixel's last one averages the four parked samples -- the same box resolve expression as everywhere else.
 template <bool TEX, bool REC>
-__global__ __launch_bounds__(256, REC ? R3N_TEX_OCC : 1) void k_resolve_edges(ShadeArgs a) {
+__global__ __launch_bounds__(256, REC ? R3N_MS_OCC : 1) void k_resolve_edges(ShadeArgs a) {
     __shared__ LdsDirLight s_dir[R3N_MAX_DIR_LIGHTS];
     __shared__ LdsPointLight s_point[R3N_MAX_POINT_LIGHTS];
     __shared__ float s_decode[512];
