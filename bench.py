@@ -569,6 +569,26 @@ def main():
                                   "waves per SIMD.  `bound` keeps the label of the nearer roofline (the HBM figure is `frac_hbm`)"})
         else:
             rs["bound_note"] = "VALU-bound kernel (no PMC pass of these sources on record: only the HBM figure can be quoted)"
+        # Every other stage against the bound it has: a stage whose counted traffic is below its algorithmic
+        # bytes is served by the Infinity Cache -- `bound` says so, `achieved` stays an on-die rate; a stage whose vector ALUs are
+        # busy >= 75 % of the launch is vector-issue bound: `frac` = useful f32 flops / vector peak, the HBM figure beside it.
+        for st_name, rr in rooflines.items():
+            if st_name == "shade":
+                continue
+            vv = rr.get("valu") or {}
+            if rr.get("cache_served"):
+                rr["bound"] = "cache"
+                rr["bound_note"] = "inputs served by the 256-MB Infinity Cache (counted memory-side traffic below the algorithmic bytes): `achieved` is algorithmic bytes / time, not HBM bandwidth"
+            elif (vv.get("busy") or 0.0) >= 0.75 and vv.get("useful_tflops"):
+                rr.update({"bound": "valu", "frac_hbm": rr["frac"], "achieved_hbm_GBps": rr["achieved"], "peak_hbm_GBps": rr["peak"],
+                           "achieved": vv["useful_tflops"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": vv["useful_frac_of_vector_peak"],
+                           "frac_note": f"vector ALUs busy {vv['busy']:.2f} of the launch (SQ_ACTIVE_INST_VALU): bound by vector issue; frac = executed f32 flops "
+                                        "(64 x SQ_INSTS_VALU_FLOPS_FP32) / launch time / 157.3 TFLOP/s -- low because most of the instructions are not "
+                                        "flops (edge tests, address and mask arithmetic, conversions, exact-division sequences)"})
+            elif vv.get("busy") is not None:
+                rr["bound_note"] = (f"neither roofline binds: vector ALUs busy {vv['busy']:.2f}, HBM fraction {rr['frac']:.3f}; the rasterisers are bound by "
+                                    "instruction issue (scalar + vector) and the rate of memory-side atomics (profiles/r06_summary.md section 2: with every "
+                                    "atomic ablated the shadow work-item launch keeps two thirds of its time)")
         dominant = max(rooflines, key=lambda st: stage_ms[st])
         roof = dict(rooflines[dominant], dominant_by="largest kernel time per frame in the HIP-event stage table")
         # the whole frame against the HBM roofline: the sum of the stages' algorithmic bytes per frame over the frame time
