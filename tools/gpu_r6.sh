@@ -21,6 +21,8 @@ for w in "$@"; do
       timeout 1700 python -m pytest tests -q -m gpu --durations=12 > "$out/pytest_all.log" 2>&1; echo "pytest rc=$?"; tail -30 "$out/pytest_all.log" | cut -c1-260;;
     variants:*)  # variants:NAME:BENCH FLAGS... -- every variants/lib_*.so on the bench (tools/variants.py), log under NAME
       IFS=: read -r _ vname vflags <<< "$w"; VARIANT_FLAGS="$vflags" timeout 1500 python tools/variants.py run --steps 20 > "$out/variants_$vname.txt" 2>&1; cat "$out/variants_$vname.txt" | cut -c1-420;;
+    static:*)  # static:SECONDS:FIRST_SEED -- the randomised campaign, three frames per case
+      IFS=: read -r _ secs first <<< "$w"; timeout $((secs + 120)) python tools/fuzz_parity.py --seconds "$secs" --first-seed "$first" > "$out/fuzz_static_$first.txt" 2>&1; tail -4 "$out/fuzz_static_$first.txt" | cut -c1-300;;
     mutate:*)  # mutate:SECONDS:FIRST_SEED -- the randomised campaign with world edits (material key flips included)
       IFS=: read -r _ secs first <<< "$w"; timeout $((secs + 120)) python tools/fuzz_parity.py --mutate --seconds "$secs" --first-seed "$first" > "$out/fuzz_mutate_$first.txt" 2>&1; tail -4 "$out/fuzz_mutate_$first.txt" | cut -c1-300;;
     asyncsoak:*)  # asyncsoak:SERIAL:REPEAT -- the asynchronous shim with comm_serial = SERIAL, two-rank and many-rank cases
