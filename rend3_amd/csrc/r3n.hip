@@ -2504,7 +2504,6 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
             }
         if (d->exchange && d->n_shadow_views && d->exchange(d->exchange_user, R3N_EXCHANGE_SHADOW) != 0)
             return fail(c, R3N_ERR_STATE, "render_frame: the shadow exchange callback failed");
-        if (native && d->n_shadow_views) TRY(comm_exchange_shadows(c, d));
         return R3N_OK;
     };
     auto viewport_pass1 = [&]() -> int {
@@ -2518,6 +2517,11 @@ int r3n_render_frame(r3n_ctx *c, const r3n_frame_desc *d) {
     else { TRY(shadow_nodes()); TRY(viewport_pass1()); }
     if (d->exchange && d->exchange(d->exchange_user, R3N_EXCHANGE_PASS1) != 0) return fail(c, R3N_ERR_STATE, "render_frame: the pass-1 exchange callback failed");
     if (native) TRY(c->comm.by_objects ? comm_reduce_pass1(c) : comm_exchange_pass1(c));
+    // The shadow views' broadcast is ENQUEUED here, behind the pass-1 exchange, although the views were drawn first: under the one
+    // total order of the collectives (comm_order_begin) the main stream's pass-1 exchange would otherwise wait for the shadow lanes'
+    // broadcast -- i.e. for the shadow views, the longest chain of the frame -- before Hi-Z could start.  In this order the broadcast
+    // waits for the (early, short) pass-1 exchange instead, and nothing but the resolve waits for the atlas, as before.
+    if (native && d->n_shadow_views) TRY(comm_exchange_shadows(c, d));
     TRY(r3n_hi_z(c));                         // hi_z (base.rs:162)
     TRY(r3n_cull(c, R3N_CAMERA_VIEWPORT));    // pbr_culling (base.rs:169)
     // pbr_render_opaque_residual_triangles (base.rs:172)
