@@ -1040,7 +1040,11 @@ __global__ __launch_bounds__(256, (S == 1 && !TEX) ? 5 : (REC ? (S == 1 ? (CLS =
         const uint32_t n_here = n_unique;
 #pragma unroll 1
         for (uint32_t k = 0, sm_at = 0; k < n_here; ++k, ++sm_at) {
-            while (first_of[sm_at == 0u ? 0 : (sm_at == 1u ? 1 : (sm_at == 2u ? 2 : 3))] != sm_at) ++sm_at;  // next leader sample
+            // next leader sample.  BOUNDED on purpose: there is always a leader at or behind sm_at (n_here counts them), so the bound never
+            // binds in a correct execution -- but a build of this kernel (round 6: a six-line change elsewhere in the fragment stage,
+            // -O3, occupancy target 5) spun in exactly this loop on the device until the process was killed, returned with the bound in
+            // place, and produced the oracle's bits (profiles/r06_native_hang.md): a search that cannot leave [0, S) cannot hang the GPU
+            while (sm_at < (uint32_t)(S - 1) && first_of[sm_at == 0u ? 0 : (sm_at == 1u ? 1 : (sm_at == 2u ? 2 : 3))] != sm_at) ++sm_at;
             const uint32_t id = sm_at == 0u ? ids[0] : (sm_at == 1u ? ids[1] : (sm_at == 2u ? ids[2] : ids[3]));
             float v[4];
             if (id == 0u) {
