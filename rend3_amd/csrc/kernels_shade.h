@@ -142,6 +142,7 @@ struct BlendApplyArgs {
     const uint32_t *vals;             // nodes: canonical slot + 1
     const uint32_t *head;             // per pixel sample: first node, R3N_INVALID = none
     uint32_t first_sample, n_samples; // the samples of the rows this rank resolves
+    uint32_t capacity;                // nodes the pass can hold: no list is longer, no sample is blended more often (loop bounds)
     ushort4 *samples;  // S == 1: the HDR target itself; S == 4: the per-sample colours
 };
 
@@ -1173,9 +1174,13 @@ __global__ __launch_bounds__(256) void k_blend_apply(ShadeArgs a, BlendApplyArgs
                   (float)__builtin_bit_cast(_Float16, d16.z), (float)__builtin_bit_cast(_Float16, d16.w)};
     bool first = true;
     uint32_t last = 0u;
-    for (;;) {
+    // Both loops carry a bound that never binds on a well-formed list (a list has at most `capacity` nodes, every round consumes
+    // one): the shape -- a data-dependent loop inside a data-dependent loop around the whole fragment stage -- is the one a build of
+    // the multisampled resolve spun in this round (profiles/r06_native_hang.md); a traversal that is bounded cannot hang the GPU.
+    for (uint32_t round = 0; round < b.capacity; ++round) {
         uint32_t best = R3N_INVALID, best_order = 0xFFFFFFFFu;
-        for (uint32_t n = head; n != R3N_INVALID;) {
+        uint32_t steps = 0;
+        for (uint32_t n = head; n != R3N_INVALID && steps < b.capacity; ++steps) {
             const unsigned long long k = b.keys[n];
             const uint32_t order = (uint32_t)k;
             if ((first || order > last) && order <= best_order) { best = n; best_order = order; }

@@ -2088,6 +2088,7 @@ static int forward_blend(r3n_ctx *c) {
     ba.head = c->frag_head.as<uint32_t>();
     ba.first_sample = (uint32_t)first_sample;
     ba.n_samples = (uint32_t)n_samples;
+    ba.capacity = c->frag_capacity;
     ba.samples = S == 4 ? c->samples16.as<ushort4>() : c->hdr16.as<ushort4>();
     if (S == 4 && !c->samples16.p) return fail(c, R3N_ERR_STATE, "forward: r3n_blend_order_write must precede r3n_resolve_opaque");
     {
